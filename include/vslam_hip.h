@@ -1,0 +1,152 @@
+/* vslam_hip.h -- C ABI of libvslam_hip.so: the MI355X (gfx950) per-frame tracking hot path.
+ *
+ * The reference (juuso-oskari/visual_slam, src/v2) has no FFI of its own: its native boundary is the pybind11
+ * modules cv2 and g2o.  Each entry point below replaces one of those delegations and cites the reference call site
+ * (file:line relative to the reference root) whose arithmetic it takes over.  The Python classes in
+ * visual_slam_amd/ (FeatureExtractor, FeatureMatcher, BundleAdjustment ...) keep the reference's signatures and call
+ * these functions through ctypes.
+ *
+ * Conventions
+ *   - every function returns VS_OK (0) or a negative vs_status; the message is available from vs_last_error().
+ *   - "host" entry points take caller-owned host buffers (C-contiguous unless a stride is given), copy in, run the
+ *     kernels on the context's stream, copy out and return synchronously.
+ *   - "_dev" entry points take device pointers that are already resident in HBM, enqueue on the given hipStream_t
+ *     (passed as void*; NULL = the context's stream) and return WITHOUT synchronising.  They are what bench.py, the
+ *     query-sharded matcher (device tensors handed to RCCL) and a resident map use.
+ *   - one vs_ctx per process and GPU; a ctx is not thread-safe.
+ *   - bit-exact contracts (integer work) and tolerance contracts (FP64 BA) are stated per function.
+ */
+#ifndef VSLAM_HIP_H
+#define VSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vs_ctx vs_ctx;
+
+typedef enum vs_status {
+  VS_OK = 0,
+  VS_EINVAL = -1, /* bad argument (null pointer, negative size, T < 2 for k=2 ...) */
+  VS_ENOMEM = -2, /* host or device allocation failed */
+  VS_EHIP = -3,   /* a HIP runtime call or kernel launch failed */
+  VS_ENOTPD = -4, /* reserved: BA reports indefinite systems in vs_ba_result, it does not fail the call */
+  VS_ECAP = -5    /* an output capacity given by the caller is too small */
+} vs_status;
+
+#define VS_ABI_VERSION 1
+#define VS_DESC_BYTES 32 /* BRIEF-256 */
+
+/* ---- context ---------------------------------------------------------------------------------------------- */
+int vs_abi_version(void);
+int vs_create(vs_ctx** out, int device);
+int vs_destroy(vs_ctx* ctx);
+/* last error message of ctx (or of the failed vs_create when ctx == NULL); never NULL */
+const char* vs_last_error(const vs_ctx* ctx);
+/* the context's hipStream_t as void* (so torch / RCCL work can be ordered against it) */
+void* vs_stream(vs_ctx* ctx);
+int vs_synchronize(vs_ctx* ctx);
+
+/* ---- A2: gray conversion ------------------------------------------------------------------------------------
+ * replaces np.mean(img, axis=2).astype(np.uint8)            (src/v2/frame.py:11)
+ * gray[y][x] = (b + g + r) / 3 (integer division; exact for all 766 sums).  bgr rows are `stride` bytes apart. */
+int vs_gray_mean3_u8(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* gray /*[h][w]*/);
+
+/* ---- A3: keypoint detection ---------------------------------------------------------------------------------
+ * replaces cv2.goodFeaturesToTrack(...) / the detector of cv2.ORB_create()   (src/v2/frame.py:8,11-12)
+ * FAST-9 on the 16-pixel radius-3 circle with threshold `thr`; score = largest threshold at which the pixel is
+ * still a corner; kept iff score is strictly greater than the score of all 8 neighbours (non-corners score 0);
+ * pixels closer than `border` (>= 3) to the image edge are never keypoints.  If more than max_kp survive, the
+ * max_kp with the highest score are kept (ties: lower y*w+x first).  Output order is row-major (y, then x).
+ * xy[i] = (x, y) as float32 -- the layout cv2.KeyPoint_convert returns (src/v2/frame.py:14).  Bit-exact. */
+int vs_fast9_detect(vs_ctx* ctx, const uint8_t* gray, int w, int h, int stride, int thr, int border, int max_kp,
+                    float* xy /*[max_kp][2]*/, uint8_t* score /*[max_kp] or NULL*/, int* n_out);
+
+/* ---- A4: description ----------------------------------------------------------------------------------------
+ * replaces self.extractor.compute(img, kps)                 (src/v2/frame.py:7-8,13)
+ * BRIEF-256 on 5x5 box sums with the committed pattern include/vs_brief_pattern.h.  Keypoints are rounded to the
+ * nearest pixel (half to even); those whose 31x31 patch leaves the image are dropped, as extractor.compute drops
+ * them: desc/keep_idx hold the survivors in input order, keep_idx[j] = index into xy.  Bit-exact. */
+int vs_brief256(vs_ctx* ctx, const uint8_t* gray, int w, int h, int stride, const float* xy, int n,
+                uint8_t* desc /*[n][32]*/, int32_t* keep_idx /*[n]*/, int* n_out);
+
+/* ---- A2+A3+A4 fused: FeatureExtractor.compute_features ---------------------------------------------------------
+ * replaces the whole body of compute_features(img)          (src/v2/frame.py:10-14)
+ * == vs_gray_mean3_u8 -> vs_fast9_detect(border = 15) -> vs_brief256, in two kernel launches with one upload of
+ * the BGR frame.  Because detection already excludes the 15-pixel border no keypoint is dropped by description. */
+int vs_detect_describe_bgr(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int thr, int max_kp,
+                           float* xy /*[max_kp][2]*/, uint8_t* score /*[max_kp] or NULL*/,
+                           uint8_t* desc /*[max_kp][32]*/, int* n_out);
+
+/* ---- A5: brute-force Hamming 2-NN ---------------------------------------------------------------------------
+ * replaces cv2.BFMatcher(NORM_HAMMING).knnMatch(desc1, desc2, k=2)   (src/v2/frame.py:18,23)
+ * For every query row the two train rows of smallest Hamming distance, ascending; ties -> lower train index
+ * first.  idx[q] = {best, second}, dist[q] likewise.  nt >= 2 required (the reference raises on unpacking
+ * otherwise, src/v2/frame.py:30); nq == 0 is legal.  Bit-exact. */
+int vs_hamming_knn2(vs_ctx* ctx, const uint8_t* q /*[nq][32]*/, int nq, const uint8_t* t /*[nt][32]*/, int nt,
+                    int32_t* idx /*[nq][2]*/, int32_t* dist /*[nq][2]*/);
+
+/* ---- A5+A6: 2-NN + Lowe ratio test + ordered compaction -------------------------------------------------------
+ * replaces knnMatch + the `m.distance < ratio * n.distance` loop     (src/v2/frame.py:23-47)
+ * Keeps query i iff (double)d1 < ratio * (double)d2 -- the comparison Python performs.  Survivors are written in
+ * query order: match_q[j], match_t[j], match_d[j].  Bit-exact. */
+int vs_match_ratio(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
+                   int32_t* match_q /*[nq]*/, int32_t* match_t /*[nq]*/, int32_t* match_d /*[nq]*/, int* n_out);
+
+/* device-resident variants (no copies, no synchronisation).  d_idx/d_dist: int32[nq][2] in HBM. */
+int vs_hamming_knn2_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_idx, void* d_dist,
+                        void* stream);
+/* d_n_out: one int32 in HBM receiving the match count */
+int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, double ratio, void* d_match_q,
+                       void* d_match_t, void* d_match_d, void* d_n_out, void* stream);
+
+/* ---- A9-A16: bundle adjustment ------------------------------------------------------------------------------
+ * replaces the g2o graph the reference builds and optimises          (src/v2/LocalBA.py:20-94,115-131,39-42)
+ *   solver      : Levenberg-Marquardt( BlockSolverSE3( Cholesky ) ), points marginalised (Schur complement)
+ *   add_pose    : poses[i] = 4x4 camera-to-world, row-major; internally (t, unit q) as g2o::SBACam (LocalBA.py:56-65)
+ *   add_point   : points[j] (LocalBA.py:68-77)
+ *   add_edge    : EdgeProjectP2MC residual pi(K * w2n * [X;1]) - uv, information I2 (or obs_info), Huber(huber_delta)
+ *                 (LocalBA.py:79-94)
+ *   AddScalingEdge: EdgeSBAScale residual m - |t_child - t_parent|, information 1, RobustKernelDCS (LocalBA.py:115-131)
+ *   optimize    : initialize_optimization(); optimize(max_iterations) (LocalBA.py:39-42)
+ * All arithmetic in FP64.  Contract: final poses within 1e-4 relative Frobenius norm of the CPU oracle. */
+typedef struct vs_ba_problem {
+  int32_t n_poses, n_points, n_obs, n_scale;
+  const double* poses;        /* [n_poses][16] */
+  const uint8_t* pose_fixed;  /* [n_poses] */
+  const double* points;       /* [n_points][3] */
+  const uint8_t* point_fixed; /* [n_points] */
+  const int32_t* obs_pose;    /* [n_obs] index into poses */
+  const int32_t* obs_point;   /* [n_obs] index into points */
+  const double* obs_uv;       /* [n_obs][2] */
+  const double* obs_info;     /* [n_obs][3] = (xx, xy, yy) or NULL for identity */
+  const int32_t* scale_parent; /* [n_scale] index into poses */
+  const int32_t* scale_child;  /* [n_scale] */
+  const double* scale_meas;    /* [n_scale] */
+  double fx, fy, cx, cy;
+  double huber_delta; /* sqrt(5.991) in the reference; <= 0 disables the robust kernel */
+  double dcs_phi;     /* RobustKernelDCS delta, 1.0 in g2o */
+  int32_t max_iterations; /* 10 in the reference (LocalBA.py:39) */
+  int32_t reserved;
+} vs_ba_problem;
+
+typedef struct vs_ba_result {
+  double* poses_out;     /* [n_poses][16] optimised camera-to-world matrices (may alias nothing in the problem) */
+  double* points_out;    /* [n_points][3] */
+  double* chi2_trace;    /* [max_iterations] robust chi2 after each outer iteration, or NULL */
+  double* lambda_trace;  /* [max_iterations] damping after each outer iteration, or NULL */
+  double chi2_initial, chi2_final, lambda_final;
+  int32_t iterations;    /* outer LM iterations executed */
+  int32_t trials;        /* inner trials (linear solves) executed in total */
+  int32_t not_pd;        /* trials whose reduced system was not positive definite (the reference's debug.txt case) */
+  int32_t terminated;    /* 1 if LM stopped before max_iterations (10 rejected trials or zero gain) */
+} vs_ba_result;
+
+int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* problem, vs_ba_result* result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSLAM_HIP_H */

@@ -1,0 +1,938 @@
+/* vs_oracle.c -- CPU restatement of the per-frame tracking hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may load this library; the product
+ * (visual_slam_amd/, libvslam_hip.so) never links, imports or calls it.
+ *
+ * PARITY UNPINNED against the reference's native libraries: the reference (juuso-oskari/visual_slam) delegates all
+ * arithmetic on this path to OpenCV and g2o through pybind11 (src/v2/frame.py:2,7-14,18,23; src/v2/LocalBA.py:3,
+ * 20-25,39-42,56-94,115-131).  Neither library (source, headers, wheels or binaries) exists in this container or on
+ * the GPU box, the reference has no tests, golden vectors or fixtures, and BASELINE.json replaces
+ * the live Shi-Tomasi/SIFT/L2 path by FAST/BRIEF/Hamming.  What this file restates and from where:
+ *   vo_gray_mean3_u8     src/v2/frame.py:11           np.mean(img,axis=2).astype(np.uint8) == (b+g+r)/3
+ *   vo_fast9_*           src/v2/frame.py:8,11-12      FAST-9/16 (Rosten & Drummond 2006) as cv2.ORB's detector uses it:
+ *                                                      segment test, score = largest passing threshold, 3x3 NMS
+ *   vo_brief256          src/v2/frame.py:8,13         BRIEF-256 (Calonder et al. 2010) on 5x5 box sums, committed pattern
+ *   vo_hamming_knn2      src/v2/frame.py:18,23        BFMatcher(NORM_HAMMING).knnMatch(k=2): ascending, ties -> lower index
+ *   vo_match_ratio       src/v2/frame.py:25-47        Lowe ratio loop, survivors in query order
+ *   vo_ba_solve          src/v2/LocalBA.py:20-94,115-131,39-42  the g2o graph: SBACam/VertexCam, VertexSBAPointXYZ
+ *                                                      (marginalised), EdgeProjectP2MC + Huber, EdgeSBAScale + DCS,
+ *                                                      BlockSolverSE3 Schur + Cholesky, OptimizationAlgorithmLevenberg
+ *                        g2o (RainerKuemmerle/g2o, as wrapped by uoip/g2opy; version not pinned by the reference):
+ *                        published algorithm restated from SURVEY.md 3.4 / 8a-A16.
+ * Pinned by: definition-level known-answer tests and an independent NumPy twin (tests/), closed-form BA scenes
+ * (noise-free scene converges to ground truth, analytic Jacobians vs central differences), and the reference's
+ * debug.txt dump (an indefinite 90x90 reduced camera system: the Cholesky must reject it).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#include "../include/vslam_hip.h"
+#include "../include/vs_brief_pattern.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define VO_EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------------ gray (A2) */
+VO_EXPORT int vo_gray_mean3_u8(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray) {
+  if (!bgr || !gray || w <= 0 || h <= 0 || stride < 3 * w) return VS_EINVAL;
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* row = bgr + (size_t)y * stride;
+    for (int x = 0; x < w; ++x) gray[(size_t)y * w + x] = (uint8_t)((row[3 * x] + row[3 * x + 1] + row[3 * x + 2]) / 3);
+  }
+  return VS_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ FAST (A3) */
+/* Bresenham circle of radius 3, clockwise from 12 o'clock */
+static const int8_t kCircle[16][2] = {{0, -3}, {1, -3}, {2, -2}, {3, -1}, {3, 0},  {3, 1},   {2, 2},   {1, 3},
+                                      {0, 3},  {-1, 3}, {-2, 2}, {-3, 1}, {-3, 0}, {-3, -1}, {-2, -2}, {-1, -3}};
+
+/* m = max over the 16 arcs of 9 contiguous circle pixels of min_j (p_j - c), and the same for (c - p_j).
+ * The pixel is a corner at threshold t iff m > t, so the largest passing threshold is m - 1. */
+static int fast9_maxmin(const uint8_t* img, int stride, int x, int y) {
+  int c = img[(size_t)y * stride + x];
+  int d[16];
+  for (int k = 0; k < 16; ++k) d[k] = (int)img[(size_t)(y + kCircle[k][1]) * stride + (x + kCircle[k][0])] - c;
+  int best = -255;
+  for (int s = 0; s < 16; ++s) {
+    int mn = 255, mx = -255;
+    for (int j = 0; j < 9; ++j) {
+      int v = d[(s + j) & 15];
+      if (v < mn) mn = v;
+      if (v > mx) mx = v;
+    }
+    if (mn > best) best = mn;   /* all brighter by at least mn */
+    if (-mx > best) best = -mx; /* all darker by at least -mx */
+  }
+  return best;
+}
+
+/* score map: 0 for non-corners, (largest passing threshold) for corners; border pixels 0 */
+VO_EXPORT int vo_fast9_score_map(const uint8_t* gray, int w, int h, int stride, int thr, int border, uint8_t* score) {
+  if (!gray || !score || w <= 0 || h <= 0 || stride < w || thr < 1 || thr > 254 || border < 3) return VS_EINVAL;
+  memset(score, 0, (size_t)w * h);
+  for (int y = border; y < h - border; ++y)
+    for (int x = border; x < w - border; ++x) {
+      int m = fast9_maxmin(gray, stride, x, y);
+      if (m > thr) score[(size_t)y * w + x] = (uint8_t)(m - 1);
+    }
+  return VS_OK;
+}
+
+VO_EXPORT int vo_fast9_detect(const uint8_t* gray, int w, int h, int stride, int thr, int border, int max_kp, float* xy,
+                              uint8_t* score_out, int* n_out) {
+  if (!xy || !n_out || max_kp < 0) return VS_EINVAL;
+  uint8_t* score = (uint8_t*)malloc((size_t)w * h > 0 ? (size_t)w * h : 1);
+  if (!score) return VS_ENOMEM;
+  int rc = vo_fast9_score_map(gray, w, h, stride, thr, border, score);
+  if (rc != VS_OK) {
+    free(score);
+    return rc;
+  }
+  /* pass 1: NMS survivors and their score histogram */
+  uint8_t* keep = (uint8_t*)calloc((size_t)w * h, 1);
+  if (!keep) {
+    free(score);
+    return VS_ENOMEM;
+  }
+  long hist[256];
+  memset(hist, 0, sizeof hist);
+  long total = 0;
+  for (int y = border; y < h - border; ++y)
+    for (int x = border; x < w - border; ++x) {
+      int s = score[(size_t)y * w + x];
+      if (!s) continue;
+      int ok = 1;
+      for (int dy = -1; dy <= 1 && ok; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          if (!dx && !dy) continue;
+          if (score[(size_t)(y + dy) * w + (x + dx)] >= s) {
+            ok = 0;
+            break;
+          }
+        }
+      if (ok) {
+        keep[(size_t)y * w + x] = 1;
+        hist[s]++;
+        total++;
+      }
+    }
+  /* pass 2: cap -- keep every survivor with score > cut and the first `quota` (row-major) with score == cut */
+  int cut = 0;
+  long quota = 0;
+  if (total > max_kp) {
+    long above = 0;
+    cut = 255;
+    while (cut > 0 && above + hist[cut] <= max_kp) {
+      above += hist[cut];
+      --cut;
+    }
+    quota = max_kp - above; /* 0 <= quota < hist[cut] */
+  }
+  int n = 0;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      if (!keep[(size_t)y * w + x]) continue;
+      int s = score[(size_t)y * w + x];
+      if (total > max_kp) {
+        if (s < cut) continue;
+        if (s == cut) {
+          if (quota <= 0) continue;
+          --quota;
+        }
+      }
+      xy[2 * n] = (float)x;
+      xy[2 * n + 1] = (float)y;
+      if (score_out) score_out[n] = (uint8_t)s;
+      ++n;
+    }
+  *n_out = n;
+  free(keep);
+  free(score);
+  return VS_OK;
+}
+
+/* ----------------------------------------------------------------------------------------------- BRIEF (A4) */
+static const int8_t kBrief[VS_BRIEF_NTESTS][4] = VS_BRIEF_PATTERN_INIT;
+
+/* box[y][x] = sum of the 5x5 window centred on (x, y); 0 where the window leaves the image */
+VO_EXPORT int vo_boxsum5(const uint8_t* gray, int w, int h, int stride, uint16_t* box) {
+  if (!gray || !box || w <= 0 || h <= 0 || stride < w) return VS_EINVAL;
+  memset(box, 0, sizeof(uint16_t) * (size_t)w * h);
+  for (int y = 2; y < h - 2; ++y)
+    for (int x = 2; x < w - 2; ++x) {
+      int s = 0;
+      for (int dy = -2; dy <= 2; ++dy)
+        for (int dx = -2; dx <= 2; ++dx) s += gray[(size_t)(y + dy) * stride + (x + dx)];
+      box[(size_t)y * w + x] = (uint16_t)s;
+    }
+  return VS_OK;
+}
+
+VO_EXPORT int vo_brief256(const uint8_t* gray, int w, int h, int stride, const float* xy, int n, uint8_t* desc,
+                          int32_t* keep_idx, int* n_out) {
+  if (!gray || !n_out || n < 0 || (n > 0 && (!xy || !desc))) return VS_EINVAL;
+  uint16_t* box = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)w * h);
+  if (!box) return VS_ENOMEM;
+  int rc = vo_boxsum5(gray, w, h, stride, box);
+  if (rc != VS_OK) {
+    free(box);
+    return rc;
+  }
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    long x = lrintf(xy[2 * i]), y = lrintf(xy[2 * i + 1]); /* round half to even */
+    if (x < VS_BRIEF_BORDER || y < VS_BRIEF_BORDER || x >= w - VS_BRIEF_BORDER || y >= h - VS_BRIEF_BORDER) continue;
+    uint8_t* d = desc + (size_t)m * VS_DESC_BYTES;
+    memset(d, 0, VS_DESC_BYTES);
+    for (int k = 0; k < VS_BRIEF_NTESTS; ++k) {
+      int a = box[(size_t)(y + kBrief[k][1]) * w + (x + kBrief[k][0])];
+      int b = box[(size_t)(y + kBrief[k][3]) * w + (x + kBrief[k][2])];
+      if (a < b) d[k >> 3] |= (uint8_t)(1u << (k & 7));
+    }
+    if (keep_idx) keep_idx[m] = i;
+    ++m;
+  }
+  *n_out = m;
+  free(box);
+  return VS_OK;
+}
+
+VO_EXPORT int vo_detect_describe_bgr(const uint8_t* bgr, int w, int h, int stride, int thr, int max_kp, float* xy,
+                                     uint8_t* score, uint8_t* desc, int* n_out) {
+  if (!bgr || w <= 0 || h <= 0) return VS_EINVAL;
+  uint8_t* gray = (uint8_t*)malloc((size_t)w * h);
+  if (!gray) return VS_ENOMEM;
+  int rc = vo_gray_mean3_u8(bgr, w, h, stride, gray);
+  int n = 0, m = 0;
+  if (rc == VS_OK) rc = vo_fast9_detect(gray, w, h, w, thr, VS_BRIEF_BORDER, max_kp, xy, score, &n);
+  if (rc == VS_OK) rc = vo_brief256(gray, w, h, w, xy, n, desc, NULL, &m);
+  if (rc == VS_OK && m != n) rc = VS_EINVAL; /* cannot happen: detection border == BRIEF border */
+  if (rc == VS_OK) *n_out = n;
+  free(gray);
+  return rc;
+}
+
+/* --------------------------------------------------------------------------------------------- Hamming (A5) */
+static inline int hamming256(const uint64_t* a, const uint64_t* b) {
+  return __builtin_popcountll(a[0] ^ b[0]) + __builtin_popcountll(a[1] ^ b[1]) + __builtin_popcountll(a[2] ^ b[2]) +
+         __builtin_popcountll(a[3] ^ b[3]);
+}
+
+/* threads <= 0: all OpenMP threads; returns the number of threads used through *threads_used (may be NULL) */
+VO_EXPORT int vo_hamming_knn2_mt(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist,
+                                 int threads, int* threads_used) {
+  if (nq < 0 || nt < 2 || (nq > 0 && (!q || !idx || !dist)) || !t) return VS_EINVAL;
+  int used = 1;
+#ifdef _OPENMP
+  used = threads > 0 ? threads : omp_get_max_threads();
+#pragma omp parallel for schedule(static) num_threads(used)
+#endif
+  for (int i = 0; i < nq; ++i) {
+    uint64_t qa[4];
+    memcpy(qa, q + (size_t)i * 32, 32);
+    int d1 = 1 << 30, d2 = 1 << 30, i1 = -1, i2 = -1;
+    for (int j = 0; j < nt; ++j) {
+      uint64_t tb[4];
+      memcpy(tb, t + (size_t)j * 32, 32);
+      int d = hamming256(qa, tb);
+      if (d < d1) { /* strict: an equal distance at a higher index never displaces a lower index */
+        d2 = d1;
+        i2 = i1;
+        d1 = d;
+        i1 = j;
+      } else if (d < d2) {
+        d2 = d;
+        i2 = j;
+      }
+    }
+    idx[2 * i] = i1;
+    idx[2 * i + 1] = i2;
+    dist[2 * i] = d1;
+    dist[2 * i + 1] = d2;
+  }
+  if (threads_used) *threads_used = used;
+  return VS_OK;
+}
+
+VO_EXPORT int vo_hamming_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist) {
+  return vo_hamming_knn2_mt(q, nq, t, nt, idx, dist, 1, NULL);
+}
+
+/* ----------------------------------------------------------------------------------------------- ratio (A6) */
+VO_EXPORT int vo_match_ratio(const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio, int32_t* match_q,
+                             int32_t* match_t, int32_t* match_d, int* n_out) {
+  if (!n_out) return VS_EINVAL;
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(nq > 0 ? nq : 1));
+  int32_t* dist = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(nq > 0 ? nq : 1));
+  if (!idx || !dist) {
+    free(idx);
+    free(dist);
+    return VS_ENOMEM;
+  }
+  int rc = vo_hamming_knn2(q, nq, t, nt, idx, dist);
+  if (rc == VS_OK) {
+    int m = 0;
+    for (int i = 0; i < nq; ++i)
+      if ((double)dist[2 * i] < ratio * (double)dist[2 * i + 1]) { /* frame.py:33 */
+        match_q[m] = i;
+        match_t[m] = idx[2 * i];
+        match_d[m] = dist[2 * i];
+        ++m;
+      }
+    *n_out = m;
+  }
+  free(idx);
+  free(dist);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------- dense Cholesky (A16) */
+/* In-place lower Cholesky of the n x n row-major symmetric matrix a (only the lower triangle is read).
+ * Returns 0, or k+1 if the k-th pivot is not positive (matrix not positive definite, or NaN). */
+VO_EXPORT int vo_cholesky_lower(double* a, int n) {
+  for (int j = 0; j < n; ++j) {
+    double s = a[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) s -= a[(size_t)j * n + k] * a[(size_t)j * n + k];
+    if (!(s > 0.0)) return j + 1;
+    double l = sqrt(s);
+    a[(size_t)j * n + j] = l;
+    for (int i = j + 1; i < n; ++i) {
+      double v = a[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) v -= a[(size_t)i * n + k] * a[(size_t)j * n + k];
+      a[(size_t)i * n + j] = v / l;
+    }
+  }
+  return 0;
+}
+
+static void chol_solve(const double* L, int n, double* x /* in: rhs, out: solution */) {
+  for (int i = 0; i < n; ++i) {
+    double s = x[i];
+    for (int k = 0; k < i; ++k) s -= L[(size_t)i * n + k] * x[k];
+    x[i] = s / L[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double s = x[i];
+    for (int k = i + 1; k < n; ++k) s -= L[(size_t)k * n + i] * x[k];
+    x[i] = s / L[(size_t)i * n + i];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ BA (A9-16) */
+typedef struct {
+  double t[3];
+  double q[4]; /* x y z w */
+  double w2n[3][4];
+  double dR[3][3][3]; /* dRdx, dRdy, dRdz */
+} cam_t;
+
+static void quat_from_R(const double* m /* row-major 4x4, top-left 3x3 used */, double* q) {
+#define M(r, c) m[(r)*4 + (c)]
+  double tr = M(0, 0) + M(1, 1) + M(2, 2);
+  if (tr > 0.0) {
+    double s = sqrt(tr + 1.0);
+    q[3] = 0.5 * s;
+    s = 0.5 / s;
+    q[0] = (M(2, 1) - M(1, 2)) * s;
+    q[1] = (M(0, 2) - M(2, 0)) * s;
+    q[2] = (M(1, 0) - M(0, 1)) * s;
+  } else {
+    int i = 0;
+    if (M(1, 1) > M(0, 0)) i = 1;
+    if (M(2, 2) > M(i, i)) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+    q[i] = 0.5 * s;
+    s = 0.5 / s;
+    q[3] = (M(k, j) - M(j, k)) * s;
+    q[j] = (M(j, i) + M(i, j)) * s;
+    q[k] = (M(k, i) + M(i, k)) * s;
+  }
+#undef M
+  /* SE3Quat::normalizeRotation */
+  if (q[3] < 0.0)
+    for (int a = 0; a < 4; ++a) q[a] = -q[a];
+  double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int a = 0; a < 4; ++a) q[a] /= nrm;
+}
+
+static void R_from_quat(const double* q, double R[3][3]) {
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+         tyz = tz * y, tzz = tz * z;
+  R[0][0] = 1 - (tyy + tzz);
+  R[0][1] = txy - twz;
+  R[0][2] = txz + twy;
+  R[1][0] = txy + twz;
+  R[1][1] = 1 - (txx + tzz);
+  R[1][2] = tyz - twx;
+  R[2][0] = txz - twy;
+  R[2][1] = tyz + twx;
+  R[2][2] = 1 - (txx + tyy);
+}
+
+/* SBACam::setTransform + setDr: w2n = [R^T | -R^T t]; dRd{x,y,z} = dRid{x,y,z} * R^T */
+static void cam_refresh(cam_t* c) {
+  double R[3][3];
+  R_from_quat(c->q, R);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) c->w2n[i][j] = R[j][i];
+    c->w2n[i][3] = -(c->w2n[i][0] * c->t[0] + c->w2n[i][1] * c->t[1] + c->w2n[i][2] * c->t[2]);
+  }
+  static const double dRi[3][3][3] = {{{0, 0, 0}, {0, 0, 2}, {0, -2, 0}},
+                                      {{0, 0, -2}, {0, 0, 0}, {2, 0, 0}},
+                                      {{0, 2, 0}, {-2, 0, 0}, {0, 0, 0}}};
+  for (int a = 0; a < 3; ++a)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += dRi[a][i][k] * c->w2n[k][j];
+        c->dR[a][i][j] = s;
+      }
+}
+
+/* SBACam::update: t += d[0:3]; q <- q * (d[3:6], sqrt(1 - |d[3:6]|^2)); normalise */
+static void cam_update(cam_t* c, const double* d) {
+  for (int i = 0; i < 3; ++i) c->t[i] += d[i];
+  double bx = d[3], by = d[4], bz = d[5];
+  double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz)); /* NaN if the step is too large: trial is then rejected */
+  double ax = c->q[0], ay = c->q[1], az = c->q[2], aw = c->q[3];
+  double w = aw * bw - ax * bx - ay * by - az * bz;
+  double x = aw * bx + ax * bw + ay * bz - az * by;
+  double y = aw * by + ay * bw + az * bx - ax * bz;
+  double z = aw * bz + az * bw + ax * by - ay * bx;
+  double nrm = sqrt(x * x + y * y + z * z + w * w);
+  c->q[0] = x / nrm;
+  c->q[1] = y / nrm;
+  c->q[2] = z / nrm;
+  c->q[3] = w / nrm;
+  cam_refresh(c);
+}
+
+typedef struct {
+  const vs_ba_problem* p;
+  cam_t* cams;
+  double* pts;    /* [n_points][3] */
+  int* pose_slot; /* free-pose index or -1 */
+  int* pt_slot;   /* free-point index or -1 */
+  int nfp, nfl;   /* free poses, free points */
+  /* linear system */
+  double* Hpp; /* [6nfp][6nfp] */
+  double* bp;  /* [6nfp] */
+  double* Hll; /* [nfl][9] */
+  double* bl;  /* [nfl][3] */
+  double* Hpl; /* [n_obs][18]: 6x3 block J_cam^T W J_pt of each observation with both ends free */
+  double* x;   /* [6nfp + 3nfl] */
+} ba_t;
+
+/* EdgeProjectP2MC::computeError */
+static void proj_error(const ba_t* s, int o, double e[2]) {
+  const vs_ba_problem* p = s->p;
+  const cam_t* c = &s->cams[p->obs_pose[o]];
+  const double* X = &s->pts[3 * p->obs_point[o]];
+  double pc[3];
+  for (int i = 0; i < 3; ++i) pc[i] = c->w2n[i][0] * X[0] + c->w2n[i][1] * X[1] + c->w2n[i][2] * X[2] + c->w2n[i][3];
+  /* w2i = Kcam * w2n */
+  double u = p->fx * pc[0] + p->cx * pc[2], v = p->fy * pc[1] + p->cy * pc[2], wz = pc[2];
+  e[0] = u / wz - p->obs_uv[2 * o];
+  e[1] = v / wz - p->obs_uv[2 * o + 1];
+}
+
+/* EdgeProjectP2MC::linearizeOplus: Ji = d e / d point (2x3), Jj = d e / d cam (2x6) */
+static void proj_jac(const ba_t* s, int o, double Ji[2][3], double Jj[2][6]) {
+  const vs_ba_problem* p = s->p;
+  const cam_t* c = &s->cams[p->obs_pose[o]];
+  const double* X = &s->pts[3 * p->obs_point[o]];
+  double pc[3];
+  for (int i = 0; i < 3; ++i) pc[i] = c->w2n[i][0] * X[0] + c->w2n[i][1] * X[1] + c->w2n[i][2] * X[2] + c->w2n[i][3];
+  double px = pc[0], py = pc[1], pz = pc[2];
+  double ipz2 = 1.0 / (pz * pz);
+  double ipz2fx = ipz2 * p->fx, ipz2fy = ipz2 * p->fy;
+  double pwt[3] = {X[0] - c->t[0], X[1] - c->t[1], X[2] - c->t[2]};
+  for (int a = 0; a < 3; ++a) { /* rotation columns 3..5 */
+    double dp[3];
+    for (int i = 0; i < 3; ++i) dp[i] = c->dR[a][i][0] * pwt[0] + c->dR[a][i][1] * pwt[1] + c->dR[a][i][2] * pwt[2];
+    Jj[0][3 + a] = (pz * dp[0] - px * dp[2]) * ipz2fx;
+    Jj[1][3 + a] = (pz * dp[1] - py * dp[2]) * ipz2fy;
+  }
+  for (int a = 0; a < 3; ++a) { /* translation columns 0..2 and the point Jacobian */
+    double dp[3] = {c->w2n[0][a], c->w2n[1][a], c->w2n[2][a]};
+    Ji[0][a] = (pz * dp[0] - px * dp[2]) * ipz2fx;
+    Ji[1][a] = (pz * dp[1] - py * dp[2]) * ipz2fy;
+    Jj[0][a] = (pz * (-dp[0]) - px * (-dp[2])) * ipz2fx;
+    Jj[1][a] = (pz * (-dp[1]) - py * (-dp[2])) * ipz2fy;
+  }
+}
+
+static void obs_info(const vs_ba_problem* p, int o, double W[3]) {
+  if (p->obs_info) {
+    W[0] = p->obs_info[3 * o];
+    W[1] = p->obs_info[3 * o + 1];
+    W[2] = p->obs_info[3 * o + 2];
+  } else {
+    W[0] = 1;
+    W[1] = 0;
+    W[2] = 1;
+  }
+}
+
+/* RobustKernelHuber::robustify */
+static void huber(double delta, double e2, double rho[2]) {
+  double dsqr = delta * delta;
+  if (e2 <= dsqr) {
+    rho[0] = e2;
+    rho[1] = 1.0;
+  } else {
+    double sqrte = sqrt(e2);
+    rho[0] = 2 * sqrte * delta - dsqr;
+    rho[1] = delta / sqrte;
+  }
+}
+
+/* RobustKernelDCS::robustify */
+static void dcs(double phi, double e2, double rho[2]) {
+  double scale = (2.0 * phi) / (phi + e2);
+  if (scale >= 1.0) {
+    rho[0] = e2;
+    rho[1] = 1.0;
+  } else {
+    rho[0] = scale * e2 * scale;
+    rho[1] = scale * scale;
+  }
+}
+
+static int obs_active(const ba_t* s, int o) {
+  return s->pose_slot[s->p->obs_pose[o]] >= 0 || s->pt_slot[s->p->obs_point[o]] >= 0;
+}
+static int scale_active(const ba_t* s, int k) {
+  return s->pose_slot[s->p->scale_parent[k]] >= 0 || s->pose_slot[s->p->scale_child[k]] >= 0;
+}
+
+/* EdgeSBAScale::computeError */
+static double scale_error_t(const double* t1, const double* t2, double meas) {
+  double dx = t2[0] - t1[0], dy = t2[1] - t1[1], dz = t2[2] - t1[2];
+  return meas - sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+/* computeActiveErrors + activeRobustChi2 */
+static double robust_chi2(const ba_t* s) {
+  const vs_ba_problem* p = s->p;
+  double chi = 0;
+  for (int o = 0; o < p->n_obs; ++o) {
+    if (!obs_active(s, o)) continue;
+    double e[2], W[3];
+    proj_error(s, o, e);
+    obs_info(p, o, W);
+    double e2 = e[0] * (W[0] * e[0] + W[1] * e[1]) + e[1] * (W[1] * e[0] + W[2] * e[1]);
+    if (p->huber_delta > 0) {
+      double rho[2];
+      huber(p->huber_delta, e2, rho);
+      chi += rho[0];
+    } else
+      chi += e2;
+  }
+  for (int k = 0; k < p->n_scale; ++k) {
+    if (!scale_active(s, k)) continue;
+    double e = scale_error_t(s->cams[p->scale_parent[k]].t, s->cams[p->scale_child[k]].t, p->scale_meas[k]);
+    double rho[2];
+    dcs(p->dcs_phi, e * e, rho);
+    chi += rho[0];
+  }
+  return chi;
+}
+
+/* BlockSolver::buildSystem: linearize every active edge and accumulate the quadratic form */
+static void build_system(ba_t* s) {
+  const vs_ba_problem* p = s->p;
+  int np = 6 * s->nfp;
+  memset(s->Hpp, 0, sizeof(double) * (size_t)np * np);
+  memset(s->bp, 0, sizeof(double) * (size_t)np);
+  memset(s->Hll, 0, sizeof(double) * 9 * (size_t)s->nfl);
+  memset(s->bl, 0, sizeof(double) * 3 * (size_t)s->nfl);
+  memset(s->Hpl, 0, sizeof(double) * 18 * (size_t)p->n_obs);
+  for (int o = 0; o < p->n_obs; ++o) {
+    if (!obs_active(s, o)) continue;
+    int cs = s->pose_slot[p->obs_pose[o]], ls = s->pt_slot[p->obs_point[o]];
+    double e[2], W[3], Ji[2][3], Jj[2][6];
+    proj_error(s, o, e);
+    proj_jac(s, o, Ji, Jj);
+    obs_info(p, o, W);
+    double We[2] = {W[0] * e[0] + W[1] * e[1], W[1] * e[0] + W[2] * e[1]};
+    double e2 = e[0] * We[0] + e[1] * We[1];
+    double rho[2] = {e2, 1.0};
+    if (p->huber_delta > 0) huber(p->huber_delta, e2, rho);
+    double r[2] = {-We[0] * rho[1], -We[1] * rho[1]};                 /* omega_r * rho' */
+    double wW[3] = {rho[1] * W[0], rho[1] * W[1], rho[1] * W[2]};     /* robustInformation */
+    double WJi[2][3], WJj[2][6];
+    for (int a = 0; a < 3; ++a) {
+      WJi[0][a] = wW[0] * Ji[0][a] + wW[1] * Ji[1][a];
+      WJi[1][a] = wW[1] * Ji[0][a] + wW[2] * Ji[1][a];
+    }
+    for (int a = 0; a < 6; ++a) {
+      WJj[0][a] = wW[0] * Jj[0][a] + wW[1] * Jj[1][a];
+      WJj[1][a] = wW[1] * Jj[0][a] + wW[2] * Jj[1][a];
+    }
+    if (ls >= 0) {
+      for (int a = 0; a < 3; ++a) {
+        s->bl[3 * ls + a] += Ji[0][a] * r[0] + Ji[1][a] * r[1];
+        for (int b = 0; b < 3; ++b) s->Hll[9 * ls + 3 * a + b] += Ji[0][a] * WJi[0][b] + Ji[1][a] * WJi[1][b];
+      }
+    }
+    if (cs >= 0) {
+      for (int a = 0; a < 6; ++a) {
+        s->bp[6 * cs + a] += Jj[0][a] * r[0] + Jj[1][a] * r[1];
+        for (int b = 0; b < 6; ++b)
+          s->Hpp[(size_t)(6 * cs + a) * np + 6 * cs + b] += Jj[0][a] * WJj[0][b] + Jj[1][a] * WJj[1][b];
+      }
+      if (ls >= 0)
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 3; ++b) s->Hpl[18 * (size_t)o + 3 * a + b] = Jj[0][a] * WJi[0][b] + Jj[1][a] * WJi[1][b];
+    }
+  }
+  /* EdgeSBAScale: numeric Jacobian (central differences, delta 1e-9, through VertexCam::oplus), information 1, DCS */
+  for (int k = 0; k < p->n_scale; ++k) {
+    if (!scale_active(s, k)) continue;
+    int v[2] = {p->scale_parent[k], p->scale_child[k]};
+    int sl[2] = {s->pose_slot[v[0]], s->pose_slot[v[1]]};
+    double m = p->scale_meas[k];
+    double e = scale_error_t(s->cams[v[0]].t, s->cams[v[1]].t, m);
+    double J[2][6];
+    memset(J, 0, sizeof J);
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+    for (int side = 0; side < 2; ++side) {
+      if (sl[side] < 0) continue;
+      for (int d = 0; d < 3; ++d) { /* rotation increments leave the translation, hence the error, unchanged */
+        double tp[3], tm[3];
+        memcpy(tp, s->cams[v[side]].t, sizeof tp);
+        memcpy(tm, s->cams[v[side]].t, sizeof tm);
+        tp[d] += delta;
+        tm[d] += -delta;
+        double ep = side == 0 ? scale_error_t(tp, s->cams[v[1]].t, m) : scale_error_t(s->cams[v[0]].t, tp, m);
+        double em = side == 0 ? scale_error_t(tm, s->cams[v[1]].t, m) : scale_error_t(s->cams[v[0]].t, tm, m);
+        J[side][d] = scalar * (ep - em);
+      }
+    }
+    double rho[2];
+    dcs(p->dcs_phi, e * e, rho);
+    double r = -e * rho[1], w = rho[1];
+    for (int si = 0; si < 2; ++si) {
+      if (sl[si] < 0) continue;
+      for (int a = 0; a < 6; ++a) {
+        s->bp[6 * sl[si] + a] += J[si][a] * r;
+        for (int sj = 0; sj < 2; ++sj) {
+          if (sl[sj] < 0) continue;
+          for (int b = 0; b < 6; ++b) s->Hpp[(size_t)(6 * sl[si] + a) * np + 6 * sl[sj] + b] += J[si][a] * w * J[sj][b];
+        }
+      }
+    }
+  }
+}
+
+static void inv3(const double* D, double* inv) {
+  double c00 = D[4] * D[8] - D[5] * D[7], c01 = D[5] * D[6] - D[3] * D[8], c02 = D[3] * D[7] - D[4] * D[6];
+  double det = D[0] * c00 + D[1] * c01 + D[2] * c02;
+  double id = 1.0 / det;
+  inv[0] = c00 * id;
+  inv[1] = (D[2] * D[7] - D[1] * D[8]) * id;
+  inv[2] = (D[1] * D[5] - D[2] * D[4]) * id;
+  inv[3] = c01 * id;
+  inv[4] = (D[0] * D[8] - D[2] * D[6]) * id;
+  inv[5] = (D[2] * D[3] - D[0] * D[5]) * id;
+  inv[6] = c02 * id;
+  inv[7] = (D[1] * D[6] - D[0] * D[7]) * id;
+  inv[8] = (D[0] * D[4] - D[1] * D[3]) * id;
+}
+
+/* BlockSolver::solve with damping lambda already chosen: returns 1 on success, 0 if the reduced system is not PD.
+ * obs_by_pt / pt_start: observations grouped by free-point slot. */
+static int solve_system(ba_t* s, double lambda, const int* pt_start, const int* obs_by_pt, double* S, double* bs,
+                        double* Dinv_all) {
+  const vs_ba_problem* p = s->p;
+  int np = 6 * s->nfp;
+  for (size_t i = 0; i < (size_t)np * np; ++i) S[i] = s->Hpp[i];
+  for (int i = 0; i < np; ++i) {
+    S[(size_t)i * np + i] += lambda;
+    bs[i] = s->bp[i];
+  }
+  for (int l = 0; l < s->nfl; ++l) {
+    double D[9];
+    memcpy(D, &s->Hll[9 * l], sizeof D);
+    D[0] += lambda;
+    D[4] += lambda;
+    D[8] += lambda;
+    double* Dinv = &Dinv_all[9 * l];
+    inv3(D, Dinv);
+    double db[3];
+    for (int a = 0; a < 3; ++a)
+      db[a] = Dinv[3 * a] * s->bl[3 * l] + Dinv[3 * a + 1] * s->bl[3 * l + 1] + Dinv[3 * a + 2] * s->bl[3 * l + 2];
+    for (int ii = pt_start[l]; ii < pt_start[l + 1]; ++ii) {
+      int oi = obs_by_pt[ii];
+      int ci = s->pose_slot[p->obs_pose[oi]];
+      if (ci < 0) continue;
+      const double* Bi = &s->Hpl[18 * (size_t)oi];
+      double Y[18]; /* Bi * Dinv */
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 3; ++b)
+          Y[3 * a + b] = Bi[3 * a] * Dinv[b] + Bi[3 * a + 1] * Dinv[3 + b] + Bi[3 * a + 2] * Dinv[6 + b];
+      for (int a = 0; a < 6; ++a) bs[6 * ci + a] -= Bi[3 * a] * db[0] + Bi[3 * a + 1] * db[1] + Bi[3 * a + 2] * db[2];
+      for (int jj = pt_start[l]; jj < pt_start[l + 1]; ++jj) {
+        int oj = obs_by_pt[jj];
+        int cj = s->pose_slot[p->obs_pose[oj]];
+        if (cj < 0) continue;
+        const double* Bj = &s->Hpl[18 * (size_t)oj];
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 6; ++b)
+            S[(size_t)(6 * ci + a) * np + 6 * cj + b] -=
+                Y[3 * a] * Bj[3 * b] + Y[3 * a + 1] * Bj[3 * b + 1] + Y[3 * a + 2] * Bj[3 * b + 2];
+      }
+    }
+  }
+  if (vo_cholesky_lower(S, np) != 0) return 0;
+  chol_solve(S, np, bs);
+  memcpy(s->x, bs, sizeof(double) * (size_t)np);
+  for (int l = 0; l < s->nfl; ++l) {
+    double cl[3] = {s->bl[3 * l], s->bl[3 * l + 1], s->bl[3 * l + 2]};
+    for (int ii = pt_start[l]; ii < pt_start[l + 1]; ++ii) {
+      int oi = obs_by_pt[ii];
+      int ci = s->pose_slot[p->obs_pose[oi]];
+      if (ci < 0) continue;
+      const double* Bi = &s->Hpl[18 * (size_t)oi];
+      for (int b = 0; b < 3; ++b)
+        for (int a = 0; a < 6; ++a) cl[b] -= Bi[3 * a + b] * s->x[6 * ci + a];
+    }
+    const double* Dinv = &Dinv_all[9 * l];
+    for (int a = 0; a < 3; ++a) s->x[np + 3 * l + a] = Dinv[3 * a] * cl[0] + Dinv[3 * a + 1] * cl[1] + Dinv[3 * a + 2] * cl[2];
+  }
+  return 1;
+}
+
+static void pose_matrix(const cam_t* c, double* out16) {
+  double R[3][3];
+  R_from_quat(c->q, R);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) out16[4 * i + j] = R[i][j];
+    out16[4 * i + 3] = c->t[i];
+  }
+  out16[12] = out16[13] = out16[14] = 0.0;
+  out16[15] = 1.0;
+}
+
+VO_EXPORT int vo_ba_solve(const vs_ba_problem* p, vs_ba_result* res) {
+  if (!p || !res || p->n_poses < 0 || p->n_points < 0 || p->n_obs < 0 || p->n_scale < 0 || p->max_iterations < 0)
+    return VS_EINVAL;
+  for (int o = 0; o < p->n_obs; ++o)
+    if (p->obs_pose[o] < 0 || p->obs_pose[o] >= p->n_poses || p->obs_point[o] < 0 || p->obs_point[o] >= p->n_points)
+      return VS_EINVAL;
+  for (int k = 0; k < p->n_scale; ++k)
+    if (p->scale_parent[k] < 0 || p->scale_parent[k] >= p->n_poses || p->scale_child[k] < 0 ||
+        p->scale_child[k] >= p->n_poses)
+      return VS_EINVAL;
+  ba_t s;
+  memset(&s, 0, sizeof s);
+  s.p = p;
+  s.cams = (cam_t*)calloc((size_t)p->n_poses + 1, sizeof(cam_t));
+  s.pts = (double*)malloc(sizeof(double) * 3 * ((size_t)p->n_points + 1));
+  s.pose_slot = (int*)malloc(sizeof(int) * ((size_t)p->n_poses + 1));
+  s.pt_slot = (int*)malloc(sizeof(int) * ((size_t)p->n_points + 1));
+  for (int i = 0; i < p->n_poses; ++i) {
+    const double* m = p->poses + 16 * (size_t)i;
+    quat_from_R(m, s.cams[i].q);
+    s.cams[i].t[0] = m[3];
+    s.cams[i].t[1] = m[7];
+    s.cams[i].t[2] = m[11];
+    cam_refresh(&s.cams[i]);
+    s.pose_slot[i] = p->pose_fixed[i] ? -1 : s.nfp++;
+  }
+  for (int j = 0; j < p->n_points; ++j) {
+    memcpy(&s.pts[3 * j], p->points + 3 * (size_t)j, sizeof(double) * 3);
+    s.pt_slot[j] = p->point_fixed[j] ? -1 : s.nfl++;
+  }
+  int np = 6 * s.nfp, nx = np + 3 * s.nfl;
+  s.Hpp = (double*)malloc(sizeof(double) * ((size_t)np * np + 1));
+  s.bp = (double*)malloc(sizeof(double) * ((size_t)np + 1));
+  s.Hll = (double*)malloc(sizeof(double) * (9 * (size_t)s.nfl + 1));
+  s.bl = (double*)malloc(sizeof(double) * (3 * (size_t)s.nfl + 1));
+  s.Hpl = (double*)malloc(sizeof(double) * (18 * (size_t)p->n_obs + 1));
+  s.x = (double*)calloc((size_t)nx + 1, sizeof(double));
+  double* S = (double*)malloc(sizeof(double) * ((size_t)np * np + 1));
+  double* bs = (double*)malloc(sizeof(double) * ((size_t)np + 1));
+  double* Dinv = (double*)malloc(sizeof(double) * (9 * (size_t)s.nfl + 1));
+  cam_t* cams_bak = (cam_t*)malloc(sizeof(cam_t) * ((size_t)p->n_poses + 1));
+  double* pts_bak = (double*)malloc(sizeof(double) * 3 * ((size_t)p->n_points + 1));
+  /* observations grouped by free point (stable) */
+  int* pt_start = (int*)calloc((size_t)s.nfl + 2, sizeof(int));
+  int* obs_by_pt = (int*)malloc(sizeof(int) * ((size_t)p->n_obs + 1));
+  for (int o = 0; o < p->n_obs; ++o) {
+    int l = s.pt_slot[p->obs_point[o]];
+    if (l >= 0) pt_start[l + 1]++;
+  }
+  for (int l = 0; l < s.nfl; ++l) pt_start[l + 1] += pt_start[l];
+  {
+    int* fill = (int*)malloc(sizeof(int) * ((size_t)s.nfl + 1));
+    memcpy(fill, pt_start, sizeof(int) * (size_t)s.nfl);
+    for (int o = 0; o < p->n_obs; ++o) {
+      int l = s.pt_slot[p->obs_point[o]];
+      if (l >= 0) obs_by_pt[fill[l]++] = o;
+    }
+    free(fill);
+  }
+
+  double lambda = 0, ni = 2;
+  int it = 0, trials = 0, not_pd = 0, terminated = 0;
+  double chi_first = robust_chi2(&s), chi_last = chi_first;
+  res->chi2_initial = chi_first;
+  if (nx == 0) goto done; /* nothing to optimise */
+  for (it = 0; it < p->max_iterations;) {
+    /* OptimizationAlgorithmLevenberg::solve(it) */
+    double currentChi = robust_chi2(&s), tempChi = currentChi;
+    build_system(&s);
+    if (it == 0) { /* computeLambdaInit: tau * max |diag(H)| over the free vertices */
+      double mx = 0;
+      for (int i = 0; i < np; ++i) mx = fmax(fabs(s.Hpp[(size_t)i * np + i]), mx);
+      for (int l = 0; l < s.nfl; ++l)
+        for (int a = 0; a < 3; ++a) mx = fmax(fabs(s.Hll[9 * l + 4 * a]), mx);
+      lambda = 1e-5 * mx;
+      ni = 2;
+    }
+    double rho = 0;
+    int qmax = 0, stop_nonfinite = 0;
+    do {
+      memcpy(cams_bak, s.cams, sizeof(cam_t) * (size_t)p->n_poses); /* push */
+      memcpy(pts_bak, s.pts, sizeof(double) * 3 * (size_t)p->n_points);
+      int ok2 = solve_system(&s, lambda, pt_start, obs_by_pt, S, bs, Dinv);
+      ++trials;
+      if (!ok2) ++not_pd;
+      /* _optimizer->update(x) -- with a failed solve g2o applies the stale x and pops it again below */
+      for (int i = 0; i < p->n_poses; ++i)
+        if (s.pose_slot[i] >= 0) cam_update(&s.cams[i], &s.x[6 * s.pose_slot[i]]);
+      for (int j = 0; j < p->n_points; ++j)
+        if (s.pt_slot[j] >= 0)
+          for (int a = 0; a < 3; ++a) s.pts[3 * j + a] += s.x[np + 3 * s.pt_slot[j] + a];
+      tempChi = robust_chi2(&s);
+      if (!ok2) tempChi = DBL_MAX;
+      rho = currentChi - tempChi;
+      double scale = 0; /* computeScale */
+      for (int j = 0; j < np; ++j) scale += s.x[j] * (lambda * s.x[j] + s.bp[j]);
+      for (int l = 0; l < s.nfl; ++l)
+        for (int a = 0; a < 3; ++a) scale += s.x[np + 3 * l + a] * (lambda * s.x[np + 3 * l + a] + s.bl[3 * l + a]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1.0 - pow(2 * rho - 1, 3);
+        alpha = fmin(alpha, 2.0 / 3.0);
+        double scaleFactor = fmax(1.0 / 3.0, alpha);
+        lambda *= scaleFactor;
+        ni = 2;
+        currentChi = tempChi;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        memcpy(s.cams, cams_bak, sizeof(cam_t) * (size_t)p->n_poses); /* pop */
+        memcpy(s.pts, pts_bak, sizeof(double) * 3 * (size_t)p->n_points);
+        if (!isfinite(lambda)) {
+          stop_nonfinite = 1;
+          break;
+        }
+      }
+      ++qmax;
+    } while (rho < 0 && qmax < 10);
+    chi_last = currentChi;
+    if (res->chi2_trace) res->chi2_trace[it] = currentChi;
+    if (res->lambda_trace) res->lambda_trace[it] = lambda;
+    ++it;
+    if (qmax == 10 || rho == 0 || stop_nonfinite) {
+      terminated = 1;
+      break;
+    }
+  }
+done:
+  res->chi2_final = chi_last;
+  res->lambda_final = lambda;
+  res->iterations = it;
+  res->trials = trials;
+  res->not_pd = not_pd;
+  res->terminated = terminated;
+  if (res->poses_out)
+    for (int i = 0; i < p->n_poses; ++i) pose_matrix(&s.cams[i], res->poses_out + 16 * (size_t)i);
+  if (res->points_out) memcpy(res->points_out, s.pts, sizeof(double) * 3 * (size_t)p->n_points);
+  free(s.cams);
+  free(s.pts);
+  free(s.pose_slot);
+  free(s.pt_slot);
+  free(s.Hpp);
+  free(s.bp);
+  free(s.Hll);
+  free(s.bl);
+  free(s.Hpl);
+  free(s.x);
+  free(S);
+  free(bs);
+  free(Dinv);
+  free(cams_bak);
+  free(pts_bak);
+  free(pt_start);
+  free(obs_by_pt);
+  return VS_OK;
+}
+
+/* test hooks: residual and analytic Jacobians of one projection edge for an arbitrary camera/point */
+VO_EXPORT int vo_ba_edge(const double* pose16, const double* X, const double* K4, const double* uv, double* e2,
+                         double* Ji6, double* Jj12) {
+  vs_ba_problem p;
+  memset(&p, 0, sizeof p);
+  int32_t zero = 0;
+  uint8_t nf = 0;
+  p.n_poses = p.n_points = p.n_obs = 1;
+  p.poses = pose16;
+  p.points = X;
+  p.pose_fixed = &nf;
+  p.point_fixed = &nf;
+  p.obs_pose = &zero;
+  p.obs_point = &zero;
+  p.obs_uv = uv;
+  p.fx = K4[0];
+  p.fy = K4[1];
+  p.cx = K4[2];
+  p.cy = K4[3];
+  ba_t s;
+  memset(&s, 0, sizeof s);
+  cam_t c;
+  memset(&c, 0, sizeof c);
+  quat_from_R(pose16, c.q);
+  c.t[0] = pose16[3];
+  c.t[1] = pose16[7];
+  c.t[2] = pose16[11];
+  cam_refresh(&c);
+  double pt[3] = {X[0], X[1], X[2]};
+  s.p = &p;
+  s.cams = &c;
+  s.pts = pt;
+  double Ji[2][3], Jj[2][6];
+  proj_error(&s, 0, e2);
+  proj_jac(&s, 0, Ji, Jj);
+  memcpy(Ji6, Ji, sizeof Ji);
+  memcpy(Jj12, Jj, sizeof Jj);
+  return VS_OK;
+}
+
+/* test hook: apply SBACam::update to a pose matrix */
+VO_EXPORT int vo_ba_pose_update(const double* pose16, const double* d6, double* out16) {
+  cam_t c;
+  memset(&c, 0, sizeof c);
+  quat_from_R(pose16, c.q);
+  c.t[0] = pose16[3];
+  c.t[1] = pose16[7];
+  c.t[2] = pose16[11];
+  cam_refresh(&c);
+  cam_update(&c, d6);
+  pose_matrix(&c, out16);
+  return VS_OK;
+}
