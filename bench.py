@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X tracking hot path (contract: see the task description / DESIGN.md).
+
+A "step" is one pass of the brute-force Hamming 2-NN match (the reference's knnMatch, src/v2/frame.py:23) over one
+batch of synthetic descriptors already resident in HBM:
+  N = 1 : BASELINE.json configs[2] -- 10 000 x 10 000 x 256-bit, k = 2 (the configuration the metric is quoted on)
+  N > 1 : weak scaling -- every rank matches its own 10 000-query shard against the replicated 10 000-row train set,
+          then one RCCL all-gather of the per-shard best matches (16 B per query) assembles the N*10 000 results.
+value = distance evaluations (Q*T) of all ranks / wall time of the K timed steps, in Gmatches/s.
+
+Rank 0 prints ONE JSON line.  Extra objects on the line: roofline (dominant kernel, HIP-event timed in this run),
+cpu_baseline (the CPU oracle timed on this box's host cores), frames (the 640x480 detect+describe -> match -> motion
+BA stream, frames/s), config.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_MATCH = 32           # SURVEY.md 8d streamed-operand model: one 32-byte train descriptor per evaluation
+VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9  # 3.93e13: integer VALU issues a wave64 op every 4 cycles per SIMD (measured
+                                      # 36-38e12 with tools/valu_probe.hip; only f32 FMA-class ops run at twice that)
+OPS_PER_MATCH = 19             # 8 v_xor + 8 v_bcnt + v_lshl_or + v_med3 + v_min
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--nq", type=int, default=10000, help="queries per rank")
+    ap.add_argument("--nt", type=int, default=10000, help="train descriptors (replicated)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frames", action="store_true")
+    ap.add_argument("--target-blocks", type=int, default=0, help="tuning: workgroups per launch of the match kernel")
+    return ap.parse_args()
+
+
+def cpu_baseline(nq, nt):
+    """Time the CPU oracle (kind 'port': the reference's cv2 path cannot run here) on this host."""
+    import tempfile
+    from oracle import oracle
+    from visual_slam_amd.workloads import match_workload
+    lib = None
+    try:  # give the CPU its best shot: rebuild for this host's ISA into a scratch file
+        tmp = os.path.join(tempfile.gettempdir(), "libvs_oracle_native_%d.so" % os.getpid())
+        oracle.build(force=True, lib_path=tmp, extra_cflags=["-O3", "-march=native"])
+        lib = oracle.load(tmp)
+    except Exception:
+        lib = oracle.load()
+    q, t = match_workload(nq, nt)
+    cores = os.cpu_count() or 1
+    oracle.hamming_knn2(q[:512], t, threads=0, lib=lib)  # warm
+    times = []
+    t_end = time.time() + 12.0
+    while len(times) < 5 or (time.time() < t_end and len(times) < 40):
+        t0 = time.perf_counter()
+        oracle.hamming_knn2(q, t, threads=0, lib=lib)
+        times.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    oracle.hamming_knn2(q, t, threads=1, lib=lib)
+    t1 = time.perf_counter() - t0
+    med = statistics.median(times)
+    return {"value": nq * nt / med / 1e9, "unit": "Gmatches/s", "cores": cores, "kind": "port",
+            "sample": "full %dx%d cfg3 workload, CPU oracle (C, -O3 -march=native, OpenMP %d threads), median of %d runs"
+                      % (nq, nt, cores, len(times)),
+            "single_thread_value": nq * nt / t1 / 1e9}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the tracking hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from visual_slam_amd import Context, _capi
+    from visual_slam_amd.sharded import ShardedMatcher
+    from visual_slam_amd.workloads import match_workload
+    import visual_slam_amd.context as vctx
+    ctx = Context(local_rank)
+    vctx._DEFAULT = ctx
+    if args.target_blocks:
+        _capi.load().vs_match_set_target_blocks(args.target_blocks)
+
+    nq, nt = args.nq, args.nt
+    q_np, t_np = match_workload(nq, nt)
+    if world > 1:  # weak scaling: every rank owns a different 10k-query shard, same train set
+        q_np, _ = match_workload(nq, nt, seed=100 + rank)
+        _, t_np = match_workload(nq, nt)
+    matcher = ShardedMatcher()
+    stream = matcher.torch_stream()  # the library's stream, shared with torch copies, events and RCCL
+    torch.cuda.set_stream(stream)
+    q = torch.from_numpy(q_np).to(dev)
+    t = torch.from_numpy(t_np).to(dev)
+
+    def step():
+        idx, dst = matcher.knn2_local_shard(q, t)
+        if world > 1:
+            idx, dst = matcher.gather_shards(idx, dst, nq * world)
+        return idx, dst
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    total_matches = float(nq) * nt * world
+    value = total_matches / (ms_per_step * 1e-3) / 1e9
+
+    # ---- dominant kernel, HIP events on the launch stream, same process, right after the timed region
+    roof = None
+    if rank == 0:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in evs:
+            a.record()
+            matcher.knn2_local_shard(q, t)
+            b.record()
+        torch.cuda.synchronize()
+        call_ms = statistics.mean(a.elapsed_time(b) for a, b in evs)
+        # the C-ABI call launches hamming_partial_kernel (dominant) + hamming_merge_kernel; split measured by rocprofv3
+        # (profiles/), the event pair brackets both, so `achieved` below is a lower bound for the dominant kernel
+        achieved = BYTES_PER_MATCH * float(nq) * nt / (call_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "hamming_partial_kernel(+merge)", "kernel_ms": call_ms,
+                "algorithmic_bytes_per_launch": BYTES_PER_MATCH * float(nq) * nt,
+                "valu_ceiling_gmatches": VALU_LANE_OPS / OPS_PER_MATCH / 1e9,
+                "valu_frac": (float(nq) * nt / (call_ms * 1e-3)) / (VALU_LANE_OPS / OPS_PER_MATCH)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        line = {
+            "metric": "10k x 10k 256-bit Hamming 2-NN brute-force match throughput", "value": value,
+            "unit": "Gmatches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 (xor + popcount on 256-bit descriptors)", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: %d x %d x 256-bit descriptors, k=2, per GPU%s"
+                                   % (nq, nt, "" if world == 1 else "; %d query shards + RCCL all-gather" % world),
+                       "queries_per_gpu": nq, "train": nt, "parallelism": "query-shard x%d" % world},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(nq, nt)
+            except Exception as e:  # never lose the GPU numbers to a host-side problem
+                line["cpu_baseline"] = {"error": repr(e)}
+        if not args.no_frames:
+            try:
+                from visual_slam_amd.harness import bench_frames
+                line["frames"] = bench_frames(ctx)
+            except Exception as e:
+                line["frames"] = {"error": repr(e)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

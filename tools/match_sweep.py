@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Interleaved timing of the Hamming-match kernel variants / grid sizes on one GPU (dev tool, not part of the product).
+Usage: python tools/match_sweep.py [nq nt]"""
+import ctypes as C
+import os
+import statistics
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visual_slam_amd import Context, _capi  # noqa: E402
+from visual_slam_amd.workloads import match_workload  # noqa: E402
+
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+nt = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3").split(",")]
+blocks = [int(v) for v in os.environ.get("BLOCKS", "256,512,1024,2048").split(",")]
+ctx = Context(0)
+lib = _capi.load()
+lib.vs_match_set_variant.restype = C.c_int
+lib.vs_match_set_variant.argtypes = [C.c_int]
+stream = torch.cuda.ExternalStream(ctx.stream)
+q_np, t_np = match_workload(nq, nt)
+with torch.cuda.stream(stream):
+    q = torch.from_numpy(q_np).cuda()
+    t = torch.from_numpy(t_np).cuda()
+    idx = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+    dst = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+    ref = None
+    res = {}
+    for rnd in range(5):
+        for v in variants:
+            for b in blocks:
+                lib.vs_match_set_variant(v)
+                lib.vs_match_set_target_blocks(b)
+                for _ in range(3):
+                    ctx.hamming_knn2_dev(q.data_ptr(), nq, t.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                n = 20
+                for _ in range(n):
+                    ctx.hamming_knn2_dev(q.data_ptr(), nq, t.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+                e1.record(stream)
+                stream.synchronize()
+                res.setdefault((v, b), []).append(e0.elapsed_time(e1) / n * 1e3)
+                cur = (idx.cpu().numpy().copy(), dst.cpu().numpy().copy())
+                if ref is None:
+                    ref = cur
+                assert np.array_equal(ref[0], cur[0]) and np.array_equal(ref[1], cur[1]), (v, b)
+for (v, b), ts in sorted(res.items()):
+    med = statistics.median(ts)
+    print("variant %d blocks %5d : %8.1f us/call (min %.1f)  %7.0f Gmatches/s" % (v, b, med, min(ts), nq * nt / med / 1e3))

@@ -1,0 +1,119 @@
+"""ctypes binding of libvslam_hip.so (include/vslam_hip.h).  There is NO CPU fallback: if the library is missing,
+or no MI355X is present, the calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvslam_hip.so")
+_LIB = None
+
+VS_OK, VS_EINVAL, VS_ENOMEM, VS_EHIP, VS_ENOTPD, VS_ECAP = 0, -1, -2, -3, -4, -5
+
+c_u8p = C.POINTER(C.c_uint8)
+c_i32p = C.POINTER(C.c_int32)
+c_f32p = C.POINTER(C.c_float)
+c_f64p = C.POINTER(C.c_double)
+c_intp = C.POINTER(C.c_int)
+
+
+class VsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libvslam_hip: %s (status %d)" % (msg, code))
+        self.code = code
+
+
+class BAProblem(C.Structure):
+    _fields_ = [
+        ("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32), ("n_scale", C.c_int32),
+        ("poses", c_f64p), ("pose_fixed", c_u8p), ("points", c_f64p), ("point_fixed", c_u8p),
+        ("obs_pose", c_i32p), ("obs_point", c_i32p), ("obs_uv", c_f64p), ("obs_info", c_f64p),
+        ("scale_parent", c_i32p), ("scale_child", c_i32p), ("scale_meas", c_f64p),
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("huber_delta", C.c_double), ("dcs_phi", C.c_double),
+        ("max_iterations", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class BAResult(C.Structure):
+    _fields_ = [
+        ("poses_out", c_f64p), ("points_out", c_f64p), ("chi2_trace", c_f64p), ("lambda_trace", c_f64p),
+        ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+        ("iterations", C.c_int32), ("trials", C.c_int32), ("not_pd", C.c_int32), ("terminated", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every entry point declared in include/vslam_hip.h
+SIGNATURES = {
+    "vs_abi_version": (C.c_int, []),
+    "vs_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "vs_destroy": (C.c_int, [C.c_void_p]),
+    "vs_last_error": (C.c_char_p, [C.c_void_p]),
+    "vs_stream": (C.c_void_p, [C.c_void_p]),
+    "vs_synchronize": (C.c_int, [C.c_void_p]),
+    "vs_gray_mean3_u8": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, c_u8p]),
+    "vs_fast9_detect": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
+                                  c_u8p, c_intp]),
+    "vs_brief256": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_u8p, c_i32p, c_intp]),
+    "vs_detect_describe_bgr": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
+                                         c_u8p, c_u8p, c_intp]),
+    "vs_hamming_knn2": (C.c_int, [C.c_void_p, c_u8p, C.c_int, c_u8p, C.c_int, c_i32p, c_i32p]),
+    "vs_match_ratio": (C.c_int, [C.c_void_p, c_u8p, C.c_int, c_u8p, C.c_int, C.c_double, c_i32p, c_i32p, c_i32p,
+                                 c_intp]),
+    "vs_hamming_knn2_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "vs_match_ratio_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vs_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(BAResult)]),
+}
+
+
+def load():
+    """Load libvslam_hip.so.  Raises ImportError with build instructions when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `make -C visual_slam_amd/csrc` (or __graft_entry__.build()). "
+                          "There is no CPU fallback for the tracking hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:  # reported by tests/test_abi.py; calling it raises AttributeError
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    lib._vs_missing = missing
+    try:  # optional tuning hook, not part of the ABI
+        lib.vs_match_set_target_blocks.restype = C.c_int
+        lib.vs_match_set_target_blocks.argtypes = [C.c_int]
+    except AttributeError:
+        pass
+    _LIB = lib
+    return lib
+
+
+def device_count():
+    """Number of HIP devices, without creating a context (0 in the CPU-only build container)."""
+    try:
+        hip = C.CDLL("libamdhip64.so")
+    except OSError:
+        return 0
+    n = C.c_int(0)
+    rc = hip.hipGetDeviceCount(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def as_u8(a, shape_tail=None):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if shape_tail is not None:
+        a = a.reshape((-1,) + tuple(shape_tail))
+    return a

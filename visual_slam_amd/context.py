@@ -1,0 +1,184 @@
+"""Context: one libvslam_hip context (one GPU, one stream) with NumPy-friendly wrappers around the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import VsError, c_f32p, c_f64p, c_i32p, c_u8p, ptr
+
+
+class Context:
+    """Owns a vs_ctx.  Raises VsError when no MI355X is available -- the product has no CPU path."""
+
+    def __init__(self, device=0):
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        rc = self._lib.vs_create(C.byref(h), int(device))
+        if rc != 0:
+            raise VsError(rc, self._lib.vs_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise VsError(rc, self._lib.vs_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    @property
+    def stream(self):
+        return self._lib.vs_stream(self._h)
+
+    def synchronize(self):
+        self._chk(self._lib.vs_synchronize(self._h))
+
+    # ------------------------------------------------------------------ detection / description (A2-A4)
+    def gray_mean3(self, bgr):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w, c = bgr.shape
+        assert c == 3
+        out = np.empty((h, w), np.uint8)
+        self._chk(self._lib.vs_gray_mean3_u8(self._h, ptr(bgr, c_u8p), w, h, 3 * w, ptr(out, c_u8p)))
+        return out
+
+    def fast9_detect(self, gray, thr=20, border=3, max_kp=3000):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        xy = np.zeros((max(max_kp, 1), 2), np.float32)
+        sc = np.zeros(max(max_kp, 1), np.uint8)
+        n = C.c_int(0)
+        self._chk(self._lib.vs_fast9_detect(self._h, ptr(gray, c_u8p), w, h, w, thr, border, max_kp, ptr(xy, c_f32p),
+                                            ptr(sc, c_u8p), C.byref(n)))
+        return xy[:n.value].copy(), sc[:n.value].copy()
+
+    def brief256(self, gray, xy):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        h, w = gray.shape
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        n = xy.shape[0]
+        desc = np.zeros((max(n, 1), 32), np.uint8)
+        keep = np.zeros(max(n, 1), np.int32)
+        m = C.c_int(0)
+        self._chk(self._lib.vs_brief256(self._h, ptr(gray, c_u8p), w, h, w, ptr(xy, c_f32p), n, ptr(desc, c_u8p),
+                                        ptr(keep, c_i32p), C.byref(m)))
+        return desc[:m.value].copy(), keep[:m.value].copy()
+
+    def detect_describe_bgr(self, bgr, thr=20, max_kp=3000):
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w, c = bgr.shape
+        assert c == 3
+        xy = np.zeros((max(max_kp, 1), 2), np.float32)
+        sc = np.zeros(max(max_kp, 1), np.uint8)
+        desc = np.zeros((max(max_kp, 1), 32), np.uint8)
+        n = C.c_int(0)
+        self._chk(self._lib.vs_detect_describe_bgr(self._h, ptr(bgr, c_u8p), w, h, 3 * w, thr, max_kp, ptr(xy, c_f32p),
+                                                   ptr(sc, c_u8p), ptr(desc, c_u8p), C.byref(n)))
+        return xy[:n.value].copy(), sc[:n.value].copy(), desc[:n.value].copy()
+
+    # ------------------------------------------------------------------ matching (A5, A6)
+    @staticmethod
+    def _desc(a):
+        a = np.ascontiguousarray(a, np.uint8)
+        if a.ndim != 2 or a.shape[1] != 32:
+            a = a.reshape(-1, 32)
+        return a
+
+    def hamming_knn2(self, q, t):
+        q, t = self._desc(q), self._desc(t)
+        nq, nt = q.shape[0], t.shape[0]
+        idx = np.zeros((max(nq, 1), 2), np.int32)
+        dist = np.zeros((max(nq, 1), 2), np.int32)
+        self._chk(self._lib.vs_hamming_knn2(self._h, ptr(q, c_u8p), nq, ptr(t, c_u8p), nt, ptr(idx, c_i32p),
+                                            ptr(dist, c_i32p)))
+        return idx[:nq].copy(), dist[:nq].copy()
+
+    def match_ratio(self, q, t, ratio=0.8):
+        q, t = self._desc(q), self._desc(t)
+        nq, nt = q.shape[0], t.shape[0]
+        mq = np.zeros(max(nq, 1), np.int32)
+        mt = np.zeros(max(nq, 1), np.int32)
+        md = np.zeros(max(nq, 1), np.int32)
+        n = C.c_int(0)
+        self._chk(self._lib.vs_match_ratio(self._h, ptr(q, c_u8p), nq, ptr(t, c_u8p), nt, float(ratio), ptr(mq, c_i32p),
+                                           ptr(mt, c_i32p), ptr(md, c_i32p), C.byref(n)))
+        return mq[:n.value].copy(), mt[:n.value].copy(), md[:n.value].copy()
+
+    def hamming_knn2_dev(self, d_q, nq, d_t, nt, d_idx, d_dist, stream=None):
+        """Device pointers (ints, e.g. torch.Tensor.data_ptr()); enqueues, does not synchronise."""
+        self._chk(self._lib.vs_hamming_knn2_dev(self._h, C.c_void_p(d_q), int(nq), C.c_void_p(d_t), int(nt),
+                                                C.c_void_p(d_idx), C.c_void_p(d_dist),
+                                                C.c_void_p(stream) if stream else None))
+
+    def match_ratio_dev(self, d_q, nq, d_t, nt, ratio, d_mq, d_mt, d_md, d_n, stream=None):
+        self._chk(self._lib.vs_match_ratio_dev(self._h, C.c_void_p(d_q), int(nq), C.c_void_p(d_t), int(nt),
+                                               float(ratio), C.c_void_p(d_mq), C.c_void_p(d_mt), C.c_void_p(d_md),
+                                               C.c_void_p(d_n), C.c_void_p(stream) if stream else None))
+
+    # ------------------------------------------------------------------ bundle adjustment (A9-A16)
+    def ba_solve(self, poses, pose_fixed, points, point_fixed, obs_pose, obs_point, obs_uv, K,
+                 huber_delta=float(np.sqrt(5.991)), max_iterations=10, scale_edges=None, obs_info=None, dcs_phi=1.0):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
+        points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8)
+        point_fixed = np.ascontiguousarray(point_fixed, np.uint8)
+        obs_pose = np.ascontiguousarray(obs_pose, np.int32)
+        obs_point = np.ascontiguousarray(obs_point, np.int32)
+        obs_uv = np.ascontiguousarray(obs_uv, np.float64).reshape(-1, 2)
+        p = _capi.BAProblem()
+        p.n_poses, p.n_points, p.n_obs = poses.shape[0], points.shape[0], obs_pose.shape[0]
+        p.poses, p.pose_fixed = ptr(poses, c_f64p), ptr(pose_fixed, c_u8p)
+        p.points, p.point_fixed = ptr(points, c_f64p), ptr(point_fixed, c_u8p)
+        p.obs_pose, p.obs_point, p.obs_uv = ptr(obs_pose, c_i32p), ptr(obs_point, c_i32p), ptr(obs_uv, c_f64p)
+        keep = []
+        if obs_info is not None:
+            obs_info = np.ascontiguousarray(obs_info, np.float64).reshape(-1, 3)
+            p.obs_info = ptr(obs_info, c_f64p)
+        if scale_edges is not None and len(scale_edges[0]):
+            sp = np.ascontiguousarray(scale_edges[0], np.int32)
+            sc = np.ascontiguousarray(scale_edges[1], np.int32)
+            sm = np.ascontiguousarray(scale_edges[2], np.float64)
+            keep = [sp, sc, sm]
+            p.n_scale = sp.shape[0]
+            p.scale_parent, p.scale_child, p.scale_meas = ptr(sp, c_i32p), ptr(sc, c_i32p), ptr(sm, c_f64p)
+        p.fx, p.fy, p.cx, p.cy = (float(v) for v in K)
+        p.huber_delta = float(huber_delta) if huber_delta else 0.0
+        p.dcs_phi = float(dcs_phi)
+        p.max_iterations = int(max_iterations)
+        r = _capi.BAResult()
+        poses_out = np.zeros_like(poses)
+        points_out = np.zeros_like(points)
+        chi = np.full(max(max_iterations, 1), np.nan)
+        lam = np.full(max(max_iterations, 1), np.nan)
+        r.poses_out, r.points_out = ptr(poses_out, c_f64p), ptr(points_out, c_f64p)
+        r.chi2_trace, r.lambda_trace = ptr(chi, c_f64p), ptr(lam, c_f64p)
+        self._chk(self._lib.vs_ba_solve(self._h, C.byref(p), C.byref(r)))
+        del keep
+        return dict(poses=poses_out.reshape(-1, 4, 4), points=points_out, chi2_trace=chi[:r.iterations].copy(),
+                    lambda_trace=lam[:r.iterations].copy(), chi2_initial=r.chi2_initial, chi2_final=r.chi2_final,
+                    lambda_final=r.lambda_final, iterations=r.iterations, trials=r.trials, not_pd=r.not_pd,
+                    terminated=r.terminated)
+
+
+_DEFAULT = None
+
+
+def default_context():
+    """Process-wide context on the GPU of this rank (LOCAL_RANK, else device 0)."""
+    global _DEFAULT
+    if _DEFAULT is None:
+        import os
+        _DEFAULT = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _DEFAULT

@@ -1,0 +1,94 @@
+// vs_internal.h -- private helpers shared by the translation units of libvslam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vslam_hip.h"
+
+#define VS_API extern "C" __attribute__((visibility("default")))
+
+// growable device / pinned-host scratch buffer owned by the context
+struct vs_buf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct vs_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipDeviceProp_t prop;
+  char err[512];
+  // matcher
+  vs_buf d_q, d_t, d_idx, d_dist, d_partial, d_mq, d_mt, d_md, d_cnt;
+  // detector
+  vs_buf d_bgr, d_gray, d_box, d_raw, d_bandcnt, d_hist, d_xy, d_score, d_desc, d_n, d_xy_in, d_keep;
+  // bundle adjustment
+  vs_buf d_ba;      // one arena, carved per solve
+  vs_buf h_pin;     // pinned staging (small read-backs)
+  vs_buf h_pin_big; // pinned staging (frames, descriptors)
+};
+
+extern char g_vs_create_error[512];
+
+static inline int vs_fail(vs_ctx* ctx, int code, const char* fmt, const char* a = "", const char* b = "") {
+  char* dst = ctx ? ctx->err : g_vs_create_error;
+  snprintf(dst, 512, fmt, a, b);
+  return code;
+}
+
+#define VS_HIP(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e_ = (call);                                                                      \
+    if (e_ != hipSuccess) return vs_fail(ctx, VS_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+#define VS_LAUNCH_CHECK(ctx, name)                                                                   \
+  do {                                                                                               \
+    hipError_t e_ = hipGetLastError();                                                               \
+    if (e_ != hipSuccess) return vs_fail(ctx, VS_EHIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+
+// grow-only device buffer
+static inline int vs_reserve(vs_ctx* ctx, vs_buf* b, size_t bytes) {
+  if (bytes <= b->cap && b->p) return VS_OK;
+  if (bytes < 256) bytes = 256;
+  size_t want = bytes + bytes / 4;  // headroom so a growing map does not reallocate every frame
+  if (b->p) {
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VS_HIP(ctx, hipFree(b->p));
+    b->p = nullptr;
+    b->cap = 0;
+  }
+  hipError_t e = hipMalloc(&b->p, want);
+  if (e != hipSuccess) return vs_fail(ctx, VS_ENOMEM, "hipMalloc(%s) failed: %s", "scratch", hipGetErrorString(e));
+  b->cap = want;
+  return VS_OK;
+}
+
+static inline int vs_reserve_pinned(vs_ctx* ctx, vs_buf* b, size_t bytes) {
+  if (bytes <= b->cap && b->p) return VS_OK;
+  if (bytes < 4096) bytes = 4096;
+  if (b->p) {
+    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VS_HIP(ctx, hipHostFree(b->p));
+    b->p = nullptr;
+    b->cap = 0;
+  }
+  hipError_t e = hipHostMalloc(&b->p, bytes + bytes / 4, hipHostMallocDefault);
+  if (e != hipSuccess) return vs_fail(ctx, VS_ENOMEM, "hipHostMalloc(%s) failed: %s", "staging", hipGetErrorString(e));
+  b->cap = bytes + bytes / 4;
+  return VS_OK;
+}
+
+#define VS_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != VS_OK) return rc_; \
+  } while (0)
+
+static inline hipStream_t vs_pick_stream(vs_ctx* ctx, void* s) { return s ? (hipStream_t)s : ctx->stream; }
+
+// implemented in vs_match.hip / vs_detect.hip / vs_ba.hip
+void vs_ctx_free_buffers(vs_ctx* ctx);
