@@ -80,6 +80,12 @@ int vs_detect_describe_bgr(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int st
                            float* xy /*[max_kp][2]*/, uint8_t* score /*[max_kp] or NULL*/,
                            uint8_t* desc /*[max_kp][32]*/, int* n_out);
 
+/* device-resident variant: d_bgr rows are `pitch` bytes apart (pitch % 4 == 0, at least 4 bytes of slack after the
+ * last row); outputs are device arrays xy float[max_kp][2], score u8[max_kp] (or NULL), desc u8[max_kp][32]
+ * (8-byte aligned), n_out int32[1].  Enqueues two kernels on `stream` (NULL = the context's) without synchronising. */
+int vs_detect_describe_bgr_dev(vs_ctx* ctx, const void* d_bgr, int w, int h, int pitch, int thr, int max_kp,
+                               void* d_xy, void* d_score, void* d_desc, void* d_n_out, void* stream);
+
 /* ---- A5: brute-force Hamming 2-NN ---------------------------------------------------------------------------
  * replaces cv2.BFMatcher(NORM_HAMMING).knnMatch(desc1, desc2, k=2)   (src/v2/frame.py:18,23)
  * For every query row the two train rows of smallest Hamming distance, ascending; ties -> lower train index

@@ -1,0 +1,106 @@
+"""GPU parity: HIP gray / FAST-9 + NMS + cap / BRIEF-256 vs the CPU oracle, through the C ABI.  Bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import icl_frame
+from visual_slam_amd.workloads import synthetic_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq_detect(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape, (x.shape, y.shape)
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (37, 53), (64, 64), (100, 301), (33, 1030)])
+def test_gray(vs, oracle, shape):
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, (*shape, 3), dtype=np.uint8)
+    assert np.array_equal(vs.gray_mean3(img), oracle.gray_mean3(img))
+
+
+@pytest.mark.parametrize("shape,seed", [((64, 64), 1), ((48, 100), 2), ((97, 61), 3), ((480, 640), 4), ((35, 257), 5),
+                                        ((130, 1026), 6), ((7, 9), 7)])
+def test_fast_detect_matches_oracle(vs, oracle, shape, seed):
+    img = synthetic_frame(shape[1], shape[0], seed)[:, :, 0]
+    for thr, border in ((20, 3), (35, 15), (10, 4), (1, 3), (254, 3)):
+        for cap in (100000, 3000, 40, 7, 1, 0):
+            _eq_detect(vs.fast9_detect(img, thr, border, cap), oracle.fast9_detect(img, thr, border, cap))
+
+
+def test_fast_known_answers_on_gpu(vs):
+    img = np.full((40, 64), 50, np.uint8)
+    pos = [(10, 40 - 30), (20, 8), (20, 30), (30, 12), (40, 25)]
+    for x, y in pos:
+        img[y, x] = 150
+    xy, sc = vs.fast9_detect(img, thr=20, border=3, max_kp=3)
+    want = sorted(pos, key=lambda p: (p[1], p[0]))[:3]
+    assert [tuple(p) for p in xy.astype(int)] == want and set(sc) == {99}
+    img[:] = 100
+    img[10, 10] = 121
+    xy, sc = vs.fast9_detect(img, thr=20, border=3, max_kp=10)
+    assert xy.tolist() == [[10.0, 10.0]] and sc.tolist() == [20]
+    img[10, 10] = 120  # difference == thr is not a corner
+    xy, _ = vs.fast9_detect(img, thr=20, border=3, max_kp=10)
+    assert len(xy) == 0
+
+
+def test_brief_matches_oracle(vs, oracle):
+    img = synthetic_frame(200, 120, 5)[:, :, 0]
+    rng = np.random.default_rng(4)
+    n = 2500
+    xy = np.stack([rng.uniform(-5, 205, n), rng.uniform(-5, 125, n)], 1).astype(np.float32)
+    xy[:8] = [[15, 15], [184, 104], [14.4, 20], [14.5, 20], [15.5, 20], [184.5, 30], [185, 30], [40, 104.5]]
+    d, keep = vs.brief256(img, xy)
+    od, okeep = oracle.brief256(img, xy)
+    assert np.array_equal(keep, okeep) and np.array_equal(d, od)
+    d, keep = vs.brief256(img, np.zeros((0, 2), np.float32))
+    assert d.shape == (0, 32)
+    d, keep = vs.brief256(img, np.array([[0, 0], [1, 1]], np.float32))  # all dropped
+    assert d.shape == (0, 32) and keep.shape == (0,)
+
+
+@pytest.mark.parametrize("i", range(0, 20, 3))
+def test_detect_describe_icl_frames(vs, oracle, i):
+    bgr = icl_frame(i)
+    _eq_detect(vs.detect_describe_bgr(bgr, 20, 3000), oracle.detect_describe_bgr(bgr, 20, 3000))
+
+
+@pytest.mark.parametrize("cap", [3000, 500, 64, 1])
+def test_detect_describe_synthetic_and_caps(vs, oracle, cap):
+    bgr = synthetic_frame(640, 480, 2)
+    a = vs.detect_describe_bgr(bgr, 20, cap)
+    b = oracle.detect_describe_bgr(bgr, 20, cap)
+    _eq_detect(a, b)
+    assert len(a[0]) == min(cap, len(oracle.detect_describe_bgr(bgr, 20, 100000)[0]))
+    # composition property: fused == gray -> detect(border 15) -> brief
+    g = vs.gray_mean3(bgr)
+    xy, sc = vs.fast9_detect(g, 20, 15, cap)
+    d, keep = vs.brief256(g, xy)
+    assert np.array_equal(xy, a[0]) and np.array_equal(sc, a[1]) and np.array_equal(d, a[2]) and len(keep) == len(xy)
+
+
+def test_odd_sizes_and_strided_color(vs, oracle):
+    rng = np.random.default_rng(11)
+    for shape in ((61, 75), (33, 130), (90, 643)):
+        g = synthetic_frame(shape[1], shape[0], shape[0])[:, :, 0]
+        bgr = np.stack([g, np.roll(g, 1, 0), np.roll(g, 2, 1)], 2)
+        bgr = np.ascontiguousarray(bgr)
+        bgr[::7, ::5, 1] = rng.integers(0, 256, bgr[::7, ::5, 1].shape, dtype=np.uint8)
+        _eq_detect(vs.detect_describe_bgr(bgr, 15, 3000), oracle.detect_describe_bgr(bgr, 15, 3000))
+
+
+def test_flat_image_yields_nothing(vs):
+    bgr = np.full((480, 640, 3), 77, np.uint8)
+    xy, sc, d = vs.detect_describe_bgr(bgr, 20, 3000)
+    assert xy.shape == (0, 2) and d.shape == (0, 32)
+
+
+def test_deterministic(vs):
+    bgr = icl_frame(5)
+    a = vs.detect_describe_bgr(bgr, 20, 3000)
+    b = vs.detect_describe_bgr(bgr, 20, 3000)
+    _eq_detect(a, b)

@@ -58,6 +58,8 @@ SIGNATURES = {
     "vs_brief256": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_u8p, c_i32p, c_intp]),
     "vs_detect_describe_bgr": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
                                          c_u8p, c_u8p, c_intp]),
+    "vs_detect_describe_bgr_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vs_hamming_knn2": (C.c_int, [C.c_void_p, c_u8p, C.c_int, c_u8p, C.c_int, c_i32p, c_i32p]),
     "vs_match_ratio": (C.c_int, [C.c_void_p, c_u8p, C.c_int, c_u8p, C.c_int, C.c_double, c_i32p, c_i32p, c_i32p,
                                  c_intp]),
