@@ -1,0 +1,157 @@
+"""GPU parity: HIP bundle adjustment (LM + Schur, FP64) vs the CPU oracle through the C ABI.
+
+Contract (BASELINE.json): every pose within 1e-4 relative Frobenius norm of the reference optimizer.  The kernels
+follow the oracle's arithmetic order, so the tests also assert a much tighter agreement (1e-8) to catch logic errors
+that the loose contract would hide.
+"""
+import numpy as np
+import pytest
+
+from visual_slam_amd.workloads import ba_workload
+
+pytestmark = pytest.mark.gpu
+HUBER = float(np.sqrt(5.991))
+CONTRACT = 1e-4
+TIGHT = 1e-8
+
+
+def _args(w):
+    return (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
+
+
+def _compare(g, o, tight=TIGHT):
+    rel = [np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(g["poses"], o["poses"])]
+    assert max(rel) <= CONTRACT, max(rel)          # the contract
+    assert max(rel) <= tight, max(rel)             # what the implementation actually achieves
+    assert np.allclose(g["points"], o["points"], rtol=0, atol=max(tight, 1e-12) * 10)
+    assert np.isclose(g["chi2_initial"], o["chi2_initial"], rtol=1e-10)
+    assert np.isclose(g["chi2_final"], o["chi2_final"], rtol=1e-9)
+    # Once LM has converged to machine precision the gain ratio is rounding noise, so accept/reject decisions (and with
+    # them the trial count and lambda) may legitimately differ; before that point the two runs must walk in lock step.
+    tr = np.concatenate([[o["chi2_initial"]], o["chi2_trace"]])
+    live = np.nonzero(np.abs(np.diff(tr)) > 1e-9 * tr[1:])[0]
+    n_live = int(live[-1]) + 1 if len(live) else 0
+    assert np.allclose(g["chi2_trace"][:n_live], o["chi2_trace"][:n_live], rtol=1e-7)
+    assert np.allclose(g["lambda_trace"][:max(n_live - 1, 0)], o["lambda_trace"][:max(n_live - 1, 0)], rtol=1e-6)
+    if n_live == len(o["chi2_trace"]):
+        assert g["iterations"] == o["iterations"] and g["trials"] == o["trials"]
+        assert g["terminated"] == o["terminated"] and g["not_pd"] == o["not_pd"]
+    return max(rel)
+
+
+def test_cfg4_10_cameras_2000_points(vs, oracle):
+    w = ba_workload()  # BASELINE.json configs[3]
+    g = vs.ba_solve(*_args(w), huber_delta=HUBER, max_iterations=10)
+    o = oracle.ba_solve(*_args(w), huber_delta=HUBER, max_iterations=10)
+    worst = _compare(g, o)
+    assert g["iterations"] == 10 and g["chi2_final"] < 0.15 * g["chi2_initial"]
+    print("cfg4 worst relative pose difference vs oracle: %.3e" % worst)
+
+
+@pytest.mark.parametrize("n_cams,n_points,vis,seed", [(3, 20, 1.0, 5), (2, 300, 1.0, 6), (6, 150, 0.6, 13), (15, 400, 0.5, 21),
+                                                    (5, 60, 1.0, 7)])
+def test_small_scenes(vs, oracle, n_cams, n_points, vis, seed):
+    w = ba_workload(n_cams=n_cams, n_points=n_points, seed=seed, visibility=vis)
+    _compare(vs.ba_solve(*_args(w)), oracle.ba_solve(*_args(w)))
+
+
+def test_no_robust_kernel_and_information(vs, oracle):
+    w = ba_workload(n_cams=4, n_points=100, seed=31, outlier_frac=0)
+    _compare(vs.ba_solve(*_args(w), huber_delta=0), oracle.ba_solve(*_args(w), huber_delta=0))
+    rng = np.random.default_rng(1)
+    n = len(w["obs_pose"])
+    a = rng.uniform(0.5, 2.0, n)
+    c = rng.uniform(0.5, 2.0, n)
+    b = rng.uniform(-0.3, 0.3, n)
+    info = np.stack([a, b, c], 1)
+    _compare(vs.ba_solve(*_args(w), obs_info=info), oracle.ba_solve(*_args(w), obs_info=info))
+
+
+def test_motion_only(vs, oracle):
+    w = ba_workload(n_cams=8, n_points=500, seed=9, point_sigma=0, visibility=0.7)
+    w["point_fixed"][:] = 1
+    w["pose_fixed"][[0, 3]] = 1
+    g = vs.ba_solve(*_args(w))
+    o = oracle.ba_solve(*_args(w))
+    _compare(g, o)
+    assert np.array_equal(g["points"], w["points"]) and np.allclose(g["poses"][3], w["poses"][3], atol=1e-15)
+
+
+def test_scale_edges(vs, oracle):
+    w = ba_workload(n_cams=5, n_points=80, seed=4, noise_px=0.2, outlier_frac=0)
+    meas = [np.linalg.norm(w["poses_gt"][i][:3, 3] - w["poses_gt"][i - 1][:3, 3]) * (1.0 + 0.05 * i) for i in range(1, 5)]
+    se = ([0, 1, 2, 3], [1, 2, 3, 4], meas)
+    g = vs.ba_solve(*_args(w), scale_edges=se)
+    o = oracle.ba_solve(*_args(w), scale_edges=se)
+    _compare(g, o)
+    g0 = vs.ba_solve(*_args(w))
+    assert not np.allclose(g["poses"], g0["poses"], atol=1e-9)
+
+
+def test_mixed_fixed_points_and_unobserved_points(vs, oracle):
+    w = ba_workload(n_cams=5, n_points=120, seed=17, visibility=0.8)
+    w["point_fixed"][::3] = 1
+    keep = w["obs_point"] % 10 != 7  # points 7, 17, ... lose all observations
+    for k in ("obs_pose", "obs_point", "obs_uv"):
+        w[k] = w[k][keep]
+    _compare(vs.ba_solve(*_args(w)), oracle.ba_solve(*_args(w)))
+
+
+def test_duplicate_observations_use_the_atomic_path(vs, oracle):
+    w = ba_workload(n_cams=3, n_points=30, seed=23)
+    for k in ("obs_pose", "obs_point"):
+        w[k] = np.concatenate([w[k], w[k][:12]])
+    w["obs_uv"] = np.concatenate([w["obs_uv"], w["obs_uv"][:12] + 0.3])
+    _compare(vs.ba_solve(*_args(w)), oracle.ba_solve(*_args(w)), tight=1e-7)
+
+
+def test_large_windows_take_the_global_memory_paths(vs, oracle):
+    # 18 free cameras -> 108 x 108 (slab in HBM, factorisation in LDS); 25 free cameras -> 144 x 144 (both in HBM)
+    for n_cams in (19, 26):
+        w = ba_workload(n_cams=n_cams, n_points=300, seed=n_cams, visibility=0.5)
+        _compare(vs.ba_solve(*_args(w), max_iterations=5), oracle.ba_solve(*_args(w), max_iterations=5))
+
+
+def test_noise_free_converges_to_ground_truth(vs):
+    w = ba_workload(n_cams=5, n_points=60, seed=7, noise_px=0, outlier_frac=0)
+    w["pose_fixed"][1] = 1
+    w["poses"][1] = w["poses_gt"][1]
+    g = vs.ba_solve(*_args(w), max_iterations=40)
+    assert g["chi2_final"] < 1e-12 * g["chi2_initial"]
+    assert np.allclose(g["poses"], w["poses_gt"], atol=1e-6) and np.allclose(g["points"], w["points_gt"], atol=1e-5)
+
+
+@pytest.mark.parametrize("seed,st,sd,sp", [(3, 1.5, 40, 1.5), (6, 1.5, 40, 1.5), (7, 0.8, 25, 1.0), (1, 0.8, 25, 1.0)])
+def test_rejected_steps_and_termination(vs, oracle, seed, st, sd, sp):
+    # a terrible start forces rejected trials (lambda growth, restore) in both implementations; seed 1 also terminates
+    w = ba_workload(n_cams=4, n_points=50, seed=seed, pose_sigma_t=st, pose_sigma_deg=sd, point_sigma=sp)
+    g = vs.ba_solve(*_args(w), max_iterations=15)
+    o = oracle.ba_solve(*_args(w), max_iterations=15)
+    assert o["trials"] > o["iterations"] and g["trials"] > g["iterations"]
+    # 25-40 degree start errors make the LM path ill-conditioned: rounding differences of 1e-16 in the first
+    # linearisation grow along the 15 iterations, so only the contract (1e-4) is asserted here, not lock step
+    rel = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(g["poses"], o["poses"]))
+    print("wild start seed %d: worst relative pose difference %.2e, chi2 %.6f vs %.6f" % (seed, rel, g["chi2_final"], o["chi2_final"]))
+    assert rel <= CONTRACT
+    assert np.isclose(g["chi2_final"], o["chi2_final"], rtol=1e-2)
+    assert np.isclose(g["chi2_trace"][0], o["chi2_trace"][0], rtol=1e-9)
+
+
+def test_everything_fixed_and_zero_iterations(vs, oracle):
+    w = ba_workload(n_cams=3, n_points=10, seed=2)
+    g = vs.ba_solve(*_args(w), max_iterations=0)
+    o = oracle.ba_solve(*_args(w), max_iterations=0)
+    assert g["iterations"] == 0 and np.isclose(g["chi2_initial"], o["chi2_initial"], rtol=1e-12)
+    assert np.allclose(g["poses"], w["poses"], atol=1e-12)
+    w["pose_fixed"][:] = 1
+    w["point_fixed"][:] = 1
+    g = vs.ba_solve(*_args(w))
+    assert g["iterations"] == 0 and np.allclose(g["poses"], w["poses"], atol=1e-12)
+
+
+def test_deterministic(vs):
+    w = ba_workload(n_cams=6, n_points=400, seed=77, visibility=0.7)
+    a = vs.ba_solve(*_args(w))
+    b = vs.ba_solve(*_args(w))
+    assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"])
+    assert np.array_equal(a["chi2_trace"], b["chi2_trace"])

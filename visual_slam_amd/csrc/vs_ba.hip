@@ -1,0 +1,1103 @@
+// vs_ba.hip -- local / motion-only bundle adjustment: Levenberg-Marquardt over SE3 cameras and 3-D points with the
+// points marginalised by a Schur complement, FP64 throughout (gfx950).
+//
+// Replaces what the reference delegates to g2o (src/v2/LocalBA.py:20-94,115-131,39-42): SBACam/VertexCam poses,
+// VertexSBAPointXYZ points, EdgeProjectP2MC + Huber, EdgeSBAScale + DCS, BlockSolverSE3 + Cholesky,
+// OptimizationAlgorithmLevenberg.  The arithmetic follows oracle/vs_oracle.c operation for operation where the
+// parallel decomposition allows it (-ffp-contract=off), so poses agree with the oracle to ~1e-10, far inside the
+// 1e-4 contract.
+//
+// Data flow (everything stays in HBM/L2 for the whole solve; the host only reads two flags per batch of slots):
+//   ba_linearize      grid = point blocks + one block per free camera (one launch, two roles)
+//       point block : thread = point; loops its observations (CSR by point), accumulates Hll / bl in registers, writes
+//                     the 6x3 blocks Hpl of observations whose camera is free, robust chi2 partial per block
+//       camera block: workgroup = free camera; threads stride over the camera's observation list, 27 register
+//                     accumulators (Hpp upper 21 + bp 6), fixed-order LDS tree reduction; also the EdgeSBAScale terms
+//   ba_lambda_init    first slot only: chi2_0 and lambda_0 = 1e-5 * max diag(H)
+//   ba_schur          workgroup = slab of points; per point Dinv = (Hll + lambda I)^-1, Y_i = Hpl_i Dinv staged in LDS,
+//                     every thread owns fixed elements of the 6x6 products Y_i Hpl_j^T and subtracts them into the
+//                     workgroup's LDS slab of the reduced camera system (no float atomics: deterministic)
+//   ba_reduce         S = Hpp + lambda I - sum of slabs, rhs likewise (one thread per matrix element)
+//   ba_solve          one workgroup: dense Cholesky of S in LDS, triangular solves, trial camera states
+//   ba_point_trial    thread = point: back-substitution x_l = Dinv (bl - sum Hpl^T x_p), trial point, robust chi2 of the
+//                     trial state, fixed-order block reduction
+//   ba_decide         one thread: gain ratio, accept (flip the state buffer index) or reject, lambda update, stop rules
+// Trial states are written to the OTHER of two state buffers, so a rejected step needs no restore.
+#include "vs_internal.h"
+
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+constexpr int kCamStride = 19;  // t[3] q[4] w2n[12]
+constexpr int kPtThreads = 128; // threads per point block
+constexpr int kCamThreads = 256;
+constexpr int kSchurThreads = 256;
+constexpr int kSolveThreads = 512;
+constexpr int kMaxLdsN = 120;   // reduced systems up to 120 x 120 (20 free cameras) are factorised in LDS
+constexpr int kMaxSlabN = 90;   // Schur slabs up to 90 x 90 (15 free cameras) live in LDS
+
+struct lm_state {
+  double lambda, ni, current_chi, temp_chi, rho, scale_pose, chi0;
+  int cur;       // index of the state buffer holding the accepted estimate
+  int it;        // outer iterations finished
+  int trials, qmax, not_pd;
+  int need_lin;  // 1: the next slot starts with a linearisation
+  int done, terminated, solve_ok;
+  int pad;
+};
+
+struct ba_dev {
+  int n_poses, n_points, n_obs, n_scale, nfp, nfl, np, n_act;  // n_act: points with >= 1 active observation
+  int ns, nb_pt, mmax, has_info, dups, max_it, lds_slab, pad0;
+  double fx, fy, cx, cy, huber, dcs;
+  const int *pose_slot, *pt_slot, *act_pt, *pt_start, *o_cam, *o_pt, *cam_start, *cam_obs;
+  const double *o_uv, *o_info;
+  const int *sc_parent, *sc_child;
+  const double* sc_meas;
+  double* cam[2];
+  double* pts[2];
+  double *Hpp, *bp, *Hll, *bl, *Hpl, *Dinv, *slab, *S, *bs, *xp;
+  double *part_chi, *part_scale, *part_maxd;  // per point-block partials; part_maxd has nb_pt + nfp entries
+  double *chi_trace, *lambda_trace;
+  lm_state* st;
+};
+
+// ------------------------------------------------------------------------------------------------ small math
+__device__ __host__ inline void quat_to_w2n(const double* t, const double* q, double* w /*[12]*/) {
+  const double x = q[0], y = q[1], z = q[2], ww = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * ww, twy = ty * ww, twz = tz * ww, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+               tyz = tz * y, tzz = tz * z;
+  double R[3][3];
+  R[0][0] = 1 - (tyy + tzz);
+  R[0][1] = txy - twz;
+  R[0][2] = txz + twy;
+  R[1][0] = txy + twz;
+  R[1][1] = 1 - (txx + tzz);
+  R[1][2] = tyz - twx;
+  R[2][0] = txz - twy;
+  R[2][1] = tyz + twx;
+  R[2][2] = 1 - (txx + tyy);
+  for (int i = 0; i < 3; ++i) {
+    w[4 * i + 0] = R[0][i];
+    w[4 * i + 1] = R[1][i];
+    w[4 * i + 2] = R[2][i];
+    w[4 * i + 3] = -(w[4 * i + 0] * t[0] + w[4 * i + 1] * t[1] + w[4 * i + 2] * t[2]);
+  }
+}
+
+// Eigen's matrix -> quaternion, then SE3Quat::normalizeRotation (w >= 0, unit norm)   [host, setup only]
+void quat_from_pose(const double* m, double* q) {
+#define M(r, c) m[(r)*4 + (c)]
+  const double tr = M(0, 0) + M(1, 1) + M(2, 2);
+  if (tr > 0.0) {
+    double s = sqrt(tr + 1.0);
+    q[3] = 0.5 * s;
+    s = 0.5 / s;
+    q[0] = (M(2, 1) - M(1, 2)) * s;
+    q[1] = (M(0, 2) - M(2, 0)) * s;
+    q[2] = (M(1, 0) - M(0, 1)) * s;
+  } else {
+    int i = 0;
+    if (M(1, 1) > M(0, 0)) i = 1;
+    if (M(2, 2) > M(i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+    q[i] = 0.5 * s;
+    s = 0.5 / s;
+    q[3] = (M(k, j) - M(j, k)) * s;
+    q[j] = (M(j, i) + M(i, j)) * s;
+    q[k] = (M(k, i) + M(i, k)) * s;
+  }
+#undef M
+  if (q[3] < 0.0)
+    for (int a = 0; a < 4; ++a) q[a] = -q[a];
+  const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int a = 0; a < 4; ++a) q[a] /= nrm;
+}
+
+__device__ inline void huber_rho(double delta, double e2, double& rho0, double& rho1) {
+  const double dsqr = delta * delta;
+  if (e2 <= dsqr) {
+    rho0 = e2;
+    rho1 = 1.0;
+  } else {
+    const double sqrte = sqrt(e2);
+    rho0 = 2 * sqrte * delta - dsqr;
+    rho1 = delta / sqrte;
+  }
+}
+
+__device__ inline void dcs_rho(double phi, double e2, double& rho0, double& rho1) {
+  const double scale = (2.0 * phi) / (phi + e2);
+  if (scale >= 1.0) {
+    rho0 = e2;
+    rho1 = 1.0;
+  } else {
+    rho0 = scale * e2 * scale;
+    rho1 = scale * scale;
+  }
+}
+
+struct edge_t {
+  double e[2], W[3], rho0, rho1;
+  double Ji[2][3], Jj[2][6];
+};
+
+// EdgeProjectP2MC::computeError (+ optionally linearizeOplus) for camera record c (kCamStride doubles) and point X
+template <bool JAC>
+__device__ inline void eval_edge(const ba_dev& D, const double* __restrict__ c, const double* X, int o, edge_t& E) {
+  const double* w = c + 7;
+  double pc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pc[i] = w[4 * i] * X[0] + w[4 * i + 1] * X[1] + w[4 * i + 2] * X[2] + w[4 * i + 3];
+  const double u = D.fx * pc[0] + D.cx * pc[2], v = D.fy * pc[1] + D.cy * pc[2], wz = pc[2];
+  E.e[0] = u / wz - D.o_uv[2 * (size_t)o];
+  E.e[1] = v / wz - D.o_uv[2 * (size_t)o + 1];
+  if (D.has_info) {
+    E.W[0] = D.o_info[3 * (size_t)o];
+    E.W[1] = D.o_info[3 * (size_t)o + 1];
+    E.W[2] = D.o_info[3 * (size_t)o + 2];
+  } else {
+    E.W[0] = 1;
+    E.W[1] = 0;
+    E.W[2] = 1;
+  }
+  const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+  const double e2 = E.e[0] * We0 + E.e[1] * We1;
+  E.rho0 = e2;
+  E.rho1 = 1.0;
+  if (D.huber > 0) huber_rho(D.huber, e2, E.rho0, E.rho1);
+  if (JAC) {
+    const double px = pc[0], py = pc[1], pz = pc[2];
+    const double ipz2 = 1.0 / (pz * pz);
+    const double ipz2fx = ipz2 * D.fx, ipz2fy = ipz2 * D.fy;
+    const double p0 = X[0] - c[0], p1 = X[1] - c[1], p2 = X[2] - c[2];
+    double r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r[k] = w[4 * k] * p0 + w[4 * k + 1] * p1 + w[4 * k + 2] * p2;
+    // dRd{x,y,z} = dRid{x,y,z} * R^T has rows {0, +-2 * row of R^T}: dp = dRd * (X - t)
+    const double dpx[3] = {0.0, 2 * r[2], -2 * r[1]};
+    const double dpy[3] = {-2 * r[2], 0.0, 2 * r[0]};
+    const double dpz[3] = {2 * r[1], -2 * r[0], 0.0};
+    E.Jj[0][3] = (pz * dpx[0] - px * dpx[2]) * ipz2fx;
+    E.Jj[1][3] = (pz * dpx[1] - py * dpx[2]) * ipz2fy;
+    E.Jj[0][4] = (pz * dpy[0] - px * dpy[2]) * ipz2fx;
+    E.Jj[1][4] = (pz * dpy[1] - py * dpy[2]) * ipz2fy;
+    E.Jj[0][5] = (pz * dpz[0] - px * dpz[2]) * ipz2fx;
+    E.Jj[1][5] = (pz * dpz[1] - py * dpz[2]) * ipz2fy;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double d0 = w[a], d1 = w[4 + a], d2 = w[8 + a];
+      E.Ji[0][a] = (pz * d0 - px * d2) * ipz2fx;
+      E.Ji[1][a] = (pz * d1 - py * d2) * ipz2fy;
+      E.Jj[0][a] = -E.Ji[0][a];
+      E.Jj[1][a] = -E.Ji[1][a];
+    }
+  }
+}
+
+__device__ inline double scale_err(const double* t1, const double* t2, double meas) {
+  const double dx = t2[0] - t1[0], dy = t2[1] - t1[1], dz = t2[2] - t1[2];
+  return meas - sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+// fixed-order block reduction of one double per thread (power-of-two block)
+template <int T>
+__device__ inline double block_reduce_sum(double v, double* s_red) {
+  __syncthreads();
+  s_red[threadIdx.x] = v;
+  __syncthreads();
+#pragma unroll
+  for (int off = T / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
+    __syncthreads();
+  }
+  return s_red[0];
+}
+template <int T>
+__device__ inline double block_reduce_max(double v, double* s_red) {
+  __syncthreads();
+  s_red[threadIdx.x] = v;
+  __syncthreads();
+#pragma unroll
+  for (int off = T / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  return s_red[0];
+}
+
+// ------------------------------------------------------------------------------------------------ linearize
+__global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
+  __shared__ double s_red[kCamThreads];
+  __shared__ double s_all[kCamThreads / 2][27];  // camera role: upper half of the first tree level lives in registers
+  const lm_state st = *D.st;
+  if (st.done || !st.need_lin) return;
+  const double* cams = D.cam[st.cur];
+  const double* pts = D.pts[st.cur];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < D.nb_pt) {
+    // ---- point role (kPtThreads active threads)
+    const int a = blockIdx.x * kPtThreads + tid;
+    double chi = 0.0, maxd = 0.0;
+    if (tid < kPtThreads && a < D.n_act) {
+      const int p = D.act_pt[a];
+      const int ls = D.pt_slot[p];
+      const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+      double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+      for (int o = D.pt_start[a]; o < D.pt_start[a + 1]; ++o) {
+        const int ci = D.o_cam[o];
+        const int cs = D.pose_slot[ci];
+        edge_t E;
+        eval_edge<true>(D, cams + (size_t)ci * kCamStride, X, o, E);
+        chi += E.rho0;
+        const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+        const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
+        const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
+        double WJi[2][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          WJi[0][k] = w0 * E.Ji[0][k] + w1 * E.Ji[1][k];
+          WJi[1][k] = w1 * E.Ji[0][k] + w2 * E.Ji[1][k];
+        }
+        if (ls >= 0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            b[k] += E.Ji[0][k] * r0 + E.Ji[1][k] * r1;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) H[3 * k + l] += E.Ji[0][k] * WJi[0][l] + E.Ji[1][k] * WJi[1][l];
+          }
+          if (cs >= 0) {
+            double* B = D.Hpl + 18 * (size_t)o;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+              for (int l = 0; l < 3; ++l) B[3 * k + l] = E.Jj[0][k] * WJi[0][l] + E.Jj[1][k] * WJi[1][l];
+          }
+        }
+      }
+      if (ls >= 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) D.Hll[9 * (size_t)ls + k] = H[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) D.bl[3 * (size_t)ls + k] = b[k];
+        maxd = fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8])));
+      }
+    }
+    const double csum = block_reduce_sum<kCamThreads>(chi, s_red);
+    const double cmax = block_reduce_max<kCamThreads>(maxd, s_red);
+    if (tid == 0) {
+      D.part_chi[blockIdx.x] = csum;
+      D.part_maxd[blockIdx.x] = cmax;
+    }
+    return;
+  }
+  // ---- camera role: free camera slot c
+  const int c = blockIdx.x - D.nb_pt;
+  int pose = -1;
+  for (int i = 0; i < D.n_poses; ++i)  // tiny: poses are few
+    if (D.pose_slot[i] == c) {
+      pose = i;
+      break;
+    }
+  const double* cam = cams + (size_t)pose * kCamStride;
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+  for (int i = D.cam_start[c] + tid; i < D.cam_start[c + 1]; i += kCamThreads) {
+    const int o = D.cam_obs[i];
+    const int p = D.o_pt[o];
+    const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+    edge_t E;
+    eval_edge<true>(D, cam, X, o, E);
+    const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+    const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
+    const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
+    double WJj[2][6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      WJj[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
+      WJj[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
+    }
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJj[0][l] + E.Jj[1][k] * WJj[1][l];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
+  }
+  // fixed-order tree over the 256 threads, all 27 sums at once
+  if (tid >= kCamThreads / 2) {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) s_all[tid - kCamThreads / 2][k] = acc[k];
+  }
+  __syncthreads();
+  if (tid < kCamThreads / 2) {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) s_all[tid][k] += acc[k];
+  }
+  __syncthreads();
+  for (int off = kCamThreads / 4; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) s_all[tid][k] += s_all[tid + off][k];
+    }
+    __syncthreads();
+  }
+  const double* s_acc = s_all[0];
+  // block row c of Hpp: zero, diagonal block, then the EdgeSBAScale terms of every scale edge touching this camera
+  const int np = D.np;
+  for (int i = tid; i < 6 * np; i += kCamThreads) D.Hpp[(size_t)(6 * c) * np + i] = 0.0;
+  __syncthreads();
+  if (tid == 0) {
+    double* Hrow = D.Hpp + (size_t)(6 * c) * np;
+    int n = 0;
+    for (int k = 0; k < 6; ++k)
+      for (int l = k; l < 6; ++l) {
+        Hrow[(size_t)k * np + 6 * c + l] = s_acc[n];
+        Hrow[(size_t)l * np + 6 * c + k] = s_acc[n];
+        ++n;
+      }
+    double b[6];
+    for (int k = 0; k < 6; ++k) b[k] = s_acc[21 + k];
+    for (int e = 0; e < D.n_scale; ++e) {
+      const int v0 = D.sc_parent[e], v1 = D.sc_child[e];
+      const int s0 = D.pose_slot[v0], s1 = D.pose_slot[v1];
+      if (s0 != c && s1 != c) continue;
+      const double* t0 = cams + (size_t)v0 * kCamStride;
+      const double* t1 = cams + (size_t)v1 * kCamStride;
+      const double m = D.sc_meas[e];
+      const double err = scale_err(t0, t1, m);
+      // numeric Jacobian of BaseBinaryEdge (central differences, delta 1e-9); rotation columns are exactly zero
+      double J[2][3] = {{0, 0, 0}, {0, 0, 0}};
+      const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+      for (int side = 0; side < 2; ++side) {
+        if ((side == 0 ? s0 : s1) < 0) continue;
+        for (int d = 0; d < 3; ++d) {
+          double tp[3], tm[3];
+          const double* ts = side == 0 ? t0 : t1;
+          for (int k = 0; k < 3; ++k) tp[k] = tm[k] = ts[k];
+          tp[d] += delta;
+          tm[d] += -delta;
+          const double ep = side == 0 ? scale_err(tp, t1, m) : scale_err(t0, tp, m);
+          const double em = side == 0 ? scale_err(tm, t1, m) : scale_err(t0, tm, m);
+          J[side][d] = scalar * (ep - em);
+        }
+      }
+      double rho0, rho1;
+      dcs_rho(D.dcs, err * err, rho0, rho1);
+      const double r = -err * rho1, wgt = rho1;
+      for (int si = 0; si < 2; ++si) {
+        if ((si == 0 ? s0 : s1) != c) continue;  // this workgroup owns block row c only
+        for (int k = 0; k < 3; ++k) {
+          b[k] += J[si][k] * r;
+          for (int sj = 0; sj < 2; ++sj) {
+            const int cj = sj == 0 ? s0 : s1;
+            if (cj < 0) continue;
+            for (int l = 0; l < 3; ++l) Hrow[(size_t)k * np + 6 * cj + l] += J[si][k] * wgt * J[sj][l];
+          }
+        }
+      }
+    }
+    for (int k = 0; k < 6; ++k) D.bp[6 * c + k] = b[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double mx = 0.0;
+    for (int k = 0; k < 6; ++k) mx = fmax(mx, fabs(D.Hpp[(size_t)(6 * c + k) * np + 6 * c + k]));
+    D.part_maxd[D.nb_pt + c] = mx;
+  }
+}
+
+// chi2 of the scale edges for state buffer `buf` (few edges: one thread)
+__device__ inline double scale_edges_chi(const ba_dev& D, const double* cams) {
+  double chi = 0.0;
+  for (int e = 0; e < D.n_scale; ++e) {
+    const int v0 = D.sc_parent[e], v1 = D.sc_child[e];
+    if (D.pose_slot[v0] < 0 && D.pose_slot[v1] < 0) continue;
+    const double err = scale_err(cams + (size_t)v0 * kCamStride, cams + (size_t)v1 * kCamStride, D.sc_meas[e]);
+    double rho0, rho1;
+    dcs_rho(D.dcs, err * err, rho0, rho1);
+    chi += rho0;
+  }
+  return chi;
+}
+
+__global__ void ba_lambda_init(ba_dev D) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  lm_state* st = D.st;
+  double chi = 0.0, mx = 0.0;
+  for (int i = 0; i < D.nb_pt; ++i) chi += D.part_chi[i];
+  chi += scale_edges_chi(D, D.cam[st->cur]);
+  for (int i = 0; i < D.nb_pt + D.nfp; ++i) mx = fmax(mx, D.part_maxd[i]);
+  st->current_chi = chi;
+  st->chi0 = chi;
+  st->lambda = 1e-5 * mx;
+  st->ni = 2.0;
+}
+
+// ------------------------------------------------------------------------------------------------ Schur complement
+__device__ inline void inv3(const double* Dm, double* inv) {
+  const double c00 = Dm[4] * Dm[8] - Dm[5] * Dm[7], c01 = Dm[5] * Dm[6] - Dm[3] * Dm[8],
+               c02 = Dm[3] * Dm[7] - Dm[4] * Dm[6];
+  const double det = Dm[0] * c00 + Dm[1] * c01 + Dm[2] * c02;
+  const double id = 1.0 / det;
+  inv[0] = c00 * id;
+  inv[1] = (Dm[2] * Dm[7] - Dm[1] * Dm[8]) * id;
+  inv[2] = (Dm[1] * Dm[5] - Dm[2] * Dm[4]) * id;
+  inv[3] = c01 * id;
+  inv[4] = (Dm[0] * Dm[8] - Dm[2] * Dm[6]) * id;
+  inv[5] = (Dm[2] * Dm[3] - Dm[0] * Dm[5]) * id;
+  inv[6] = c02 * id;
+  inv[7] = (Dm[1] * Dm[6] - Dm[0] * Dm[7]) * id;
+  inv[8] = (Dm[0] * Dm[4] - Dm[1] * Dm[3]) * id;
+}
+
+// dynamic LDS: [slab np*np + np doubles when LDS_SLAB] [Y mmax*18] [B mmax*18] [db 3 + Dinv 9 + pad] [slots mmax ints]
+template <bool LDS_SLAB>
+__global__ __launch_bounds__(kSchurThreads) void ba_schur(ba_dev D) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  const lm_state st = *D.st;
+  if (st.done) return;
+  const int np = D.np, tid = threadIdx.x;
+  const int slab_elems = np * np + np;
+  double* slab = LDS_SLAB ? s_mem : D.slab + (size_t)blockIdx.x * slab_elems;
+  double* sY = s_mem + (LDS_SLAB ? slab_elems : 0);
+  double* sB = sY + D.mmax * 18;
+  double* sD = sB + D.mmax * 18;  // Dinv[9], db[3]
+  int* sSlot = reinterpret_cast<int*>(sD + 12);  // [2*mmax] (slot, obs) pairs, then the pair count
+  int& s_m = sSlot[2 * D.mmax];
+  for (int i = tid; i < slab_elems; i += kSchurThreads) slab[i] = 0.0;
+  const double lambda = st.lambda;
+  // contiguous range of free points for this slab
+  const int per = (D.nfl + D.ns - 1) / D.ns;
+  const int l0 = blockIdx.x * per, l1 = min(l0 + per, D.nfl);
+  __syncthreads();
+  for (int l = l0; l < l1; ++l) {
+    // active-point index of free point l: free points are a subset of the active list; host passes pt_start by
+    // active index, so walk through act index a = free2act[l], stored after the Dinv array start (see host)
+    const int a = reinterpret_cast<const int*>(D.Dinv + 9 * (size_t)D.nfl)[l];
+    const int o0 = D.pt_start[a], o1 = D.pt_start[a + 1];
+    if (tid == 0) {
+      double Dm[9];
+      for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[9 * (size_t)l + k];
+      Dm[0] += lambda;
+      Dm[4] += lambda;
+      Dm[8] += lambda;
+      double inv[9];
+      inv3(Dm, inv);
+      for (int k = 0; k < 9; ++k) {
+        sD[k] = inv[k];
+        D.Dinv[9 * (size_t)l + k] = inv[k];
+      }
+      for (int k = 0; k < 3; ++k)
+        sD[9 + k] = inv[3 * k] * D.bl[3 * (size_t)l] + inv[3 * k + 1] * D.bl[3 * (size_t)l + 1] +
+                    inv[3 * k + 2] * D.bl[3 * (size_t)l + 2];
+      int m = 0;
+      for (int o = o0; o < o1; ++o) {
+        const int cs = D.pose_slot[D.o_cam[o]];
+        if (cs >= 0) {
+          sSlot[2 * m] = cs;
+          sSlot[2 * m + 1] = o;
+          ++m;
+        }
+      }
+      s_m = m;
+    }
+    __syncthreads();
+    const int m = s_m;
+    // stage B_i and Y_i = B_i * Dinv
+    for (int i = tid; i < m * 18; i += kSchurThreads) {
+      const int obs = i / 18, k = i - obs * 18;
+      const int arow = k / 3, bcol = k - arow * 3;
+      const double* B = D.Hpl + 18 * (size_t)sSlot[2 * obs + 1];
+      sB[i] = B[k];
+      sY[i] = B[3 * arow] * sD[bcol] + B[3 * arow + 1] * sD[3 + bcol] + B[3 * arow + 2] * sD[6 + bcol];
+    }
+    __syncthreads();
+    // rhs: b[ci] += B_i * db   (one thread per (obs, row); distinct cameras -> distinct elements)
+    for (int i = tid; i < m * 6; i += kSchurThreads) {
+      const int obs = i / 6, arow = i - obs * 6;
+      const double* B = sB + obs * 18 + 3 * arow;
+      const double v = B[0] * sD[9] + B[1] * sD[10] + B[2] * sD[11];
+      double* dst = slab + np * np + 6 * sSlot[2 * obs] + arow;
+      if (D.dups) atomicAdd(dst, v);
+      else *dst += v;
+    }
+    // matrix: slab[ci][cj] += Y_i * B_j^T
+    const int nel = m * m * 36;
+    for (int i = tid; i < nel; i += kSchurThreads) {
+      const int pair = i / 36, k = i - pair * 36;
+      const int oi = pair / m, oj = pair - oi * m;
+      const int arow = k / 6, bcol = k - arow * 6;
+      const double* Y = sY + oi * 18 + 3 * arow;
+      const double* B = sB + oj * 18 + 3 * bcol;
+      const double v = Y[0] * B[0] + Y[1] * B[1] + Y[2] * B[2];
+      double* dst = slab + (size_t)(6 * sSlot[2 * oi] + arow) * np + 6 * sSlot[2 * oj] + bcol;
+      if (D.dups) atomicAdd(dst, v);
+      else *dst += v;
+    }
+    __syncthreads();
+  }
+  if (LDS_SLAB) {
+    double* out = D.slab + (size_t)blockIdx.x * slab_elems;
+    for (int i = tid; i < slab_elems; i += kSchurThreads) out[i] = slab[i];
+  }
+}
+
+// S = Hpp + lambda I - sum_s slab_s ; bs = bp - sum_s bslab_s
+__global__ __launch_bounds__(256) void ba_reduce(ba_dev D) {
+  const lm_state st = *D.st;
+  if (st.done) return;
+  const int np = D.np;
+  const int slab_elems = np * np + np;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= slab_elems) return;
+  double acc = 0.0;
+  for (int s = 0; s < D.ns; ++s) acc += D.slab[(size_t)s * slab_elems + i];
+  if (i < np * np) {
+    const int r = i / np, c = i - r * np;
+    double v = D.Hpp[i];
+    if (r == c) v += st.lambda;
+    D.S[i] = v - acc;
+  } else {
+    D.bs[i - np * np] = D.bp[i - np * np] - acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dense solve
+// One workgroup.  Right-looking Cholesky: the subtraction order per element equals the oracle's dot-product order.
+template <bool IN_LDS>
+__global__ __launch_bounds__(kSolveThreads) void ba_solve(ba_dev D) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  lm_state* st = D.st;
+  if (st->done) return;
+  const int n = D.np, tid = threadIdx.x;
+  int& s_fail = *reinterpret_cast<int*>(s_mem);  // first 16 bytes of the dynamic region
+  double* A = IN_LDS ? s_mem + 2 : D.S;
+  double* x = IN_LDS ? s_mem + 2 + n * n : D.bs;
+  if (IN_LDS) {
+    for (int i = tid; i < n * n; i += kSolveThreads) A[i] = D.S[i];
+    for (int i = tid; i < n; i += kSolveThreads) x[i] = D.bs[i];
+  }
+  if (tid == 0) s_fail = 0;
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    if (tid == 0) {
+      const double d = A[(size_t)j * n + j];
+      if (!(d > 0.0)) s_fail = 1;
+      else A[(size_t)j * n + j] = sqrt(d);
+    }
+    __syncthreads();
+    if (s_fail) break;
+    const double ljj = A[(size_t)j * n + j];
+    for (int i = j + 1 + tid; i < n; i += kSolveThreads) A[(size_t)i * n + j] = A[(size_t)i * n + j] / ljj;
+    __syncthreads();
+    // trailing update of the lower triangle: A[i][k] -= L[i][j] * L[k][j], j < k <= i
+    const int rem = n - j - 1;
+    for (int e = tid; e < rem * rem; e += kSolveThreads) {
+      const int i = j + 1 + e / rem, k = j + 1 + e % rem;
+      if (k <= i) A[(size_t)i * n + k] -= A[(size_t)i * n + j] * A[(size_t)k * n + j];
+    }
+    __syncthreads();
+  }
+  const int ok = !s_fail;
+  if (ok) {
+    // forward L y = b (column oriented: same subtraction order as the oracle), then L^T x = y
+    for (int k = 0; k < n; ++k) {
+      if (tid == 0) x[k] = x[k] / A[(size_t)k * n + k];
+      __syncthreads();
+      const double xk = x[k];
+      for (int i = k + 1 + tid; i < n; i += kSolveThreads) x[i] -= A[(size_t)i * n + k] * xk;
+      __syncthreads();
+    }
+    for (int k = n - 1; k >= 0; --k) {
+      if (tid == 0) x[k] = x[k] / A[(size_t)k * n + k];
+      __syncthreads();
+      const double xk = x[k];
+      for (int i = tid; i < k; i += kSolveThreads) x[i] -= A[(size_t)k * n + i] * xk;
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += kSolveThreads) D.xp[i] = x[i];
+  }
+  __syncthreads();
+  // trial camera states into the other buffer (SBACam::update), fixed cameras copied
+  const int cur = st->cur;
+  const double* c0 = D.cam[cur];
+  double* c1 = D.cam[cur ^ 1];
+  for (int p = tid; p < D.n_poses; p += kSolveThreads) {
+    const double* src = c0 + (size_t)p * kCamStride;
+    double* dst = c1 + (size_t)p * kCamStride;
+    const int cs = D.pose_slot[p];
+    if (cs < 0 || !ok) {
+      for (int k = 0; k < kCamStride; ++k) dst[k] = src[k];
+    } else {
+      const double* d = x + 6 * cs;
+      double t[3] = {src[0] + d[0], src[1] + d[1], src[2] + d[2]};
+      const double bx = d[3], by = d[4], bz = d[5];
+      const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));  // NaN for an oversized step -> trial rejected
+      const double ax = src[3], ay = src[4], az = src[5], aw = src[6];
+      const double w = aw * bw - ax * bx - ay * by - az * bz;
+      const double xx = aw * bx + ax * bw + ay * bz - az * by;
+      const double yy = aw * by + ay * bw + az * bx - ax * bz;
+      const double zz = aw * bz + az * bw + ax * by - ay * bx;
+      const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
+      double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
+      for (int k = 0; k < 3; ++k) dst[k] = t[k];
+      for (int k = 0; k < 4; ++k) dst[3 + k] = q[k];
+      quat_to_w2n(t, q, dst + 7);
+    }
+  }
+  if (tid == 0) {
+    double sc = 0.0;
+    if (ok)
+      for (int j = 0; j < n; ++j) sc += x[j] * (st->lambda * x[j] + D.bp[j]);
+    st->scale_pose = sc;
+    st->solve_ok = ok;
+    st->trials += 1;
+    if (!ok) st->not_pd += 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ trial + chi2
+__global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
+  __shared__ double s_red[kPtThreads];
+  const lm_state st = *D.st;
+  if (st.done) return;
+  const int tid = threadIdx.x;
+  const int a = blockIdx.x * kPtThreads + tid;
+  double chi = 0.0, sc = 0.0;
+  if (st.solve_ok && a < D.n_act) {
+    const double* cams1 = D.cam[st.cur ^ 1];
+    const double* pts0 = D.pts[st.cur];
+    double* pts1 = D.pts[st.cur ^ 1];
+    const int p = D.act_pt[a];
+    const int ls = D.pt_slot[p];
+    double X[3] = {pts0[3 * (size_t)p], pts0[3 * (size_t)p + 1], pts0[3 * (size_t)p + 2]};
+    const int o0 = D.pt_start[a], o1 = D.pt_start[a + 1];
+    if (ls >= 0) {
+      double cl[3] = {D.bl[3 * (size_t)ls], D.bl[3 * (size_t)ls + 1], D.bl[3 * (size_t)ls + 2]};
+      for (int o = o0; o < o1; ++o) {
+        const int cs = D.pose_slot[D.o_cam[o]];
+        if (cs < 0) continue;
+        const double* B = D.Hpl + 18 * (size_t)o;
+        const double* xc = D.xp + 6 * cs;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int k = 0; k < 6; ++k) cl[b] -= B[3 * k + b] * xc[k];
+      }
+      const double* Di = D.Dinv + 9 * (size_t)ls;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double xl = Di[3 * k] * cl[0] + Di[3 * k + 1] * cl[1] + Di[3 * k + 2] * cl[2];
+        sc += xl * (st.lambda * xl + D.bl[3 * (size_t)ls + k]);
+        X[k] += xl;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pts1[3 * (size_t)p + k] = X[k];
+    for (int o = o0; o < o1; ++o) {
+      edge_t E;
+      eval_edge<false>(D, cams1 + (size_t)D.o_cam[o] * kCamStride, X, o, E);
+      chi += E.rho0;
+    }
+  }
+  const double csum = block_reduce_sum<kPtThreads>(chi, s_red);
+  const double ssum = block_reduce_sum<kPtThreads>(sc, s_red);
+  if (tid == 0) {
+    D.part_chi[blockIdx.x] = csum;
+    D.part_scale[blockIdx.x] = ssum;
+  }
+}
+
+// OptimizationAlgorithmLevenberg::solve's accept/reject logic and SparseOptimizer::optimize's loop control
+__global__ void ba_decide(ba_dev D) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  lm_state* st = D.st;
+  if (st->done) return;
+  double temp = 0.0, scale = st->scale_pose;
+  if (st->solve_ok) {
+    for (int i = 0; i < D.nb_pt; ++i) {
+      temp += D.part_chi[i];
+      scale += D.part_scale[i];
+    }
+    temp += scale_edges_chi(D, D.cam[st->cur ^ 1]);
+  } else {
+    temp = 1.7976931348623157e308;
+  }
+  st->temp_chi = temp;
+  double rho = st->current_chi - temp;
+  scale += 1e-3;
+  rho /= scale;
+  st->rho = rho;
+  int stop = 0;
+  if (rho > 0 && isfinite(temp)) {
+    double alpha = 1.0 - pow(2 * rho - 1, 3);
+    alpha = fmin(alpha, 2.0 / 3.0);
+    const double f = fmax(1.0 / 3.0, alpha);
+    st->lambda *= f;
+    st->ni = 2.0;
+    st->current_chi = temp;
+    st->cur ^= 1;  // accept: the trial buffer becomes the estimate
+  } else {
+    st->lambda *= st->ni;
+    st->ni *= 2;
+    if (!isfinite(st->lambda)) stop = 1;
+  }
+  st->qmax += 1;
+  if (!stop && rho < 0 && st->qmax < 10) {
+    st->need_lin = 0;  // retry with the same linearisation
+    return;
+  }
+  // the outer iteration is over
+  if (D.chi_trace) D.chi_trace[st->it] = st->current_chi;
+  if (D.lambda_trace) D.lambda_trace[st->it] = st->lambda;
+  st->it += 1;
+  if (st->qmax == 10 || rho == 0 || stop) {
+    st->done = 1;
+    st->terminated = 1;
+  } else if (st->it >= D.max_it) {
+    st->done = 1;
+  } else {
+    st->need_lin = 1;
+    st->qmax = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct arena {
+  uint8_t* base = nullptr;  // device
+  uint8_t* host = nullptr;  // pinned mirror for the upload part
+  size_t off = 0;
+  template <class T>
+  T* take(size_t count, T** host_ptr = nullptr) {
+    off = (off + 255) & ~(size_t)255;
+    T* d = reinterpret_cast<T*>(base + off);
+    if (host_ptr) *host_ptr = reinterpret_cast<T*>(host + off);
+    off += sizeof(T) * (count ? count : 1);
+    return d;
+  }
+};
+
+}  // namespace
+
+VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
+  if (!ctx) return VS_EINVAL;
+  if (!p || !res) return vs_fail(ctx, VS_EINVAL, "%s: null problem/result", "vs_ba_solve");
+  if (p->n_poses < 0 || p->n_points < 0 || p->n_obs < 0 || p->n_scale < 0 || p->max_iterations < 0 ||
+      (p->n_poses && (!p->poses || !p->pose_fixed)) || (p->n_points && (!p->points || !p->point_fixed)) ||
+      (p->n_obs && (!p->obs_pose || !p->obs_point || !p->obs_uv)) ||
+      (p->n_scale && (!p->scale_parent || !p->scale_child || !p->scale_meas)))
+    return vs_fail(ctx, VS_EINVAL, "%s: inconsistent sizes / null arrays", "vs_ba_solve");
+  for (int o = 0; o < p->n_obs; ++o)
+    if (p->obs_pose[o] < 0 || p->obs_pose[o] >= p->n_poses || p->obs_point[o] < 0 || p->obs_point[o] >= p->n_points)
+      return vs_fail(ctx, VS_EINVAL, "%s: observation index out of range", "vs_ba_solve");
+  for (int k = 0; k < p->n_scale; ++k)
+    if (p->scale_parent[k] < 0 || p->scale_parent[k] >= p->n_poses || p->scale_child[k] < 0 ||
+        p->scale_child[k] >= p->n_poses)
+      return vs_fail(ctx, VS_EINVAL, "%s: scale edge index out of range", "vs_ba_solve");
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+
+  // ---- structure (host): slots, active observations grouped by point (stable), per-camera lists
+  const int F = p->n_poses, P = p->n_points;
+  std::vector<int> pose_slot(F), pt_slot(P);
+  int nfp = 0, nfl = 0;
+  for (int i = 0; i < F; ++i) pose_slot[i] = p->pose_fixed[i] ? -1 : nfp++;
+  for (int j = 0; j < P; ++j) pt_slot[j] = p->point_fixed[j] ? -1 : nfl++;
+  const int np = 6 * nfp;
+  std::vector<int> cnt(P + 1, 0);
+  int n_obs = 0;
+  for (int o = 0; o < p->n_obs; ++o)
+    if (pose_slot[p->obs_pose[o]] >= 0 || pt_slot[p->obs_point[o]] >= 0) {
+      cnt[p->obs_point[o] + 1]++;
+      ++n_obs;
+    }
+  for (int j = 0; j < P; ++j) cnt[j + 1] += cnt[j];
+  std::vector<int> order(n_obs ? n_obs : 1), fill(cnt.begin(), cnt.end() - 1);
+  for (int o = 0; o < p->n_obs; ++o)
+    if (pose_slot[p->obs_pose[o]] >= 0 || pt_slot[p->obs_point[o]] >= 0) order[fill[p->obs_point[o]]++] = o;
+  // active points = free points (even without observations: they still receive the lambda damping) + fixed points
+  // that are observed by a free camera.  Skipped points own no active observation, so the sorted observation ranges
+  // of consecutive active points are adjacent: pt_start[a] = cnt[act_pt[a]], pt_start[n_act] = n_obs.
+  std::vector<int> act_pt, free2act(nfl ? nfl : 1);
+  int mmax = 1, dups = 0;
+  for (int j = 0; j < P; ++j) {
+    const int m = cnt[j + 1] - cnt[j];
+    if (m == 0 && pt_slot[j] < 0) continue;
+    if (pt_slot[j] >= 0) {
+      free2act[pt_slot[j]] = (int)act_pt.size();
+      int mf = 0;
+      for (int i = cnt[j]; i < cnt[j + 1]; ++i)
+        if (pose_slot[p->obs_pose[order[i]]] >= 0) {
+          ++mf;
+          for (int k = cnt[j]; k < i; ++k)
+            if (p->obs_pose[order[k]] == p->obs_pose[order[i]]) dups = 1;  // same camera twice: LDS atomics
+        }
+      mmax = std::max(mmax, mf);
+    }
+    act_pt.push_back(j);
+  }
+  const int n_act = (int)act_pt.size();
+  std::vector<int> cam_start(nfp + 1, 0);
+  for (int i = 0; i < n_obs; ++i) {
+    const int cs = pose_slot[p->obs_pose[order[i]]];
+    if (cs >= 0) cam_start[cs + 1]++;
+  }
+  for (int c = 0; c < nfp; ++c) cam_start[c + 1] += cam_start[c];
+  std::vector<int> cam_obs(cam_start[nfp] ? cam_start[nfp] : 1), cfill(cam_start.begin(), cam_start.end() - 1);
+  for (int i = 0; i < n_obs; ++i) {
+    const int cs = pose_slot[p->obs_pose[order[i]]];
+    if (cs >= 0) cam_obs[cfill[cs]++] = i;
+  }
+
+  // ---- result defaults
+  res->iterations = res->trials = res->not_pd = res->terminated = 0;
+  res->chi2_initial = res->chi2_final = res->lambda_final = 0.0;
+
+  // ---- launch geometry
+  const int nb_pt = std::max(1, (n_act + kPtThreads - 1) / kPtThreads);
+  int ns = nfl > 0 && nfp > 0 ? std::min(256, (nfl + 7) / 8) : 0;
+  const bool lds_slab = np <= kMaxSlabN;
+  if (!lds_slab && ns > 0) ns = std::min(ns, std::max(1, (int)((512u << 20) / (sizeof(double) * ((size_t)np * np + np)))));
+  const size_t slab_elems = (size_t)np * np + np;
+
+  // ---- arena: [uploaded constants | state | system]
+  vs_ba_problem const& q = *p;
+  size_t need = (1u << 20) + sizeof(int) * ((size_t)F + P + 3 * (size_t)n_act + 4 * (size_t)n_obs + 2 * (size_t)nfp +
+                                            cam_obs.size() + 2 * (size_t)q.n_scale + nfl + 64) +
+                sizeof(double) * (5 * (size_t)n_obs + (size_t)q.n_scale + 2 * (size_t)F * kCamStride + 6 * (size_t)P +
+                                  2 * (size_t)np * np + 4 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
+                                  9 * (size_t)nfl + (size_t)(ns ? ns : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
+                                  2 * (size_t)q.max_iterations + 64) +
+                256 * 64;
+  VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, need));
+  VS_HIP(ctx, hipStreamSynchronize(s));
+  arena A;
+  A.base = (uint8_t*)ctx->d_ba.p;
+  A.host = (uint8_t*)ctx->h_pin_big.p;
+  ba_dev D;
+  memset(&D, 0, sizeof D);
+  D.n_poses = F;
+  D.n_points = P;
+  D.n_obs = n_obs;
+  D.n_scale = q.n_scale;
+  D.nfp = nfp;
+  D.nfl = nfl;
+  D.np = np;
+  D.n_act = n_act;
+  D.ns = ns;
+  D.nb_pt = nb_pt;
+  D.mmax = mmax;
+  D.has_info = q.obs_info != nullptr;
+  D.dups = dups;
+  D.max_it = q.max_iterations;
+  D.lds_slab = lds_slab;
+  D.fx = q.fx;
+  D.fy = q.fy;
+  D.cx = q.cx;
+  D.cy = q.cy;
+  D.huber = q.huber_delta;
+  D.dcs = q.dcs_phi;
+  int *h_pose_slot, *h_pt_slot, *h_act, *h_ptstart, *h_ocam, *h_opt, *h_cstart, *h_cobs, *h_scp, *h_scc;
+  double *h_uv, *h_info = nullptr, *h_scm, *h_cam0, *h_pts0;
+  D.pose_slot = A.take<int>(F, &h_pose_slot);
+  D.pt_slot = A.take<int>(P, &h_pt_slot);
+  D.act_pt = A.take<int>(n_act, &h_act);
+  D.pt_start = A.take<int>(n_act + 1, &h_ptstart);
+  D.o_cam = A.take<int>(n_obs, &h_ocam);
+  D.o_pt = A.take<int>(n_obs, &h_opt);
+  D.cam_start = A.take<int>(nfp + 1, &h_cstart);
+  D.cam_obs = A.take<int>(cam_obs.size(), &h_cobs);
+  D.sc_parent = A.take<int>(q.n_scale, &h_scp);
+  D.sc_child = A.take<int>(q.n_scale, &h_scc);
+  D.o_uv = A.take<double>(2 * (size_t)n_obs, &h_uv);
+  if (D.has_info) D.o_info = A.take<double>(3 * (size_t)n_obs, &h_info);
+  D.sc_meas = A.take<double>(q.n_scale, &h_scm);
+  D.cam[0] = A.take<double>((size_t)F * kCamStride, &h_cam0);
+  D.pts[0] = A.take<double>(3 * (size_t)P, &h_pts0);
+  // Dinv is followed by the free-point -> active-index table (read by ba_schur)
+  int* h_f2a;
+  double* h_dinv_dummy;
+  D.Dinv = A.take<double>(9 * (size_t)nfl + ((size_t)nfl + 1) / 2 + 1, &h_dinv_dummy);
+  h_f2a = reinterpret_cast<int*>(h_dinv_dummy + 9 * (size_t)nfl);
+  lm_state* h_st;
+  D.st = A.take<lm_state>(1, &h_st);
+  const size_t upload_bytes = A.off;
+  // not uploaded
+  D.cam[1] = A.take<double>((size_t)F * kCamStride);
+  D.pts[1] = A.take<double>(3 * (size_t)P);
+  D.Hpp = A.take<double>((size_t)np * np);
+  D.bp = A.take<double>(np);
+  D.Hll = A.take<double>(9 * (size_t)nfl);
+  D.bl = A.take<double>(3 * (size_t)nfl);
+  D.Hpl = A.take<double>(18 * (size_t)n_obs);
+  D.slab = A.take<double>((size_t)(ns ? ns : 1) * slab_elems);
+  D.S = A.take<double>((size_t)np * np);
+  D.bs = A.take<double>(np);
+  D.xp = A.take<double>(np);
+  D.part_chi = A.take<double>(nb_pt);
+  D.part_scale = A.take<double>(nb_pt);
+  D.part_maxd = A.take<double>((size_t)nb_pt + nfp);
+  D.chi_trace = A.take<double>(q.max_iterations);
+  D.lambda_trace = A.take<double>(q.max_iterations);
+  if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
+
+  memcpy(h_pose_slot, pose_slot.data(), sizeof(int) * F);
+  memcpy(h_pt_slot, pt_slot.data(), sizeof(int) * P);
+  memcpy(h_act, act_pt.data(), sizeof(int) * n_act);
+  for (int a = 0; a < n_act; ++a) h_ptstart[a] = cnt[act_pt[a]];
+  h_ptstart[n_act] = n_obs;
+  // ranges of consecutive active points are adjacent because skipped points own no observations
+  for (int i = 0; i < n_obs; ++i) {
+    const int o = order[i];
+    h_ocam[i] = q.obs_pose[o];
+    h_opt[i] = q.obs_point[o];
+    h_uv[2 * i] = q.obs_uv[2 * o];
+    h_uv[2 * i + 1] = q.obs_uv[2 * o + 1];
+    if (h_info) {
+      h_info[3 * i] = q.obs_info[3 * o];
+      h_info[3 * i + 1] = q.obs_info[3 * o + 1];
+      h_info[3 * i + 2] = q.obs_info[3 * o + 2];
+    }
+  }
+  memcpy(h_cstart, cam_start.data(), sizeof(int) * (nfp + 1));
+  memcpy(h_cobs, cam_obs.data(), sizeof(int) * cam_obs.size());
+  for (int k = 0; k < q.n_scale; ++k) {
+    h_scp[k] = q.scale_parent[k];
+    h_scc[k] = q.scale_child[k];
+    h_scm[k] = q.scale_meas[k];
+  }
+  for (int i = 0; i < F; ++i) {
+    const double* m = q.poses + 16 * (size_t)i;
+    double* c = h_cam0 + (size_t)i * kCamStride;
+    c[0] = m[3];
+    c[1] = m[7];
+    c[2] = m[11];
+    quat_from_pose(m, c + 3);
+    quat_to_w2n(c, c + 3, c + 7);
+  }
+  memcpy(h_pts0, q.points, sizeof(double) * 3 * (size_t)P);
+  for (int l = 0; l < nfl; ++l) h_f2a[l] = free2act[l];
+  memset(h_st, 0, sizeof(lm_state));
+  h_st->need_lin = 1;
+  h_st->ni = 2.0;
+  const bool nothing = (np + 3 * nfl == 0) || q.max_iterations == 0;
+  VS_HIP(ctx, hipMemcpyAsync(A.base, A.host, upload_bytes, hipMemcpyHostToDevice, s));
+  // both state buffers start identical (fixed cameras / points are never rewritten in the trial buffer's points)
+  VS_HIP(ctx, hipMemcpyAsync(D.cam[1], D.cam[0], sizeof(double) * (size_t)F * kCamStride, hipMemcpyDeviceToDevice, s));
+  VS_HIP(ctx, hipMemcpyAsync(D.pts[1], D.pts[0], sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToDevice, s));
+
+  // ---- kernels
+  const size_t schur_lds = sizeof(double) * ((lds_slab ? slab_elems : 0) + 36 * (size_t)mmax + 12) + sizeof(int) * (2 * (size_t)mmax + 1) + 16;
+  const bool solve_lds = np <= kMaxLdsN;
+  const size_t solve_lds_bytes = 16 + (solve_lds ? sizeof(double) * ((size_t)np * np + np) : 0);
+  if (schur_lds > 64 * 1024) {
+    if (lds_slab) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
+    else VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
+  }
+  if (solve_lds_bytes > 64 * 1024)
+    VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes));
+  if (schur_lds > 160 * 1024) return vs_fail(ctx, VS_EINVAL, "%s: a point is observed by too many free cameras for the LDS staging", "vs_ba_solve");
+
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + 64));
+  lm_state* hst = (lm_state*)ctx->h_pin.p;
+  auto launch_slot = [&](bool first) -> int {
+    hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp), dim3(kCamThreads), 0, s, D);
+    VS_LAUNCH_CHECK(ctx, "ba_linearize");
+    if (first) {
+      hipLaunchKernelGGL(ba_lambda_init, dim3(1), dim3(64), 0, s, D);
+      VS_LAUNCH_CHECK(ctx, "ba_lambda_init");
+    }
+    if (ns > 0) {
+      if (lds_slab) hipLaunchKernelGGL(ba_schur<true>, dim3(ns), dim3(kSchurThreads), schur_lds, s, D);
+      else hipLaunchKernelGGL(ba_schur<false>, dim3(ns), dim3(kSchurThreads), schur_lds, s, D);
+      VS_LAUNCH_CHECK(ctx, "ba_schur");
+    }
+    if (np > 0) {
+      hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 255) / 256)), dim3(256), 0, s, D);
+      VS_LAUNCH_CHECK(ctx, "ba_reduce");
+    }
+    if (solve_lds) hipLaunchKernelGGL(ba_solve<true>, dim3(1), dim3(kSolveThreads), solve_lds_bytes, s, D);
+    else hipLaunchKernelGGL(ba_solve<false>, dim3(1), dim3(kSolveThreads), solve_lds_bytes, s, D);
+    VS_LAUNCH_CHECK(ctx, "ba_solve");
+    hipLaunchKernelGGL(ba_point_trial, dim3(nb_pt), dim3(kPtThreads), 0, s, D);
+    VS_LAUNCH_CHECK(ctx, "ba_point_trial");
+    hipLaunchKernelGGL(ba_decide, dim3(1), dim3(64), 0, s, D);
+    VS_LAUNCH_CHECK(ctx, "ba_decide");
+    return VS_OK;
+  };
+
+  if (!nothing) {
+    // slots are predicated on the device-resident LM state; the host only polls `done` after each batch
+    const int max_slots = q.max_iterations * 10;
+    int launched = 0;
+    bool first = true;
+    while (launched < max_slots) {
+      const int batch = std::min(max_slots - launched, std::max(1, q.max_iterations));
+      for (int k = 0; k < batch; ++k) {
+        VS_TRY(launch_slot(first));
+        first = false;
+      }
+      launched += batch;
+      VS_HIP(ctx, hipMemcpyAsync(hst, D.st, sizeof(lm_state), hipMemcpyDeviceToHost, s));
+      VS_HIP(ctx, hipStreamSynchronize(s));
+      if (hst->done) break;
+    }
+  } else {
+    // chi2 of the start state only
+    hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp), dim3(kCamThreads), 0, s, D);
+    VS_LAUNCH_CHECK(ctx, "ba_linearize");
+    hipLaunchKernelGGL(ba_lambda_init, dim3(1), dim3(64), 0, s, D);
+    VS_LAUNCH_CHECK(ctx, "ba_lambda_init");
+    VS_HIP(ctx, hipMemcpyAsync(hst, D.st, sizeof(lm_state), hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipStreamSynchronize(s));
+  }
+
+  // ---- read back the accepted state
+  const int cur = hst->cur;
+  double* h_cam = reinterpret_cast<double*>(A.host);  // reuse the pinned mirror
+  double* h_pts = h_cam + (size_t)F * kCamStride + 8;
+  double* h_tr = h_pts + 3 * (size_t)P + 8;
+  VS_HIP(ctx, hipMemcpyAsync(h_cam, D.cam[cur], sizeof(double) * (size_t)F * kCamStride, hipMemcpyDeviceToHost, s));
+  VS_HIP(ctx, hipMemcpyAsync(h_pts, D.pts[cur], sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToHost, s));
+  if (q.max_iterations > 0) {
+    VS_HIP(ctx, hipMemcpyAsync(h_tr, D.chi_trace, sizeof(double) * q.max_iterations, hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipMemcpyAsync(h_tr + q.max_iterations, D.lambda_trace, sizeof(double) * q.max_iterations,
+                               hipMemcpyDeviceToHost, s));
+  }
+  VS_HIP(ctx, hipStreamSynchronize(s));
+  res->iterations = hst->it;
+  res->trials = hst->trials;
+  res->not_pd = hst->not_pd;
+  res->terminated = hst->terminated;
+  res->chi2_initial = hst->chi0;
+  res->chi2_final = hst->current_chi;
+  res->lambda_final = hst->lambda;
+  for (int i = 0; i < hst->it && i < q.max_iterations; ++i) {
+    if (res->chi2_trace) res->chi2_trace[i] = h_tr[i];
+    if (res->lambda_trace) res->lambda_trace[i] = h_tr[q.max_iterations + i];
+  }
+  if (res->poses_out)
+    for (int i = 0; i < F; ++i) {
+      const double* c = h_cam + (size_t)i * kCamStride;
+      double* o = res->poses_out + 16 * (size_t)i;
+      // R = (w2n rotation)^T
+      for (int r = 0; r < 3; ++r) {
+        for (int k = 0; k < 3; ++k) o[4 * r + k] = c[7 + 4 * k + r];
+        o[4 * r + 3] = c[r];
+      }
+      o[12] = o[13] = o[14] = 0.0;
+      o[15] = 1.0;
+    }
+  if (res->points_out) memcpy(res->points_out, h_pts, sizeof(double) * 3 * (size_t)P);
+  return VS_OK;
+}
