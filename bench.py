@@ -75,6 +75,38 @@ def cpu_baseline(nq, nt):
             "single_thread_value": nq * nt / t1 / 1e9}
 
 
+def frames_leg(ctx, cpu=True):
+    """frames/s of the 640x480 ICL-NUIM stream (detect+describe -> match -> motion-only BA), GPU path and -- as the
+    checker/baseline only -- the CPU oracle through the same harness."""
+    from visual_slam_amd.harness import HUBER, bench_frames, load_sequence, track_sequence
+    out, poses = bench_frames(ctx)
+    if cpu:
+        from oracle import oracle
+        oracle.load()
+
+        def detect(bgr):
+            xy, _, desc = oracle.detect_describe_bgr(bgr, 20, 3000)
+            return xy, desc
+
+        def match(q, t):
+            mq, mt, _ = oracle.match_ratio(q, t, 0.8)
+            return mq, mt
+
+        def ba(*problem):
+            return oracle.ba_solve(*problem, huber_delta=HUBER, max_iterations=10)
+
+        frames, depth0 = load_sequence(20)
+        t0 = time.perf_counter()
+        cposes, cstages, _ = track_sequence(detect, match, ba, frames, depth0)
+        cdt = time.perf_counter() - t0
+        out["cpu_frames_per_s"] = len(frames) / cdt
+        out["cpu_stage_ms_per_frame"] = {k: v / len(frames) * 1e3 for k, v in cstages.items()}
+        out["cpu_cores_used"] = 1
+        out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
+                                                         for a, b in zip(poses, cposes)))
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -180,8 +212,7 @@ def main():
                 line["cpu_baseline"] = {"error": repr(e)}
         if not args.no_frames:
             try:
-                from visual_slam_amd.harness import bench_frames
-                line["frames"] = bench_frames(ctx)
+                line["frames"] = frames_leg(ctx, cpu=(world == 1 and not args.no_cpu_baseline))
             except Exception as e:
                 line["frames"] = {"error": repr(e)}
         print(json.dumps(line))

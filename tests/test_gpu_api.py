@@ -1,0 +1,93 @@
+"""GPU: the src/v2-style Python API end to end on the HIP library, checked against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, icl_frame
+from visual_slam_amd.workloads import ICL_NUIM_K, ba_workload, match_workload
+
+pytestmark = pytest.mark.gpu
+
+
+def test_extractor_and_matcher_drop_in(vs, oracle):
+    from visual_slam_amd.frame import FeatureExtractor, FeatureMatcher, Frame
+    ex, ma = FeatureExtractor(context=vs), FeatureMatcher(context=vs)
+    f0 = Frame(os.path.join(GOLDEN, "icl_nuim", "rgb", "0.png"), os.path.join(GOLDEN, "icl_nuim", "depth0.png"), 0)
+    f1 = Frame(icl_frame(1), None, 1)
+    assert f0.rgb.shape == (480, 640, 3) and np.array_equal(f0.rgb, icl_frame(0))
+    kp0, ft0, rgb0 = f0.process_frame(ex)
+    kp1, ft1, _ = f1.process_frame(ex)
+    assert kp0.dtype == np.float32 and kp0.shape[1] == 2 and ft0.shape == (len(kp0), 32) and rgb0 is f0.rgb
+    oxy, _, odesc = oracle.detect_describe_bgr(icl_frame(0), 20, 3000)
+    assert np.array_equal(kp0, oxy) and np.array_equal(ft0, odesc)
+    matches, p1, d1, p2, d2 = ma.match_features(kp0, ft0, kp1, ft1)
+    oq, ot, od = oracle.match_ratio(ft0, ft1, 0.8)
+    assert [m[0].queryIdx for m in matches] == oq.tolist() and [m[0].trainIdx for m in matches] == ot.tolist()
+    assert [m[0].distance for m in matches] == od.astype(float).tolist()
+    assert np.array_equal(p1, kp0[oq]) and np.array_equal(p2, kp1[ot]) and np.array_equal(d1, ft0[oq]) and np.array_equal(d2, ft1[ot])
+    assert len(matches) > 100
+    assert f0.depth.shape == (480, 640, 3)
+    with pytest.raises(ValueError):  # the reference cannot unpack (m, n) with a single train descriptor
+        ma.match_features(kp0, ft0, kp1[:1], ft1[:1])
+    m0 = ma.match_features(kp0[:0], ft0[:0], kp1, ft1)
+    assert len(m0[0]) == 0 and m0[1].shape == (0, 2)
+
+
+def test_bundle_adjustment_class_on_gpu(vs, oracle):
+    from test_host_api import _scene_map
+    from visual_slam_amd.LocalBA import BundleAdjustment, Camera
+    w = ba_workload(n_cams=5, n_points=120, seed=33)
+    m_gpu, m_cpu = _scene_map(w), _scene_map(w)
+    BundleAdjustment(Camera(*ICL_NUIM_K), context=vs).localBundleAdjustement(m_gpu)
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve).localBundleAdjustement(m_cpu)
+    for i in range(5):
+        a, b = m_gpu.GetFrame(i).GetPose(), m_cpu.GetFrame(i).GetPose()
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-8
+    assert np.allclose(m_gpu.GetAll3DPoints(), m_cpu.GetAll3DPoints(), atol=1e-8)
+    m_gpu, m_cpu = _scene_map(w), _scene_map(w)
+    BundleAdjustment(Camera(*ICL_NUIM_K), context=vs).motionOnlyBundleAdjustement(m_gpu)
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve).motionOnlyBundleAdjustement(m_cpu)
+    for i in range(5):
+        a, b = m_gpu.GetFrame(i).GetPose(), m_cpu.GetFrame(i).GetPose()
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-8
+
+
+def test_tracking_harness_gpu_equals_oracle(vs, oracle):
+    """BASELINE.json configs[0]: the first 20 frames end to end (here: traj3), GPU vs CPU path."""
+    from visual_slam_amd import harness
+
+    def odetect(bgr):
+        xy, _, desc = oracle.detect_describe_bgr(bgr, 20, 3000)
+        return xy, desc
+
+    def omatch(q, t):
+        mq, mt, _ = oracle.match_ratio(q, t, 0.8)
+        return mq, mt
+
+    def oba(*p):
+        return oracle.ba_solve(*p, huber_delta=harness.HUBER, max_iterations=10)
+
+    frames, depth0 = harness.load_sequence(20)
+    gposes, _, gn = harness.track_sequence(*harness.gpu_callables(vs), frames, depth0)
+    cposes, _, cn = harness.track_sequence(odetect, omatch, oba, frames, depth0)
+    assert gn == cn and min(gn) > 100
+    rel = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(gposes, cposes))
+    assert rel < 1e-4, rel
+    step = np.linalg.norm(np.diff(gposes[:, :3, 3], axis=0), axis=1)
+    assert step.max() < 0.05  # consecutive ICL-NUIM frames are millimetres apart: the tracker must not jump
+
+
+def test_sharded_matcher_world1_hip_path(vs, oracle):
+    import torch
+    import visual_slam_amd.context as vctx
+    from visual_slam_amd.sharded import ShardedMatcher
+    vctx._DEFAULT = vs
+    q, t = match_workload(3000, 2000, seed=8)
+    m = ShardedMatcher()
+    with torch.cuda.stream(m.torch_stream()):
+        dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+        idx, dist = m.knn2(dq, dt)
+        idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    oidx, odist = oracle.hamming_knn2(q, t)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)

@@ -1,0 +1,136 @@
+"""CPU: the Python mirror of src/v2 (Frame / Point / Map / BundleAdjustment / FeatureMatcher plumbing) -- host logic
+only; the numeric back end is injected (the oracle) because no GPU exists here."""
+import numpy as np
+import pytest
+
+from visual_slam_amd.LocalBA import BundleAdjustment, Camera, Isometry3d
+from visual_slam_amd.frame import DMatch, Frame, MatchList
+from visual_slam_amd.map import Map
+from visual_slam_amd.point import Point
+from visual_slam_amd.workloads import ICL_NUIM_K, ba_workload
+
+
+def _frame(i, pose=None, key=False):
+    f = Frame(np.zeros((4, 4, 3), np.uint8), None, i)
+    if pose is not None:
+        f.AddPose(pose)
+    if key:
+        f.SetAsKeyFrame()
+    return f
+
+
+def test_frame_point_map_semantics():
+    m = Map()
+    f0, f1 = _frame(0, np.eye(4), key=True), _frame(1, np.eye(4))
+    m.AddFrame(0, f0)
+    with pytest.raises(Exception, match="Duplicate frame"):
+        m.AddFrame(0, f0)
+    m.AddParentAndPose(parent_id=0, frame_id=1, frame_obj=f1, rel_pose_trans=np.eye(4), pose=np.eye(4))
+    assert list(f1.GetParentIDs()) == [0] and m.GetFrame(1) is f1 and not f1.IsKeyFrame() and f0.IsKeyFrame()
+    for pid in (1, 2, 3):
+        p = Point(np.array([pid, 0.0, 5.0]), pid)
+        p.AddFrame(f0, np.array([10.0 * pid, 20.0]), np.full(32, pid, np.uint8))
+        m.AddPoint3D(pid, p)
+    with pytest.raises(Exception, match="Duplicate point3d"):
+        m.AddPoint3D(1, Point(np.zeros(3), 1))
+    m.AddPointToFrameCorrespondences([1, 3], np.array([[1.0, 2.0], [3.0, 4.0]]), np.zeros((2, 32), np.uint8), f1)
+    uv, desc, xyz, ids = m.GetImagePointsWithFrameID(1)
+    assert ids.tolist() == [1, 3] and uv.tolist() == [[1.0, 2.0], [3.0, 4.0]] and xyz.shape == (2, 3)
+    assert m.GetPointsVisibleToFrames([0, 1]) == [1, 3]
+    assert m.GetPoint(2).GetNVisibleFrames() == 1 and m.GetPoint(1).IsVisibleTo(1) and not m.GetPoint(2).IsVisibleTo(1)
+    assert m.GetPoint(1).GetImagePoint(7) is None
+    cp = m.GetCopyOfPointObjects(1)
+    assert sorted(cp) == [1, 3] and list(cp[1].frames) == [1] and cp[1] is not m.GetPoint(1)
+    cp[1].UpdatePoint(np.zeros(3))
+    assert m.GetPoint(1).Get3dPoint()[0] == 1.0  # the copy does not alias the map's point
+    m.DiscardOutlierMapPoints(n_visible_frames=2)
+    assert sorted(m.points_3d) == [1, 3]
+    with pytest.raises(Exception, match="No frame yet added"):
+        m.UpdatePose(np.eye(4), 9)
+    with pytest.raises(Exception, match="No point yet added"):
+        m.UpdatePoint3D(np.zeros(3), 2)
+    assert m.GetAll3DPoints().shape == (2, 3) and len(m.GetAllPoses()) == 2
+    assert m.Get3DPointsWithIDs([3]).tolist() == [[3.0, 0.0, 5.0]]
+
+
+def test_matchlist_behaves_like_the_reference_list():
+    ml = MatchList([4, 9], [7, 1], [12, 30])
+    assert len(ml) == 2 and ml[1][0].trainIdx == 1 and ml[-1][0].queryIdx == 9 and isinstance(ml[0][0], DMatch)
+    assert [m[0].queryIdx for m in ml] == [4, 9] and ml[0][0].distance == 12.0
+    with pytest.raises(IndexError):
+        ml[2]
+
+
+def test_isometry_helpers():
+    R = np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    T = Isometry3d(R, np.array([1.0, 2, 3]))
+    assert np.allclose((T * T.inverse()).matrix(), np.eye(4))
+    assert np.allclose(T.matrix()[:3, 3], [1, 2, 3]) and T.orientation() is R
+
+
+def _scene_map(w):
+    m = Map()
+    frames = []
+    for i, pose in enumerate(w["poses"]):
+        f = _frame(i, pose, key=(i == 0))
+        if i == 0:
+            m.AddFrame(0, f)
+        else:
+            rel = np.linalg.inv(w["poses"][i - 1]) @ pose
+            m.AddParentAndPose(parent_id=i - 1, frame_id=i, frame_obj=f, rel_pose_trans=rel, pose=pose)
+        frames.append(f)
+    for j, X in enumerate(w["points"]):
+        m.AddPoint3D(j + 1, Point(X.copy(), j + 1))
+    for c, p, uv in zip(w["obs_pose"], w["obs_point"], w["obs_uv"]):
+        m.GetPoint(int(p) + 1).AddFrame(frames[c], uv, np.zeros(32, np.uint8))
+    return m
+
+
+def test_local_ba_builds_the_same_problem_as_the_flat_arrays(oracle):
+    w = ba_workload(n_cams=4, n_points=40, seed=8)
+    m = _scene_map(w)
+    ba = BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve)
+    ba.localBundleAdjustement(m)
+    meas = [np.linalg.norm((np.linalg.inv(w["poses"][i - 1]) @ w["poses"][i])[:3, 3]) for i in range(1, 4)]
+    ref = oracle.ba_solve(w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"],
+                          w["obs_uv"], w["K"], scale_edges=([0, 1, 2], [1, 2, 3], meas))
+    for i in range(4):
+        assert np.allclose(m.GetFrame(i).GetPose(), ref["poses"][i], atol=1e-12)
+    assert np.allclose(m.GetPoint(7).Get3dPoint(), ref["points"][6], atol=1e-12)
+    assert ba.result["iterations"] == ref["iterations"] and ba.dropped_edges == 0
+    assert np.allclose(ba.get_pose(2).matrix(), ref["poses"][2]) and ba.get_point(1).shape == (3,)
+
+
+def test_local_ba_scale_normalisation(oracle):
+    w = ba_workload(n_cams=2, n_points=60, seed=12)
+    m = _scene_map(w)
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve).localBundleAdjustement(m, scale=True)
+    norms = np.linalg.norm(m.GetAll3DPoints(), axis=1)
+    assert np.isclose(np.median(norms), 1.0, atol=1e-9)  # LocalBA.py:178-190: everything divided by the median norm
+
+
+def test_motion_only_ba_fixes_keyframes_and_points(oracle):
+    w = ba_workload(n_cams=4, n_points=50, seed=14, point_sigma=0)
+    m = _scene_map(w)
+    m.GetFrame(2).SetAsKeyFrame()
+    before = {i: m.GetFrame(i).GetPose().copy() for i in range(4)}
+    pts_before = m.GetAll3DPoints().copy()
+    ba = BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve)
+    ba.motionOnlyBundleAdjustement(m)
+    assert np.allclose(m.GetFrame(0).GetPose(), before[0], atol=1e-14) and np.allclose(m.GetFrame(2).GetPose(), before[2], atol=1e-14)
+    assert not np.allclose(m.GetFrame(1).GetPose(), before[1], atol=1e-9)
+    assert np.array_equal(m.GetAll3DPoints(), pts_before)
+    assert ba.result["chi2_final"] < ba.result["chi2_initial"]
+
+
+def test_ba_api_edge_cases(capsys):
+    ba = BundleAdjustment(Camera(*ICL_NUIM_K), solver=lambda *a, **k: None)
+    ba.add_point(1, np.zeros(3))
+    ba.add_point(1, np.ones(3))
+    assert "already existing point" in capsys.readouterr().out
+    ba.add_edge(point_id=1, pose_id=5, measurement=np.zeros(2), edge_id=0)  # missing pose: dropped silently as in g2o
+    assert ba.dropped_edges == 1
+    with pytest.raises(NotImplementedError):
+        ba.add_edge_between_poses(0, 1, np.eye(4))
+    ba.optimize()  # no poses: nothing to do
+    assert ba.result is None

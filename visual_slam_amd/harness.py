@@ -1,0 +1,126 @@
+"""Headless tracking harness: the call pattern of the reference's tracking loop (src/v2/main.py:173-214) restricted to
+the hot path -- detect+describe -> match against the last key frame's map points -> motion-only BA over the local map.
+
+What is NOT reproduced (out of scope this round): two-view essential-matrix initialisation, PnP-RANSAC
+and new-point triangulation.  The harness therefore initialises the map from frame 0's keypoints back-projected with
+the dataset's depth image (camera 0 = world) and starts every frame's pose at the previous frame's optimised pose
+(the motion between consecutive ICL-NUIM frames is millimetres); no ground-truth pose is used.
+
+Data: the first 20 RGB frames of ICL-NUIM living-room trajectory 3 (the trajectory present in the reference's data/;
+BASELINE.json names traj0, which is not there -- SURVEY.md 0) committed under tests/golden/icl_nuim/.
+"""
+import os
+import time
+
+import numpy as np
+
+from .frame import imread
+from .workloads import ICL_NUIM_K
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ICL_DIR = os.path.join(ROOT, "tests", "golden", "icl_nuim")
+HUBER = float(np.sqrt(5.991))
+
+
+def load_sequence(n_frames=20):
+    frames = [imread(os.path.join(ICL_DIR, "rgb", "%d.png" % i)) for i in range(n_frames)]
+    if any(f is None for f in frames):
+        raise FileNotFoundError("ICL-NUIM fixture frames missing under %s" % ICL_DIR)
+    from PIL import Image
+    depth0 = np.asarray(Image.open(os.path.join(ICL_DIR, "depth0.png"))).astype(np.float64) / 5000.0  # metres
+    return frames, depth0
+
+
+def backproject(xy, depth, K=ICL_NUIM_K):
+    fx, fy, cx, cy = K
+    z = depth[xy[:, 1].astype(int), xy[:, 0].astype(int)]
+    return np.stack([(xy[:, 0] - cx) * z / fx, (xy[:, 1] - cy) * z / fy, z], 1)
+
+
+class LocalMapArrays:
+    """SoA local map of one tracking period: key frame 0 fixed, map points fixed, one free pose per tracked frame and
+    the accumulated observations -- what motionOnlyBundleAdjustement builds from the object graph every frame
+    (LocalBA.py:195-214), kept as arrays so nothing is rebuilt."""
+
+    def __init__(self, points):
+        self.points = np.ascontiguousarray(points, np.float64)
+        self.poses = [np.eye(4)]
+        self.obs_pose, self.obs_point, self.obs_uv = [], [], []
+
+    def add_frame(self, pose, point_idx, uv):
+        k = len(self.poses)
+        self.poses.append(np.array(pose, np.float64))
+        self.obs_pose.append(np.full(len(point_idx), k, np.int32))
+        self.obs_point.append(np.asarray(point_idx, np.int32))
+        self.obs_uv.append(np.asarray(uv, np.float64))
+
+    def problem(self):
+        n = len(self.poses)
+        fixed = np.zeros(n, np.uint8)
+        fixed[0] = 1
+        return (np.stack(self.poses), fixed, self.points, np.ones(len(self.points), np.uint8),
+                np.concatenate(self.obs_pose), np.concatenate(self.obs_point), np.concatenate(self.obs_uv), ICL_NUIM_K)
+
+
+def track_sequence(detect, match, ba, frames, depth0, max_kp=3000):
+    """One tracking period.  detect(bgr) -> (xy, desc); match(q, t) -> (mq, mt); ba(*problem) -> dict(poses=...).
+    Returns (poses [n,4,4], stage seconds dict, per-frame match counts)."""
+    t_det = t_match = t_ba = 0.0
+    t0 = time.perf_counter()
+    xy0, desc0 = detect(frames[0])
+    t_det += time.perf_counter() - t0
+    lm = LocalMapArrays(backproject(xy0, depth0))
+    n_matches = []
+    for k in range(1, len(frames)):
+        t0 = time.perf_counter()
+        xy, desc = detect(frames[k])
+        t1 = time.perf_counter()
+        mq, mt = match(desc0, desc)
+        t2 = time.perf_counter()
+        lm.add_frame(lm.poses[-1], mq, xy[mt])
+        res = ba(*lm.problem())
+        for i in range(1, len(lm.poses)):
+            lm.poses[i] = res["poses"][i]
+        t3 = time.perf_counter()
+        t_det += t1 - t0
+        t_match += t2 - t1
+        t_ba += t3 - t2
+        n_matches.append(len(mq))
+    return np.stack(lm.poses), {"detect_describe": t_det, "match": t_match, "motion_ba": t_ba}, n_matches
+
+
+def gpu_callables(ctx):
+    def detect(bgr):
+        xy, _, desc = ctx.detect_describe_bgr(bgr, 20, 3000)
+        return xy, desc
+
+    def match(q, t):
+        mq, mt, _ = ctx.match_ratio(q, t, 0.8)
+        return mq, mt
+
+    def ba(*problem):
+        return ctx.ba_solve(*problem, huber_delta=HUBER, max_iterations=10)
+
+    return detect, match, ba
+
+
+def bench_frames(ctx, repeats=5):
+    """frames/s of the 20-frame ICL-NUIM stream through the host C ABI (PNG decode excluded, H2D copies included).
+    Returns (report dict, poses) -- bench.py times the CPU oracle through track_sequence() for the comparison."""
+    frames, depth0 = load_sequence(20)
+    det, mat, ba = gpu_callables(ctx)
+    track_sequence(det, mat, ba, frames[:4], depth0)  # warm-up (allocations, code objects)
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        poses, stages, nm = track_sequence(det, mat, ba, frames, depth0)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, stages, poses, nm)
+    dt, stages, poses, nm = best
+    out = {"frames_per_s": len(frames) / dt, "n_frames": len(frames), "seconds": dt,
+           "stage_ms_per_frame": {k: v / len(frames) * 1e3 for k, v in stages.items()},
+           "mean_matches": float(np.mean(nm)), "resolution": "640x480",
+           "data": "ICL-NUIM living-room traj3 frames 0-19 (fixtures)",
+           "note": "host C-ABI path incl. H2D/D2H copies; map initialised from depth of frame 0, no PnP (SURVEY 8f)"}
+    return out, poses
