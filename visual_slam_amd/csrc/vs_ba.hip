@@ -771,6 +771,261 @@ __global__ void ba_decide(ba_dev D) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ motion-only BA
+// motionOnlyBundleAdjustement (reference LocalBA.py:195-229) has no free points and no scale edges: the normal
+// equations are block diagonal (one 6x6 system per free camera) and the whole problem of a tracking period fits one
+// compute unit.  This kernel runs the complete LM loop in ONE launch: one workgroup, waves own cameras, lanes stride
+// over the camera's observations, fixed-order butterfly reductions, per-camera 6x6 Cholesky in registers, trial states
+// in LDS.  No host round trip, no kernel boundary inside the solve.
+constexpr int kMoThreads = 1024;
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// LDS: cam0[F*19] cam1[F*19] H[nfp*36] b[nfp*6] x[nfp*6] chi[nfp] scl[nfp] maxd[nfp] | ints: pose_of[nfp] ok[nfp]
+__global__ __launch_bounds__(kMoThreads) void ba_motion_kernel(ba_dev D) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int F = D.n_poses, nfp = D.nfp, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* cam0 = sm;
+  double* cam1 = cam0 + (size_t)F * kCamStride;
+  double* sH = cam1 + (size_t)F * kCamStride;
+  double* sb = sH + (size_t)nfp * 36;
+  double* sx = sb + (size_t)nfp * 6;
+  double* s_chi = sx + (size_t)nfp * 6;
+  double* s_scl = s_chi + nfp;
+  double* s_maxd = s_scl + nfp;
+  double* s_lm = s_maxd + nfp;  // [0] lambda [1] ni [2] current chi [3] flag: 0 retry, 1 next iteration, 2 stop
+  int* s_pose = reinterpret_cast<int*>(s_lm + 4);
+  int* s_ok = s_pose + nfp;
+  lm_state* st = D.st;
+  const double* g_cam = D.cam[0];
+  const double* pts = D.pts[0];
+  for (int i = tid; i < F * kCamStride; i += kMoThreads) cam0[i] = cam1[i] = g_cam[i];
+  for (int p = tid; p < F; p += kMoThreads)
+    if (D.pose_slot[p] >= 0) s_pose[D.pose_slot[p]] = p;
+  __syncthreads();
+  double* cur = cam0;
+  double* trial = cam1;
+  int it = 0, trials = 0, not_pd = 0, terminated = 0;
+  double chi0 = 0.0;
+  for (; it < D.max_it;) {
+    // ---- linearise at `cur`
+    for (int c = wave; c < nfp; c += kMoThreads / 64) {
+      const double* cam = cur + (size_t)s_pose[c] * kCamStride;
+      double acc[27], chi = 0.0;
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+      for (int i = D.cam_start[c] + lane; i < D.cam_start[c + 1]; i += 64) {
+        const int o = D.cam_obs[i];
+        const int p = D.o_pt[o];
+        const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+        edge_t E;
+        eval_edge<true>(D, cam, X, o, E);
+        chi += E.rho0;
+        const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+        const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
+        const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
+        double WJ[2][6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          WJ[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
+          WJ[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
+        }
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+          for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJ[0][l] + E.Jj[1][k] * WJ[1][l];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
+      }
+#pragma unroll
+      for (int k = 0; k < 27; ++k) acc[k] = wave_sum(acc[k]);
+      chi = wave_sum(chi);
+      if (lane == 0) {
+        int n = 0;
+        double mx = 0.0;
+        for (int k = 0; k < 6; ++k)
+          for (int l = k; l < 6; ++l) {
+            sH[c * 36 + 6 * k + l] = acc[n];
+            sH[c * 36 + 6 * l + k] = acc[n];
+            if (k == l) mx = fmax(mx, fabs(acc[n]));
+            ++n;
+          }
+        for (int k = 0; k < 6; ++k) sb[c * 6 + k] = acc[21 + k];
+        s_chi[c] = chi;
+        s_maxd[c] = mx;
+      }
+    }
+    __syncthreads();
+    if (tid == 0 && it == 0) {
+      double chi = 0.0, mx = 0.0;
+      for (int c = 0; c < nfp; ++c) {
+        chi += s_chi[c];
+        mx = fmax(mx, s_maxd[c]);
+      }
+      s_lm[0] = 1e-5 * mx;
+      s_lm[1] = 2.0;
+      s_lm[2] = chi;
+      chi0 = chi;
+    }
+    __syncthreads();
+    // ---- trials
+    int qmax = 0, flag = 0;
+    double rho = 0.0;
+    do {
+      const double lambda = s_lm[0];
+      if (tid < nfp) {
+        const int c = tid;
+        double A[6][6], x[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+#pragma unroll
+          for (int l = 0; l < 6; ++l) A[k][l] = sH[c * 36 + 6 * k + l];
+          A[k][k] += lambda;
+          x[k] = sb[c * 6 + k];
+        }
+        int ok = 1;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const double d = A[j][j];
+          if (!(d > 0.0)) ok = 0;
+          const double ljj = sqrt(d);
+          A[j][j] = ljj;
+#pragma unroll
+          for (int i = j + 1; i < 6; ++i) A[i][j] = A[i][j] / ljj;
+#pragma unroll
+          for (int i = j + 1; i < 6; ++i)
+#pragma unroll
+            for (int k = j + 1; k <= i; ++k) A[i][k] -= A[i][j] * A[k][j];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          x[k] = x[k] / A[k][k];
+#pragma unroll
+          for (int i = k + 1; i < 6; ++i) x[i] -= A[i][k] * x[k];
+        }
+#pragma unroll
+        for (int k = 5; k >= 0; --k) {
+          x[k] = x[k] / A[k][k];
+#pragma unroll
+          for (int i = 0; i < k; ++i) x[i] -= A[k][i] * x[k];
+        }
+        double sc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          sx[c * 6 + k] = x[k];
+          sc += x[k] * (lambda * x[k] + sb[c * 6 + k]);
+        }
+        s_scl[c] = sc;
+        s_ok[c] = ok;
+        // SBACam::update into the trial buffer
+        const double* src = cur + (size_t)s_pose[c] * kCamStride;
+        double* dst = trial + (size_t)s_pose[c] * kCamStride;
+        double t[3] = {src[0] + x[0], src[1] + x[1], src[2] + x[2]};
+        const double bx = x[3], by = x[4], bz = x[5];
+        const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));
+        const double ax = src[3], ay = src[4], az = src[5], aw = src[6];
+        const double w = aw * bw - ax * bx - ay * by - az * bz;
+        const double xx = aw * bx + ax * bw + ay * bz - az * by;
+        const double yy = aw * by + ay * bw + az * bx - ax * bz;
+        const double zz = aw * bz + az * bw + ax * by - ay * bx;
+        const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
+        double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
+        for (int k = 0; k < 3; ++k) dst[k] = t[k];
+        for (int k = 0; k < 4; ++k) dst[3 + k] = q[k];
+        quat_to_w2n(t, q, dst + 7);
+      }
+      __syncthreads();
+      // robust chi2 of the trial state
+      for (int c = wave; c < nfp; c += kMoThreads / 64) {
+        const double* cam = trial + (size_t)s_pose[c] * kCamStride;
+        double chi = 0.0;
+        for (int i = D.cam_start[c] + lane; i < D.cam_start[c + 1]; i += 64) {
+          const int o = D.cam_obs[i];
+          const int p = D.o_pt[o];
+          const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+          edge_t E;
+          eval_edge<false>(D, cam, X, o, E);
+          chi += E.rho0;
+        }
+        chi = wave_sum(chi);
+        if (lane == 0) s_chi[c] = chi;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int ok = 1;
+        double temp = 0.0, scale = 0.0;
+        for (int c = 0; c < nfp; ++c) {
+          ok &= s_ok[c];
+          temp += s_chi[c];
+          scale += s_scl[c];
+        }
+        if (!ok) temp = 1.7976931348623157e308;
+        double r = s_lm[2] - temp;
+        scale += 1e-3;
+        r /= scale;
+        int stop = 0, accepted = 0;
+        if (r > 0 && isfinite(temp)) {
+          double alpha = 1.0 - pow(2 * r - 1, 3);
+          alpha = fmin(alpha, 2.0 / 3.0);
+          s_lm[0] *= fmax(1.0 / 3.0, alpha);
+          s_lm[1] = 2.0;
+          s_lm[2] = temp;
+          accepted = 1;
+        } else {
+          s_lm[0] *= s_lm[1];
+          s_lm[1] *= 2;
+          if (!isfinite(s_lm[0])) stop = 1;
+        }
+        s_lm[3] = (double)(accepted | (stop << 1) | ((ok ? 0 : 1) << 2));
+        s_scl[0] = r;  // broadcast rho
+      }
+      __syncthreads();
+      const int bits = (int)s_lm[3];
+      rho = s_scl[0];
+      ++trials;
+      if (bits & 4) ++not_pd;
+      if (bits & 1) {  // accepted: the trial buffer becomes the estimate
+        double* tmp = cur;
+        cur = trial;
+        trial = tmp;
+      }
+      ++qmax;
+      flag = (bits & 2) ? 2 : 0;
+      __syncthreads();
+    } while (flag == 0 && rho < 0 && qmax < 10);
+    if (tid == 0) {
+      if (D.chi_trace) D.chi_trace[it] = s_lm[2];
+      if (D.lambda_trace) D.lambda_trace[it] = s_lm[0];
+    }
+    ++it;
+    if (qmax == 10 || rho == 0 || flag == 2) {
+      terminated = 1;
+      break;
+    }
+  }
+  __syncthreads();
+  // accepted estimate -> state buffer 0 (the host reads buffer st->cur = 0)
+  double* out = D.cam[0];
+  for (int i = tid; i < F * kCamStride; i += kMoThreads) out[i] = cur[i];
+  if (tid == 0) {
+    st->lambda = s_lm[0];
+    st->ni = s_lm[1];
+    st->current_chi = s_lm[2];
+    st->chi0 = chi0;
+    st->cur = 0;
+    st->it = it;
+    st->trials = trials;
+    st->not_pd = not_pd;
+    st->terminated = terminated;
+    st->done = 1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 struct arena {
   uint8_t* base = nullptr;  // device
@@ -1036,7 +1291,17 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     return VS_OK;
   };
 
-  if (!nothing) {
+  const size_t mo_lds = sizeof(double) * (2 * (size_t)F * kCamStride + 51 * (size_t)nfp + 8) + sizeof(int) * 2 * (size_t)nfp + 16;
+  const bool motion_only = !nothing && nfl == 0 && q.n_scale == 0 && nfp > 0 && nfp <= kMoThreads && mo_lds <= 150 * 1024;
+  if (motion_only) {
+    // block-diagonal problem: the whole LM loop in one launch of one workgroup
+    if (mo_lds > 64 * 1024)
+      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_motion_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mo_lds));
+    hipLaunchKernelGGL(ba_motion_kernel, dim3(1), dim3(kMoThreads), mo_lds, s, D);
+    VS_LAUNCH_CHECK(ctx, "ba_motion_kernel");
+    VS_HIP(ctx, hipMemcpyAsync(hst, D.st, sizeof(lm_state), hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipStreamSynchronize(s));
+  } else if (!nothing) {
     // slots are predicated on the device-resident LM state; the host only polls `done` after each batch
     const int max_slots = q.max_iterations * 10;
     int launched = 0;

@@ -16,6 +16,8 @@
 //   * the ratio test + ordered compaction is one workgroup using wave ballots and popcounts for the prefix.
 #include "vs_internal.h"
 
+#include <vector>
+
 namespace {
 
 constexpr int kWaves = 4;                  // waves per workgroup
@@ -237,6 +239,13 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int2* __restr
 }
 
 int g_target_blocks = 1024;  // ~4 workgroups (16 waves) per CU
+
+// optional per-kernel timing (bench.py): hipEvents on the launch stream around the two kernels of each call
+bool g_profile = false;
+struct prof_rec {
+  hipEvent_t e0, e1, e2;
+};
+std::vector<prof_rec> g_prof;
 int g_variant = 0;           // see launch_partial
 
 typedef void (*partial_fn)(const uint4*, int, const uint32_t*, int, int, int, uint2*);
@@ -304,14 +313,53 @@ VS_API int vs_hamming_knn2_dev(vs_ctx* ctx, const void* d_q, int nq, const void*
   VS_TRY(vs_reserve(ctx, &ctx->d_partial, sizeof(uint2) * (size_t)nchunks * nq));
   const int tile_q = 64 * kVariants[g_variant].qpl;
   dim3 grid((nq + tile_q - 1) / tile_q, nchunks);
+  prof_rec pr{};
+  if (g_profile) {
+    VS_HIP(ctx, hipEventCreate(&pr.e0));
+    VS_HIP(ctx, hipEventCreate(&pr.e1));
+    VS_HIP(ctx, hipEventCreate(&pr.e2));
+    VS_HIP(ctx, hipEventRecord(pr.e0, s));
+  }
   hipLaunchKernelGGL(kVariants[g_variant].fn, grid, dim3(64 * kWaves), 0, s, (const uint4*)d_q, nq,
                      (const uint32_t*)d_t, nt, chunk_len, sub_len, (uint2*)ctx->d_partial.p);
   VS_LAUNCH_CHECK(ctx, "hamming_partial_kernel");
+  if (g_profile) VS_HIP(ctx, hipEventRecord(pr.e1, s));
   const long merge_threads = (long)nq * kMergeLanes;
   hipLaunchKernelGGL(hamming_merge_kernel, dim3((unsigned)((merge_threads + 255) / 256)), dim3(256), 0, s,
                      (const uint2*)ctx->d_partial.p, nq, nchunks, chunk_len, (int2*)d_idx, (int2*)d_dist);
   VS_LAUNCH_CHECK(ctx, "hamming_merge_kernel");
+  if (g_profile) {
+    VS_HIP(ctx, hipEventRecord(pr.e2, s));
+    g_prof.push_back(pr);
+  }
   return VS_OK;
+}
+
+// bench hooks (not part of the stable ABI): HIP-event timing of the two match kernels on their launch stream
+VS_API int vs_match_profile(int enable) {
+  g_profile = enable != 0;
+  return 0;
+}
+// synchronises, returns the number of profiled calls and their mean kernel durations in milliseconds, then clears
+VS_API int vs_match_profile_read(float* partial_ms, float* merge_ms) {
+  double a = 0, b = 0;
+  int n = 0;
+  for (prof_rec& r : g_prof) {
+    float x = 0, y = 0;
+    if (hipEventSynchronize(r.e2) == hipSuccess && hipEventElapsedTime(&x, r.e0, r.e1) == hipSuccess &&
+        hipEventElapsedTime(&y, r.e1, r.e2) == hipSuccess) {
+      a += x;
+      b += y;
+      ++n;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+    (void)hipEventDestroy(r.e2);
+  }
+  g_prof.clear();
+  if (partial_ms) *partial_ms = n ? (float)(a / n) : 0.f;
+  if (merge_ms) *merge_ms = n ? (float)(b / n) : 0.f;
+  return n;
 }
 
 VS_API int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, double ratio,
