@@ -104,6 +104,10 @@ int vs_match_ratio(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int 
 /* device-resident variants (no copies, no synchronisation).  d_idx/d_dist: int32[nq][2] in HBM. */
 int vs_hamming_knn2_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_idx, void* d_dist,
                         void* stream);
+/* same, one 16-byte row per query: d_out int32[nq][4] = (idx0, idx1, dist0, dist1) -- the layout the query-sharded
+ * matcher hands to the RCCL all-gather (north_star: "all-gather of per-shard best matches") */
+int vs_hamming_knn2_packed_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_out,
+                               void* stream);
 /* d_n_out: one int32 in HBM receiving the match count */
 int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, double ratio, void* d_match_q,
                        void* d_match_t, void* d_match_d, void* d_n_out, void* stream);

@@ -65,6 +65,8 @@ SIGNATURES = {
                                  c_intp]),
     "vs_hamming_knn2_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
+    "vs_hamming_knn2_packed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                             C.c_void_p]),
     "vs_match_ratio_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vs_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(BAResult)]),

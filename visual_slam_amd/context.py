@@ -122,6 +122,11 @@ class Context:
                                                 C.c_void_p(d_idx), C.c_void_p(d_dist),
                                                 C.c_void_p(stream) if stream else None))
 
+    def hamming_knn2_packed_dev(self, d_q, nq, d_t, nt, d_out, stream=None):
+        """d_out: int32[nq][4] = (idx0, idx1, dist0, dist1) per query, 16-byte aligned; enqueues only."""
+        self._chk(self._lib.vs_hamming_knn2_packed_dev(self._h, C.c_void_p(d_q), int(nq), C.c_void_p(d_t), int(nt),
+                                                       C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
+
     def match_ratio_dev(self, d_q, nq, d_t, nt, ratio, d_mq, d_mt, d_md, d_n, stream=None):
         self._chk(self._lib.vs_match_ratio_dev(self._h, C.c_void_p(d_q), int(nq), C.c_void_p(d_t), int(nt),
                                                float(ratio), C.c_void_p(d_mq), C.c_void_p(d_mt), C.c_void_p(d_md),

@@ -64,6 +64,9 @@ struct ba_dev {
   double *part_chi, *part_scale, *part_maxd;  // per point-block partials; part_maxd has nb_pt + nfp entries
   double *chi_trace, *lambda_trace;
   lm_state* st;
+  // motion-only kernel: camera-major observation copy cut into chunks of 64
+  const double *mo_X, *mo_uv, *mo_info;  // [n_obs_free_cam][3|2|3] in camera-major (cam_start) order
+  double *mo_part, *mo_H;                // [2][nfp][4] per-camera partials by step parity; [nfp][42] H upper + b
 };
 
 // ------------------------------------------------------------------------------------------------ small math
@@ -150,18 +153,19 @@ struct edge_t {
 
 // EdgeProjectP2MC::computeError (+ optionally linearizeOplus) for camera record c (kCamStride doubles) and point X
 template <bool JAC>
-__device__ inline void eval_edge(const ba_dev& D, const double* __restrict__ c, const double* X, int o, edge_t& E) {
+__device__ inline void eval_edge(const ba_dev& D, const double* __restrict__ c, const double* X, const double* uv,
+                                 const double* info, edge_t& E) {
   const double* w = c + 7;
   double pc[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) pc[i] = w[4 * i] * X[0] + w[4 * i + 1] * X[1] + w[4 * i + 2] * X[2] + w[4 * i + 3];
   const double u = D.fx * pc[0] + D.cx * pc[2], v = D.fy * pc[1] + D.cy * pc[2], wz = pc[2];
-  E.e[0] = u / wz - D.o_uv[2 * (size_t)o];
-  E.e[1] = v / wz - D.o_uv[2 * (size_t)o + 1];
-  if (D.has_info) {
-    E.W[0] = D.o_info[3 * (size_t)o];
-    E.W[1] = D.o_info[3 * (size_t)o + 1];
-    E.W[2] = D.o_info[3 * (size_t)o + 2];
+  E.e[0] = u / wz - uv[0];
+  E.e[1] = v / wz - uv[1];
+  if (info) {
+    E.W[0] = info[0];
+    E.W[1] = info[1];
+    E.W[2] = info[2];
   } else {
     E.W[0] = 1;
     E.W[1] = 0;
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
         const int ci = D.o_cam[o];
         const int cs = D.pose_slot[ci];
         edge_t E;
-        eval_edge<true>(D, cams + (size_t)ci * kCamStride, X, o, E);
+        eval_edge<true>(D, cams + (size_t)ci * kCamStride, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
         chi += E.rho0;
         const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
         const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
     const int p = D.o_pt[o];
     const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
     edge_t E;
-    eval_edge<true>(D, cam, X, o, E);
+    eval_edge<true>(D, cam, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
     const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
     const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
     const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
     for (int k = 0; k < 3; ++k) pts1[3 * (size_t)p + k] = X[k];
     for (int o = o0; o < o1; ++o) {
       edge_t E;
-      eval_edge<false>(D, cams1 + (size_t)D.o_cam[o] * kCamStride, X, o, E);
+      eval_edge<false>(D, cams1 + (size_t)D.o_cam[o] * kCamStride, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
       chi += E.rho0;
     }
   }
@@ -773,256 +777,307 @@ __global__ void ba_decide(ba_dev D) {
 
 // ------------------------------------------------------------------------------------------------ motion-only BA
 // motionOnlyBundleAdjustement (reference LocalBA.py:195-229) has no free points and no scale edges: the normal
-// equations are block diagonal (one 6x6 system per free camera) and the whole problem of a tracking period fits one
-// compute unit.  This kernel runs the complete LM loop in ONE launch: one workgroup, waves own cameras, lanes stride
-// over the camera's observations, fixed-order butterfly reductions, per-camera 6x6 Cholesky in registers, trial states
-// in LDS.  No host round trip, no kernel boundary inside the solve.
-constexpr int kMoThreads = 1024;
+// equations are block diagonal, so linearisation, the 6x6 solve, the trial state and the trial chi2 of one camera need
+// nothing from any other camera.  The only global coupling of g2o's LM is the accept/reject decision (sums of chi2 and
+// of the gain denominator over all cameras) and lambda_0 (max diagonal).
+// => ONE kernel launch per LM trial, one workgroup per free camera, spread over the CUs, and the decision on the
+// previous trial is recomputed redundantly in the prologue of the next launch from the per-camera partials (the same
+// inputs and code in every workgroup give the same answer; workgroup 0 records it).  No grid barrier, no host round
+// trip: the host enqueues 1 + max_iterations launches and polls `done` once.
+//   step 0           : linearise only (lambda_0 needs the maximum over ALL cameras)
+//   step s >= 1      : decide(step s-1) -> [re-linearise if a step was accepted] -> solve -> trial state -> trial chi2
+// State and partials are double buffered by step parity; observations are read from a camera-major copy
+// (mo_X / mo_uv / mo_info) so every load is coalesced and index-free.
+constexpr int kMoThreads = 256;
 
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
-}
+struct mo_state {
+  double lambda, ni, current_chi, chi0;
+  int cur, it, trials, qmax, not_pd, need_lin, done, terminated;
+  int stage;  // 0: nothing yet, 1: the previous launch only linearised (iteration 0), 2: it ran a trial
+  int seq;
+};
 
-// LDS: cam0[F*19] cam1[F*19] H[nfp*36] b[nfp*6] x[nfp*6] chi[nfp] scl[nfp] maxd[nfp] | ints: pose_of[nfp] ok[nfp]
-__global__ __launch_bounds__(kMoThreads) void ba_motion_kernel(ba_dev D) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int F = D.n_poses, nfp = D.nfp, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  double* cam0 = sm;
-  double* cam1 = cam0 + (size_t)F * kCamStride;
-  double* sH = cam1 + (size_t)F * kCamStride;
-  double* sb = sH + (size_t)nfp * 36;
-  double* sx = sb + (size_t)nfp * 6;
-  double* s_chi = sx + (size_t)nfp * 6;
-  double* s_scl = s_chi + nfp;
-  double* s_maxd = s_scl + nfp;
-  double* s_lm = s_maxd + nfp;  // [0] lambda [1] ni [2] current chi [3] flag: 0 retry, 1 next iteration, 2 stop
-  int* s_pose = reinterpret_cast<int*>(s_lm + 4);
-  int* s_ok = s_pose + nfp;
-  lm_state* st = D.st;
-  const double* g_cam = D.cam[0];
-  const double* pts = D.pts[0];
-  for (int i = tid; i < F * kCamStride; i += kMoThreads) cam0[i] = cam1[i] = g_cam[i];
-  for (int p = tid; p < F; p += kMoThreads)
-    if (D.pose_slot[p] >= 0) s_pose[D.pose_slot[p]] = p;
-  __syncthreads();
-  double* cur = cam0;
-  double* trial = cam1;
-  int it = 0, trials = 0, not_pd = 0, terminated = 0;
-  double chi0 = 0.0;
-  for (; it < D.max_it;) {
-    // ---- linearise at `cur`
-    for (int c = wave; c < nfp; c += kMoThreads / 64) {
-      const double* cam = cur + (size_t)s_pose[c] * kCamStride;
-      double acc[27], chi = 0.0;
+// sums 28 doubles per thread over the workgroup in a fixed order; result in s_out[0..27]
+__device__ inline void block_reduce28(double (&acc)[28], double (*s_all)[28], double* s_out, int tid) {
+  if (tid >= kMoThreads / 2) {
 #pragma unroll
-      for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-      for (int i = D.cam_start[c] + lane; i < D.cam_start[c + 1]; i += 64) {
-        const int o = D.cam_obs[i];
-        const int p = D.o_pt[o];
-        const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
-        edge_t E;
-        eval_edge<true>(D, cam, X, o, E);
-        chi += E.rho0;
-        const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
-        const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
-        const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
-        double WJ[2][6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          WJ[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
-          WJ[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
-        }
-        int n = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-          for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJ[0][l] + E.Jj[1][k] * WJ[1][l];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
-      }
-#pragma unroll
-      for (int k = 0; k < 27; ++k) acc[k] = wave_sum(acc[k]);
-      chi = wave_sum(chi);
-      if (lane == 0) {
-        int n = 0;
-        double mx = 0.0;
-        for (int k = 0; k < 6; ++k)
-          for (int l = k; l < 6; ++l) {
-            sH[c * 36 + 6 * k + l] = acc[n];
-            sH[c * 36 + 6 * l + k] = acc[n];
-            if (k == l) mx = fmax(mx, fabs(acc[n]));
-            ++n;
-          }
-        for (int k = 0; k < 6; ++k) sb[c * 6 + k] = acc[21 + k];
-        s_chi[c] = chi;
-        s_maxd[c] = mx;
-      }
-    }
-    __syncthreads();
-    if (tid == 0 && it == 0) {
-      double chi = 0.0, mx = 0.0;
-      for (int c = 0; c < nfp; ++c) {
-        chi += s_chi[c];
-        mx = fmax(mx, s_maxd[c]);
-      }
-      s_lm[0] = 1e-5 * mx;
-      s_lm[1] = 2.0;
-      s_lm[2] = chi;
-      chi0 = chi;
-    }
-    __syncthreads();
-    // ---- trials
-    int qmax = 0, flag = 0;
-    double rho = 0.0;
-    do {
-      const double lambda = s_lm[0];
-      if (tid < nfp) {
-        const int c = tid;
-        double A[6][6], x[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-#pragma unroll
-          for (int l = 0; l < 6; ++l) A[k][l] = sH[c * 36 + 6 * k + l];
-          A[k][k] += lambda;
-          x[k] = sb[c * 6 + k];
-        }
-        int ok = 1;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const double d = A[j][j];
-          if (!(d > 0.0)) ok = 0;
-          const double ljj = sqrt(d);
-          A[j][j] = ljj;
-#pragma unroll
-          for (int i = j + 1; i < 6; ++i) A[i][j] = A[i][j] / ljj;
-#pragma unroll
-          for (int i = j + 1; i < 6; ++i)
-#pragma unroll
-            for (int k = j + 1; k <= i; ++k) A[i][k] -= A[i][j] * A[k][j];
-        }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          x[k] = x[k] / A[k][k];
-#pragma unroll
-          for (int i = k + 1; i < 6; ++i) x[i] -= A[i][k] * x[k];
-        }
-#pragma unroll
-        for (int k = 5; k >= 0; --k) {
-          x[k] = x[k] / A[k][k];
-#pragma unroll
-          for (int i = 0; i < k; ++i) x[i] -= A[k][i] * x[k];
-        }
-        double sc = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          sx[c * 6 + k] = x[k];
-          sc += x[k] * (lambda * x[k] + sb[c * 6 + k]);
-        }
-        s_scl[c] = sc;
-        s_ok[c] = ok;
-        // SBACam::update into the trial buffer
-        const double* src = cur + (size_t)s_pose[c] * kCamStride;
-        double* dst = trial + (size_t)s_pose[c] * kCamStride;
-        double t[3] = {src[0] + x[0], src[1] + x[1], src[2] + x[2]};
-        const double bx = x[3], by = x[4], bz = x[5];
-        const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));
-        const double ax = src[3], ay = src[4], az = src[5], aw = src[6];
-        const double w = aw * bw - ax * bx - ay * by - az * bz;
-        const double xx = aw * bx + ax * bw + ay * bz - az * by;
-        const double yy = aw * by + ay * bw + az * bx - ax * bz;
-        const double zz = aw * bz + az * bw + ax * by - ay * bx;
-        const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
-        double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
-        for (int k = 0; k < 3; ++k) dst[k] = t[k];
-        for (int k = 0; k < 4; ++k) dst[3 + k] = q[k];
-        quat_to_w2n(t, q, dst + 7);
-      }
-      __syncthreads();
-      // robust chi2 of the trial state
-      for (int c = wave; c < nfp; c += kMoThreads / 64) {
-        const double* cam = trial + (size_t)s_pose[c] * kCamStride;
-        double chi = 0.0;
-        for (int i = D.cam_start[c] + lane; i < D.cam_start[c + 1]; i += 64) {
-          const int o = D.cam_obs[i];
-          const int p = D.o_pt[o];
-          const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
-          edge_t E;
-          eval_edge<false>(D, cam, X, o, E);
-          chi += E.rho0;
-        }
-        chi = wave_sum(chi);
-        if (lane == 0) s_chi[c] = chi;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int ok = 1;
-        double temp = 0.0, scale = 0.0;
-        for (int c = 0; c < nfp; ++c) {
-          ok &= s_ok[c];
-          temp += s_chi[c];
-          scale += s_scl[c];
-        }
-        if (!ok) temp = 1.7976931348623157e308;
-        double r = s_lm[2] - temp;
-        scale += 1e-3;
-        r /= scale;
-        int stop = 0, accepted = 0;
-        if (r > 0 && isfinite(temp)) {
-          double alpha = 1.0 - pow(2 * r - 1, 3);
-          alpha = fmin(alpha, 2.0 / 3.0);
-          s_lm[0] *= fmax(1.0 / 3.0, alpha);
-          s_lm[1] = 2.0;
-          s_lm[2] = temp;
-          accepted = 1;
-        } else {
-          s_lm[0] *= s_lm[1];
-          s_lm[1] *= 2;
-          if (!isfinite(s_lm[0])) stop = 1;
-        }
-        s_lm[3] = (double)(accepted | (stop << 1) | ((ok ? 0 : 1) << 2));
-        s_scl[0] = r;  // broadcast rho
-      }
-      __syncthreads();
-      const int bits = (int)s_lm[3];
-      rho = s_scl[0];
-      ++trials;
-      if (bits & 4) ++not_pd;
-      if (bits & 1) {  // accepted: the trial buffer becomes the estimate
-        double* tmp = cur;
-        cur = trial;
-        trial = tmp;
-      }
-      ++qmax;
-      flag = (bits & 2) ? 2 : 0;
-      __syncthreads();
-    } while (flag == 0 && rho < 0 && qmax < 10);
-    if (tid == 0) {
-      if (D.chi_trace) D.chi_trace[it] = s_lm[2];
-      if (D.lambda_trace) D.lambda_trace[it] = s_lm[0];
-    }
-    ++it;
-    if (qmax == 10 || rho == 0 || flag == 2) {
-      terminated = 1;
-      break;
-    }
+    for (int k = 0; k < 28; ++k) s_all[tid - kMoThreads / 2][k] = acc[k];
   }
   __syncthreads();
-  // accepted estimate -> state buffer 0 (the host reads buffer st->cur = 0)
-  double* out = D.cam[0];
-  for (int i = tid; i < F * kCamStride; i += kMoThreads) out[i] = cur[i];
+  if (tid < kMoThreads / 2) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) s_all[tid][k] += acc[k];
+  }
+  __syncthreads();
+  for (int off = kMoThreads / 4; off > 0; off >>= 1) {
+    if (tid < off) {
+#pragma unroll
+      for (int k = 0; k < 28; ++k) s_all[tid][k] += s_all[tid + off][k];
+    }
+    __syncthreads();
+  }
+  if (tid < 28) s_out[tid] = s_all[0][tid];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step) {
+  __shared__ double s_all[kMoThreads / 2][28];
+  __shared__ double s_sum[28];
+  __shared__ double s_part[3][kMoThreads];  // chi, scale / maxd, ok of up to 256 cameras (strided beyond)
+  __shared__ mo_state s_st;
+  __shared__ double s_x[6];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, c = blockIdx.x, nfp = D.nfp;
+  mo_state* g_state = reinterpret_cast<mo_state*>(D.st);
+  const double* prev_part = D.mo_part + (size_t)((step + 1) & 1) * 4 * nfp;
+  double* my_part = D.mo_part + (size_t)(step & 1) * 4 * nfp;
+
+  // ---- prologue: every workgroup derives the current LM state from the previous launch's state + partials
+  if (tid == 0) s_st = g_state[(step + 1) & 1];
+  __syncthreads();
+  if (s_st.stage != 0 && !s_st.done) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;  // fixed order: thread t sums cameras t, t+256, ... then thread 0 sums threads
+    for (int k = tid; k < nfp; k += kMoThreads) {
+      a0 += prev_part[4 * k];
+      if (s_st.stage == 1) a1 = fmax(a1, prev_part[4 * k + 3]);
+      else a1 += prev_part[4 * k + 1];
+      a2 += prev_part[4 * k + 2];  // number of cameras whose 6x6 system was not positive definite
+    }
+    s_part[0][tid] = a0;
+    s_part[1][tid] = a1;
+    s_part[2][tid] = a2;
+    __syncthreads();
+    if (tid == 0) {
+      mo_state st = s_st;
+      const int n = min(nfp, kMoThreads);
+      double chi = 0.0, second = 0.0, bad = 0.0;
+      for (int k = 0; k < n; ++k) {
+        chi += s_part[0][k];
+        if (st.stage == 1) second = fmax(second, s_part[1][k]);
+        else second += s_part[1][k];
+        bad += s_part[2][k];
+      }
+      if (st.stage == 1) {  // iteration 0 has just been linearised: computeLambdaInit + the first chi2
+        st.lambda = 1e-5 * second;
+        st.ni = 2.0;
+        st.current_chi = chi;
+        st.chi0 = chi;
+        st.need_lin = 0;
+      } else {  // a trial has just been evaluated
+        double temp = chi, scale = second;
+        st.trials += 1;
+        if (bad > 0.0) {
+          temp = 1.7976931348623157e308;
+          st.not_pd += 1;
+        }
+        double rho = st.current_chi - temp;
+        scale += 1e-3;
+        rho /= scale;
+        int stop = 0;
+        if (rho > 0 && isfinite(temp)) {
+          double alpha = 1.0 - pow(2 * rho - 1, 3);
+          alpha = fmin(alpha, 2.0 / 3.0);
+          st.lambda *= fmax(1.0 / 3.0, alpha);
+          st.ni = 2.0;
+          st.current_chi = temp;
+          st.cur ^= 1;  // accept: the trial buffer becomes the estimate
+        } else {
+          st.lambda *= st.ni;
+          st.ni *= 2;
+          if (!isfinite(st.lambda)) stop = 1;
+        }
+        st.qmax += 1;
+        if (!stop && rho < 0 && st.qmax < 10) {
+          st.need_lin = 0;  // retry with the same linearisation
+        } else {
+          if (c == 0) {
+            if (D.chi_trace) D.chi_trace[st.it] = st.current_chi;
+            if (D.lambda_trace) D.lambda_trace[st.it] = st.lambda;
+          }
+          st.it += 1;
+          if (st.qmax == 10 || rho == 0 || stop) {
+            st.done = 1;
+            st.terminated = 1;
+          } else if (st.it >= D.max_it) {
+            st.done = 1;
+          } else {
+            st.need_lin = 1;
+            st.qmax = 0;
+          }
+        }
+      }
+      s_st = st;
+    }
+    __syncthreads();
+  }
+  mo_state st = s_st;
+  st.seq = step;
+  if (st.done) {
+    if (c == 0 && tid == 0) g_state[step & 1] = st;
+    return;
+  }
+
+  // ---- this camera
+  int pose = -1;
+  for (int i = 0; i < D.n_poses; ++i)
+    if (D.pose_slot[i] == c) {
+      pose = i;
+      break;
+    }
+  const double* cam = D.cam[st.cur] + (size_t)pose * kCamStride;
+  const int o0 = D.cam_start[c], o1 = D.cam_start[c + 1];
+  double* gH = D.mo_H + (size_t)c * 42;
+  const bool lin_only = st.need_lin && st.it == 0 && st.stage == 0;
+  if (st.need_lin) {
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+    for (int i = o0 + tid; i < o1; i += kMoThreads) {
+      const double X[3] = {D.mo_X[3 * (size_t)i], D.mo_X[3 * (size_t)i + 1], D.mo_X[3 * (size_t)i + 2]};
+      edge_t E;
+      eval_edge<true>(D, cam, X, D.mo_uv + 2 * (size_t)i, D.has_info ? D.mo_info + 3 * (size_t)i : nullptr, E);
+      const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+      const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
+      const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
+      double WJ[2][6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        WJ[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
+        WJ[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
+      }
+      int n = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJ[0][l] + E.Jj[1][k] * WJ[1][l];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
+      acc[27] += E.rho0;
+    }
+    block_reduce28(acc, s_all, s_sum, tid);
+    if (tid < 27) gH[tid] = s_sum[tid];  // upper triangle (21) + b (6), re-read by retries of this linearisation
+    if (lin_only) {
+      if (tid == 0) {
+        double mx = 0.0;
+        int n = 0;
+        for (int k = 0; k < 6; ++k) {
+          mx = fmax(mx, fabs(s_sum[n]));
+          n += 6 - k;
+        }
+        my_part[4 * c] = s_sum[27];
+        my_part[4 * c + 1] = 0.0;
+        my_part[4 * c + 2] = 0.0;
+        my_part[4 * c + 3] = mx;
+        if (c == 0) {
+          st.stage = 1;
+          g_state[step & 1] = st;
+        }
+      }
+      return;
+    }
+  } else {
+    if (tid < 27) s_sum[tid] = gH[tid];
+    __syncthreads();
+  }
+
+  // ---- 6x6 solve (H + lambda I) x = b and SBACam::update into the trial buffer: one thread
+  double* trial = D.cam[st.cur ^ 1] + (size_t)pose * kCamStride;
   if (tid == 0) {
-    st->lambda = s_lm[0];
-    st->ni = s_lm[1];
-    st->current_chi = s_lm[2];
-    st->chi0 = chi0;
-    st->cur = 0;
-    st->it = it;
-    st->trials = trials;
-    st->not_pd = not_pd;
-    st->terminated = terminated;
-    st->done = 1;
+    double A[6][6], x[6];
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int l = k; l < 6; ++l) {
+        A[k][l] = s_sum[n];
+        A[l][k] = s_sum[n];
+        ++n;
+      }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      A[k][k] += st.lambda;
+      x[k] = s_sum[21 + k];
+    }
+    int ok = 1;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const double d = A[j][j];
+      if (!(d > 0.0)) ok = 0;
+      const double ljj = sqrt(d);
+      A[j][j] = ljj;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i) A[i][j] = A[i][j] / ljj;
+#pragma unroll
+      for (int i = j + 1; i < 6; ++i)
+#pragma unroll
+        for (int k = j + 1; k <= i; ++k) A[i][k] -= A[i][j] * A[k][j];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      x[k] = x[k] / A[k][k];
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) x[i] -= A[i][k] * x[k];
+    }
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+      x[k] = x[k] / A[k][k];
+#pragma unroll
+      for (int i = 0; i < k; ++i) x[i] -= A[k][i] * x[k];
+    }
+    double sc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sc += x[k] * (st.lambda * x[k] + s_sum[21 + k]);
+    double t[3] = {cam[0] + x[0], cam[1] + x[1], cam[2] + x[2]};
+    const double bx = x[3], by = x[4], bz = x[5];
+    const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));
+    const double ax = cam[3], ay = cam[4], az = cam[5], aw = cam[6];
+    const double w = aw * bw - ax * bx - ay * by - az * bz;
+    const double xx = aw * bx + ax * bw + ay * bz - az * by;
+    const double yy = aw * by + ay * bw + az * bx - ax * bz;
+    const double zz = aw * bz + az * bw + ax * by - ay * bx;
+    const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
+    double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
+    double rec[kCamStride];
+    for (int k = 0; k < 3; ++k) rec[k] = t[k];
+    for (int k = 0; k < 4; ++k) rec[3 + k] = q[k];
+    quat_to_w2n(t, q, rec + 7);
+    for (int k = 0; k < kCamStride; ++k) {
+      trial[k] = rec[k];
+      s_all[0][k] = rec[k];  // the workgroup evaluates the trial from LDS
+    }
+    s_x[0] = sc;
+    s_ok = ok;
+  }
+  __syncthreads();
+  // ---- robust chi2 of this camera's trial state
+  double tcam[kCamStride];
+#pragma unroll
+  for (int k = 0; k < kCamStride; ++k) tcam[k] = s_all[0][k];
+  const double scl = s_x[0];
+  const int ok = s_ok;
+  __syncthreads();
+  double chi = 0.0;
+  for (int i = o0 + tid; i < o1; i += kMoThreads) {
+    const double X[3] = {D.mo_X[3 * (size_t)i], D.mo_X[3 * (size_t)i + 1], D.mo_X[3 * (size_t)i + 2]};
+    edge_t E;
+    eval_edge<false>(D, tcam, X, D.mo_uv + 2 * (size_t)i, D.has_info ? D.mo_info + 3 * (size_t)i : nullptr, E);
+    chi += E.rho0;
+  }
+  s_part[0][tid] = chi;
+  __syncthreads();
+  for (int off = kMoThreads / 2; off > 0; off >>= 1) {
+    if (tid < off) s_part[0][tid] += s_part[0][tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    my_part[4 * c] = s_part[0][0];
+    my_part[4 * c + 1] = scl;
+    my_part[4 * c + 2] = ok ? 0.0 : 1.0;
+    my_part[4 * c + 3] = 0.0;
+    if (c == 0) {
+      st.stage = 2;
+      g_state[step & 1] = st;
+    }
   }
 }
 
@@ -1113,6 +1168,9 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     if (cs >= 0) cam_obs[cfill[cs]++] = i;
   }
 
+  // ---- motion-only fast path (block-diagonal problem): one launch per LM trial, one workgroup per free camera
+  const bool motion_only = nfl == 0 && p->n_scale == 0 && nfp > 0 && p->max_iterations > 0;
+
   // ---- result defaults
   res->iterations = res->trials = res->not_pd = res->terminated = 0;
   res->chi2_initial = res->chi2_final = res->lambda_final = 0.0;
@@ -1132,7 +1190,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
                                   2 * (size_t)np * np + 4 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
                                   9 * (size_t)nfl + (size_t)(ns ? ns : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
                                   2 * (size_t)q.max_iterations + 64) +
-                256 * 64;
+                256 * 64 + (motion_only ? sizeof(double) * (8 * cam_obs.size() + 50 * (size_t)nfp + 64) : 0);
   VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, need));
   VS_HIP(ctx, hipStreamSynchronize(s));
@@ -1177,6 +1235,15 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.o_uv = A.take<double>(2 * (size_t)n_obs, &h_uv);
   if (D.has_info) D.o_info = A.take<double>(3 * (size_t)n_obs, &h_info);
   D.sc_meas = A.take<double>(q.n_scale, &h_scm);
+  double *h_mx = nullptr, *h_muv = nullptr, *h_minfo = nullptr;
+  mo_state* h_mst = nullptr;
+  mo_state* d_mst = nullptr;
+  if (motion_only) {
+    D.mo_X = A.take<double>(3 * cam_obs.size(), &h_mx);
+    D.mo_uv = A.take<double>(2 * cam_obs.size(), &h_muv);
+    if (D.has_info) D.mo_info = A.take<double>(3 * cam_obs.size(), &h_minfo);
+    d_mst = A.take<mo_state>(2, &h_mst);
+  }
   D.cam[0] = A.take<double>((size_t)F * kCamStride, &h_cam0);
   D.pts[0] = A.take<double>(3 * (size_t)P, &h_pts0);
   // Dinv is followed by the free-point -> active-index table (read by ba_schur)
@@ -1204,6 +1271,10 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.part_maxd = A.take<double>((size_t)nb_pt + nfp);
   D.chi_trace = A.take<double>(q.max_iterations);
   D.lambda_trace = A.take<double>(q.max_iterations);
+  if (motion_only) {
+    D.mo_part = A.take<double>(8 * (size_t)nfp);
+    D.mo_H = A.take<double>(42 * (size_t)nfp);
+  }
   if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
 
   memcpy(h_pose_slot, pose_slot.data(), sizeof(int) * F);
@@ -1222,6 +1293,25 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       h_info[3 * i] = q.obs_info[3 * o];
       h_info[3 * i + 1] = q.obs_info[3 * o + 1];
       h_info[3 * i + 2] = q.obs_info[3 * o + 2];
+    }
+  }
+  if (motion_only) {
+    memset(h_mst, 0, 2 * sizeof(mo_state));
+    h_mst[1].need_lin = 1;  // step 0 reads the state of parity 1
+    h_mst[1].ni = 2.0;
+    for (int i = 0; i < cam_start[nfp]; ++i) {
+      const int o = order[cam_obs[i]];
+      const double* X = q.points + 3 * (size_t)q.obs_point[o];
+      h_mx[3 * i] = X[0];
+      h_mx[3 * i + 1] = X[1];
+      h_mx[3 * i + 2] = X[2];
+      h_muv[2 * i] = q.obs_uv[2 * o];
+      h_muv[2 * i + 1] = q.obs_uv[2 * o + 1];
+      if (h_minfo) {
+        h_minfo[3 * i] = q.obs_info[3 * o];
+        h_minfo[3 * i + 1] = q.obs_info[3 * o + 1];
+        h_minfo[3 * i + 2] = q.obs_info[3 * o + 2];
+      }
     }
   }
   memcpy(h_cstart, cam_start.data(), sizeof(int) * (nfp + 1));
@@ -1263,8 +1353,8 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes));
   if (schur_lds > 160 * 1024) return vs_fail(ctx, VS_EINVAL, "%s: a point is observed by too many free cameras for the LDS staging", "vs_ba_solve");
 
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + 64));
-  lm_state* hst = (lm_state*)ctx->h_pin.p;
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + sizeof(mo_state) + 128));
+  lm_state* hst = reinterpret_cast<lm_state*>((uint8_t*)ctx->h_pin.p + 128);
   auto launch_slot = [&](bool first) -> int {
     hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp), dim3(kCamThreads), 0, s, D);
     VS_LAUNCH_CHECK(ctx, "ba_linearize");
@@ -1291,16 +1381,35 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     return VS_OK;
   };
 
-  const size_t mo_lds = sizeof(double) * (2 * (size_t)F * kCamStride + 51 * (size_t)nfp + 8) + sizeof(int) * 2 * (size_t)nfp + 16;
-  const bool motion_only = !nothing && nfl == 0 && q.n_scale == 0 && nfp > 0 && nfp <= kMoThreads && mo_lds <= 150 * 1024;
-  if (motion_only) {
-    // block-diagonal problem: the whole LM loop in one launch of one workgroup
-    if (mo_lds > 64 * 1024)
-      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_motion_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mo_lds));
-    hipLaunchKernelGGL(ba_motion_kernel, dim3(1), dim3(kMoThreads), mo_lds, s, D);
-    VS_LAUNCH_CHECK(ctx, "ba_motion_kernel");
-    VS_HIP(ctx, hipMemcpyAsync(hst, D.st, sizeof(lm_state), hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipStreamSynchronize(s));
+  if (motion_only && !nothing) {
+    // one launch per LM trial (+1: iteration 0 is linearised on its own, lambda_0 needs all cameras); the launches are
+    // predicated on the device-resident state, the host polls it once per batch
+    ba_dev Dm = D;
+    Dm.st = reinterpret_cast<lm_state*>(d_mst);
+    mo_state* hms = reinterpret_cast<mo_state*>(ctx->h_pin.p);
+    const int max_steps = 1 + q.max_iterations * 10;
+    int step = 0;
+    for (;;) {
+      const int batch = std::min(max_steps + 1 - step, q.max_iterations + 2);  // LIN + trials + the deciding launch
+      for (int k = 0; k < batch; ++k, ++step) {
+        hipLaunchKernelGGL(ba_motion_step, dim3(nfp), dim3(kMoThreads), 0, s, Dm, step);
+        VS_LAUNCH_CHECK(ctx, "ba_motion_step");
+      }
+      VS_HIP(ctx, hipMemcpyAsync(hms, d_mst + ((step - 1) & 1), sizeof(mo_state), hipMemcpyDeviceToHost, s));
+      VS_HIP(ctx, hipStreamSynchronize(s));
+      if (hms->done || step > max_steps) break;
+    }
+    // translate to the common read-back record
+    mo_state fin = *hms;
+    hst->cur = fin.cur;
+    hst->it = fin.it;
+    hst->trials = fin.trials;
+    hst->not_pd = fin.not_pd;
+    hst->terminated = fin.terminated;
+    hst->chi0 = fin.chi0;
+    hst->current_chi = fin.current_chi;
+    hst->lambda = fin.lambda;
+    hst->done = fin.done;
   } else if (!nothing) {
     // slots are predicated on the device-resident LM state; the host only polls `done` after each batch
     const int max_slots = q.max_iterations * 10;

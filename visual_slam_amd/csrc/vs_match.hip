@@ -155,7 +155,9 @@ __global__ __launch_bounds__(64 * kWaves) void hamming_partial_kernel(const uint
 
 // kMergeLanes lanes per query: lane g folds chunks g, g + L, ... (all its loads are issued before the first use),
 // then log2(L) xor-shuffles combine the lanes.  Ties cannot occur between chunks (distinct global indices).
+// PACKED: one 16-byte row (idx0, idx1, dist0, dist1) per query -- the layout the query-sharded matcher all-gathers.
 constexpr int kMergeLanes = 8;
+template <bool PACKED>
 __global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2* __restrict__ partial, int nq, int nchunks,
                                                              int chunk_len, int2* __restrict__ idx,
                                                              int2* __restrict__ dist) {
@@ -193,8 +195,13 @@ __global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2* __restr
     B2 = S2;
   }
   if (g == 0 && q < nq) {
-    idx[q] = make_int2((int)(B1 & 0xFFFFFFFFull), (int)(B2 & 0xFFFFFFFFull));
-    dist[q] = make_int2((int)(B1 >> 32), (int)(B2 >> 32));
+    if (PACKED) {
+      reinterpret_cast<int4*>(idx)[q] =
+          make_int4((int)(B1 & 0xFFFFFFFFull), (int)(B2 & 0xFFFFFFFFull), (int)(B1 >> 32), (int)(B2 >> 32));
+    } else {
+      idx[q] = make_int2((int)(B1 & 0xFFFFFFFFull), (int)(B2 & 0xFFFFFFFFull));
+      dist[q] = make_int2((int)(B1 >> 32), (int)(B2 >> 32));
+    }
   }
 }
 
@@ -300,11 +307,11 @@ VS_API int vs_match_set_variant(int v) {
   return g_variant;
 }
 
-VS_API int vs_hamming_knn2_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_idx,
-                               void* d_dist, void* stream) {
+static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_idx, void* d_dist,
+                         bool packed, void* stream) {
   VS_TRY(check_args(ctx, d_q, nq, d_t, nt, "vs_hamming_knn2_dev"));
   if (nq == 0) return VS_OK;
-  if (!d_idx || !d_dist) return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_hamming_knn2_dev");
+  if (!d_idx || (!packed && !d_dist)) return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_hamming_knn2_dev");
   hipStream_t s = vs_pick_stream(ctx, stream);
   int chunk_len, sub_len, nchunks;
   plan_chunks(nq, nt, &chunk_len, &sub_len, &nchunks);
@@ -325,14 +332,29 @@ VS_API int vs_hamming_knn2_dev(vs_ctx* ctx, const void* d_q, int nq, const void*
   VS_LAUNCH_CHECK(ctx, "hamming_partial_kernel");
   if (g_profile) VS_HIP(ctx, hipEventRecord(pr.e1, s));
   const long merge_threads = (long)nq * kMergeLanes;
-  hipLaunchKernelGGL(hamming_merge_kernel, dim3((unsigned)((merge_threads + 255) / 256)), dim3(256), 0, s,
-                     (const uint2*)ctx->d_partial.p, nq, nchunks, chunk_len, (int2*)d_idx, (int2*)d_dist);
+  if (packed)
+    hipLaunchKernelGGL(hamming_merge_kernel<true>, dim3((unsigned)((merge_threads + 255) / 256)), dim3(256), 0, s,
+                       (const uint2*)ctx->d_partial.p, nq, nchunks, chunk_len, (int2*)d_idx, (int2*)nullptr);
+  else
+    hipLaunchKernelGGL(hamming_merge_kernel<false>, dim3((unsigned)((merge_threads + 255) / 256)), dim3(256), 0, s,
+                       (const uint2*)ctx->d_partial.p, nq, nchunks, chunk_len, (int2*)d_idx, (int2*)d_dist);
   VS_LAUNCH_CHECK(ctx, "hamming_merge_kernel");
   if (g_profile) {
     VS_HIP(ctx, hipEventRecord(pr.e2, s));
     g_prof.push_back(pr);
   }
   return VS_OK;
+}
+
+VS_API int vs_hamming_knn2_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_idx,
+                               void* d_dist, void* stream) {
+  return knn2_dev_impl(ctx, d_q, nq, d_t, nt, d_idx, d_dist, false, stream);
+}
+
+VS_API int vs_hamming_knn2_packed_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_out,
+                                      void* stream) {
+  if (ctx && ((uintptr_t)d_out & 15)) return vs_fail(ctx, VS_EINVAL, "%s: output must be 16-byte aligned", "vs_hamming_knn2_packed_dev");
+  return knn2_dev_impl(ctx, d_q, nq, d_t, nt, d_out, nullptr, true, stream);
 }
 
 // bench hooks (not part of the stable ABI): HIP-event timing of the two match kernels on their launch stream

@@ -7,10 +7,65 @@ distributed code at all; the call it shards is FeatureMatcher.m
 
 Partition: rank r owns queries [r*ceil(Q/W), (r+1)*ceil(Q/W)); the train set is replicated, so every
 rank produces final (global train index, distance) pairs for its queries and no cross-rank tie-breaking exists.  The
-exchange is a single all-gather of 16 bytes per query (idx[2], dist[2] as int32), padded to equal shard sizes.
-At world_size 1 the same code path runs without a collective.
+exchange is a single all-gather of 16 bytes per query -- the kernel writes (idx0, idx1, dist0, dist1) rows directly in
+the gather layout (vs_hamming_knn2_packed_dev), shards padded to equal length.  At world_size 1 the same code path runs
+without a collective.
+
+Streaming use (bench.py --gpus N): `submit()` enqueues the local match and starts the all-gather asynchronously on
+RCCL's stream; `collect()` of step k is called after `submit()` of step k+1, so the collective of one step overlaps
+the kernels of the next (two rotating buffer sets).
 """
-import numpy as np
+
+
+class RcclAllGather:
+    """Direct ncclAllGather on a communicator of our own (created next to torch's, bootstrap through
+    torch.distributed), issued on a dedicated HIP stream.  torch.distributed's Python path costs 30-50 us of host time
+    per collective, more than half a 10k x 10k match step; the raw call costs a few microseconds, and running it on its
+    own stream lets it overlap the next step's kernels.  (RCCL = the NCCL API on ROCm; the library torch itself
+    loaded is used so only one RCCL lives in the process.)"""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        import os
+        import torch
+        import torch.distributed as dist
+        self._C = C
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.lib = C.CDLL(path if os.path.exists(path) else "librccl.so")
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_byte * 128)]
+
+        self.lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        self.lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        self.lib.ncclGetErrorString.restype = C.c_char_p
+        uid = UniqueId()
+        if self.rank == 0:
+            self._chk(self.lib.ncclGetUniqueId(C.byref(uid)))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        self.comm = C.c_void_p()
+        self._chk(self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank))
+        self.stream = torch.cuda.Stream(device=dev)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("RCCL error %d: %s" % (rc, self.lib.ncclGetErrorString(rc).decode()))
+
+    def all_gather_int32(self, recv, send):
+        """recv [W*n] int32, send [n] int32 device tensors; enqueued on self.stream."""
+        self._chk(self.lib.ncclAllGather(self._C.c_void_p(send.data_ptr()), self._C.c_void_p(recv.data_ptr()),
+                                         send.numel(), 2, self.comm, self._C.c_void_p(self.stream.cuda_stream)))
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
 
 
 def shard_bounds(n_query, world_size, rank):
@@ -37,12 +92,13 @@ class ShardedMatcher:
             self.world = dist.get_world_size(group)
         else:
             self.rank, self.world = 0, 1
-        self._local = local_knn2 if local_knn2 is not None else self._hip_local
+        self._local = local_knn2
         self._ctx = None
         self._stream = None
-        self._out = None
-        self._packed = None
-        self._gathered = None
+        self._bufs = {}   # (slot, rows) -> (packed [rows,4], gathered [W*rows,4])
+        self._slot = 0
+        self._rccl = None
+        self._rccl_failed = False
 
     # ---- HIP path: torch device tensors in, torch device tensors out, no host copies, no synchronisation
     def torch_stream(self):
@@ -56,50 +112,91 @@ class ShardedMatcher:
             self._stream = torch.cuda.ExternalStream(self._ctx.stream, device=torch.device("cuda", self._ctx.device))
         return self._stream
 
-    def _hip_local(self, q, t):
+    def _buffers(self, rows, device, slot):
         import torch
+        key = (slot, rows, str(device))
+        if key not in self._bufs:
+            packed = torch.empty((max(rows, 1), 4), dtype=torch.int32, device=device)
+            gathered = torch.empty((self.world * max(rows, 1), 4), dtype=torch.int32, device=device) \
+                if self.world > 1 or self._dist.is_initialized() else None
+            self._bufs[key] = (packed, gathered)
+        return self._bufs[key]
+
+    def _local_packed(self, q, t, rows, slot):
+        """Match this rank's queries; returns the packed [rows, 4] tensor (first len(q) rows valid)."""
+        import torch
+        nq, nt = q.shape[0], t.shape[0]
+        packed, _ = self._buffers(rows, q.device, slot)
+        if self._local is not None:  # injected kernel (CPU tests)
+            idx, dist = self._local(q, t)
+            packed[:nq, 0:2] = idx
+            packed[:nq, 2:4] = dist
+            return packed
         self.torch_stream()
         if not (q.is_cuda and t.is_cuda and q.dtype == torch.uint8 and t.dtype == torch.uint8):
             raise TypeError("the HIP matcher needs uint8 device tensors [n, 32]")
-        nq, nt = q.shape[0], t.shape[0]
-        if self._out is None or self._out[0].shape[0] < max(nq, 1) or self._out[0].device != q.device:
-            self._out = (torch.empty((max(nq, 1), 2), dtype=torch.int32, device=q.device),
-                         torch.empty((max(nq, 1), 2), dtype=torch.int32, device=q.device))
-        idx, dist = self._out
         # NULL stream argument = the context's stream (the one torch_stream() wraps)
-        self._ctx.hamming_knn2_dev(q.data_ptr(), nq, t.data_ptr(), nt, idx.data_ptr(), dist.data_ptr(), None)
-        return idx[:nq], dist[:nq]
+        self._ctx.hamming_knn2_packed_dev(q.data_ptr(), nq, t.data_ptr(), nt, packed.data_ptr(), None)
+        return packed
 
     def knn2_local_shard(self, q_shard, train):
-        """The per-rank compute only (what bench.py times at world_size 1)."""
-        return self._local(q_shard, train)
+        """The per-rank compute only (what bench.py times at world size 1): (idx, dist) views of the packed rows."""
+        nq = q_shard.shape[0]
+        packed = self._local_packed(q_shard, train, nq, 0)
+        return packed[:nq, 0:2], packed[:nq, 2:4]
+
+    def submit(self, q_shard, train, n_query):
+        """Enqueue the local match of this rank's shard and start the all-gather (async).  Returns a ticket."""
+        b, e, per = shard_bounds(n_query, self.world, self.rank)
+        assert q_shard.shape[0] == e - b, "q_shard must be this rank's slice of the query set"
+        slot = self._slot
+        self._slot ^= 1
+        packed = self._local_packed(q_shard, train, per, slot)
+        _, gathered = self._buffers(per, q_shard.device, slot)
+        work = None
+        if gathered is not None and self._dist.is_initialized():
+            work = self._start_all_gather(gathered, packed)
+            out = gathered
+        else:
+            out = packed
+        return (work, out, n_query)
+
+    def _start_all_gather(self, gathered, packed):
+        import os
+        import torch
+        if packed.is_cuda and self._local is None and not self._rccl_failed \
+                and os.environ.get("VS_SHARDED_TORCH_COLLECTIVE", "0") != "1":
+            try:
+                if self._rccl is None:
+                    self._rccl = RcclAllGather(self.group)
+                    self._events = {}
+                key = packed.data_ptr()
+                if key not in self._events:               # one (ready, done) event pair per rotating buffer
+                    self._events[key] = (torch.cuda.Event(), torch.cuda.Event())
+                ready, done = self._events[key]
+                ready.record(self.torch_stream())          # after the match kernels of this step
+                self._rccl.stream.wait_event(ready)
+                self._rccl.all_gather_int32(gathered, packed)
+                done.record(self._rccl.stream)
+                return ("event", done)
+            except (OSError, AttributeError, RuntimeError):
+                self._rccl_failed = True                   # fall back to torch.distributed below
+        return ("work", self._dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True))
+
+    def collect(self, ticket):
+        """Wait for a ticket's all-gather; returns (idx [Q,2], dist [Q,2]).  With the ceil partition only trailing ranks
+        are short, so the first Q rows of the gathered buffer are exactly the queries in order."""
+        work, out, n_query = ticket
+        if work is not None:
+            kind, h = work
+            if kind == "event":
+                self.torch_stream().wait_event(h)  # stream-side wait, the host does not block
+            else:
+                h.wait()
+        return out[:n_query, 0:2], out[:n_query, 2:4]
 
     def knn2(self, query, train):
         """query: the FULL query set (replicated input, as the reference's caller holds it); returns full results."""
-        import torch
         nq = query.shape[0]
-        b, e, per = shard_bounds(nq, self.world, self.rank)
-        idx, dist = self._local(query[b:e], train)
-        if self.world == 1:
-            return idx, dist
-        return self.gather_shards(idx, dist, nq)
-
-    def gather_shards(self, idx, dist, n_query):
-        """All-gather (idx, dist) of this rank's shard; shards are padded to ceil(Q/W) rows so the collective is a plain
-        equal-size all-gather (one RCCL call, 16 B per query)."""
-        import torch
-        b, e, per = shard_bounds(n_query, self.world, self.rank)
-        dev = idx.device
-        if self._packed is None or self._packed.shape[0] != per or self._packed.device != dev:
-            self._packed = torch.empty((per, 4), dtype=torch.int32, device=dev)
-            self._gathered = torch.empty((self.world * per, 4), dtype=torch.int32, device=dev)
-        n = e - b
-        self._packed[:n, 0:2] = idx
-        self._packed[:n, 2:4] = dist
-        if n < per:
-            self._packed[n:] = -1
-        self._dist.all_gather_into_tensor(self._gathered, self._packed, group=self.group)
-        out = self._gathered[:n_query] if per * self.world >= n_query else self._gathered
-        # rows of rank r sit at [r*per, r*per + len_r); with ceil partition only trailing ranks are short, so the
-        # first n_query rows are exactly the queries in order
-        return out[:, 0:2], out[:, 2:4]
+        b, e, _ = shard_bounds(nq, self.world, self.rank)
+        return self.collect(self.submit(query[b:e], train, nq))
