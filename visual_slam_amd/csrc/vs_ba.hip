@@ -7,21 +7,25 @@
 // parallel decomposition allows it (-ffp-contract=off), so poses agree with the oracle to ~1e-10, far inside the
 // 1e-4 contract.
 //
-// Data flow (everything stays in HBM/L2 for the whole solve; the host only reads two flags per batch of slots):
+// Data flow (everything stays in HBM/L2 for the whole solve; the host only polls a `done` flag per batch of launches):
+//  general problem (free points => Schur complement), one "slot" per LM trial, every kernel predicated on the
+//  device-resident LM state:
 //   ba_linearize      grid = point blocks + one block per free camera (one launch, two roles)
 //       point block : thread = point; loops its observations (CSR by point), accumulates Hll / bl in registers, writes
-//                     the 6x3 blocks Hpl of observations whose camera is free, robust chi2 partial per block
+//                     the 6x3 blocks Hpl (stored contiguously per free point), robust chi2 partial per block
 //       camera block: workgroup = free camera; threads stride over the camera's observation list, 27 register
 //                     accumulators (Hpp upper 21 + bp 6), fixed-order LDS tree reduction; also the EdgeSBAScale terms
 //   ba_lambda_init    first slot only: chi2_0 and lambda_0 = 1e-5 * max diag(H)
-//   ba_schur          workgroup = slab of points; per point Dinv = (Hll + lambda I)^-1, Y_i = Hpl_i Dinv staged in LDS,
-//                     every thread owns fixed elements of the 6x6 products Y_i Hpl_j^T and subtracts them into the
-//                     workgroup's LDS slab of the reduced camera system (no float atomics: deterministic)
+//   ba_schur          workgroup = slab of points; (Hll + lambda I)^-1 for the slab's points up front, then per point
+//                     Y_i = Hpl_i Dinv staged in LDS and every thread owns fixed elements of the 6x6 products Y_i Hpl_j^T,
+//                     accumulated into the workgroup's LDS slab of the reduced camera system (no float atomics)
 //   ba_reduce         S = Hpp + lambda I - sum of slabs, rhs likewise (one thread per matrix element)
-//   ba_solve          one workgroup: dense Cholesky of S in LDS, triangular solves, trial camera states
+//   ba_solve_wave     one wave: dense Cholesky of S in LDS (n <= 126; ba_solve<false> in HBM beyond), triangular solves,
+//                     trial camera states
 //   ba_point_trial    thread = point: back-substitution x_l = Dinv (bl - sum Hpl^T x_p), trial point, robust chi2 of the
 //                     trial state, fixed-order block reduction
 //   ba_decide         one thread: gain ratio, accept (flip the state buffer index) or reject, lambda update, stop rules
+//  motion-only problem (no free points, no scale edges => block diagonal): ba_motion_step, see below.
 // Trial states are written to the OTHER of two state buffers, so a rejected step needs no restore.
 #include "vs_internal.h"
 
@@ -37,7 +41,7 @@ constexpr int kPtThreads = 128; // threads per point block
 constexpr int kCamThreads = 256;
 constexpr int kSchurThreads = 256;
 constexpr int kSolveThreads = 512;
-constexpr int kMaxLdsN = 120;   // reduced systems up to 120 x 120 (20 free cameras) are factorised in LDS
+constexpr int kMaxLdsN = 126;   // reduced systems up to 126 x 126 (21 free cameras) are factorised in LDS by one wave
 constexpr int kMaxSlabN = 90;   // Schur slabs up to 90 x 90 (15 free cameras) live in LDS
 
 struct lm_state {
@@ -55,6 +59,7 @@ struct ba_dev {
   int ns, nb_pt, mmax, has_info, dups, max_it, lds_slab, pad0;
   double fx, fy, cx, cy, huber, dcs;
   const int *pose_slot, *pt_slot, *act_pt, *pt_start, *o_cam, *o_pt, *cam_start, *cam_obs;
+  const int *o_hpl, *fp_start, *fp_slot;  // Hpl block index of an observation (-1: none); per free point: its blocks
   const double *o_uv, *o_info;
   const int *sc_parent, *sc_child;
   const double* sc_meas;
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
             for (int l = 0; l < 3; ++l) H[3 * k + l] += E.Ji[0][k] * WJi[0][l] + E.Ji[1][k] * WJi[1][l];
           }
           if (cs >= 0) {
-            double* B = D.Hpl + 18 * (size_t)o;
+            double* B = D.Hpl + 18 * (size_t)D.o_hpl[o];
 #pragma unroll
             for (int k = 0; k < 6; ++k)
 #pragma unroll
@@ -463,7 +468,9 @@ __device__ inline void inv3(const double* Dm, double* inv) {
   inv[8] = (Dm[0] * Dm[4] - Dm[1] * Dm[3]) * id;
 }
 
-// dynamic LDS: [slab np*np + np doubles when LDS_SLAB] [Y mmax*18] [B mmax*18] [db 3 + Dinv 9 + pad] [slots mmax ints]
+// dynamic LDS: [slab np*np + np doubles when LDS_SLAB] [Dinv+db: per*12] [Y mmax*18] [B mmax*18] [slots mmax ints]
+// The Hpl blocks of a free point are contiguous (fp_start), so staging is one coalesced read without index chasing;
+// (Hll + lambda I)^-1 of all the slab's points is computed up front by one thread per point.
 template <bool LDS_SLAB>
 __global__ __launch_bounds__(kSchurThreads) void ba_schur(ba_dev D) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
@@ -471,66 +478,52 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur(ba_dev D) {
   if (st.done) return;
   const int np = D.np, tid = threadIdx.x;
   const int slab_elems = np * np + np;
+  const int per = (D.nfl + D.ns - 1) / D.ns;
   double* slab = LDS_SLAB ? s_mem : D.slab + (size_t)blockIdx.x * slab_elems;
-  double* sY = s_mem + (LDS_SLAB ? slab_elems : 0);
+  double* sDi = s_mem + (LDS_SLAB ? slab_elems : 0);  // [per][12]: Dinv (9) + Dinv*bl (3)
+  double* sY = sDi + (size_t)per * 12;
   double* sB = sY + D.mmax * 18;
-  double* sD = sB + D.mmax * 18;  // Dinv[9], db[3]
-  int* sSlot = reinterpret_cast<int*>(sD + 12);  // [2*mmax] (slot, obs) pairs, then the pair count
-  int& s_m = sSlot[2 * D.mmax];
+  int* sSlot = reinterpret_cast<int*>(sB + D.mmax * 18);
   for (int i = tid; i < slab_elems; i += kSchurThreads) slab[i] = 0.0;
   const double lambda = st.lambda;
-  // contiguous range of free points for this slab
-  const int per = (D.nfl + D.ns - 1) / D.ns;
   const int l0 = blockIdx.x * per, l1 = min(l0 + per, D.nfl);
+  for (int l = l0 + tid; l < l1; l += kSchurThreads) {
+    double Dm[9], inv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[9 * (size_t)l + k];
+    Dm[0] += lambda;
+    Dm[4] += lambda;
+    Dm[8] += lambda;
+    inv3(Dm, inv);
+    const double b0 = D.bl[3 * (size_t)l], b1 = D.bl[3 * (size_t)l + 1], b2 = D.bl[3 * (size_t)l + 2];
+    double* d = sDi + (size_t)(l - l0) * 12;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      d[k] = inv[k];
+      D.Dinv[9 * (size_t)l + k] = inv[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d[9 + k] = inv[3 * k] * b0 + inv[3 * k + 1] * b1 + inv[3 * k + 2] * b2;
+  }
   __syncthreads();
   for (int l = l0; l < l1; ++l) {
-    // active-point index of free point l: free points are a subset of the active list; host passes pt_start by
-    // active index, so walk through act index a = free2act[l], stored after the Dinv array start (see host)
-    const int a = reinterpret_cast<const int*>(D.Dinv + 9 * (size_t)D.nfl)[l];
-    const int o0 = D.pt_start[a], o1 = D.pt_start[a + 1];
-    if (tid == 0) {
-      double Dm[9];
-      for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[9 * (size_t)l + k];
-      Dm[0] += lambda;
-      Dm[4] += lambda;
-      Dm[8] += lambda;
-      double inv[9];
-      inv3(Dm, inv);
-      for (int k = 0; k < 9; ++k) {
-        sD[k] = inv[k];
-        D.Dinv[9 * (size_t)l + k] = inv[k];
-      }
-      for (int k = 0; k < 3; ++k)
-        sD[9 + k] = inv[3 * k] * D.bl[3 * (size_t)l] + inv[3 * k + 1] * D.bl[3 * (size_t)l + 1] +
-                    inv[3 * k + 2] * D.bl[3 * (size_t)l + 2];
-      int m = 0;
-      for (int o = o0; o < o1; ++o) {
-        const int cs = D.pose_slot[D.o_cam[o]];
-        if (cs >= 0) {
-          sSlot[2 * m] = cs;
-          sSlot[2 * m + 1] = o;
-          ++m;
-        }
-      }
-      s_m = m;
-    }
-    __syncthreads();
-    const int m = s_m;
-    // stage B_i and Y_i = B_i * Dinv
+    const int base = D.fp_start[l], m = D.fp_start[l + 1] - base;
+    const double* sD = sDi + (size_t)(l - l0) * 12;
     for (int i = tid; i < m * 18; i += kSchurThreads) {
       const int obs = i / 18, k = i - obs * 18;
       const int arow = k / 3, bcol = k - arow * 3;
-      const double* B = D.Hpl + 18 * (size_t)sSlot[2 * obs + 1];
+      const double* B = D.Hpl + 18 * (size_t)(base + obs);
       sB[i] = B[k];
       sY[i] = B[3 * arow] * sD[bcol] + B[3 * arow + 1] * sD[3 + bcol] + B[3 * arow + 2] * sD[6 + bcol];
     }
+    for (int i = tid; i < m; i += kSchurThreads) sSlot[i] = D.fp_slot[base + i];
     __syncthreads();
-    // rhs: b[ci] += B_i * db   (one thread per (obs, row); distinct cameras -> distinct elements)
+    // rhs: slab_b[ci] += B_i * (Dinv bl)   (one thread per (obs, row); distinct cameras -> distinct elements)
     for (int i = tid; i < m * 6; i += kSchurThreads) {
       const int obs = i / 6, arow = i - obs * 6;
       const double* B = sB + obs * 18 + 3 * arow;
       const double v = B[0] * sD[9] + B[1] * sD[10] + B[2] * sD[11];
-      double* dst = slab + np * np + 6 * sSlot[2 * obs] + arow;
+      double* dst = slab + np * np + 6 * sSlot[obs] + arow;
       if (D.dups) atomicAdd(dst, v);
       else *dst += v;
     }
@@ -543,7 +536,7 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur(ba_dev D) {
       const double* Y = sY + oi * 18 + 3 * arow;
       const double* B = sB + oj * 18 + 3 * bcol;
       const double v = Y[0] * B[0] + Y[1] * B[1] + Y[2] * B[2];
-      double* dst = slab + (size_t)(6 * sSlot[2 * oi] + arow) * np + 6 * sSlot[2 * oj] + bcol;
+      double* dst = slab + (size_t)(6 * sSlot[oi] + arow) * np + 6 * sSlot[oj] + bcol;
       if (D.dups) atomicAdd(dst, v);
       else *dst += v;
     }
@@ -564,7 +557,15 @@ __global__ __launch_bounds__(256) void ba_reduce(ba_dev D) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= slab_elems) return;
   double acc = 0.0;
-  for (int s = 0; s < D.ns; ++s) acc += D.slab[(size_t)s * slab_elems + i];
+  int s = 0;
+  for (; s + 8 <= D.ns; s += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = D.slab[(size_t)(s + u) * slab_elems + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; s < D.ns; ++s) acc += D.slab[(size_t)s * slab_elems + i];
   if (i < np * np) {
     const int r = i / np, c = i - r * np;
     double v = D.Hpp[i];
@@ -669,6 +670,113 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve(ba_dev D) {
   }
 }
 
+// Small systems (n <= 128): ONE wave factorises in LDS with no workgroup barriers at all.  Lane i owns rows i and i+64;
+// column j is finished by its owners, then every lane updates its own rows reading column j as LDS broadcasts.  The
+// subtraction order per element is the oracle's (k ascending).  Row stride is odd, so the 64 row-owners hit distinct banks.
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64) void ba_solve_wave(ba_dev D) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  lm_state* st = D.st;
+  if (st->done) return;
+  const int n = D.np, lane = threadIdx.x;
+  const int ld = n | 1;
+  double* A = s_mem;
+  double* x = s_mem + (size_t)n * ld;
+  for (int i = lane; i < n * n; i += 64) A[(i / n) * ld + (i % n)] = D.S[i];
+  for (int i = lane; i < n; i += 64) x[i] = D.bs[i];
+  wave_lds_sync();
+  int ok = 1;
+  for (int j = 0; j < n; ++j) {
+    const double d = A[j * ld + j];
+    if (!(d > 0.0)) {  // wave-uniform (broadcast read)
+      ok = 0;
+      break;
+    }
+    const double ljj = sqrt(d);
+    for (int i = lane; i < n; i += 64)
+      if (i > j) A[i * ld + j] = A[i * ld + j] / ljj;
+    if (lane == 0) A[j * ld + j] = ljj;
+    wave_lds_sync();
+    for (int i = lane; i < n; i += 64) {
+      if (i <= j) continue;
+      const double lij = A[i * ld + j];
+      double* row = A + i * ld;
+      int k = j + 1;
+      for (; k + 8 <= i + 1; k += 8) {  // 16 independent LDS reads in flight, then 8 stores
+        double cv[8], rv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          cv[u] = A[(k + u) * ld + j];
+          rv[u] = row[k + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) row[k + u] = rv[u] - lij * cv[u];
+      }
+      for (; k <= i; ++k) row[k] -= lij * A[k * ld + j];
+    }
+    wave_lds_sync();
+  }
+  if (ok) {
+    for (int k = 0; k < n; ++k) {
+      const double xk = x[k] / A[k * ld + k];
+      wave_lds_sync();  // every lane has read x[k] before its owner overwrites it
+      if (lane == 0) x[k] = xk;
+      for (int i = lane; i < n; i += 64)
+        if (i > k) x[i] -= A[i * ld + k] * xk;
+      wave_lds_sync();
+    }
+    for (int k = n - 1; k >= 0; --k) {
+      const double xk = x[k] / A[k * ld + k];
+      wave_lds_sync();
+      if (lane == 0) x[k] = xk;
+      for (int i = lane; i < k; i += 64) x[i] -= A[k * ld + i] * xk;
+      wave_lds_sync();
+    }
+    for (int i = lane; i < n; i += 64) D.xp[i] = x[i];
+  }
+  // trial camera states into the other buffer (SBACam::update), fixed cameras copied
+  const int cur = st->cur;
+  const double* c0 = D.cam[cur];
+  double* c1 = D.cam[cur ^ 1];
+  for (int p = lane; p < D.n_poses; p += 64) {
+    const double* src = c0 + (size_t)p * kCamStride;
+    double* dst = c1 + (size_t)p * kCamStride;
+    const int cs = D.pose_slot[p];
+    if (cs < 0 || !ok) {
+      for (int k = 0; k < kCamStride; ++k) dst[k] = src[k];
+    } else {
+      const double* d = x + 6 * cs;
+      double t[3] = {src[0] + d[0], src[1] + d[1], src[2] + d[2]};
+      const double bx = d[3], by = d[4], bz = d[5];
+      const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));  // NaN for an oversized step -> trial rejected
+      const double ax = src[3], ay = src[4], az = src[5], aw = src[6];
+      const double w = aw * bw - ax * bx - ay * by - az * bz;
+      const double xx = aw * bx + ax * bw + ay * bz - az * by;
+      const double yy = aw * by + ay * bw + az * bx - ax * bz;
+      const double zz = aw * bz + az * bw + ax * by - ay * bx;
+      const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
+      double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
+      for (int k = 0; k < 3; ++k) dst[k] = t[k];
+      for (int k = 0; k < 4; ++k) dst[3 + k] = q[k];
+      quat_to_w2n(t, q, dst + 7);
+    }
+  }
+  if (lane == 0) {
+    double sc = 0.0;
+    if (ok)
+      for (int j = 0; j < n; ++j) sc += x[j] * (st->lambda * x[j] + D.bp[j]);
+    st->scale_pose = sc;
+    st->solve_ok = ok;
+    st->trials += 1;
+    if (!ok) st->not_pd += 1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ trial + chi2
 __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
   __shared__ double s_red[kPtThreads];
@@ -690,7 +798,7 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
       for (int o = o0; o < o1; ++o) {
         const int cs = D.pose_slot[D.o_cam[o]];
         if (cs < 0) continue;
-        const double* B = D.Hpl + 18 * (size_t)o;
+        const double* B = D.Hpl + 18 * (size_t)D.o_hpl[o];
         const double* xc = D.xp + 6 * cs;
 #pragma unroll
         for (int b = 0; b < 3; ++b)
@@ -1137,13 +1245,12 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   // active points = free points (even without observations: they still receive the lambda damping) + fixed points
   // that are observed by a free camera.  Skipped points own no active observation, so the sorted observation ranges
   // of consecutive active points are adjacent: pt_start[a] = cnt[act_pt[a]], pt_start[n_act] = n_obs.
-  std::vector<int> act_pt, free2act(nfl ? nfl : 1);
+  std::vector<int> act_pt;
   int mmax = 1, dups = 0;
   for (int j = 0; j < P; ++j) {
     const int m = cnt[j + 1] - cnt[j];
     if (m == 0 && pt_slot[j] < 0) continue;
     if (pt_slot[j] >= 0) {
-      free2act[pt_slot[j]] = (int)act_pt.size();
       int mf = 0;
       for (int i = cnt[j]; i < cnt[j + 1]; ++i)
         if (pose_slot[p->obs_pose[order[i]]] >= 0) {
@@ -1168,6 +1275,22 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     if (cs >= 0) cam_obs[cfill[cs]++] = i;
   }
 
+  // Hpl blocks exist for observations whose point AND camera are free; they are stored contiguously per free point
+  std::vector<int> o_hpl(n_obs ? n_obs : 1, -1), fp_start(nfl + 1, 0), fp_slot;
+  for (int j = 0; j < P; ++j) {
+    if (pt_slot[j] < 0) continue;
+    fp_start[pt_slot[j]] = (int)fp_slot.size();
+    for (int i = cnt[j]; i < cnt[j + 1]; ++i) {
+      const int cs = pose_slot[p->obs_pose[order[i]]];
+      if (cs >= 0) {
+        o_hpl[i] = (int)fp_slot.size();
+        fp_slot.push_back(cs);
+      }
+    }
+  }
+  fp_start[nfl] = (int)fp_slot.size();
+  const int n_hpl = (int)fp_slot.size();
+
   // ---- motion-only fast path (block-diagonal problem): one launch per LM trial, one workgroup per free camera
   const bool motion_only = nfl == 0 && p->n_scale == 0 && nfp > 0 && p->max_iterations > 0;
 
@@ -1190,7 +1313,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
                                   2 * (size_t)np * np + 4 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
                                   9 * (size_t)nfl + (size_t)(ns ? ns : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
                                   2 * (size_t)q.max_iterations + 64) +
-                256 * 64 + (motion_only ? sizeof(double) * (8 * cam_obs.size() + 50 * (size_t)nfp + 64) : 0);
+                256 * 64 + sizeof(int) * (2 * (size_t)n_obs + nfl + 16) + (motion_only ? sizeof(double) * (8 * cam_obs.size() + 50 * (size_t)nfp + 64) : 0);
   VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, need));
   VS_HIP(ctx, hipStreamSynchronize(s));
@@ -1232,6 +1355,13 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.cam_obs = A.take<int>(cam_obs.size(), &h_cobs);
   D.sc_parent = A.take<int>(q.n_scale, &h_scp);
   D.sc_child = A.take<int>(q.n_scale, &h_scc);
+  int *h_ohpl, *h_fps, *h_fpl;
+  D.o_hpl = A.take<int>(n_obs, &h_ohpl);
+  D.fp_start = A.take<int>(nfl + 1, &h_fps);
+  D.fp_slot = A.take<int>(n_hpl, &h_fpl);
+  memcpy(h_ohpl, o_hpl.data(), sizeof(int) * (size_t)n_obs);
+  memcpy(h_fps, fp_start.data(), sizeof(int) * ((size_t)nfl + 1));
+  if (n_hpl) memcpy(h_fpl, fp_slot.data(), sizeof(int) * (size_t)n_hpl);
   D.o_uv = A.take<double>(2 * (size_t)n_obs, &h_uv);
   if (D.has_info) D.o_info = A.take<double>(3 * (size_t)n_obs, &h_info);
   D.sc_meas = A.take<double>(q.n_scale, &h_scm);
@@ -1246,11 +1376,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   }
   D.cam[0] = A.take<double>((size_t)F * kCamStride, &h_cam0);
   D.pts[0] = A.take<double>(3 * (size_t)P, &h_pts0);
-  // Dinv is followed by the free-point -> active-index table (read by ba_schur)
-  int* h_f2a;
-  double* h_dinv_dummy;
-  D.Dinv = A.take<double>(9 * (size_t)nfl + ((size_t)nfl + 1) / 2 + 1, &h_dinv_dummy);
-  h_f2a = reinterpret_cast<int*>(h_dinv_dummy + 9 * (size_t)nfl);
+  D.Dinv = A.take<double>(9 * (size_t)nfl);
   lm_state* h_st;
   D.st = A.take<lm_state>(1, &h_st);
   const size_t upload_bytes = A.off;
@@ -1261,7 +1387,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.bp = A.take<double>(np);
   D.Hll = A.take<double>(9 * (size_t)nfl);
   D.bl = A.take<double>(3 * (size_t)nfl);
-  D.Hpl = A.take<double>(18 * (size_t)n_obs);
+  D.Hpl = A.take<double>(18 * (size_t)n_hpl);
   D.slab = A.take<double>((size_t)(ns ? ns : 1) * slab_elems);
   D.S = A.take<double>((size_t)np * np);
   D.bs = A.take<double>(np);
@@ -1331,7 +1457,6 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     quat_to_w2n(c, c + 3, c + 7);
   }
   memcpy(h_pts0, q.points, sizeof(double) * 3 * (size_t)P);
-  for (int l = 0; l < nfl; ++l) h_f2a[l] = free2act[l];
   memset(h_st, 0, sizeof(lm_state));
   h_st->need_lin = 1;
   h_st->ni = 2.0;
@@ -1342,15 +1467,16 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   VS_HIP(ctx, hipMemcpyAsync(D.pts[1], D.pts[0], sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToDevice, s));
 
   // ---- kernels
-  const size_t schur_lds = sizeof(double) * ((lds_slab ? slab_elems : 0) + 36 * (size_t)mmax + 12) + sizeof(int) * (2 * (size_t)mmax + 1) + 16;
+  const int schur_per = ns > 0 ? (nfl + ns - 1) / ns : 0;
+  const size_t schur_lds = sizeof(double) * ((lds_slab ? slab_elems : 0) + 12 * (size_t)schur_per + 36 * (size_t)mmax) + sizeof(int) * ((size_t)mmax + 1) + 16;
   const bool solve_lds = np <= kMaxLdsN;
-  const size_t solve_lds_bytes = 16 + (solve_lds ? sizeof(double) * ((size_t)np * np + np) : 0);
+  const size_t solve_lds_bytes = 16 + (solve_lds ? sizeof(double) * ((size_t)np * (np | 1) + np) : 0);
   if (schur_lds > 64 * 1024) {
     if (lds_slab) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
     else VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
   }
   if (solve_lds_bytes > 64 * 1024)
-    VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes));
+    VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes));
   if (schur_lds > 160 * 1024) return vs_fail(ctx, VS_EINVAL, "%s: a point is observed by too many free cameras for the LDS staging", "vs_ba_solve");
 
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + sizeof(mo_state) + 128));
@@ -1371,7 +1497,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 255) / 256)), dim3(256), 0, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_reduce");
     }
-    if (solve_lds) hipLaunchKernelGGL(ba_solve<true>, dim3(1), dim3(kSolveThreads), solve_lds_bytes, s, D);
+    if (solve_lds) hipLaunchKernelGGL(ba_solve_wave, dim3(1), dim3(64), solve_lds_bytes, s, D);
     else hipLaunchKernelGGL(ba_solve<false>, dim3(1), dim3(kSolveThreads), solve_lds_bytes, s, D);
     VS_LAUNCH_CHECK(ctx, "ba_solve");
     hipLaunchKernelGGL(ba_point_trial, dim3(nb_pt), dim3(kPtThreads), 0, s, D);
