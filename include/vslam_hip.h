@@ -19,6 +19,7 @@
 #ifndef VSLAM_HIP_H
 #define VSLAM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -48,6 +49,12 @@ const char* vs_last_error(const vs_ctx* ctx);
 /* the context's hipStream_t as void* (so torch / RCCL work can be ordered against it) */
 void* vs_stream(vs_ctx* ctx);
 int vs_synchronize(vs_ctx* ctx);
+
+/* Pinned host memory (optional).  Host entry points accept any host pointer; when a frame lives in memory obtained
+ * here (or otherwise pinned) it is DMA-ed directly instead of going through the context's staging buffer.  In the
+ * reference the frame comes from cv2.imread (src/v2/frame.py:54); visual_slam_amd.frame.imread can decode into this. */
+int vs_host_alloc(vs_ctx* ctx, size_t bytes, void** out);
+int vs_host_free(vs_ctx* ctx, void* p);
 
 /* ---- A2: gray conversion ------------------------------------------------------------------------------------
  * replaces np.mean(img, axis=2).astype(np.uint8)            (src/v2/frame.py:11)

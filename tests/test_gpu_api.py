@@ -91,3 +91,35 @@ def test_sharded_matcher_world1_hip_path(vs, oracle):
         idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
     oidx, odist = oracle.hamming_knn2(q, t)
     assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+
+
+def test_descriptor_cache_never_serves_stale_data(vs, oracle):
+    """The host matcher keeps device copies keyed by (address, n, content fingerprint): in-place edits and buffer
+    re-use must still give the oracle's answer."""
+    q, t = match_workload(800, 700, seed=21)
+    a = vs.hamming_knn2(q, t)
+    assert np.array_equal(a[0], oracle.hamming_knn2(q, t)[0])
+    t[5] ^= 0xFF                      # same address, different content
+    q[::7] = np.roll(q[::7], 3, axis=1)
+    b = vs.hamming_knn2(q, t)
+    o = oracle.hamming_knn2(q, t)
+    assert np.array_equal(b[0], o[0]) and np.array_equal(b[1], o[1])
+    for seed in range(10):            # more sets than cache slots, all through the same two host buffers
+        q2, t2 = match_workload(800, 700, seed=100 + seed)
+        q[...] = q2
+        t[...] = t2
+        mq, mt, md = vs.match_ratio(q, t, 0.8)
+        oq, ot, od = oracle.match_ratio(q2, t2, 0.8)
+        assert np.array_equal(mq, oq) and np.array_equal(mt, ot) and np.array_equal(md, od)
+
+
+def test_pinned_frames_and_resident_descriptors(vs, oracle):
+    bgr = icl_frame(2)
+    pinned = vs.pin(bgr)
+    a = vs.detect_describe_bgr(pinned, 20, 3000)
+    b = oracle.detect_describe_bgr(bgr, 20, 3000)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    a2 = vs.detect_describe_bgr(icl_frame(3), 20, 3000)
+    mq, mt, md = vs.match_ratio(a[2], a2[2], 0.8)   # both descriptor sets are already resident on the device
+    oq, ot, od = oracle.match_ratio(b[2], oracle.detect_describe_bgr(icl_frame(3), 20, 3000)[2], 0.8)
+    assert np.array_equal(mq, oq) and np.array_equal(mt, ot) and np.array_equal(md, od)

@@ -52,6 +52,8 @@ SIGNATURES = {
     "vs_last_error": (C.c_char_p, [C.c_void_p]),
     "vs_stream": (C.c_void_p, [C.c_void_p]),
     "vs_synchronize": (C.c_int, [C.c_void_p]),
+    "vs_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vs_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "vs_gray_mean3_u8": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, c_u8p]),
     "vs_fast9_detect": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
                                   c_u8p, c_intp]),

@@ -17,10 +17,14 @@ class Context:
         if rc != 0:
             raise VsError(rc, self._lib.vs_last_error(None).decode())
         self._h = h
+        self._pinned = []
         self.device = int(device)
 
     def close(self):
         if getattr(self, "_h", None):
+            for p in self._pinned:  # arrays handed out by pinned_empty() must not be used after close()
+                self._lib.vs_host_free(self._h, p)
+            self._pinned = []
             self._lib.vs_destroy(self._h)
             self._h = None
 
@@ -86,7 +90,25 @@ class Context:
         n = C.c_int(0)
         self._chk(self._lib.vs_detect_describe_bgr(self._h, ptr(bgr, c_u8p), w, h, 3 * w, thr, max_kp, ptr(xy, c_f32p),
                                                    ptr(sc, c_u8p), ptr(desc, c_u8p), C.byref(n)))
-        return xy[:n.value].copy(), sc[:n.value].copy(), desc[:n.value].copy()
+        # views, not copies: the library remembers the device copy of `desc` by its host address + content fingerprint,
+        # so handing this very array to match_ratio / hamming_knn2 skips the upload
+        return xy[:n.value], sc[:n.value], desc[:n.value]
+
+    def pinned_empty(self, shape, dtype=np.uint8):
+        """NumPy array in pinned host memory (vs_host_alloc): frames placed here are DMA-ed without a staging copy."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        self._chk(self._lib.vs_host_alloc(self._h, nbytes, C.byref(p)))
+        self._pinned.append(p)
+        buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def pin(self, array):
+        """Copy of `array` in pinned host memory."""
+        out = self.pinned_empty(array.shape, array.dtype)
+        out[...] = array
+        return out
 
     # ------------------------------------------------------------------ matching (A5, A6)
     @staticmethod

@@ -59,7 +59,7 @@ struct ba_dev {
   int ns, nb_pt, mmax, has_info, dups, max_it, lds_slab, pad0;
   double fx, fy, cx, cy, huber, dcs;
   const int *pose_slot, *pt_slot, *act_pt, *pt_start, *o_cam, *o_pt, *cam_start, *cam_obs;
-  const int *o_hpl, *fp_start, *fp_slot;  // Hpl block index of an observation (-1: none); per free point: its blocks
+  const int *o_hpl, *fp_start, *fp_slot, *slot_pose;  // slot_pose[free camera slot] = pose index  // Hpl block index of an observation (-1: none); per free point: its blocks
   const double *o_uv, *o_info;
   const int *sc_parent, *sc_child;
   const double* sc_meas;
@@ -308,12 +308,7 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
   }
   // ---- camera role: free camera slot c
   const int c = blockIdx.x - D.nb_pt;
-  int pose = -1;
-  for (int i = 0; i < D.n_poses; ++i)  // tiny: poses are few
-    if (D.pose_slot[i] == c) {
-      pose = i;
-      break;
-    }
+  const int pose = D.slot_pose[c];
   const double* cam = cams + (size_t)pose * kCamStride;
   double acc[27];
 #pragma unroll
@@ -940,6 +935,30 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
   const double* prev_part = D.mo_part + (size_t)((step + 1) & 1) * 4 * nfp;
   double* my_part = D.mo_part + (size_t)(step & 1) * 4 * nfp;
 
+  // ---- everything whose ADDRESS does not depend on the decision is requested first, so that the launch pays one
+  // HBM/L2 round trip instead of four dependent ones (caches are cold after every kernel boundary): this thread's
+  // first observation, the stored normal equations, both state buffers' record of this camera
+  const int pose = D.slot_pose[c];
+  const int o0 = D.cam_start[c], o1 = D.cam_start[c + 1];
+  double* gH = D.mo_H + (size_t)c * 42;
+  double preX[3] = {0, 0, 0}, preUV[2] = {0, 0}, preW[3] = {1, 0, 1};
+  const int i_first = o0 + tid;
+  if (i_first < o1) {
+    preX[0] = D.mo_X[3 * (size_t)i_first];
+    preX[1] = D.mo_X[3 * (size_t)i_first + 1];
+    preX[2] = D.mo_X[3 * (size_t)i_first + 2];
+    preUV[0] = D.mo_uv[2 * (size_t)i_first];
+    preUV[1] = D.mo_uv[2 * (size_t)i_first + 1];
+    if (D.has_info) {
+      preW[0] = D.mo_info[3 * (size_t)i_first];
+      preW[1] = D.mo_info[3 * (size_t)i_first + 1];
+      preW[2] = D.mo_info[3 * (size_t)i_first + 2];
+    }
+  }
+  const double pre_gh = tid < 27 ? gH[tid] : 0.0;
+  const double pre_cam0 = tid < kCamStride ? D.cam[0][(size_t)pose * kCamStride + tid] : 0.0;
+  const double pre_cam1 = tid < kCamStride ? D.cam[1][(size_t)pose * kCamStride + tid] : 0.0;
+
   // ---- prologue: every workgroup derives the current LM state from the previous launch's state + partials
   if (tid == 0) s_st = g_state[(step + 1) & 1];
   __syncthreads();
@@ -1025,25 +1044,25 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
     return;
   }
 
-  // ---- this camera
-  int pose = -1;
-  for (int i = 0; i < D.n_poses; ++i)
-    if (D.pose_slot[i] == c) {
-      pose = i;
-      break;
-    }
-  const double* cam = D.cam[st.cur] + (size_t)pose * kCamStride;
-  const int o0 = D.cam_start[c], o1 = D.cam_start[c + 1];
-  double* gH = D.mo_H + (size_t)c * 42;
+  // ---- this camera (its current record goes to LDS from the preloaded registers)
+  __shared__ double s_cam[kCamStride];
+  if (tid < kCamStride) s_cam[tid] = st.cur ? pre_cam1 : pre_cam0;
+  __syncthreads();
+  const double* cam = s_cam;
+  const double* preInfo = D.has_info ? preW : nullptr;
   const bool lin_only = st.need_lin && st.it == 0 && st.stage == 0;
   if (st.need_lin) {
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-    for (int i = o0 + tid; i < o1; i += kMoThreads) {
-      const double X[3] = {D.mo_X[3 * (size_t)i], D.mo_X[3 * (size_t)i + 1], D.mo_X[3 * (size_t)i + 2]};
+    for (int i = i_first; i < o1; i += kMoThreads) {
       edge_t E;
-      eval_edge<true>(D, cam, X, D.mo_uv + 2 * (size_t)i, D.has_info ? D.mo_info + 3 * (size_t)i : nullptr, E);
+      if (i == i_first) {
+        eval_edge<true>(D, cam, preX, preUV, preInfo, E);
+      } else {
+        const double X[3] = {D.mo_X[3 * (size_t)i], D.mo_X[3 * (size_t)i + 1], D.mo_X[3 * (size_t)i + 2]};
+        eval_edge<true>(D, cam, X, D.mo_uv + 2 * (size_t)i, D.has_info ? D.mo_info + 3 * (size_t)i : nullptr, E);
+      }
       const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
       const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
       const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
@@ -1084,7 +1103,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
       return;
     }
   } else {
-    if (tid < 27) s_sum[tid] = gH[tid];
+    if (tid < 27) s_sum[tid] = pre_gh;
     __syncthreads();
   }
 
@@ -1107,14 +1126,16 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
       x[k] = s_sum[21 + k];
     }
     int ok = 1;
+    double rinv[6];  // 1 / L[j][j]: one division per pivot; the divisions by the pivot become multiplications
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const double d = A[j][j];
       if (!(d > 0.0)) ok = 0;
       const double ljj = sqrt(d);
       A[j][j] = ljj;
+      rinv[j] = 1.0 / ljj;
 #pragma unroll
-      for (int i = j + 1; i < 6; ++i) A[i][j] = A[i][j] / ljj;
+      for (int i = j + 1; i < 6; ++i) A[i][j] = A[i][j] * rinv[j];
 #pragma unroll
       for (int i = j + 1; i < 6; ++i)
 #pragma unroll
@@ -1122,13 +1143,13 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      x[k] = x[k] / A[k][k];
+      x[k] = x[k] * rinv[k];
 #pragma unroll
       for (int i = k + 1; i < 6; ++i) x[i] -= A[i][k] * x[k];
     }
 #pragma unroll
     for (int k = 5; k >= 0; --k) {
-      x[k] = x[k] / A[k][k];
+      x[k] = x[k] * rinv[k];
 #pragma unroll
       for (int i = 0; i < k; ++i) x[i] -= A[k][i] * x[k];
     }
@@ -1165,10 +1186,14 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
   const int ok = s_ok;
   __syncthreads();
   double chi = 0.0;
-  for (int i = o0 + tid; i < o1; i += kMoThreads) {
-    const double X[3] = {D.mo_X[3 * (size_t)i], D.mo_X[3 * (size_t)i + 1], D.mo_X[3 * (size_t)i + 2]};
+  for (int i = i_first; i < o1; i += kMoThreads) {
     edge_t E;
-    eval_edge<false>(D, tcam, X, D.mo_uv + 2 * (size_t)i, D.has_info ? D.mo_info + 3 * (size_t)i : nullptr, E);
+    if (i == i_first) {
+      eval_edge<false>(D, tcam, preX, preUV, preInfo, E);
+    } else {
+      const double X[3] = {D.mo_X[3 * (size_t)i], D.mo_X[3 * (size_t)i + 1], D.mo_X[3 * (size_t)i + 2]};
+      eval_edge<false>(D, tcam, X, D.mo_uv + 2 * (size_t)i, D.has_info ? D.mo_info + 3 * (size_t)i : nullptr, E);
+    }
     chi += E.rho0;
   }
   s_part[0][tid] = chi;
@@ -1355,6 +1380,10 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.cam_obs = A.take<int>(cam_obs.size(), &h_cobs);
   D.sc_parent = A.take<int>(q.n_scale, &h_scp);
   D.sc_child = A.take<int>(q.n_scale, &h_scc);
+  int* h_sp;
+  D.slot_pose = A.take<int>(nfp, &h_sp);
+  for (int i = 0; i < F; ++i)
+    if (pose_slot[i] >= 0) h_sp[pose_slot[i]] = i;
   int *h_ohpl, *h_fps, *h_fpl;
   D.o_hpl = A.take<int>(n_obs, &h_ohpl);
   D.fp_start = A.take<int>(nfl + 1, &h_fps);

@@ -20,9 +20,10 @@
 
 namespace {
 
-constexpr int kBand = 4;         // image rows per workgroup
+constexpr int kBand = 2;         // image rows per workgroup
 constexpr int kHalo = 4;         // 3 (circle radius) + 1 (NMS neighbour)
 constexpr int kDetThreads = 512; // 8 waves
+constexpr int kStageUnroll = 2; // staging groups per thread with their loads in flight together
 constexpr int kSelThreads = 256;
 constexpr int kMaxDim = 4096;    // x, y packed in 12 bits each
 
@@ -101,33 +102,61 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int y0 = blockIdx.x * kBand;
 
-  // ---- 1. stage gray rows y0-kHalo .. y0+kBand+kHalo-1 in LDS, 4 pixels per thread-iteration
+  // ---- 1. stage gray rows y0-kHalo .. y0+kBand+kHalo-1 in LDS, 4 pixels per group.  The global loads of up to
+  // kStageUnroll groups per thread are all issued before the first use (the frame is read once, at HBM latency).
   const int groups_per_row = w4 >> 2;
-  for (int g = tid; g < (kBand + 2 * kHalo) * groups_per_row; g += kDetThreads) {
-    const int r = g / groups_per_row, x = (g - r * groups_per_row) << 2;
-    const int y = y0 - kHalo + r;
-    uint32_t packed = 0;
-    if (y >= 0 && y < h) {
-      const uint8_t* row = img + (size_t)y * pitch;
-      if (FROM_BGR) {
-        // 4 pixels = 12 bytes = 3 aligned dwords (pitch % 4 == 0, x % 4 == 0); rows are padded to a dword
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(row + 3 * x);
-        uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-        uint32_t g0 = ((d0 & 255) + ((d0 >> 8) & 255) + ((d0 >> 16) & 255)) / 3u;
-        uint32_t g1 = ((d0 >> 24) + (d1 & 255) + ((d1 >> 8) & 255)) / 3u;
-        uint32_t g2 = (((d1 >> 16) & 255) + (d1 >> 24) + (d2 & 255)) / 3u;
-        uint32_t g3 = (((d2 >> 8) & 255) + ((d2 >> 16) & 255) + (d2 >> 24)) / 3u;
-        packed = g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
-      } else {
-        packed = *reinterpret_cast<const uint32_t*>(row + x);
-      }
-      if (WRITE_GRAY && r >= kHalo && r < kHalo + kBand) {  // interior rows are written exactly once
+  const int ngroups = (kBand + 2 * kHalo) * groups_per_row;
+  for (int g0 = 0; g0 < ngroups; g0 += kDetThreads * kStageUnroll) {
+    uint32_t d[kStageUnroll][3];
+    int lds_off[kStageUnroll];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (x + k < w) gray_out[(size_t)y * w + x + k] = (uint8_t)(packed >> (8 * k));
+    for (int u = 0; u < kStageUnroll; ++u) {
+      const int g = g0 + u * kDetThreads + tid;
+      lds_off[u] = -1;
+      d[u][0] = d[u][1] = d[u][2] = 0;
+      if (g < ngroups) {
+        const int r = g / groups_per_row, x = (g - r * groups_per_row) << 2;
+        const int y = y0 - kHalo + r;
+        lds_off[u] = r * P + x;
+        if (y >= 0 && y < h) {
+          const uint8_t* row = img + (size_t)y * pitch;
+          if (FROM_BGR) {
+            // 4 pixels = 12 bytes = 3 aligned dwords (pitch % 4 == 0, x % 4 == 0); rows are padded to a dword
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(row + 3 * x);
+            d[u][0] = p[0];
+            d[u][1] = p[1];
+            d[u][2] = p[2];
+          } else {
+            d[u][0] = *reinterpret_cast<const uint32_t*>(row + x);
+          }
+        }
       }
     }
-    *reinterpret_cast<uint32_t*>(s_gray + r * P + x) = packed;
+#pragma unroll
+    for (int u = 0; u < kStageUnroll; ++u) {
+      if (lds_off[u] < 0) continue;
+      uint32_t packed;
+      if (FROM_BGR) {
+        const uint32_t d0 = d[u][0], d1 = d[u][1], d2 = d[u][2];
+        const uint32_t g0_ = ((d0 & 255) + ((d0 >> 8) & 255) + ((d0 >> 16) & 255)) / 3u;
+        const uint32_t g1_ = ((d0 >> 24) + (d1 & 255) + ((d1 >> 8) & 255)) / 3u;
+        const uint32_t g2_ = (((d1 >> 16) & 255) + (d1 >> 24) + (d2 & 255)) / 3u;
+        const uint32_t g3_ = (((d2 >> 8) & 255) + ((d2 >> 16) & 255) + (d2 >> 24)) / 3u;
+        packed = g0_ | (g1_ << 8) | (g2_ << 16) | (g3_ << 24);
+      } else {
+        packed = d[u][0];
+      }
+      if (WRITE_GRAY) {
+        const int r = lds_off[u] / P, x = lds_off[u] - r * P;
+        const int y = y0 - kHalo + r;
+        if (r >= kHalo && r < kHalo + kBand && y < h) {  // interior rows are written exactly once
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (x + k < w) gray_out[(size_t)y * w + x + k] = (uint8_t)(packed >> (8 * k));
+        }
+      }
+      *reinterpret_cast<uint32_t*>(s_gray + lds_off[u]) = packed;
+    }
   }
   __syncthreads();
 
@@ -245,14 +274,17 @@ __device__ __forceinline__ int block_sum(int v, int* s_tmp /* >= 4 ints */) {
 __device__ __forceinline__ void brief_wave(const uint16_t* __restrict__ box, int w, int x, int y,
                                            uint8_t* __restrict__ out32, int lane) {
   unsigned long long* out = reinterpret_cast<unsigned long long*>(out32);
+  int a[4], b[4];
 #pragma unroll
-  for (int rnd = 0; rnd < 4; ++rnd) {
+  for (int rnd = 0; rnd < 4; ++rnd) {  // 8 independent gathers in flight
     const int8x4 t = c_brief[rnd * 64 + lane];
-    const int a = box[(size_t)(y + t.v[1]) * w + (x + t.v[0])];
-    const int b = box[(size_t)(y + t.v[3]) * w + (x + t.v[2])];
-    const unsigned long long m = __ballot(a < b);
-    if (lane == 0) out[rnd] = m;
+    a[rnd] = box[(size_t)(y + t.v[1]) * w + (x + t.v[0])];
+    b[rnd] = box[(size_t)(y + t.v[3]) * w + (x + t.v[2])];
   }
+  unsigned long long m[4];
+#pragma unroll
+  for (int rnd = 0; rnd < 4; ++rnd) m[rnd] = __ballot(a[rnd] < b[rnd]);
+  if (lane < 4) out[lane] = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
 }
 
 template <bool DO_BRIEF>
@@ -458,6 +490,11 @@ int check_image(vs_ctx* ctx, const void* img, int w, int h, int stride, int bpp,
 int upload_image(vs_ctx* ctx, vs_buf* dst, const uint8_t* src, int row_bytes, int h, int stride, int* pitch_out) {
   const int pitch = (row_bytes + 3) & ~3;
   VS_TRY(vs_reserve(ctx, dst, (size_t)pitch * h + 16));
+  if (stride == pitch && vs_is_pinned(src)) {  // caller's frame is pinned (vs_host_alloc): DMA it directly
+    VS_HIP(ctx, hipMemcpyAsync(dst->p, src, (size_t)pitch * (h - 1) + row_bytes, hipMemcpyHostToDevice, ctx->stream));
+    *pitch_out = pitch;
+    return VS_OK;
+  }
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, (size_t)pitch * h + 16));
   uint8_t* stage = (uint8_t*)ctx->h_pin_big.p;
   VS_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer may still feed an earlier copy
@@ -549,7 +586,11 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   if (n < 0 || n > cap) return vs_fail(ctx, VS_EHIP, "%s: device returned an impossible keypoint count", fn);
   memcpy(xy, hp + L.off_xy, (size_t)n * 8);
   if (score) memcpy(score, hp + L.off_score, (size_t)n);
-  if (describe) memcpy(desc, hp + L.off_desc, (size_t)n * VS_DESC_BYTES);
+  if (describe) {
+    memcpy(desc, hp + L.off_desc, (size_t)n * VS_DESC_BYTES);
+    // the matcher will be handed `desc` next: keep the device copy so it is not uploaded again
+    VS_TRY(vs_desc_adopt(ctx, desc, n, res + L.off_desc));
+  }
   *n_out = n;
   return VS_OK;
 }

@@ -15,6 +15,19 @@ struct vs_buf {
   size_t cap = 0;
 };
 
+// Device-resident copies of descriptor sets the host API has seen: keyed by host pointer + row count + a 64-bit
+// fingerprint of the contents (so a re-used or modified host buffer can never alias a stale copy).  A frame's
+// descriptors are uploaded once although they are matched many times (as train this frame, as the key frame's query
+// set for every following frame), and the descriptors vs_detect_describe_bgr just produced are never uploaded at all.
+struct vs_desc_entry {
+  const void* host = nullptr;
+  int n = 0;
+  uint64_t fp = 0;
+  vs_buf dev;
+  uint64_t stamp = 0;
+};
+constexpr int VS_DESC_CACHE = 6;
+
 struct vs_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -28,7 +41,18 @@ struct vs_ctx {
   vs_buf d_ba;      // one arena, carved per solve
   vs_buf h_pin;     // pinned staging (small read-backs)
   vs_buf h_pin_big; // pinned staging (frames, descriptors)
+  vs_desc_entry desc_cache[VS_DESC_CACHE];
+  uint64_t desc_stamp = 0;
 };
+
+uint64_t vs_fingerprint(const void* p, size_t bytes);
+// device copy of the n x 32-byte descriptor set at host pointer `h` (uploads on a miss); the returned pointer stays
+// valid until VS_DESC_CACHE other sets have been used
+int vs_desc_resident(vs_ctx* ctx, const uint8_t* h, int n, const void** dev_out);
+// registers a device-side descriptor set that is known to equal the host array `h` (detector output)
+int vs_desc_adopt(vs_ctx* ctx, const uint8_t* h, int n, const void* dev_src);
+// true if `p` is pinned (hipHostMalloc / hipHostRegister) host memory
+bool vs_is_pinned(const void* p);
 
 extern char g_vs_create_error[512];
 

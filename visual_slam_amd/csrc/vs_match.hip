@@ -400,25 +400,19 @@ VS_API int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* 
   return VS_OK;
 }
 
-static int upload_descriptors(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt) {
-  VS_TRY(vs_reserve(ctx, &ctx->d_q, (size_t)VS_DESC_BYTES * (nq > 0 ? nq : 1)));
-  VS_TRY(vs_reserve(ctx, &ctx->d_t, (size_t)VS_DESC_BYTES * nt));
-  if (nq > 0) VS_HIP(ctx, hipMemcpyAsync(ctx->d_q.p, q, (size_t)VS_DESC_BYTES * nq, hipMemcpyHostToDevice, ctx->stream));
-  VS_HIP(ctx, hipMemcpyAsync(ctx->d_t.p, t, (size_t)VS_DESC_BYTES * nt, hipMemcpyHostToDevice, ctx->stream));
-  return VS_OK;
-}
-
 VS_API int vs_hamming_knn2(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx,
                            int32_t* dist) {
   VS_TRY(check_args(ctx, q, nq, t, nt, "vs_hamming_knn2"));
   if (nq == 0) return VS_OK;
   if (!idx || !dist) return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_hamming_knn2");
   VS_HIP(ctx, hipSetDevice(ctx->device));
-  VS_TRY(upload_descriptors(ctx, q, nq, t, nt));
+  const void *dq, *dt;  // device-resident copies (uploaded only when this content has not been seen at this address)
+  VS_TRY(vs_desc_resident(ctx, q, nq, &dq));
+  VS_TRY(vs_desc_resident(ctx, t, nt, &dt));
   // results go to a private pair of buffers (d_mq/d_mt) so they never alias the ratio path's d_idx/d_dist
   VS_TRY(vs_reserve(ctx, &ctx->d_mq, sizeof(int2) * (size_t)nq));
   VS_TRY(vs_reserve(ctx, &ctx->d_mt, sizeof(int2) * (size_t)nq));
-  VS_TRY(vs_hamming_knn2_dev(ctx, ctx->d_q.p, nq, ctx->d_t.p, nt, ctx->d_mq.p, ctx->d_mt.p, ctx->stream));
+  VS_TRY(vs_hamming_knn2_dev(ctx, dq, nq, dt, nt, ctx->d_mq.p, ctx->d_mt.p, ctx->stream));
   VS_HIP(ctx, hipMemcpyAsync(idx, ctx->d_mq.p, sizeof(int2) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
   VS_HIP(ctx, hipMemcpyAsync(dist, ctx->d_mt.p, sizeof(int2) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
   VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -433,23 +427,24 @@ VS_API int vs_match_ratio(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t* 
   if (nq == 0) return VS_OK;
   if (!match_q || !match_t || !match_d) return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_match_ratio");
   VS_HIP(ctx, hipSetDevice(ctx->device));
-  VS_TRY(upload_descriptors(ctx, q, nq, t, nt));
-  VS_TRY(vs_reserve(ctx, &ctx->d_mq, sizeof(int32_t) * 2 * (size_t)nq));
-  VS_TRY(vs_reserve(ctx, &ctx->d_mt, sizeof(int32_t) * 2 * (size_t)nq));
-  VS_TRY(vs_reserve(ctx, &ctx->d_md, sizeof(int32_t) * (size_t)nq));
-  VS_TRY(vs_reserve(ctx, &ctx->d_cnt, sizeof(int32_t)));
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, 64));
-  VS_TRY(vs_match_ratio_dev(ctx, ctx->d_q.p, nq, ctx->d_t.p, nt, ratio, ctx->d_mq.p, ctx->d_mt.p, ctx->d_md.p,
-                            ctx->d_cnt.p, ctx->stream));
-  VS_HIP(ctx, hipMemcpyAsync(ctx->h_pin.p, ctx->d_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  const void *dq, *dt;
+  VS_TRY(vs_desc_resident(ctx, q, nq, &dq));
+  VS_TRY(vs_desc_resident(ctx, t, nt, &dt));
+  // one device block [count (16 B) | match_q | match_t | match_d], copied back in one piece: one synchronisation
+  const size_t row = (sizeof(int32_t) * (size_t)nq + 15) & ~(size_t)15;
+  const size_t bytes = 16 + 3 * row;
+  VS_TRY(vs_reserve(ctx, &ctx->d_mq, bytes));
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, bytes));
+  uint8_t* blk = (uint8_t*)ctx->d_mq.p;
+  VS_TRY(vs_match_ratio_dev(ctx, dq, nq, dt, nt, ratio, blk + 16, blk + 16 + row, blk + 16 + 2 * row, blk, ctx->stream));
+  VS_HIP(ctx, hipMemcpyAsync(ctx->h_pin.p, blk, bytes, hipMemcpyDeviceToHost, ctx->stream));
   VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  const int n = *(int32_t*)ctx->h_pin.p;
-  if (n > 0) {
-    VS_HIP(ctx, hipMemcpyAsync(match_q, ctx->d_mq.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    VS_HIP(ctx, hipMemcpyAsync(match_t, ctx->d_mt.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    VS_HIP(ctx, hipMemcpyAsync(match_d, ctx->d_md.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
+  const uint8_t* hp = (const uint8_t*)ctx->h_pin.p;
+  const int n = *(const int32_t*)hp;
+  if (n < 0 || n > nq) return vs_fail(ctx, VS_EHIP, "%s: device returned an impossible match count", "vs_match_ratio");
+  memcpy(match_q, hp + 16, sizeof(int32_t) * (size_t)n);
+  memcpy(match_t, hp + 16 + row, sizeof(int32_t) * (size_t)n);
+  memcpy(match_d, hp + 16 + 2 * row, sizeof(int32_t) * (size_t)n);
   *n_out = n;
   return VS_OK;
 }

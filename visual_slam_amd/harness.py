@@ -108,6 +108,7 @@ def bench_frames(ctx, repeats=5):
     """frames/s of the 20-frame ICL-NUIM stream through the host C ABI (PNG decode excluded, H2D copies included).
     Returns (report dict, poses) -- bench.py times the CPU oracle through track_sequence() for the comparison."""
     frames, depth0 = load_sequence(20)
+    frames = [ctx.pin(f) for f in frames]  # decoded frames live in pinned memory: H2D is a plain DMA
     det, mat, ba = gpu_callables(ctx)
     track_sequence(det, mat, ba, frames[:4], depth0)  # warm-up (allocations, code objects)
     best = None
