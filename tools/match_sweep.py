@@ -16,7 +16,7 @@ from visual_slam_amd.workloads import match_workload  # noqa: E402
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 nt = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3").split(",")]
-blocks = [int(v) for v in os.environ.get("BLOCKS", "256,512,1024,2048").split(",")]
+blocks = [int(v) for v in os.environ.get("BLOCKS", "0,1024,2048,4096").split(",")]
 ctx = Context(0)
 lib = _capi.load()
 lib.vs_match_set_variant.restype = C.c_int

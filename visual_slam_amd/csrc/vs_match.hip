@@ -245,7 +245,7 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int2* __restr
   if (threadIdx.x == 0) *n_out = running;
 }
 
-int g_target_blocks = 1024;  // ~4 workgroups (16 waves) per CU
+int g_target_blocks = 0;     // 0: automatic plan (plan_chunks); > 0: fixed number of workgroups (tuning hook)
 
 // optional per-kernel timing (bench.py): hipEvents on the launch stream around the two kernels of each call
 bool g_profile = false;
@@ -268,13 +268,35 @@ const variant_t kVariants[] = {
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
-// chunk_len trains per workgroup (split into kWaves sub-ranges of sub_len), nchunks workgroups along y
+// chunk_len trains per workgroup (split into kWaves sub-ranges of sub_len), nchunks workgroups along y.
+// Automatic plan (g_target_blocks == 0): pick the number of train chunks that minimises
+//     ceil(workgroups / 256 CUs) * chunk_len  +  merge cost per chunk
+// over plans with 1000..4600 workgroups -- the first term is the busiest CU's share of train rows (workgroups are
+// spread round-robin, 4..16 resident per CU), the second the extra partial rows the merge kernel folds.  At 10k x 10k
+// this gives 25 chunks x 40 query tiles = 1000 workgroups, at 100k x 100k 11 x 391 = 4301 (98.8 % balanced; a fixed
+// 1024-workgroup plan loses 25 % there to 4-vs-3 workgroups per CU).
 void plan_chunks(int nq, int nt, int* chunk_len, int* sub_len, int* nchunks) {
   const variant_t& v = kVariants[g_variant];
   const int qtiles = (nq + 64 * v.qpl - 1) / (64 * v.qpl);
-  int nch = g_target_blocks / (qtiles > 0 ? qtiles : 1);
+  const int q1 = qtiles > 0 ? qtiles : 1;
+  long nch = 1;
+  if (g_target_blocks > 0) {
+    nch = g_target_blocks / q1;
+  } else {
+    const long lo = (1000 + q1 - 1) / q1, hi = 4600 / q1 > lo ? 4600 / q1 : lo;
+    double best = 1e300;
+    for (long c = lo; c <= hi; ++c) {
+      const long len = (nt + c - 1) / c;
+      if (len < 32 && c > lo) break;
+      const double cost = (double)((q1 * c + 255) / 256) * (double)len + (double)c * 4.6 * (double)q1 / 40.0;
+      if (cost < best) {
+        best = cost;
+        nch = c;
+      }
+    }
+  }
   if (nch < 1) nch = 1;
-  long len = (nt + (long)nch - 1) / nch;
+  long len = (nt + nch - 1) / nch;
   long sub = (len + kWaves - 1) / kWaves;
   sub = (sub + v.tu - 1) / v.tu * v.tu;
   if (sub < 2 * v.tu) sub = 2 * v.tu;
@@ -299,7 +321,7 @@ int check_args(vs_ctx* ctx, const void* q, int nq, const void* t, int nt, const 
 
 // tuning hook for bench sweeps (not part of the stable ABI)
 VS_API int vs_match_set_target_blocks(int blocks) {
-  if (blocks > 0) g_target_blocks = blocks;
+  if (blocks >= 0) g_target_blocks = blocks;
   return g_target_blocks;
 }
 VS_API int vs_match_set_variant(int v) {

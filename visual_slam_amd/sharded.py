@@ -195,6 +195,16 @@ class ShardedMatcher:
                 h.wait()
         return out[:n_query, 0:2], out[:n_query, 2:4]
 
+    def close(self):
+        """Destroy the direct RCCL communicator (if one was created)."""
+        if self._rccl is not None:
+            try:
+                import torch
+                torch.cuda.synchronize()
+                self._rccl.close()
+            finally:
+                self._rccl = None
+
     def knn2(self, query, train):
         """query: the FULL query set (replicated input, as the reference's caller holds it); returns full results."""
         nq = query.shape[0]
