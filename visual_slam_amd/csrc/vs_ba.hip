@@ -20,7 +20,7 @@
 //                     Y_i = Hpl_i Dinv staged in LDS and every thread owns fixed elements of the 6x6 products Y_i Hpl_j^T,
 //                     accumulated into the workgroup's LDS slab of the reduced camera system (no float atomics)
 //   ba_reduce         S = Hpp + lambda I - sum of slabs, rhs likewise (one thread per matrix element)
-//   ba_solve_wave     one wave: dense Cholesky of S in LDS (n <= 126; ba_solve<false> in HBM beyond), triangular solves,
+//   ba_solve_block    one workgroup: dense Cholesky of [S | rhs] in LDS (n <= 126; ba_solve<false> in HBM beyond), back-substitution,
 //                     trial camera states
 //   ba_point_trial    thread = point: back-substitution x_l = Dinv (bl - sum Hpl^T x_p), trial point, robust chi2 of the
 //                     trial state, fixed-order block reduction
@@ -665,80 +665,82 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve(ba_dev D) {
   }
 }
 
-// Small systems (n <= 128): ONE wave factorises in LDS with no workgroup barriers at all.  Lane i owns rows i and i+64;
-// column j is finished by its owners, then every lane updates its own rows reading column j as LDS broadcasts.  The
-// subtraction order per element is the oracle's (k ascending).  Row stride is odd, so the 64 row-owners hit distinct banks.
+// Small systems (n <= 126): one 256-thread workgroup factorises in LDS.
+//   * the right-hand side is appended as row n of the matrix, so the forward substitution L y = b happens inside the
+//     factorisation (row n receives exactly the updates of a matrix row) -- no separate sequential pass
+//   * 1/L[j][j] from v_rsq_f64 + two Newton steps (one correction for L[j][j] itself): the per-column dependent chain
+//     has no IEEE sqrt/divide sequence in it; the results differ from the oracle's sqrt/divide by <= 2 ulp
+//   * the trailing update is tiled 16 x 16 over the threads (no integer division in the loop), column j is read as
+//     LDS broadcasts; row stride is odd so the 16 row-owners of a tile hit distinct banks
+//   * the backward substitution L^T x = y runs on wave 0 alone, wave-synchronously
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(64) void ba_solve_wave(ba_dev D) {
+constexpr int kSolveBlock = 256;
+
+__global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   lm_state* st = D.st;
   if (st->done) return;
-  const int n = D.np, lane = threadIdx.x;
-  const int ld = n | 1;
-  double* A = s_mem;
-  double* x = s_mem + (size_t)n * ld;
-  for (int i = lane; i < n * n; i += 64) A[(i / n) * ld + (i % n)] = D.S[i];
-  for (int i = lane; i < n; i += 64) x[i] = D.bs[i];
-  wave_lds_sync();
+  const int n = D.np, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int ld = (n + 1) | 1;
+  double* A = s_mem;                        // (n + 1) rows of ld: rows 0..n-1 matrix, row n = rhs
+  double* rinv = s_mem + (size_t)(n + 1) * ld;  // [n]
+  int* s_flag = reinterpret_cast<int*>(rinv + n + 1);
+  for (int r = ty; r < n; r += 16)
+    for (int c = tx; c < n; c += 16) A[r * ld + c] = D.S[(size_t)r * n + c];
+  for (int c = tid; c < n; c += kSolveBlock) A[n * ld + c] = D.bs[c];
+  if (tid == 0) *s_flag = 0;
+  __syncthreads();
   int ok = 1;
   for (int j = 0; j < n; ++j) {
     const double d = A[j * ld + j];
-    if (!(d > 0.0)) {  // wave-uniform (broadcast read)
+    if (!(d > 0.0)) {  // uniform: every thread reads the same LDS word
       ok = 0;
       break;
     }
-    const double ljj = sqrt(d);
-    for (int i = lane; i < n; i += 64)
-      if (i > j) A[i * ld + j] = A[i * ld + j] / ljj;
-    if (lane == 0) A[j * ld + j] = ljj;
-    wave_lds_sync();
-    for (int i = lane; i < n; i += 64) {
-      if (i <= j) continue;
+    double r = __builtin_amdgcn_rsq(d);
+    r = r * (1.5 - 0.5 * d * r * r);
+    r = r * (1.5 - 0.5 * d * r * r);
+    double l = d * r;
+    l = l + 0.5 * r * (d - l * l);
+    __syncthreads();  // everyone has read A[j][j] before it is overwritten
+    for (int i = j + 1 + tid; i <= n; i += kSolveBlock) A[i * ld + j] *= r;
+    if (tid == 0) {
+      A[j * ld + j] = l;
+      rinv[j] = r;
+    }
+    __syncthreads();
+    for (int i = j + 1 + ty; i <= n; i += 16) {
       const double lij = A[i * ld + j];
+      const int kmax = i < n ? i : n - 1;  // the rhs row n has no diagonal element
       double* row = A + i * ld;
-      int k = j + 1;
-      for (; k + 8 <= i + 1; k += 8) {  // 16 independent LDS reads in flight, then 8 stores
-        double cv[8], rv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          cv[u] = A[(k + u) * ld + j];
-          rv[u] = row[k + u];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) row[k + u] = rv[u] - lij * cv[u];
-      }
-      for (; k <= i; ++k) row[k] -= lij * A[k * ld + j];
+      for (int k = j + 1 + tx; k <= kmax; k += 16) row[k] -= lij * A[k * ld + j];
     }
-    wave_lds_sync();
+    __syncthreads();
   }
-  if (ok) {
-    for (int k = 0; k < n; ++k) {
-      const double xk = x[k] / A[k * ld + k];
-      wave_lds_sync();  // every lane has read x[k] before its owner overwrites it
-      if (lane == 0) x[k] = xk;
-      for (int i = lane; i < n; i += 64)
-        if (i > k) x[i] -= A[i * ld + k] * xk;
-      wave_lds_sync();
-    }
+  // backward substitution on wave 0: x lives in row n
+  double* x = A + n * ld;
+  if (ok && tid < 64) {
     for (int k = n - 1; k >= 0; --k) {
-      const double xk = x[k] / A[k * ld + k];
-      wave_lds_sync();
-      if (lane == 0) x[k] = xk;
-      for (int i = lane; i < k; i += 64) x[i] -= A[k * ld + i] * xk;
+      const double xk = x[k] * rinv[k];
+      wave_lds_sync();  // every lane has read x[k] before lane 0 overwrites it
+      if (tid == 0) x[k] = xk;
+      for (int i = tid; i < k; i += 64) x[i] -= A[k * ld + i] * xk;
       wave_lds_sync();
     }
-    for (int i = lane; i < n; i += 64) D.xp[i] = x[i];
   }
+  __syncthreads();
+  if (ok)
+    for (int i = tid; i < n; i += kSolveBlock) D.xp[i] = x[i];
   // trial camera states into the other buffer (SBACam::update), fixed cameras copied
   const int cur = st->cur;
   const double* c0 = D.cam[cur];
   double* c1 = D.cam[cur ^ 1];
-  for (int p = lane; p < D.n_poses; p += 64) {
+  for (int p = tid; p < D.n_poses; p += kSolveBlock) {
     const double* src = c0 + (size_t)p * kCamStride;
     double* dst = c1 + (size_t)p * kCamStride;
     const int cs = D.pose_slot[p];
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(64) void ba_solve_wave(ba_dev D) {
       quat_to_w2n(t, q, dst + 7);
     }
   }
-  if (lane == 0) {
+  if (tid == 0) {
     double sc = 0.0;
     if (ok)
       for (int j = 0; j < n; ++j) sc += x[j] * (st->lambda * x[j] + D.bp[j]);
@@ -1499,13 +1501,13 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   const int schur_per = ns > 0 ? (nfl + ns - 1) / ns : 0;
   const size_t schur_lds = sizeof(double) * ((lds_slab ? slab_elems : 0) + 12 * (size_t)schur_per + 36 * (size_t)mmax) + sizeof(int) * ((size_t)mmax + 1) + 16;
   const bool solve_lds = np <= kMaxLdsN;
-  const size_t solve_lds_bytes = 16 + (solve_lds ? sizeof(double) * ((size_t)np * (np | 1) + np) : 0);
+  const size_t solve_lds_bytes = 32 + (solve_lds ? sizeof(double) * ((size_t)(np + 1) * ((np + 1) | 1) + np + 2) : 0);
   if (schur_lds > 64 * 1024) {
     if (lds_slab) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
     else VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
   }
   if (solve_lds_bytes > 64 * 1024)
-    VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes));
+    VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes));
   if (schur_lds > 160 * 1024) return vs_fail(ctx, VS_EINVAL, "%s: a point is observed by too many free cameras for the LDS staging", "vs_ba_solve");
 
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + sizeof(mo_state) + 128));
@@ -1526,7 +1528,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 255) / 256)), dim3(256), 0, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_reduce");
     }
-    if (solve_lds) hipLaunchKernelGGL(ba_solve_wave, dim3(1), dim3(64), solve_lds_bytes, s, D);
+    if (solve_lds) hipLaunchKernelGGL(ba_solve_block, dim3(1), dim3(kSolveBlock), solve_lds_bytes, s, D);
     else hipLaunchKernelGGL(ba_solve<false>, dim3(1), dim3(kSolveThreads), solve_lds_bytes, s, D);
     VS_LAUNCH_CHECK(ctx, "ba_solve");
     hipLaunchKernelGGL(ba_point_trial, dim3(nb_pt), dim3(kPtThreads), 0, s, D);
