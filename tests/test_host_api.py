@@ -134,3 +134,115 @@ def test_ba_api_edge_cases(capsys):
         ba.add_edge_between_poses(0, 1, np.eye(4))
     ba.optimize()  # no poses: nothing to do
     assert ba.result is None
+
+
+# ---------------------------------------------------------------------------------------------- SoA mirror of the map
+def _tracking_map(w, seed=0):
+    """A local map built through the calls main.py makes: points created with their first observation attached, then
+    per-frame AddParentAndPose + AddPointToFrameCorrespondences batches."""
+    rng = np.random.default_rng(seed)
+    m = Map()
+    frames = [_frame(i, w["poses"][i], key=(i == 0)) for i in range(len(w["poses"]))]
+    m.AddFrame(0, frames[0])
+    per_frame = {i: [] for i in range(len(frames))}
+    for c, p, uv in zip(w["obs_pose"], w["obs_point"], w["obs_uv"]):
+        per_frame[int(c)].append((int(p) + 1, uv.astype(np.float32)))
+    for pid, uv in per_frame[0]:
+        pt = Point(w["points"][pid - 1].copy(), pid)
+        pt.AddFrame(frames[0], uv, rng.integers(0, 256, 32, dtype=np.uint8))
+        m.AddPoint3D(pid, pt)
+    for i in range(1, len(frames)):
+        m.AddParentAndPose(parent_id=i - 1, frame_id=i, frame_obj=frames[i], rel_pose_trans=np.eye(4), pose=w["poses"][i])
+        obs = [(pid, uv) for pid, uv in per_frame[i] if pid in m.points_3d]
+        m.AddPointToFrameCorrespondences([o[0] for o in obs], np.array([o[1] for o in obs]),
+                                         rng.integers(0, 256, (len(obs), 32), dtype=np.uint8), frames[i])
+    return m
+
+
+def _poses(m):
+    return np.stack([m.GetFrame(i).GetPose() for i in m.frames])
+
+
+def test_soa_paths_equal_the_reference_double_loop(oracle):
+    w = ba_workload(n_cams=5, n_points=70, seed=41, visibility=0.7)
+    for method, kw in (("motionOnlyBundleAdjustement", {}), ("localBundleAdjustement", {}),
+                       ("localBundleAdjustement", {"scale": True})):
+        a, b = _tracking_map(w), _tracking_map(w)
+        fast = BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve)
+        slow = BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve, use_soa=False)
+        getattr(fast, method)(a, **kw)
+        getattr(slow, method)(b, **kw)
+        assert isinstance(fast._obs_pose, np.ndarray) and isinstance(slow._obs_pose, list)  # both paths really ran
+        assert np.array_equal(np.asarray(fast._obs_pose), np.asarray(slow._obs_pose))
+        assert np.array_equal(np.asarray(fast._obs_point), np.asarray(slow._obs_point))
+        assert np.array_equal(np.asarray(fast._obs_uv), np.stack(slow._obs_uv))
+        assert np.array_equal(_poses(a), _poses(b)) and np.array_equal(a.GetAll3DPoints(), b.GetAll3DPoints())
+        assert fast.get_point(3).tolist() == slow.get_point(3).tolist()
+
+
+def test_soa_image_points_query_equals_object_walk():
+    w = ba_workload(n_cams=4, n_points=50, seed=43, visibility=0.6)
+    m = _tracking_map(w)
+    for fid in (0, 2, 3, 9):
+        uv, desc, xyz, ids = m.GetImagePointsWithFrameID(fid)
+        m2 = _tracking_map(w)
+        m2._soa.n_obs = -1  # break the mirror: the object walk answers, after a rebuild without usable descriptors?
+        ruv, rdesc, rxyz, rids = [], [], [], []
+        for p in m2.points_3d.values():
+            hit = p.frames.get(fid)
+            if hit is not None:
+                ruv.append(hit[1]); rdesc.append(hit[2]); rxyz.append(p.location_3d); rids.append(p.ID)
+        assert np.array_equal(ids, np.array(rids)) and np.array_equal(np.asarray(uv), np.array(ruv).reshape(-1, 2) if ruv else np.array(ruv))
+        if ruv:
+            assert np.array_equal(desc, np.array(rdesc)) and np.array_equal(xyz, np.array(rxyz)) and uv.dtype == np.float32
+
+
+def test_soa_survives_edits_behind_the_maps_back(oracle):
+    w = ba_workload(n_cams=4, n_points=40, seed=45, visibility=0.8)
+    a, b = _tracking_map(w), _tracking_map(w)
+    for m in (a, b):
+        m.soa()                                                  # mirror built and valid
+        p = m.GetPoint(5)
+        p.AddFrame(m.GetFrame(3), np.array([123.0, 45.0], np.float32), np.zeros(32, np.uint8))  # direct edit (re-observation or new)
+        m.GetPoint(7).UpdatePoint(np.array([0.1, 0.2, 4.0]))      # xyz rebinding
+        m.UpdatePoint3D(np.array([0.3, -0.2, 3.5]), 9)
+        m.DiscardOutlierMapPoints(n_visible_frames=2)            # new dict object
+        extra = Point(np.array([0.0, 0.0, 5.0]), 999)
+        extra.AddFrame(m.GetFrame(1), np.array([300.0, 200.0], np.float32), np.zeros(32, np.uint8))
+        m.Store3DPoints({999: extra})
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve).motionOnlyBundleAdjustement(a)
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve, use_soa=False).motionOnlyBundleAdjustement(b)
+    assert np.array_equal(_poses(a), _poses(b))
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve).localBundleAdjustement(a)
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve, use_soa=False).localBundleAdjustement(b)
+    assert np.array_equal(_poses(a), _poses(b)) and np.array_equal(a.GetAll3DPoints(), b.GetAll3DPoints())
+
+
+def test_local_map_copy_uses_only_frames_present_in_the_map(oracle):
+    """main.py:333-345: the local map holds copies of the points with only the key frame's observation."""
+    w = ba_workload(n_cams=4, n_points=40, seed=47)
+    g = _tracking_map(w)
+    local_a, local_b = Map(), Map()
+    for lm in (local_a, local_b):
+        kf = g.GetFrame(0)
+        lm.AddFrame(0, kf)
+        lm.Store3DPoints(g.GetCopyOfPointObjects(0))
+        f = _frame(1, w["poses"][1])
+        lm.AddParentAndPose(parent_id=0, frame_id=1, frame_obj=f, rel_pose_trans=np.eye(4), pose=w["poses"][1])
+        uv, desc, xyz, ids = lm.GetImagePointsWithFrameID(0)
+        lm.AddPointToFrameCorrespondences(ids[::2], uv[::2] + 1.5, desc[::2], f)
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve).motionOnlyBundleAdjustement(local_a)
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve, use_soa=False).motionOnlyBundleAdjustement(local_b)
+    assert np.array_equal(_poses(local_a), _poses(local_b))
+    assert not np.array_equal(local_a.GetFrame(1).GetPose(), w["poses"][1])
+
+
+def test_soa_notices_an_overwritten_observation(oracle):
+    w = ba_workload(n_cams=3, n_points=30, seed=49)
+    a, b = _tracking_map(w), _tracking_map(w)
+    for m in (a, b):
+        m.soa()
+        m.GetPoint(4).AddFrame(m.GetFrame(2), np.array([50.0, 60.0], np.float32), np.zeros(32, np.uint8))  # same count
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve).motionOnlyBundleAdjustement(a)
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve, use_soa=False).motionOnlyBundleAdjustement(b)
+    assert np.array_equal(_poses(a), _poses(b))

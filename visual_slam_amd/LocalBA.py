@@ -67,9 +67,10 @@ _DCS_DEFAULT = RobustKernelDCS()
 
 
 class BundleAdjustment:
-    def __init__(self, camera, context=None, solver=None):
+    def __init__(self, camera, context=None, solver=None, use_soa=True):
         """camera: Camera(fx, fy, cx, cy).  `solver` (tests only) replaces the GPU call with a callable of the same
-        signature as Context.ba_solve."""
+        signature as Context.ba_solve; use_soa=False forces the reference's per-edge graph construction."""
+        self._use_soa = bool(use_soa)
         self.focal_length = (camera.fx, camera.fy)
         self.principal_point = (camera.cx, camera.cy)
         self.baseline = 0
@@ -161,14 +162,19 @@ class BundleAdjustment:
             from .context import default_context
             solver = (self._ctx or default_context()).ba_solve
         n_obs = len(self._obs_pose)
+        points = self._points if isinstance(self._points, np.ndarray) else (
+            np.stack(self._points) if self._points else np.zeros((0, 3)))
+        uv = self._obs_uv if isinstance(self._obs_uv, np.ndarray) else (
+            np.stack(self._obs_uv) if n_obs else np.zeros((0, 2)))
         self.result = solver(
             np.stack(self._poses), np.asarray(self._pose_fixed, np.uint8),
-            np.stack(self._points) if self._points else np.zeros((0, 3)), np.asarray(self._point_fixed, np.uint8),
+            points, np.asarray(self._point_fixed, np.uint8),
             np.asarray(self._obs_pose, np.int32), np.asarray(self._obs_point, np.int32),
-            np.stack(self._obs_uv) if n_obs else np.zeros((0, 2)), (self.fx, self.fy, self.cx, self.cy),
+            uv, (self.fx, self.fy, self.cx, self.cy),
             huber_delta=self._huber if self._huber else 0.0, max_iterations=max_iterations,
             scale_edges=(self._scale_parent, self._scale_child, self._scale_meas) if self._scale_parent else None,
-            obs_info=None if self._info_is_identity else np.asarray(self._obs_info, np.float64), dcs_phi=self._dcs)
+            obs_info=None if (self._info_is_identity or not len(self._obs_info)) else np.asarray(self._obs_info, np.float64),
+            dcs_phi=self._dcs)
 
     def save_to_file(self, filename):
         """Text dump in g2o's vocabulary (LocalBA.py:44-45); poses as translation + unit quaternion."""
@@ -203,6 +209,45 @@ class BundleAdjustment:
         i = self._point_ids[point_id]
         return np.array(self.result["points"][i] if self.result is not None else self._points[i])
 
+    # ------------------------------------------------------------------ SoA graph construction
+    def _graph_from_soa(self, map, frame_fixed, points_fixed, with_scale_edges):
+        """Builds the same problem as the reference's P x F double loop (LocalBA.py:164-172 / 207-214) from the map's
+        structure-of-arrays mirror: poses in map.frames order, points in map.points_3d order, edges point-major then
+        frame order -- identical arrays, no per-observation Python.  Returns False when the map has no mirror."""
+        if not self._use_soa or not hasattr(map, "soa") or self._poses or len(self._points) or len(self._obs_pose):
+            return False
+        s = map.soa()
+        frame_ids = list(map.frames.keys())
+        for frame_id in frame_ids:
+            frame_obj = map.frames[frame_id]
+            self.add_pose(pose_id=frame_id, pose=frame_obj.GetPose(), fixed=frame_fixed(frame_id, frame_obj))
+            if with_scale_edges and frame_id != 0:
+                for parent_ID in frame_obj.GetParentIDs():
+                    self.AddScalingEdge(parent_id=parent_ID, child_id=frame_id,
+                                        measurement=frame_obj.GetTransitionWithParentID(parent_ID))
+        P = s.n_points
+        self._point_ids = dict(zip(map.points_3d.keys(), range(P)))
+        self._points = np.array(s.xyz[:P], dtype=np.float64)
+        self._point_fixed = np.full(P, 1 if points_fixed else 0, np.uint8)
+        slot, fid, uv, _ = s.arrays()
+        if len(slot):
+            ids = np.asarray(frame_ids)
+            srt = np.argsort(ids, kind="stable")
+            pos = np.searchsorted(ids[srt], fid)
+            pos = np.clip(pos, 0, len(ids) - 1)
+            known = ids[srt][pos] == fid           # observations from frames that are not in this map are skipped
+            fpos = srt[pos]                        # position of the frame in map.frames order = pose index
+            sel = np.nonzero(known)[0]
+            order = sel[np.lexsort((fpos[sel], slot[sel]))]  # point-major, frames in map order
+            self._obs_pose = fpos[order].astype(np.int32)
+            self._obs_point = slot[order].astype(np.int32)
+            self._obs_uv = np.asarray(uv[order], np.float64)
+        else:
+            self._obs_pose, self._obs_point, self._obs_uv = np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2))
+        self._obs_info = []
+        self._huber, self._huber_set = float(_HUBER_DEFAULT.delta), True
+        return True
+
     # ------------------------------------------------------------------ the two entry points main.py calls
     def localBundleAdjustement(self, map, last_keyframe_id=None, scale=False, BAwindow=5):
         """LocalBA.py:143-190: all frames (frame 0 fixed) + scaling edge per parent, all points, one edge per
@@ -211,6 +256,19 @@ class BundleAdjustment:
         point_ids = map.points_3d.keys()
         if last_keyframe_id is not None:
             point_ids = map.GetPointsVisibleToFrames(frame_ids)
+        elif self._graph_from_soa(map, lambda fid_, f_: fid_ == 0, points_fixed=False, with_scale_edges=True):
+            self.optimize()
+            median_depth = 1
+            if scale:
+                median_depth = np.median(np.linalg.norm(self.result["points"], axis=1))
+            for frame_id in frame_ids:
+                new_pose = self.get_pose(frame_id).matrix()
+                new_pose[0:3, 3] /= median_depth
+                map.UpdatePose(new_pose=new_pose, frame_id=frame_id)
+            new_points = self.result["points"] / median_depth
+            for point_obj, x in zip(map.points_3d.values(), new_points):
+                point_obj.UpdatePoint(x)  # what map.UpdatePoint3D does, without the per-point dict lookups
+            return
         for frame_id in frame_ids:
             frame_obj = map.GetFrame(frame_id)
             if frame_id == 0:
@@ -245,6 +303,16 @@ class BundleAdjustment:
         """LocalBA.py:195-229: key frames and all points fixed, every other pose free; write back poses only."""
         frame_ids = map.frames.keys()
         point_ids = map.points_3d.keys()
+        if self._graph_from_soa(map, lambda fid_, f_: bool(f_.IsKeyFrame()), points_fixed=True, with_scale_edges=False):
+            self.optimize()
+            median_depth = 1
+            if scale:
+                median_depth = np.median(np.linalg.norm(self.result["points"], axis=1))
+            for frame_id in frame_ids:
+                new_pose = self.get_pose(frame_id).matrix()
+                new_pose[0:3, 3] /= median_depth
+                map.UpdatePose(new_pose=new_pose, frame_id=frame_id)
+            return
         for frame_id in frame_ids:
             frame_obj = map.GetFrame(frame_id)
             self.add_pose(pose_id=frame_id, pose=frame_obj.GetPose(), fixed=bool(frame_obj.IsKeyFrame()))

@@ -54,6 +54,18 @@ class MatchList(Sequence):
     def __len__(self):
         return int(self.query_idx.shape[0])
 
+    def __iter__(self):
+        # the reference's callers iterate `for m in matches: m[0].queryIdx` (main.py:187-188,210): build the objects
+        # from plain Python scalars in one pass instead of one NumPy scalar conversion per attribute
+        new = DMatch.__new__
+        for q, t, d in zip(self.query_idx.tolist(), self.train_idx.tolist(), self.distance.tolist()):
+            m = new(DMatch)
+            m.queryIdx = q
+            m.trainIdx = t
+            m.imgIdx = 0
+            m.distance = float(d)
+            yield [m]
+
     def __getitem__(self, i):
         if isinstance(i, slice):
             return [self[k] for k in range(*i.indices(len(self)))]

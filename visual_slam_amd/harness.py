@@ -89,6 +89,42 @@ def track_sequence(detect, match, ba, frames, depth0, max_kp=3000):
     return np.stack(lm.poses), {"detect_describe": t_det, "match": t_match, "motion_ba": t_ba}, n_matches
 
 
+def track_sequence_api(frames, depth0, context=None, ba_solver=None):
+    """The same tracking period written against the reference's class API exactly as src/v2/main.py:173-214 uses it:
+    Frame.process_frame -> Map.GetImagePointsWithFrameID -> FeatureMatcher.match_features ->
+    Map.AddParentAndPose / AddPointToFrameCorrespondences -> BundleAdjustment.motionOnlyBundleAdjustement.
+    Returns (poses [n,4,4], seconds)."""
+    from .LocalBA import BundleAdjustment, Camera
+    from .frame import FeatureExtractor, FeatureMatcher, Frame
+    from .map import Map
+    from .point import Point
+    extractor, matcher = FeatureExtractor(context=context), FeatureMatcher(context=context)
+    camera = Camera(*ICL_NUIM_K)
+    t0 = time.perf_counter()
+    key = Frame(frames[0], None, 0)
+    key.AddPose(np.eye(4))
+    key.SetAsKeyFrame()
+    kp0, ft0, _ = key.process_frame(extractor)
+    local_map = Map()
+    local_map.AddFrame(0, key)
+    for i, (X, uv, d) in enumerate(zip(backproject(kp0, depth0), kp0, ft0)):
+        pt = Point(location=X, id=i + 1)
+        pt.AddFrame(frame=key, uv=uv, descriptor=d)
+        local_map.AddPoint3D(point_id=i + 1, point_3d=pt)
+    for k in range(1, len(frames)):
+        cur = Frame(frames[k], None, k)
+        kp_cur, ft_cur, _ = cur.process_frame(extractor)
+        kp_prev, ft_prev, known_3d, point_ids = local_map.GetImagePointsWithFrameID(0)
+        matches, _, _, cur_pts, cur_fts = matcher.match_features(kp_prev, ft_prev, kp_cur, ft_cur)
+        prev_pose = local_map.GetFrame(k - 1).GetPose()
+        local_map.AddParentAndPose(parent_id=k - 1, frame_id=k, frame_obj=cur, rel_pose_trans=np.eye(4), pose=prev_pose)
+        local_map.AddPointToFrameCorrespondences(point_ids=[point_ids[m[0].queryIdx] for m in matches],
+                                                 image_points=cur_pts, descriptors=cur_fts, frame_obj=cur)
+        BundleAdjustment(camera, context=context, solver=ba_solver).motionOnlyBundleAdjustement(local_map)
+    dt = time.perf_counter() - t0
+    return np.stack([local_map.GetFrame(k).GetPose() for k in range(len(frames))]), dt
+
+
 def gpu_callables(ctx):
     def detect(bgr):
         xy, _, desc = ctx.detect_describe_bgr(bgr, 20, 3000)
@@ -119,7 +155,16 @@ def bench_frames(ctx, repeats=5):
         if best is None or dt < best[0]:
             best = (dt, stages, poses, nm)
     dt, stages, poses, nm = best
+    # the same period through the reference's class API (Frame / Map / FeatureMatcher / BundleAdjustment objects)
+    track_sequence_api(frames[:3], depth0, context=ctx)
+    api_dt, api_poses = None, None
+    for _ in range(max(2, repeats // 2)):
+        ap, adt = track_sequence_api(frames, depth0, context=ctx)
+        if api_dt is None or adt < api_dt:
+            api_dt, api_poses = adt, ap
     out = {"frames_per_s": len(frames) / dt, "n_frames": len(frames), "seconds": dt,
+           "class_api_frames_per_s": len(frames) / api_dt,
+           "class_api_equals_array_path": bool(np.array_equal(api_poses, poses)),
            "stage_ms_per_frame": {k: v / len(frames) * 1e3 for k, v in stages.items()},
            "mean_matches": float(np.mean(nm)), "resolution": "640x480",
            "data": "ICL-NUIM living-room traj3 frames 0-19 (fixtures)",

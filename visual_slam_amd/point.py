@@ -7,6 +7,7 @@ class Point:
         self.ID = id
         self.frames = {}  # frame_id -> (Frame, uv, descriptor)   (point.py:8-9)
         self.location_3d = location
+        self._rev = 0     # bumped by AddFrame: lets Map notice observations edited behind its back
 
     def GetID(self):
         return self.ID
@@ -19,6 +20,7 @@ class Point:
 
     def AddFrame(self, frame, uv, descriptor):
         self.frames[frame.GetID()] = (frame, uv, descriptor)
+        self._rev += 1
 
     def UpdatePoint(self, new_location):
         self.location_3d = new_location
