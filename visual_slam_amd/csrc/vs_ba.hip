@@ -668,10 +668,12 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve(ba_dev D) {
 // Small systems (n <= 126): one 256-thread workgroup factorises in LDS.
 //   * the right-hand side is appended as row n of the matrix, so the forward substitution L y = b happens inside the
 //     factorisation (row n receives exactly the updates of a matrix row) -- no separate sequential pass
-//   * 1/L[j][j] from v_rsq_f64 + two Newton steps (one correction for L[j][j] itself): the per-column dependent chain
-//     has no IEEE sqrt/divide sequence in it; the results differ from the oracle's sqrt/divide by <= 2 ulp
-//   * the trailing update is tiled 16 x 16 over the threads (no integer division in the loop), column j is read as
-//     LDS broadcasts; row stride is odd so the 16 row-owners of a tile hit distinct banks
+//   * blocked by the 6x6 camera blocks (n = 6 nb): per block column one thread factorises the diagonal block in
+//     registers, every row below solves its 6 entries against it, then the trailing update is a 6-term dot product
+//     per element tiled 16 x 16 over the threads -- nb dependent steps instead of n
+//   * 1/L[j][j] from v_rsq_f64 + two Newton steps (one correction for L[j][j] itself): no IEEE sqrt/divide sequence
+//     in the dependent chain; the results differ from the oracle's sqrt/divide by <= 2 ulp
+//   * row stride is odd so the 16 row-owners of a tile hit distinct banks
 //   * the backward substitution L^T x = y runs on wave 0 alone, wave-synchronously
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -695,30 +697,78 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   for (int c = tid; c < n; c += kSolveBlock) A[n * ld + c] = D.bs[c];
   if (tid == 0) *s_flag = 0;
   __syncthreads();
+  // ---- blocked right-looking Cholesky on the 6x6 camera blocks (n = 6 * nb); row n carries the right-hand side
   int ok = 1;
-  for (int j = 0; j < n; ++j) {
-    const double d = A[j * ld + j];
-    if (!(d > 0.0)) {  // uniform: every thread reads the same LDS word
+  const int nb = n / 6;
+  for (int J = 0; J < nb; ++J) {
+    const int j0 = 6 * J;
+    // (1) diagonal block: one thread, registers, reciprocal pivots
+    if (tid == 0) {
+      double L[6][6], ri[6];
+      int good = 1;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) L[r][c] = A[(j0 + r) * ld + j0 + c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double d = L[c][c];
+        if (!(d > 0.0)) good = 0;
+        double r = __builtin_amdgcn_rsq(d);
+        r = r * (1.5 - 0.5 * d * r * r);
+        r = r * (1.5 - 0.5 * d * r * r);
+        double l = d * r;
+        l = l + 0.5 * r * (d - l * l);
+        L[c][c] = l;
+        ri[c] = r;
+#pragma unroll
+        for (int i = c + 1; i < 6; ++i) L[i][c] = L[i][c] * r;
+#pragma unroll
+        for (int i = c + 1; i < 6; ++i)
+#pragma unroll
+          for (int k = c + 1; k <= i; ++k) L[i][k] -= L[i][c] * L[k][c];
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = 0; c <= r; ++c) A[(j0 + r) * ld + j0 + c] = L[r][c];
+        rinv[j0 + r] = ri[r];
+      }
+      if (!good) *s_flag = 1;
+    }
+    __syncthreads();
+    if (*s_flag) {  // uniform
       ok = 0;
       break;
     }
-    double r = __builtin_amdgcn_rsq(d);
-    r = r * (1.5 - 0.5 * d * r * r);
-    r = r * (1.5 - 0.5 * d * r * r);
-    double l = d * r;
-    l = l + 0.5 * r * (d - l * l);
-    __syncthreads();  // everyone has read A[j][j] before it is overwritten
-    for (int i = j + 1 + tid; i <= n; i += kSolveBlock) A[i * ld + j] *= r;
-    if (tid == 0) {
-      A[j * ld + j] = l;
-      rinv[j] = r;
+    // (2) panel: every row below the block (and the rhs row) solves  x * L_JJ^T = a  (forward substitution, 6 steps)
+    for (int r = j0 + 6 + tid; r <= n; r += kSolveBlock) {
+      double a[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) a[c] = A[r * ld + j0 + c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double v = a[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) v -= a[k] * A[(j0 + c) * ld + j0 + k];
+        a[c] = v * rinv[j0 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) A[r * ld + j0 + c] = a[c];
     }
     __syncthreads();
-    for (int i = j + 1 + ty; i <= n; i += 16) {
-      const double lij = A[i * ld + j];
-      const int kmax = i < n ? i : n - 1;  // the rhs row n has no diagonal element
-      double* row = A + i * ld;
-      for (int k = j + 1 + tx; k <= kmax; k += 16) row[k] -= lij * A[k * ld + j];
+    // (3) trailing update: A[r][c] -= sum_k A[r][j0+k] * A[c][j0+k]  for r > j0+5 (incl. rhs row), j0+5 < c <= min(r, n-1)
+    for (int r = j0 + 6 + ty; r <= n; r += 16) {
+      double ar[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ar[k] = A[r * ld + j0 + k];
+      const int cmax = r < n ? r : n - 1;
+      for (int c = j0 + 6 + tx; c <= cmax; c += 16) {
+        double acc = A[r * ld + c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc -= ar[k] * A[c * ld + j0 + k];
+        A[r * ld + c] = acc;
+      }
     }
     __syncthreads();
   }
