@@ -104,3 +104,28 @@ def test_deterministic(vs):
     a = vs.detect_describe_bgr(bgr, 20, 3000)
     b = vs.detect_describe_bgr(bgr, 20, 3000)
     _eq_detect(a, b)
+
+
+def test_random_images_property(vs, oracle):
+    """Random sizes, contrasts, thresholds, borders and caps: detection + description bit-exact."""
+    rng = np.random.default_rng(123)
+    for k in range(20):
+        h, w = int(rng.integers(8, 200)), int(rng.integers(8, 700))
+        base = synthetic_frame(w, h, int(rng.integers(0, 1000)))[:, :, 0].astype(np.int32)
+        gain = float(rng.choice([0.2, 0.5, 1.0, 3.0]))
+        g = np.clip((base - 128) * gain + 128 + rng.integers(-3, 4, base.shape), 0, 255).astype(np.uint8)
+        thr, border, cap = int(rng.integers(1, 80)), int(rng.integers(3, 20)), int(rng.choice([0, 1, 5, 50, 3000]))
+        _eq_detect(vs.fast9_detect(g, thr, border, cap), oracle.fast9_detect(g, thr, border, cap))
+        bgr = np.ascontiguousarray(np.stack([g, np.roll(g, 1, 1), g[::-1]], 2))
+        _eq_detect(vs.detect_describe_bgr(bgr, thr, cap), oracle.detect_describe_bgr(bgr, thr, cap))
+
+
+def test_saturated_and_extreme_images(vs, oracle):
+    rng = np.random.default_rng(5)
+    for img in (np.zeros((64, 96), np.uint8), np.full((64, 96), 255, np.uint8),
+                (rng.integers(0, 2, (64, 96)) * 255).astype(np.uint8),          # salt and pepper: dense corners, scores 254
+                np.tile(np.array([[0, 255], [255, 0]], np.uint8), (32, 48))):    # checkerboard
+        for cap in (3000, 10):
+            _eq_detect(vs.fast9_detect(img, 20, 3, cap), oracle.fast9_detect(img, 20, 3, cap))
+        bgr = np.ascontiguousarray(np.repeat(img[:, :, None], 3, 2))
+        _eq_detect(vs.detect_describe_bgr(bgr, 20, 3000), oracle.detect_describe_bgr(bgr, 20, 3000))

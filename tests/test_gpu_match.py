@@ -81,3 +81,47 @@ def test_deterministic(vs):
     a = vs.hamming_knn2(q, t)
     b = vs.hamming_knn2(q, t)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_cfg5_100k_x_100k_bit_exact(vs, oracle):
+    """BASELINE.json configs[4] on one GPU (the sharded variant splits exactly these queries): 1e10 distance
+    evaluations, compared row for row with the multi-threaded oracle."""
+    q, t = match_workload(100000, 100000)
+    idx, dist = vs.hamming_knn2(q, t)
+    oidx, odist = oracle.hamming_knn2(q, t, threads=0)
+    assert np.array_equal(dist, odist) and np.array_equal(idx, oidx)
+    tie = dist[:, 0] == dist[:, 1]
+    assert tie.any() and np.all(idx[tie, 0] < idx[tie, 1])
+
+
+def test_train_set_larger_than_one_index_window(vs, oracle):
+    """Packed keys carry 20 index bits: more than 2^20 train rows forces several chunks with per-chunk offsets."""
+    rng = np.random.default_rng(12)
+    nt = (1 << 21) + 12345
+    t = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    q = t[rng.integers(0, nt, 96)].copy()
+    q[:, 0] ^= 1  # distance 1 to its source row
+    q[5] = t[nt - 1]            # exact hit in the very last row
+    q[6] = t[(1 << 20)]         # exact hit at a chunk boundary
+    t[(1 << 20) + 7] = t[3]     # duplicate across chunks: the lower index must come first
+    q[7] = t[3]
+    idx, dist = vs.hamming_knn2(q, t)
+    oidx, odist = oracle.hamming_knn2(q, t, threads=0)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    assert idx[5, 0] == nt - 1 and idx[6, 0] == (1 << 20) and idx[7].tolist() == [3, (1 << 20) + 7]
+
+
+def test_random_shapes_property(vs, oracle):
+    rng = np.random.default_rng(99)
+    for _ in range(25):
+        nq = int(rng.integers(1, 3000))
+        nt = int(rng.integers(2, 5000))
+        bits = int(rng.integers(1, 9))  # low entropy -> many ties
+        q = rng.integers(0, 1 << bits, (nq, 32)).astype(np.uint8)
+        t = rng.integers(0, 1 << bits, (nt, 32)).astype(np.uint8)
+        idx, dist = vs.hamming_knn2(q, t)
+        oidx, odist = oracle.hamming_knn2(q, t, threads=0)
+        assert np.array_equal(idx, oidx) and np.array_equal(dist, odist), (nq, nt, bits)
+        ratio = float(rng.choice([0.5, 0.8, 0.9, 1.0]))
+        a, b = vs.match_ratio(q, t, ratio), oracle.match_ratio(q, t, ratio)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
