@@ -119,6 +119,19 @@ int vs_hamming_knn2_packed_dev(vs_ctx* ctx, const void* d_q, int nq, const void*
 int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, double ratio, void* d_match_q,
                        void* d_match_t, void* d_match_d, void* d_n_out, void* stream);
 
+/* ---- next row: two-view DLT triangulation --------------------------------------------------------
+ * replaces helper_functions.triangulate(pose1, pose2, pts1, pts2)     (src/v2/helper_functions.py:281-291)
+ * and the depth terms of the cheirality filter                        (src/v2/main.py:291-309)
+ * P1, P2: 3x4 projection matrices K*[R|t] row-major (CameraProjectionMatrix2, helper_functions.py:376-377);
+ * pts1/pts2: n rows of `stride` doubles whose first two entries are (u, v) (the reference passes homogeneous N x 3);
+ * X4[i] = unit right singular vector of the smallest singular value of the 4x4 DLT matrix, sign chosen so w >= 0
+ * (the reference returns LAPACK's arbitrary sign and divides by w at once).  If depth != NULL, depth[i] = (z of
+ * T1*[X/w;1], z of T2*[X/w;1]) for the 3x4 (or top of 4x4) world-to-camera transforms T1, T2 -- what main.py's filter
+ * `(proj1[2] > 0) & (proj2[2] > 0) & (proj2[2] < 1) & (proj1[2] < 1)` reads.  FP64; equals np.linalg.svd to ~1e-12. */
+int vs_triangulate_dlt(vs_ctx* ctx, const double* P1, const double* P2, const double* pts1, const double* pts2, int n,
+                       int stride, double* X4 /*[n][4]*/, const double* T1, const double* T2,
+                       double* depth /*[n][2] or NULL*/);
+
 /* ---- A9-A16: bundle adjustment ------------------------------------------------------------------------------
  * replaces the g2o graph the reference builds and optimises          (src/v2/LocalBA.py:20-94,115-131,39-42)
  *   solver      : Levenberg-Marquardt( BlockSolverSE3( Cholesky ) ), points marginalised (Schur complement)

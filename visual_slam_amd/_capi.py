@@ -71,6 +71,8 @@ SIGNATURES = {
                                              C.c_void_p]),
     "vs_match_ratio_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vs_triangulate_dlt": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p, c_f64p, C.c_int, C.c_int, c_f64p, c_f64p, c_f64p,
+                                     c_f64p]),
     "vs_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(BAResult)]),
 }
 

@@ -154,6 +154,29 @@ class Context:
                                                float(ratio), C.c_void_p(d_mq), C.c_void_p(d_mt), C.c_void_p(d_md),
                                                C.c_void_p(d_n), C.c_void_p(stream) if stream else None))
 
+    # ------------------------------------------------------------------ triangulation
+    def triangulate_dlt(self, P1, P2, pts1, pts2, T1=None, T2=None):
+        """X4 [n,4] (unit, w >= 0) and, when the world-to-camera transforms are given, depth [n,2]."""
+        P1 = np.ascontiguousarray(np.asarray(P1, np.float64)[:3, :4])
+        P2 = np.ascontiguousarray(np.asarray(P2, np.float64)[:3, :4])
+        pts1 = np.ascontiguousarray(pts1, np.float64)
+        pts2 = np.ascontiguousarray(pts2, np.float64)
+        pts1 = pts1.reshape(-1, pts1.shape[-1]) if pts1.size else pts1.reshape(0, 2)
+        pts2 = pts2.reshape(-1, pts2.shape[-1]) if pts2.size else pts2.reshape(0, 2)
+        n, stride = pts1.shape[0], max(pts1.shape[1], 2)
+        assert pts2.shape == pts1.shape
+        X4 = np.zeros((max(n, 1), 4))
+        depth = T1p = T2p = None
+        if T1 is not None:
+            T1 = np.ascontiguousarray(np.asarray(T1, np.float64)[:3, :4])
+            T2 = np.ascontiguousarray(np.asarray(T2, np.float64)[:3, :4])
+            depth = np.zeros((max(n, 1), 2))
+            T1p, T2p = ptr(T1, c_f64p), ptr(T2, c_f64p)
+        self._chk(self._lib.vs_triangulate_dlt(self._h, ptr(P1, c_f64p), ptr(P2, c_f64p), ptr(pts1, c_f64p),
+                                               ptr(pts2, c_f64p), n, stride, ptr(X4, c_f64p), T1p, T2p,
+                                               ptr(depth, c_f64p) if depth is not None else None))
+        return (X4[:n], depth[:n]) if depth is not None else X4[:n]
+
     # ------------------------------------------------------------------ bundle adjustment (A9-A16)
     def ba_solve(self, poses, pose_fixed, points, point_fixed, obs_pose, obs_point, obs_uv, K,
                  huber_delta=float(np.sqrt(5.991)), max_iterations=10, scale_edges=None, obs_info=None, dcs_phi=1.0):
