@@ -106,6 +106,24 @@ def frames_leg(ctx, cpu=True):
         out["cpu_cores_used"] = 1
         out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
                                                          for a, b in zip(poses, cposes)))
+    # the full headless driver (main.py's tracking loop + key-frame insertion: triangulation + local BA), class API
+    try:
+        from visual_slam_amd import slam
+        from visual_slam_amd.workloads import ICL_NUIM_K
+        frames, depth0 = load_sequence(20)
+        be = slam.Backends(context=ctx)
+        slam.run_sequence(frames[:7], depth0, ICL_NUIM_K, be, keyframe_gap=4)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=4)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        out["driver"] = {"frames_per_s": len(frames) / best, "keyframes": r["keyframes"], "map_points": r["n_points"],
+                         "note": "visual_slam_amd/slam.py: main.py:150-348 control flow, key frame every 5th frame, "
+                                 "init from depth of frame 0, no PnP"}
+    except Exception as e:
+        out["driver"] = {"error": repr(e)}
     return out
 
 

@@ -1,0 +1,64 @@
+"""The headless driver (visual_slam_amd/slam.py = the control flow of the reference's main.py:150-348) end to end on
+the 20 ICL-NUIM fixture frames: BASELINE.json configs[0] (traj3 instead of traj0).  CPU: the driver on
+the oracle back ends.  GPU: the same driver on the HIP back ends must take the same decisions (key frames, new
+points) and end within the BA contract of the CPU run."""
+import numpy as np
+import pytest
+
+from visual_slam_amd import harness, slam
+from visual_slam_amd.frame import MatchList
+from visual_slam_amd.workloads import ICL_NUIM_K
+
+
+class OracleExtractor:
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def compute_features(self, img):
+        xy, _, desc = self.o.detect_describe_bgr(img, 20, 3000)
+        return xy, desc
+
+
+class OracleMatcher:
+    def __init__(self, oracle):
+        self.o = oracle
+
+    def match_features(self, kp1, desc1, kp2, desc2, ratio=0.8):
+        mq, mt, md = self.o.match_ratio(desc1, desc2, ratio)
+        return MatchList(mq, mt, md), np.asarray(kp1)[mq], np.asarray(desc1)[mq], np.asarray(kp2)[mt], np.asarray(desc2)[mt]
+
+
+def oracle_backends(oracle):
+    from oracle import np_reference
+    return slam.Backends(ba_solver=oracle.ba_solve, extractor=OracleExtractor(oracle), matcher=OracleMatcher(oracle),
+                         triangulate=np_reference.triangulate)
+
+
+def _run(be, n=20, gap=4):
+    frames, depth0 = harness.load_sequence(n)
+    return slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=gap, min_tracked=80)
+
+
+def test_driver_on_the_oracle_back_ends(oracle):
+    r = _run(oracle_backends(oracle))
+    assert r["keyframes"][0] == 0 and len(r["keyframes"]) >= 3          # key frames were inserted ...
+    assert r["n_points"] > 595                                          # ... and triangulation added map points
+    assert min(r["tracked"]) > 100
+    step = np.linalg.norm(np.diff(r["poses"][:, :3, 3], axis=0), axis=1)
+    assert step.max() < 0.05                                            # millimetre motion, no jumps
+    for P in r["poses"]:
+        assert np.allclose(P[:3, :3] @ P[:3, :3].T, np.eye(3), atol=1e-9)
+    m = r["map"]
+    assert all(p.GetNVisibleFrames() >= 1 for p in m.points_3d.values()) and list(m.frames)[0] == 0
+
+
+@pytest.mark.gpu
+def test_driver_gpu_equals_oracle(vs, oracle):
+    g = _run(slam.Backends(context=vs))
+    c = _run(oracle_backends(oracle))
+    assert g["keyframes"] == c["keyframes"] and g["tracked"] == c["tracked"] and g["n_points"] == c["n_points"]
+    rel = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(g["poses"], c["poses"]))
+    assert rel < 1e-4, rel
+    pg = np.array([p.location_3d for p in g["map"].points_3d.values()])
+    pc = np.array([p.location_3d for p in c["map"].points_3d.values()])
+    assert np.allclose(pg, pc, atol=1e-6)

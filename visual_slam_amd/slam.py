@@ -1,0 +1,158 @@
+"""Headless driver: the control flow of the reference's src/v2/main.py:150-348 (tracking loop + key-frame insertion) on
+the classes of this package, without viewer, cv2 or g2o.
+
+Every arithmetic stage goes through an injectable back end so that the identical driver runs on the GPU (default) and
+on the CPU oracle (tests, bench baseline):
+    detect+describe  FeatureExtractor            main.py:181
+    match            FeatureMatcher              main.py:185, 244
+    motion-only BA   BundleAdjustment            main.py:213-214
+    triangulation    helper_functions.triangulate main.py:284
+    local BA         BundleAdjustment            main.py:322-323
+Two stages of main.py have no counterpart yet: the two-view initialisation
+(findEssentialMat / recoverPose, main.py:88-148) and cv2.solvePnPRansac (main.py:196).  They are replaced by
+  * initialisation from the first frame's keypoints back-projected with the dataset's depth image, followed by the same
+    normalisation main.py applies after its first BA (everything divided by the median point norm, LocalBA.py:178-190);
+  * the previous frame's optimised pose as the start of motion-only BA.
+The key-frame rule is main.py:221 with the frame gap as a parameter (20 there).
+"""
+import copy
+
+import numpy as np
+
+from . import helper_functions as hf
+from .LocalBA import BundleAdjustment, Camera, Isometry3d
+from .frame import FeatureExtractor, FeatureMatcher, Frame
+from .map import Map
+from .point import Point
+
+
+class Backends:
+    """extractor / matcher objects and factories for BundleAdjustment and triangulate."""
+
+    def __init__(self, context=None, ba_solver=None, extractor=None, matcher=None, triangulate=None):
+        self.extractor = extractor or FeatureExtractor(context=context)
+        self.matcher = matcher or FeatureMatcher(context=context)
+        self._ctx, self._solver = context, ba_solver
+        self.triangulate = triangulate or (lambda P1, P2, x1, x2: hf.triangulate(P1, P2, x1, x2, context=context))
+
+    def ba(self, camera):
+        return BundleAdjustment(camera, context=self._ctx, solver=self._solver)
+
+
+def _inv(pose):
+    return Isometry3d(R=pose[0:3, 0:3], t=np.asarray(pose[:3, -1]).squeeze()).inverse().matrix()
+
+
+def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, max_depth=1.0, log=None):
+    """frames: list of BGR images; depth0: metric depth of frames[0]; K4 = (fx, fy, cx, cy).
+    Returns dict(poses [n,4,4] camera-to-world, keyframes [indices], n_points, map, tracked [per frame])."""
+    fx, fy, cx, cy = K4
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    camera = Camera(fx, fy, cx, cy)
+    be = backends
+    map = Map()
+    id_frame, id_point = 0, 1
+    # ---- initialisation (replaces main.py:78-148)
+    cur_frame = Frame(frames[0], None, id_frame)
+    cur_frame.AddPose(init_pose=np.eye(4))
+    cur_frame.SetAsKeyFrame()
+    cur_frame.AddParent(None, None)
+    kp0, ft0, _ = cur_frame.process_frame(be.extractor)
+    map.AddFrame(frame_id=id_frame, frame=cur_frame)
+    z = depth0[kp0[:, 1].astype(int), kp0[:, 0].astype(int)]
+    pts = np.stack([(kp0[:, 0] - cx) * z / fx, (kp0[:, 1] - cy) * z / fy, z], 1)
+    pts = pts / np.median(np.linalg.norm(pts, axis=1))  # LocalBA.py:178-190 (scale=True): median point norm = 1
+    for X, uv, ft in zip(pts, kp0, ft0):
+        pt_object = Point(location=X, id=id_point)
+        pt_object.AddFrame(frame=cur_frame, uv=uv, descriptor=ft)
+        map.AddPoint3D(point_id=id_point, point_3d=pt_object)
+        id_point += 1
+    id_frame += 1
+    last_keyframe = copy.copy(map.GetFrame(frame_id=0))
+    local_map = Map()
+    local_map.AddFrame(last_keyframe.GetID(), last_keyframe)
+    local_map.Store3DPoints(map.GetCopyOfPointObjects(last_keyframe.GetID()))
+    id_frame_local = id_frame
+    loop_idx = 0
+    all_poses = {0: np.eye(4)}
+    keyframes, tracked = [0], []
+    # ---- tracking loop (main.py:173-348)
+    for i in range(1, len(frames)):
+        cur_frame = Frame(frames[i], None, id_frame_local)
+        kp_cur, features_cur, _ = cur_frame.process_frame(be.extractor)
+        kp_prev, features_prev, known_3d, point_IDs = local_map.GetImagePointsWithFrameID(last_keyframe.GetID())
+        matches, _, _, curMatchedPoints, curMatchedFeatures = be.matcher.match_features(kp_prev, features_prev, kp_cur,
+                                                                                         features_cur)
+        known_3d_matched_ids = [point_IDs[m[0].queryIdx] for m in matches]
+        # pose start: previous frame (stands in for solvePnPRansac, main.py:191-204)
+        W_T_prev = local_map.GetFrame(id_frame_local - 1).GetPose()
+        W_T_curr = np.array(W_T_prev, dtype=np.float64)
+        RelativePoseTransformation = _inv(W_T_prev) @ W_T_curr
+        local_map.AddParentAndPose(parent_id=id_frame_local - 1, frame_id=id_frame_local, frame_obj=cur_frame,
+                                   rel_pose_trans=RelativePoseTransformation, pose=W_T_curr)
+        local_map.AddPointToFrameCorrespondences(point_ids=known_3d_matched_ids, image_points=curMatchedPoints,
+                                                 descriptors=curMatchedFeatures, frame_obj=cur_frame)
+        be.ba(camera).motionOnlyBundleAdjustement(local_map, scale=False, save=True)
+        all_poses[i] = np.array(local_map.GetFrame(id_frame_local).GetPose())
+        tracked.append(len(curMatchedPoints))
+        # key-frame rule (main.py:221)
+        if (i - loop_idx > keyframe_gap or len(curMatchedPoints) < min_tracked) and (
+                len(curMatchedPoints) < 0.9 * len(known_3d)):
+            loop_idx = i
+            cur_frame.SetAsKeyFrame()
+            W_T_prev_key = map.GetFrame(id_frame - 1).GetPose()
+            W_T_cur_key = local_map.GetFrame(id_frame_local).GetPose()
+            cur_frame.ClearParent()
+            map.AddParentAndPose(parent_id=id_frame - 1, frame_id=id_frame, frame_obj=cur_frame,
+                                 rel_pose_trans=_inv(W_T_prev_key) @ W_T_cur_key, pose=W_T_cur_key)
+            map.AddPointToFrameCorrespondences(point_ids=known_3d_matched_ids, image_points=curMatchedPoints,
+                                               descriptors=curMatchedFeatures, frame_obj=cur_frame)
+            if id_frame >= 6 and id_frame % 4 == 0:
+                map.DiscardOutlierMapPoints(n_visible_frames=3)
+            # unmatched keypoints of the previous key frame against the new one (main.py:237-244)
+            image_points_already_in_map = map.GetImagePointsWithFrameID(id_frame - 1)[0]
+            kp1 = map.GetFrame(id_frame - 1).GetKeyPoints()
+            desc1 = map.GetFrame(id_frame - 1).GetFeatures()
+            idx = hf.GetListDiff(kp1, image_points_already_in_map)
+            kp1, desc1 = kp1[idx], desc1[idx]
+            n_new = 0
+            if len(kp1) >= 1 and len(map.GetFrame(id_frame).GetKeyPoints()) >= 2:
+                _, last_kf_pts, last_kf_fts, cur_kf_pts, cur_kf_fts = be.matcher.match_features(
+                    kp1=kp1, desc1=desc1, kp2=map.GetFrame(id_frame).GetKeyPoints(),
+                    desc2=map.GetFrame(id_frame).GetFeatures())
+                if len(last_kf_pts):
+                    p1 = _inv(map.GetFrame(id_frame - 1).GetPose())
+                    p2 = _inv(map.GetFrame(id_frame).GetPose())
+                    Proj1 = hf.CameraProjectionMatrix2(Pose=p1, K=K)
+                    Proj2 = hf.CameraProjectionMatrix2(Pose=p2, K=K)
+                    x1 = hf.MakeHomogeneous(last_kf_pts)
+                    x2 = hf.MakeHomogeneous(cur_kf_pts)
+                    new_pts = np.array(be.triangulate(Proj1, Proj2, x1, x2), dtype=np.float64)
+                    new_pts /= new_pts[:, 3:]
+                    proj1 = p1 @ new_pts.T
+                    proj2 = p2 @ new_pts.T
+                    new_pts = new_pts[:, :3]
+                    good = np.where((proj1[2] > 0) & (proj2[2] > 0) & (proj2[2] < max_depth) & (proj1[2] < max_depth))[0]
+                    for pt, uv1, uv2, ft1, ft2 in zip(new_pts[good], last_kf_pts[good], cur_kf_pts[good],
+                                                      last_kf_fts[good], cur_kf_fts[good]):
+                        pt_object = Point(location=pt, id=id_point)
+                        pt_object.AddFrame(frame=map.GetFrame(id_frame - 1), uv=uv1, descriptor=ft1)
+                        pt_object.AddFrame(frame=map.GetFrame(id_frame), uv=uv2, descriptor=ft2)
+                        map.AddPoint3D(point_id=id_point, point_3d=pt_object)
+                        id_point += 1
+                        n_new += 1
+            be.ba(camera).localBundleAdjustement(map)  # main.py:322-323
+            all_poses[i] = np.array(map.GetFrame(id_frame).GetPose())
+            keyframes.append(i)
+            if log:
+                log("key frame at image %d: %d new points, map has %d points" % (i, n_new, len(map.points_3d)))
+            last_keyframe = copy.copy(map.GetFrame(frame_id=id_frame))
+            local_map = Map()
+            local_map.AddFrame(last_keyframe.GetID(), last_keyframe)
+            id_frame += 1
+            id_frame_local = id_frame
+            local_map.Store3DPoints(map.GetCopyOfPointObjects(last_keyframe.GetID()))
+        else:
+            id_frame_local += 1
+    poses = np.stack([all_poses[i] for i in range(len(frames))])
+    return dict(poses=poses, keyframes=keyframes, n_points=len(map.points_3d), map=map, tracked=tracked)
