@@ -132,6 +132,18 @@ int vs_triangulate_dlt(vs_ctx* ctx, const double* P1, const double* P2, const do
                        int stride, double* X4 /*[n][4]*/, const double* T1, const double* T2,
                        double* depth /*[n][2] or NULL*/);
 
+/* ---- next row: PnP-RANSAC ------------------------------------------------------------------------
+ * replaces cv2.solvePnPRansac(objectPoints, imagePoints, K, [], rvec, tvec, useExtrinsicGuess=True)  (src/v2/main.py:196)
+ * Structure of OpenCV's routine with its defaults (ITERATIVE, 100 iterations, 8 px, confidence 0.99): hypothesis h =
+ * LM refinement of the extrinsic guess on 5 sampled correspondences; inliers: squared reprojection error <= thr^2;
+ * iteration budget updated by RANSACUpdateNumIters after every improvement; best model refined on its inliers.
+ * Own specification where OpenCV cannot be pinned: samples from splitmix64(seed ^ (h << 20 + k)), LM = the g2o-style
+ * LM of vs_ba_solve (one free camera, fixed points, no robust kernel, `refine_iters` iterations).
+ * pose0 / pose_out: 4x4 camera-to-world row-major (invert for rvec/tvec); inliers: indices, ascending. */
+int vs_pnp_ransac(vs_ctx* ctx, const double* obj /*[n][3]*/, const double* img /*[n][2]*/, int n, double fx, double fy,
+                  double cx, double cy, const double* pose0, int iterations, double reproj_err, double confidence,
+                  uint64_t seed, int refine_iters, double* pose_out, int32_t* inliers /*[n]*/, int* n_inliers, int* found);
+
 /* ---- A9-A16: bundle adjustment ------------------------------------------------------------------------------
  * replaces the g2o graph the reference builds and optimises          (src/v2/LocalBA.py:20-94,115-131,39-42)
  *   solver      : Levenberg-Marquardt( BlockSolverSE3( Cholesky ) ), points marginalised (Schur complement)

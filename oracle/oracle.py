@@ -75,6 +75,11 @@ def load(lib_path=None):
                                    C.POINTER(C.c_int)]
     lib.vo_cholesky_lower.argtypes = [c_f64p, C.c_int]
     lib.vo_ba_solve.argtypes = [C.POINTER(BAProblem), C.POINTER(BAResult)]
+    lib.vo_pnp_sample.argtypes = [C.c_uint64, C.c_int, C.c_int, c_i32p]
+    lib.vo_pnp_sample.restype = None
+    lib.vo_pnp_ransac.argtypes = [c_f64p, c_f64p, C.c_int, c_f64p, c_f64p, C.c_int, C.c_double, C.c_double, C.c_uint64,
+                                  C.c_int, c_f64p, c_i32p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int)]
     lib.vo_ba_edge.argtypes = [c_f64p] * 7
     lib.vo_ba_pose_update.argtypes = [c_f64p] * 3
     if lib_path is None:
@@ -267,3 +272,28 @@ def ba_pose_update(pose, d6, lib=None):
     out = np.zeros(16)
     _chk(lib.vo_ba_pose_update(_p(pose, c_f64p), _p(d6, c_f64p), _p(out, c_f64p)), "ba_pose_update")
     return out.reshape(4, 4)
+
+
+def pnp_ransac(obj, img, K, pose0, iterations=100, reproj_err=8.0, confidence=0.99, seed=0, refine_iters=10, lib=None):
+    """obj [N,3], img [N,2], pose0 = camera-to-world 4x4 guess.  Returns dict(found, pose, inliers, best_h, used)."""
+    lib = lib or load()
+    obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64)
+    pose0 = np.ascontiguousarray(pose0, np.float64).reshape(16)
+    n = obj.shape[0]
+    pose = np.zeros(16)
+    inl = np.zeros(max(n, 1), np.int32)
+    ni, found, bh, used = C.c_int(0), C.c_int(0), C.c_int(-1), C.c_int(0)
+    _chk(lib.vo_pnp_ransac(_p(obj, c_f64p), _p(img, c_f64p), n, _p(K, c_f64p), _p(pose0, c_f64p), iterations,
+                           reproj_err, confidence, seed, refine_iters, _p(pose, c_f64p), _p(inl, c_i32p), C.byref(ni),
+                           C.byref(found), C.byref(bh), C.byref(used)), "pnp_ransac")
+    return dict(found=bool(found.value), pose=pose.reshape(4, 4), inliers=inl[:ni.value].copy(), best_h=bh.value,
+                used=used.value)
+
+
+def pnp_sample(seed, h, n, lib=None):
+    lib = lib or load()
+    idx = np.zeros(5, np.int32)
+    lib.vo_pnp_sample(seed, h, n, _p(idx, c_i32p))
+    return idx

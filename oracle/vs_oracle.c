@@ -936,3 +936,156 @@ VO_EXPORT int vo_ba_pose_update(const double* pose16, const double* d6, double* 
   pose_matrix(&c, out16);
   return VS_OK;
 }
+
+/* ------------------------------------------------------------------------------------ PnP-RANSAC */
+/* Restates the structure of cv2.solvePnPRansac as the reference calls it (src/v2/main.py:196-197: useExtrinsicGuess,
+ * default flag ITERATIVE, 100 iterations, reprojection error 8 px, confidence 0.99): every hypothesis refines the
+ * extrinsic guess on a random minimal set of 5 correspondences, inliers are counted with err^2 <= thr^2, the iteration
+ * budget shrinks with RANSACUpdateNumIters, the best model is refined on its inliers.  PARITY UNPINNED against OpenCV:
+ * its RNG stream and CvLevMarq are not available; here the sample comes from a counter-based splitmix64 and the
+ * refinement is this file's own LM (vo_ba_solve with one free camera, fixed points, no robust kernel). */
+static uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+/* 5 distinct indices of hypothesis h */
+VO_EXPORT void vo_pnp_sample(uint64_t seed, int h, int n, int32_t* idx5) {
+  int got = 0;
+  for (uint64_t k = 0; got < 5; ++k) {
+    int32_t c = (int32_t)(splitmix64(seed ^ (((uint64_t)h << 20) + k)) % (uint64_t)n);
+    int dup = 0;
+    for (int j = 0; j < got; ++j) dup |= idx5[j] == c;
+    if (!dup) idx5[got++] = c;
+  }
+}
+
+static int ransac_update_iters(double p, double ep, int model_points, int max_iters) {
+  if (p < 0) p = 0;
+  if (p > 1) p = 1;
+  if (ep < 0) ep = 0;
+  if (ep > 1) ep = 1;
+  double num = 1 - p > DBL_MIN ? 1 - p : DBL_MIN;
+  double denom = 1 - pow(1 - ep, model_points);
+  if (denom < DBL_MIN) return 0;
+  num = log(num);
+  denom = log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
+}
+
+/* pose = camera-to-world 4x4 (the convention of vo_ba_solve); err2[i] = squared reprojection error */
+static void pnp_errors(const double* pose16, const double* obj, const double* img, int n, const double* K4, double* err2) {
+  cam_t c;
+  memset(&c, 0, sizeof c);
+  quat_from_R(pose16, c.q);
+  c.t[0] = pose16[3];
+  c.t[1] = pose16[7];
+  c.t[2] = pose16[11];
+  cam_refresh(&c);
+  for (int i = 0; i < n; ++i) {
+    const double* X = obj + 3 * (size_t)i;
+    double pc[3];
+    for (int k = 0; k < 3; ++k) pc[k] = c.w2n[k][0] * X[0] + c.w2n[k][1] * X[1] + c.w2n[k][2] * X[2] + c.w2n[k][3];
+    double u = (K4[0] * pc[0] + K4[2] * pc[2]) / pc[2] - img[2 * (size_t)i];
+    double v = (K4[1] * pc[1] + K4[3] * pc[2]) / pc[2] - img[2 * (size_t)i + 1];
+    err2[i] = u * u + v * v;
+  }
+}
+
+static int pnp_refine(const double* pose_in, const double* obj, const double* img, const int32_t* sel, int m,
+                      const double* K4, int iters, double* pose_out) {
+  double* pts = (double*)malloc(sizeof(double) * 3 * (size_t)m);
+  double* uv = (double*)malloc(sizeof(double) * 2 * (size_t)m);
+  int32_t* op = (int32_t*)calloc((size_t)m, sizeof(int32_t));
+  int32_t* oq = (int32_t*)malloc(sizeof(int32_t) * (size_t)m);
+  uint8_t* pf = (uint8_t*)malloc((size_t)m);
+  for (int j = 0; j < m; ++j) {
+    memcpy(pts + 3 * j, obj + 3 * (size_t)sel[j], 3 * sizeof(double));
+    memcpy(uv + 2 * j, img + 2 * (size_t)sel[j], 2 * sizeof(double));
+    oq[j] = j;
+    pf[j] = 1;
+  }
+  uint8_t pose_free = 0;
+  vs_ba_problem p;
+  memset(&p, 0, sizeof p);
+  p.n_poses = 1;
+  p.n_points = m;
+  p.n_obs = m;
+  p.poses = pose_in;
+  p.pose_fixed = &pose_free;
+  p.points = pts;
+  p.point_fixed = pf;
+  p.obs_pose = op;
+  p.obs_point = oq;
+  p.obs_uv = uv;
+  p.fx = K4[0];
+  p.fy = K4[1];
+  p.cx = K4[2];
+  p.cy = K4[3];
+  p.huber_delta = 0;
+  p.dcs_phi = 1;
+  p.max_iterations = iters;
+  vs_ba_result r;
+  memset(&r, 0, sizeof r);
+  r.poses_out = pose_out;
+  int rc = vo_ba_solve(&p, &r);
+  free(pts);
+  free(uv);
+  free(op);
+  free(oq);
+  free(pf);
+  return rc;
+}
+
+/* returns VS_OK; *found = 1 if a model with >= 5 inliers exists.  pose0/pose_out: camera-to-world 4x4 row-major. */
+VO_EXPORT int vo_pnp_ransac(const double* obj, const double* img, int n, const double* K4, const double* pose0,
+                            int iterations, double reproj_err, double confidence, uint64_t seed, int refine_iters,
+                            double* pose_out, int32_t* inliers, int* n_inliers, int* found, int* best_h, int* used) {
+  if (!obj || !img || !K4 || !pose0 || !pose_out || !inliers || !n_inliers || !found || n < 0) return VS_EINVAL;
+  *found = 0;
+  *n_inliers = 0;
+  if (best_h) *best_h = -1;
+  if (used) *used = 0;
+  memcpy(pose_out, pose0, 16 * sizeof(double));
+  if (n < 5) return VS_OK;
+  double* err2 = (double*)malloc(sizeof(double) * (size_t)n);
+  double best_pose[16];
+  int max_good = 0, niters = iterations, bh = -1;
+  const double thr2 = reproj_err * reproj_err;
+  int h = 0;
+  for (; h < niters; ++h) {
+    int32_t idx5[5];
+    double pose_h[16];
+    if (n == 5) {
+      for (int k = 0; k < 5; ++k) idx5[k] = k;
+    } else {
+      vo_pnp_sample(seed, h, n, idx5);
+    }
+    if (pnp_refine(pose0, obj, img, idx5, 5, K4, refine_iters, pose_h) != VS_OK) continue;
+    pnp_errors(pose_h, obj, img, n, K4, err2);
+    int good = 0;
+    for (int i = 0; i < n; ++i) good += err2[i] <= thr2;
+    if (good > (max_good > 4 ? max_good : 4)) {
+      max_good = good;
+      bh = h;
+      memcpy(best_pose, pose_h, sizeof best_pose);
+      niters = ransac_update_iters(confidence, (double)(n - good) / n, 5, niters);
+    }
+  }
+  if (used) *used = h;
+  if (max_good >= 5) {
+    pnp_errors(best_pose, obj, img, n, K4, err2);
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+      if (err2[i] <= thr2) inliers[m++] = i;
+    *n_inliers = m;
+    *found = 1;
+    if (best_h) *best_h = bh;
+    if (pnp_refine(best_pose, obj, img, inliers, m, K4, refine_iters, pose_out) != VS_OK)
+      memcpy(pose_out, best_pose, sizeof best_pose);
+  }
+  free(err2);
+  return VS_OK;
+}

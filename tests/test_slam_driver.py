@@ -31,7 +31,7 @@ class OracleMatcher:
 def oracle_backends(oracle):
     from oracle import np_reference
     return slam.Backends(ba_solver=oracle.ba_solve, extractor=OracleExtractor(oracle), matcher=OracleMatcher(oracle),
-                         triangulate=np_reference.triangulate)
+                         triangulate=np_reference.triangulate, pnp_solver=oracle.pnp_ransac)
 
 
 def _run(be, n=20, gap=4):
@@ -44,6 +44,7 @@ def test_driver_on_the_oracle_back_ends(oracle):
     assert r["keyframes"][0] == 0 and len(r["keyframes"]) >= 3          # key frames were inserted ...
     assert r["n_points"] > 595                                          # ... and triangulation added map points
     assert min(r["tracked"]) > 100
+    assert min(r["pnp_inliers"]) > 0.8 * min(r["tracked"])                # PnP-RANSAC found a model every frame
     step = np.linalg.norm(np.diff(r["poses"][:, :3, 3], axis=0), axis=1)
     assert step.max() < 0.05                                            # millimetre motion, no jumps
     for P in r["poses"]:
@@ -57,8 +58,10 @@ def test_driver_gpu_equals_oracle(vs, oracle):
     g = _run(slam.Backends(context=vs))
     c = _run(oracle_backends(oracle))
     assert g["keyframes"] == c["keyframes"] and g["tracked"] == c["tracked"] and g["n_points"] == c["n_points"]
+    assert g["pnp_inliers"] == c["pnp_inliers"]
     rel = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(g["poses"], c["poses"]))
     assert rel < 1e-4, rel
     pg = np.array([p.location_3d for p in g["map"].points_3d.values()])
     pc = np.array([p.location_3d for p in c["map"].points_3d.values()])
-    assert np.allclose(pg, pc, atol=1e-6)
+    # new points come out of local BA started from PnP poses that agree to ~1e-9: low-parallax points amplify that
+    assert np.abs(pg - pc).max() < 1e-5, np.abs(pg - pc).max()

@@ -177,6 +177,24 @@ class Context:
                                                ptr(depth, c_f64p) if depth is not None else None))
         return (X4[:n], depth[:n]) if depth is not None else X4[:n]
 
+    # ------------------------------------------------------------------ PnP-RANSAC
+    def pnp_ransac(self, obj, img, K, pose0, iterations=100, reproj_err=8.0, confidence=0.99, seed=0, refine_iters=10):
+        """obj [N,3], img [N,2], K = (fx, fy, cx, cy), pose0 = camera-to-world 4x4 guess.
+        Returns dict(found, pose (camera-to-world), inliers)."""
+        obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3)
+        img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)
+        pose0 = np.ascontiguousarray(pose0, np.float64).reshape(16)
+        n = obj.shape[0]
+        pose = np.zeros(16)
+        inl = np.zeros(max(n, 1), np.int32)
+        ni, found = C.c_int(0), C.c_int(0)
+        fx, fy, cx, cy = (float(v) for v in K)
+        self._chk(self._lib.vs_pnp_ransac(self._h, ptr(obj, c_f64p), ptr(img, c_f64p), n, fx, fy, cx, cy,
+                                          ptr(pose0, c_f64p), int(iterations), float(reproj_err), float(confidence),
+                                          int(seed), int(refine_iters), ptr(pose, c_f64p), ptr(inl, c_i32p),
+                                          C.byref(ni), C.byref(found)))
+        return dict(found=bool(found.value), pose=pose.reshape(4, 4), inliers=inl[:ni.value].copy())
+
     # ------------------------------------------------------------------ bundle adjustment (A9-A16)
     def ba_solve(self, poses, pose_fixed, points, point_fixed, obs_pose, obs_point, obs_uv, K,
                  huber_delta=float(np.sqrt(5.991)), max_iterations=10, scale_edges=None, obs_info=None, dcs_phi=1.0):

@@ -98,8 +98,8 @@ __device__ __host__ inline void quat_to_w2n(const double* t, const double* q, do
   }
 }
 
-// Eigen's matrix -> quaternion, then SE3Quat::normalizeRotation (w >= 0, unit norm)   [host, setup only]
-void quat_from_pose(const double* m, double* q) {
+// Eigen's matrix -> quaternion, then SE3Quat::normalizeRotation (w >= 0, unit norm)   [setup only]
+__device__ __host__ inline void quat_from_pose(const double* m, double* q) {
 #define M(r, c) m[(r)*4 + (c)]
   const double tr = M(0, 0) + M(1, 1) + M(2, 2);
   if (tr > 0.0) {
@@ -1266,6 +1266,230 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
   }
 }
 
+// ------------------------------------------------------------------------------------------------ PnP-RANSAC
+// cv2.solvePnPRansac as the reference calls it (src/v2/main.py:196-197; useExtrinsicGuess, ITERATIVE, 100 iterations,
+// 8 px, 0.99): hypothesis h refines the extrinsic guess on 5 sampled correspondences, inliers are counted over all
+// points, RANSACUpdateNumIters shrinks the budget, the best model is refined on its inliers.  One workgroup (one wave) per
+// hypothesis: lane 0 runs the 5-point LM (the same LM as ba_motion_step / the oracle, one camera, no robust kernel),
+// then the 64 lanes score the points and a ballot counts the inliers.  The sequential budget logic is replayed on the
+// host over the per-hypothesis inlier counts, so the result equals the sequential algorithm's.
+struct pnp_args {
+  const double* obj;   // [n][3]
+  const double* img;   // [n][2]
+  int n, iters_lm;
+  double fx, fy, cx, cy, thr2;
+  unsigned long long seed;
+  double cam0[kCamStride];
+  double* cam_out;     // [H][19] record re-derived from the 4x4 model
+  double* pose_out;    // [H][12] the model itself: rows of [R|t], camera-to-world
+  int* good_out;       // [H]
+};
+
+__device__ inline unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__device__ inline void pnp_err(const pnp_args& P, const double* cam, const double* X, const double* uv, double& eu,
+                               double& ev, double* pc) {
+  const double* w = cam + 7;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pc[i] = w[4 * i] * X[0] + w[4 * i + 1] * X[1] + w[4 * i + 2] * X[2] + w[4 * i + 3];
+  eu = (P.fx * pc[0] + P.cx * pc[2]) / pc[2] - uv[0];
+  ev = (P.fy * pc[1] + P.cy * pc[2]) / pc[2] - uv[1];
+}
+
+// chi2 (plain) of 5 correspondences and, if H != nullptr, the 6x6 normal equations (identity information)
+__device__ inline double pnp_system(const pnp_args& P, const double* cam, const double (*X)[3], const double (*uv)[2],
+                                    double (*H)[6], double* b) {
+  double chi = 0.0;
+  if (H) {
+    for (int a = 0; a < 6; ++a) {
+      b[a] = 0.0;
+      for (int c = 0; c < 6; ++c) H[a][c] = 0.0;
+    }
+  }
+  for (int j = 0; j < 5; ++j) {
+    double pc[3], eu, ev;
+    pnp_err(P, cam, X[j], uv[j], eu, ev, pc);
+    chi += eu * eu + ev * ev;
+    if (!H) continue;
+    const double* w = cam + 7;
+    const double px = pc[0], py = pc[1], pz = pc[2];
+    const double ipz2 = 1.0 / (pz * pz);
+    const double ipz2fx = ipz2 * P.fx, ipz2fy = ipz2 * P.fy;
+    const double p0 = X[j][0] - cam[0], p1 = X[j][1] - cam[1], p2 = X[j][2] - cam[2];
+    double r[3], J[2][6];
+    for (int k = 0; k < 3; ++k) r[k] = w[4 * k] * p0 + w[4 * k + 1] * p1 + w[4 * k + 2] * p2;
+    const double dpx[3] = {0.0, 2 * r[2], -2 * r[1]}, dpy[3] = {-2 * r[2], 0.0, 2 * r[0]}, dpz[3] = {2 * r[1], -2 * r[0], 0.0};
+    J[0][3] = (pz * dpx[0] - px * dpx[2]) * ipz2fx;
+    J[1][3] = (pz * dpx[1] - py * dpx[2]) * ipz2fy;
+    J[0][4] = (pz * dpy[0] - px * dpy[2]) * ipz2fx;
+    J[1][4] = (pz * dpy[1] - py * dpy[2]) * ipz2fy;
+    J[0][5] = (pz * dpz[0] - px * dpz[2]) * ipz2fx;
+    J[1][5] = (pz * dpz[1] - py * dpz[2]) * ipz2fy;
+    for (int a = 0; a < 3; ++a) {
+      J[0][a] = -((pz * w[a] - px * w[8 + a]) * ipz2fx);
+      J[1][a] = -((pz * w[4 + a] - py * w[8 + a]) * ipz2fy);
+    }
+    for (int a = 0; a < 6; ++a) {
+      b[a] += J[0][a] * (-eu) + J[1][a] * (-ev);
+      for (int c = 0; c < 6; ++c) H[a][c] += J[0][a] * J[0][c] + J[1][a] * J[1][c];
+    }
+  }
+  return chi;
+}
+
+__device__ inline void cam_apply(const double* src, const double* x, double* dst) {
+  double t[3] = {src[0] + x[0], src[1] + x[1], src[2] + x[2]};
+  const double bx = x[3], by = x[4], bz = x[5];
+  const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));
+  const double ax = src[3], ay = src[4], az = src[5], aw = src[6];
+  const double w = aw * bw - ax * bx - ay * by - az * bz;
+  const double xx = aw * bx + ax * bw + ay * bz - az * by;
+  const double yy = aw * by + ay * bw + az * bx - ax * bz;
+  const double zz = aw * bz + az * bw + ax * by - ay * bx;
+  const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
+  double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
+  for (int k = 0; k < 3; ++k) dst[k] = t[k];
+  for (int k = 0; k < 4; ++k) dst[3 + k] = q[k];
+  quat_to_w2n(t, q, dst + 7);
+}
+
+__global__ __launch_bounds__(64) void pnp_hypothesis_kernel(pnp_args P) {
+  __shared__ double s_cam[kCamStride];
+  const int h = blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) {
+    int idx[5];
+    if (P.n == 5) {
+      for (int k = 0; k < 5; ++k) idx[k] = k;
+    } else {
+      int got = 0;
+      for (unsigned long long k = 0; got < 5; ++k) {
+        const int c = (int)(splitmix64(P.seed ^ (((unsigned long long)h << 20) + k)) % (unsigned long long)P.n);
+        bool dup = false;
+        for (int j = 0; j < got; ++j) dup |= idx[j] == c;
+        if (!dup) idx[got++] = c;
+      }
+    }
+    double X[5][3], uv[5][2];
+    for (int j = 0; j < 5; ++j) {
+      for (int k = 0; k < 3; ++k) X[j][k] = P.obj[3 * (size_t)idx[j] + k];
+      uv[j][0] = P.img[2 * (size_t)idx[j]];
+      uv[j][1] = P.img[2 * (size_t)idx[j] + 1];
+    }
+    // Levenberg-Marquardt exactly as OptimizationAlgorithmLevenberg (one camera, five fixed points, no robust kernel)
+    double cam[kCamStride], trial[kCamStride];
+    for (int k = 0; k < kCamStride; ++k) cam[k] = P.cam0[k];
+    double lambda = 0.0, ni = 2.0;
+    for (int it = 0; it < P.iters_lm; ++it) {
+      double H[6][6], b[6];
+      double cur = pnp_system(P, cam, X, uv, H, b);
+      if (it == 0) {
+        double mx = 0.0;
+        for (int a = 0; a < 6; ++a) mx = fmax(mx, fabs(H[a][a]));
+        lambda = 1e-5 * mx;
+        ni = 2.0;
+      }
+      double rho = 0.0;
+      int qmax = 0, stop = 0;
+      do {
+        double A[6][6], x[6];
+        for (int a = 0; a < 6; ++a) {
+          for (int c = 0; c < 6; ++c) A[a][c] = H[a][c];
+          A[a][a] += lambda;
+          x[a] = b[a];
+        }
+        int ok = 1;
+        for (int j = 0; j < 6 && ok; ++j) {
+          double sdiag = A[j][j];
+          for (int k = 0; k < j; ++k) sdiag -= A[j][k] * A[j][k];
+          if (!(sdiag > 0.0)) {
+            ok = 0;
+            break;
+          }
+          const double l = sqrt(sdiag);
+          A[j][j] = l;
+          for (int i = j + 1; i < 6; ++i) {
+            double v = A[i][j];
+            for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k];
+            A[i][j] = v / l;
+          }
+        }
+        double temp = 1.7976931348623157e308;
+        if (ok) {
+          for (int i = 0; i < 6; ++i) {
+            double v = x[i];
+            for (int k = 0; k < i; ++k) v -= A[i][k] * x[k];
+            x[i] = v / A[i][i];
+          }
+          for (int i = 5; i >= 0; --i) {
+            double v = x[i];
+            for (int k = i + 1; k < 6; ++k) v -= A[k][i] * x[k];
+            x[i] = v / A[i][i];
+          }
+          cam_apply(cam, x, trial);
+          temp = pnp_system(P, trial, X, uv, nullptr, nullptr);
+        } else {
+          for (int a = 0; a < 6; ++a) x[a] = 0.0;
+        }
+        rho = cur - temp;
+        double scale = 0.0;
+        for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
+        scale += 1e-3;
+        rho /= scale;
+        if (rho > 0 && isfinite(temp)) {
+          double alpha = 1.0 - pow(2 * rho - 1, 3);
+          alpha = fmin(alpha, 2.0 / 3.0);
+          lambda *= fmax(1.0 / 3.0, alpha);
+          ni = 2.0;
+          cur = temp;
+          for (int k = 0; k < kCamStride; ++k) cam[k] = trial[k];
+        } else {
+          lambda *= ni;
+          ni *= 2;
+          if (!isfinite(lambda)) {
+            stop = 1;
+            break;
+          }
+        }
+        ++qmax;
+      } while (rho < 0 && qmax < 10);
+      if (qmax == 10 || rho == 0 || stop) break;
+    }
+    // the model is handed on as a 4x4 pose (as the sequential algorithm does): re-derive the record from that matrix
+    double m[16];
+    for (int r = 0; r < 3; ++r) {
+      for (int k = 0; k < 3; ++k) m[4 * r + k] = cam[7 + 4 * k + r];
+      m[4 * r + 3] = cam[r];
+    }
+    for (int k = 0; k < 12; ++k) P.pose_out[(size_t)h * 12 + k] = m[k];
+    quat_from_pose(m, cam + 3);
+    quat_to_w2n(cam, cam + 3, cam + 7);
+    for (int k = 0; k < kCamStride; ++k) {
+      s_cam[k] = cam[k];
+      P.cam_out[(size_t)h * kCamStride + k] = cam[k];
+    }
+  }
+  __syncthreads();
+  int good = 0;
+  for (int i0 = 0; i0 < P.n; i0 += 64) {
+    const int i = i0 + lane;
+    bool in = false;
+    if (i < P.n) {
+      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
+      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+      double eu, ev, pc[3];
+      pnp_err(P, s_cam, X, uv, eu, ev, pc);
+      in = eu * eu + ev * ev <= P.thr2;
+    }
+    good += __popcll(__ballot(in));
+  }
+  if (lane == 0) P.good_out[h] = good;
+}
+
 // ------------------------------------------------------------------------------------------------ host
 struct arena {
   uint8_t* base = nullptr;  // device
@@ -1680,5 +1904,140 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       o[15] = 1.0;
     }
   if (res->points_out) memcpy(res->points_out, h_pts, sizeof(double) * 3 * (size_t)P);
+  return VS_OK;
+}
+
+static int ransac_update_iters(double p, double ep, int model_points, int max_iters) {
+  if (p < 0) p = 0;
+  if (p > 1) p = 1;
+  if (ep < 0) ep = 0;
+  if (ep > 1) ep = 1;
+  double num = 1 - p > 2.2250738585072014e-308 ? 1 - p : 2.2250738585072014e-308;
+  double denom = 1 - pow(1 - ep, model_points);
+  if (denom < 2.2250738585072014e-308) return 0;
+  num = log(num);
+  denom = log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
+}
+
+VS_API int vs_pnp_ransac(vs_ctx* ctx, const double* obj, const double* img, int n, double fx, double fy, double cx,
+                         double cy, const double* pose0, int iterations, double reproj_err, double confidence,
+                         uint64_t seed, int refine_iters, double* pose_out, int32_t* inliers, int* n_inliers,
+                         int* found) {
+  if (!ctx) return VS_EINVAL;
+  if (!pose0 || !pose_out || !n_inliers || !found || n < 0 || iterations < 0 || refine_iters < 0 ||
+      (n > 0 && (!obj || !img || !inliers)))
+    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_pnp_ransac");
+  *found = 0;
+  *n_inliers = 0;
+  memcpy(pose_out, pose0, 16 * sizeof(double));
+  if (n < 5 || iterations == 0) return VS_OK;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int H = iterations;
+  const size_t off_img = (sizeof(double) * 3 * (size_t)n + 255) & ~(size_t)255;
+  const size_t off_cam = off_img + ((sizeof(double) * 2 * (size_t)n + 255) & ~(size_t)255);
+  const size_t off_pose = off_cam + ((sizeof(double) * kCamStride * (size_t)H + 255) & ~(size_t)255);
+  const size_t off_good = off_pose + ((sizeof(double) * 12 * (size_t)H + 255) & ~(size_t)255);
+  const size_t total = off_good + sizeof(int) * (size_t)H + 256;
+  VS_TRY(vs_reserve(ctx, &ctx->d_xy_in, total));
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, total));
+  VS_HIP(ctx, hipStreamSynchronize(s));
+  uint8_t* h = (uint8_t*)ctx->h_pin_big.p;
+  uint8_t* d = (uint8_t*)ctx->d_xy_in.p;
+  memcpy(h, obj, sizeof(double) * 3 * (size_t)n);
+  memcpy(h + off_img, img, sizeof(double) * 2 * (size_t)n);
+  VS_HIP(ctx, hipMemcpyAsync(d, h, off_cam, hipMemcpyHostToDevice, s));
+  pnp_args P;
+  P.obj = (const double*)d;
+  P.img = (const double*)(d + off_img);
+  P.n = n;
+  P.iters_lm = refine_iters;
+  P.fx = fx;
+  P.fy = fy;
+  P.cx = cx;
+  P.cy = cy;
+  P.thr2 = reproj_err * reproj_err;
+  P.seed = seed;
+  P.cam0[0] = pose0[3];
+  P.cam0[1] = pose0[7];
+  P.cam0[2] = pose0[11];
+  quat_from_pose(pose0, P.cam0 + 3);
+  quat_to_w2n(P.cam0, P.cam0 + 3, P.cam0 + 7);
+  P.cam_out = (double*)(d + off_cam);
+  P.pose_out = (double*)(d + off_pose);
+  P.good_out = (int*)(d + off_good);
+  hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(H), dim3(64), 0, s, P);
+  VS_LAUNCH_CHECK(ctx, "pnp_hypothesis_kernel");
+  VS_HIP(ctx, hipMemcpyAsync(h + off_cam, d + off_cam, total - off_cam, hipMemcpyDeviceToHost, s));
+  VS_HIP(ctx, hipStreamSynchronize(s));
+  const double* cams = (const double*)(h + off_cam);
+  const int* good = (const int*)(h + off_good);
+  // replay of the sequential RANSAC loop (budget update after every improvement) over the per-hypothesis counts
+  int max_good = 0, niters = H, best = -1;
+  for (int k = 0; k < niters && k < H; ++k) {
+    if (good[k] > (max_good > 4 ? max_good : 4)) {
+      max_good = good[k];
+      best = k;
+      niters = ransac_update_iters(confidence, (double)(n - good[k]) / n, 5, niters);
+    }
+  }
+  if (best < 0) return VS_OK;
+  // inliers of the best model (host, same arithmetic as the kernel's scoring)
+  const double* c = cams + (size_t)best * kCamStride;
+  const double* w = c + 7;
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const double* X = obj + 3 * (size_t)i;
+    double pc[3];
+    for (int k = 0; k < 3; ++k) pc[k] = w[4 * k] * X[0] + w[4 * k + 1] * X[1] + w[4 * k + 2] * X[2] + w[4 * k + 3];
+    const double eu = (fx * pc[0] + cx * pc[2]) / pc[2] - img[2 * (size_t)i];
+    const double ev = (fy * pc[1] + cy * pc[2]) / pc[2] - img[2 * (size_t)i + 1];
+    if (eu * eu + ev * ev <= P.thr2) inliers[m++] = i;
+  }
+  *n_inliers = m;
+  *found = 1;
+  double best_pose[16];
+  memcpy(best_pose, (const double*)(h + off_pose) + (size_t)best * 12, 12 * sizeof(double));
+  best_pose[12] = best_pose[13] = best_pose[14] = 0.0;
+  best_pose[15] = 1.0;
+  memcpy(pose_out, best_pose, sizeof best_pose);
+  if (m >= 1 && refine_iters > 0) {
+    // final refinement on the inliers = motion-only BA of one camera (solvePnP(inliers, useExtrinsicGuess) in OpenCV)
+    std::vector<double> pts(3 * (size_t)m), uv(2 * (size_t)m);
+    std::vector<int32_t> op(m, 0), oq(m);
+    std::vector<uint8_t> pf(m, 1);
+    for (int j = 0; j < m; ++j) {
+      memcpy(&pts[3 * j], obj + 3 * (size_t)inliers[j], 3 * sizeof(double));
+      memcpy(&uv[2 * j], img + 2 * (size_t)inliers[j], 2 * sizeof(double));
+      oq[j] = j;
+    }
+    uint8_t pose_free = 0;
+    vs_ba_problem bp;
+    memset(&bp, 0, sizeof bp);
+    bp.n_poses = 1;
+    bp.n_points = m;
+    bp.n_obs = m;
+    bp.poses = best_pose;
+    bp.pose_fixed = &pose_free;
+    bp.points = pts.data();
+    bp.point_fixed = pf.data();
+    bp.obs_pose = op.data();
+    bp.obs_point = oq.data();
+    bp.obs_uv = uv.data();
+    bp.fx = fx;
+    bp.fy = fy;
+    bp.cx = cx;
+    bp.cy = cy;
+    bp.huber_delta = 0;
+    bp.dcs_phi = 1;
+    bp.max_iterations = refine_iters;
+    vs_ba_result br;
+    memset(&br, 0, sizeof br);
+    double refined[16];
+    br.poses_out = refined;
+    VS_TRY(vs_ba_solve(ctx, &bp, &br));
+    memcpy(pose_out, refined, sizeof refined);
+  }
   return VS_OK;
 }

@@ -75,3 +75,34 @@ def transformMatrix(rvec, tvec):
     T[:3, :3] = Rotation.from_rotvec(np.asarray(rvec, np.float64).reshape(3)).as_matrix()
     T[:3, 3] = np.asarray(tvec, np.float64).reshape(3)
     return np.matrix(T)  # the reference returns np.matrix (main.py:202 slices it and squeezes with np.asarray)
+
+
+def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rvec=None, tvec=None,
+                   useExtrinsicGuess=False, iterationsCount=100, reprojectionError=8.0, confidence=0.99, inliers=None,
+                   flags=None, context=None, seed=0, solver=None):
+    """cv2.solvePnPRansac as main.py:196-197 calls it -> (retval, rvec [3,1], tvec [3,1], inliers [M,1] int32).
+
+    rvec/tvec are OpenCV's world-to-camera transform.  Hypotheses are LM refinements of the extrinsic guess on 5 sampled
+    correspondences (OpenCV's ITERATIVE solver with useExtrinsicGuess); without a guess the start is the identity
+    (OpenCV would run a DLT first - not provided).  distCoeffs must be empty.  `solver(obj, img, K4, pose0, ...)`
+    replaces Context.pnp_ransac (tests inject the CPU oracle)."""
+    if distCoeffs is not None and np.asarray(distCoeffs).size and np.any(np.asarray(distCoeffs) != 0):
+        raise ValueError("solvePnPRansac: lens distortion is not supported")
+    obj = np.asarray(objectPoints, np.float64).reshape(-1, 3)
+    img = np.asarray(imagePoints, np.float64).reshape(-1, 2)
+    Kmat = np.asarray(cameraMatrix, np.float64)
+    K4 = (Kmat[0, 0], Kmat[1, 1], Kmat[0, 2], Kmat[1, 2])
+    if useExtrinsicGuess and rvec is not None and tvec is not None:
+        c_T_w = np.asarray(transformMatrix(rvec, np.asarray(tvec, np.float64).reshape(3, 1)))
+    else:
+        c_T_w = np.eye(4)
+    pose0 = np.eye(4)
+    pose0[:3, :3] = c_T_w[:3, :3].T
+    pose0[:3, 3] = -c_T_w[:3, :3].T @ c_T_w[:3, 3]
+    run = solver or (context or default_context()).pnp_ransac
+    r = run(obj, img, K4, pose0, iterations=int(iterationsCount), reproj_err=float(reprojectionError),
+            confidence=float(confidence), seed=int(seed))
+    w_T_c = r["pose"]
+    R = w_T_c[:3, :3].T
+    t = -R @ w_T_c[:3, 3]
+    return bool(r["found"]), Rtorvec(R), t.reshape(3, 1), r["inliers"].astype(np.int32).reshape(-1, 1)

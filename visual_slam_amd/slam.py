@@ -8,11 +8,14 @@ on the CPU oracle (tests, bench baseline):
     motion-only BA   BundleAdjustment            main.py:213-214
     triangulation    helper_functions.triangulate main.py:284
     local BA         BundleAdjustment            main.py:322-323
-Two stages of main.py have no counterpart yet: the two-view initialisation
-(findEssentialMat / recoverPose, main.py:88-148) and cv2.solvePnPRansac (main.py:196).  They are replaced by
-  * initialisation from the first frame's keypoints back-projected with the dataset's depth image, followed by the same
-    normalisation main.py applies after its first BA (everything divided by the median point norm, LocalBA.py:178-190);
-  * the previous frame's optimised pose as the start of motion-only BA.
+    PnP-RANSAC       helper_functions.solvePnPRansac  main.py:196-204
+One stage of main.py has no counterpart yet: the two-view initialisation (findEssentialMat /
+recoverPose, main.py:88-148).  It is replaced by initialisation from the first frame's keypoints back-projected with the
+dataset's depth image, followed by the same normalisation main.py applies after its first BA (everything divided by the
+median point norm, LocalBA.py:178-190).
+main.py:193-194 hands solvePnPRansac the previous camera-to-world pose as if it were world-to-camera; here the guess is
+the previous world-to-camera transform (`pnp_guess="w2c"`); `pnp_guess="reference"` reproduces the reference's call,
+`pnp_guess=None` skips PnP and starts motion-only BA from the previous pose.
 The key-frame rule is main.py:221 with the frame gap as a parameter (20 there).
 """
 import copy
@@ -29,11 +32,15 @@ from .point import Point
 class Backends:
     """extractor / matcher objects and factories for BundleAdjustment and triangulate."""
 
-    def __init__(self, context=None, ba_solver=None, extractor=None, matcher=None, triangulate=None):
+    def __init__(self, context=None, ba_solver=None, extractor=None, matcher=None, triangulate=None, pnp_solver=None):
         self.extractor = extractor or FeatureExtractor(context=context)
         self.matcher = matcher or FeatureMatcher(context=context)
-        self._ctx, self._solver = context, ba_solver
+        self._ctx, self._solver, self._pnp = context, ba_solver, pnp_solver
         self.triangulate = triangulate or (lambda P1, P2, x1, x2: hf.triangulate(P1, P2, x1, x2, context=context))
+
+    def pnp(self, obj, img, K, rvec, tvec, seed):
+        return hf.solvePnPRansac(obj, img, K, None, rvec, tvec, useExtrinsicGuess=True, context=self._ctx, seed=seed,
+                                 solver=self._pnp)
 
     def ba(self, camera):
         return BundleAdjustment(camera, context=self._ctx, solver=self._solver)
@@ -43,7 +50,8 @@ def _inv(pose):
     return Isometry3d(R=pose[0:3, 0:3], t=np.asarray(pose[:3, -1]).squeeze()).inverse().matrix()
 
 
-def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, max_depth=1.0, log=None):
+def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, max_depth=1.0, log=None,
+                 pnp_guess="w2c"):
     """frames: list of BGR images; depth0: metric depth of frames[0]; K4 = (fx, fy, cx, cy).
     Returns dict(poses [n,4,4] camera-to-world, keyframes [indices], n_points, map, tracked [per frame])."""
     fx, fy, cx, cy = K4
@@ -75,7 +83,7 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
     id_frame_local = id_frame
     loop_idx = 0
     all_poses = {0: np.eye(4)}
-    keyframes, tracked = [0], []
+    keyframes, tracked, pnp_inliers = [0], [], []
     # ---- tracking loop (main.py:173-348)
     for i in range(1, len(frames)):
         cur_frame = Frame(frames[i], None, id_frame_local)
@@ -84,9 +92,20 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
         matches, _, _, curMatchedPoints, curMatchedFeatures = be.matcher.match_features(kp_prev, features_prev, kp_cur,
                                                                                          features_cur)
         known_3d_matched_ids = [point_IDs[m[0].queryIdx] for m in matches]
-        # pose start: previous frame (stands in for solvePnPRansac, main.py:191-204)
-        W_T_prev = local_map.GetFrame(id_frame_local - 1).GetPose()
-        W_T_curr = np.array(W_T_prev, dtype=np.float64)
+        known_3d_matched = np.array([known_3d[m[0].queryIdx] for m in matches]).reshape(-1, 3)
+        # pose from PnP-RANSAC with the previous frame as extrinsic guess (main.py:191-204)
+        W_T_prev = np.array(local_map.GetFrame(id_frame_local - 1).GetPose(), dtype=np.float64)
+        W_T_curr = W_T_prev.copy()
+        if pnp_guess is not None and len(known_3d_matched) >= 5:
+            guess = W_T_prev if pnp_guess == "reference" else _inv(W_T_prev)
+            retval, rvec, tvec, inl = be.pnp(known_3d_matched, curMatchedPoints, K, hf.Rtorvec(guess[:3, :3]),
+                                             np.array(guess[:3, 3]), seed=i)
+            if retval:
+                T = hf.transformMatrix(rvec, tvec)
+                W_T_curr = np.asarray(_inv(np.asarray(T)))
+            pnp_inliers.append(len(inl))
+        else:
+            pnp_inliers.append(0)
         RelativePoseTransformation = _inv(W_T_prev) @ W_T_curr
         local_map.AddParentAndPose(parent_id=id_frame_local - 1, frame_id=id_frame_local, frame_obj=cur_frame,
                                    rel_pose_trans=RelativePoseTransformation, pose=W_T_curr)
@@ -155,4 +174,5 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
         else:
             id_frame_local += 1
     poses = np.stack([all_poses[i] for i in range(len(frames))])
-    return dict(poses=poses, keyframes=keyframes, n_points=len(map.points_3d), map=map, tracked=tracked)
+    return dict(poses=poses, keyframes=keyframes, n_points=len(map.points_3d), map=map, tracked=tracked,
+                pnp_inliers=pnp_inliers)
