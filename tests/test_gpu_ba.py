@@ -106,8 +106,9 @@ def test_duplicate_observations_use_the_atomic_path(vs, oracle):
 
 
 def test_large_windows_take_the_global_memory_paths(vs, oracle):
-    # 18 free cameras -> 108 x 108 (slab in HBM, factorisation in LDS); 25 free cameras -> 144 x 144 (both in HBM)
-    for n_cams in (19, 26):
+    # 18 free cameras -> 108 x 108 (slab in HBM, factorisation in LDS); 25 / 40 free cameras -> 150 x 150 / 240 x 240
+    # (both in HBM: blocked factorisation with 24-column panels, the last one partial)
+    for n_cams in (19, 26, 41):
         w = ba_workload(n_cams=n_cams, n_points=300, seed=n_cams, visibility=0.5)
         _compare(vs.ba_solve(*_args(w), max_iterations=5), oracle.ba_solve(*_args(w), max_iterations=5))
 

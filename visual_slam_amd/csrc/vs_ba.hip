@@ -66,6 +66,8 @@ struct ba_dev {
   double* cam[2];
   double* pts[2];
   double *Hpp, *bp, *Hll, *bl, *Hpl, *Dinv, *slab, *S, *bs, *xp;
+  double* rinv;    // [np] reciprocal Cholesky pivots (large systems)
+  int* chol_fail;  // set by a panel kernel that met a non-positive pivot
   double *part_chi, *part_scale, *part_maxd;  // per point-block partials; part_maxd has nb_pt + nfp entries
   double *chi_trace, *lambda_trace;
   lm_state* st;
@@ -801,6 +803,211 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
       double t[3] = {src[0] + d[0], src[1] + d[1], src[2] + d[2]};
       const double bx = d[3], by = d[4], bz = d[5];
       const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));  // NaN for an oversized step -> trial rejected
+      const double ax = src[3], ay = src[4], az = src[5], aw = src[6];
+      const double w = aw * bw - ax * bx - ay * by - az * bz;
+      const double xx = aw * bx + ax * bw + ay * bz - az * by;
+      const double yy = aw * by + ay * bw + az * bx - ax * bz;
+      const double zz = aw * bz + az * bw + ax * by - ay * bx;
+      const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
+      double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
+      for (int k = 0; k < 3; ++k) dst[k] = t[k];
+      for (int k = 0; k < 4; ++k) dst[3 + k] = q[k];
+      quat_to_w2n(t, q, dst + 7);
+    }
+  }
+  if (tid == 0) {
+    double sc = 0.0;
+    if (ok)
+      for (int j = 0; j < n; ++j) sc += x[j] * (st->lambda * x[j] + D.bp[j]);
+    st->scale_pose = sc;
+    st->solve_ok = ok;
+    st->trials += 1;
+    if (!ok) st->not_pd += 1;
+  }
+}
+
+// Large systems (n > 126): blocked right-looking Cholesky in HBM, two launches per block column.
+//   ba_chol_panel(j0, nbw): one workgroup takes columns [j0, j0+nbw) of rows j0..n (row n = rhs, as above) into LDS,
+//     factorises them with the same 6x6 scheme as ba_solve_block and writes them back;
+//   ba_chol_update(j0, nbw): 32x32 tiles of the trailing lower triangle (and the rhs row) subtract the panel's
+//     contribution, every element in ascending column order -- the sequential algorithm's order;
+//   ba_chol_finish: blocked backward substitution by one workgroup, then the camera update epilogue.
+constexpr int kPanelThreads = 512;
+constexpr int kUpdTile = 32;
+
+__device__ inline double* chol_row(const ba_dev& D, int r) { return r < D.np ? D.S + (size_t)r * D.np : D.bs; }
+
+__global__ __launch_bounds__(kPanelThreads) void ba_chol_panel(ba_dev D, int j0, int nbw) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  if (D.st->done) return;
+  const int n = D.np, tid = threadIdx.x;
+  if (j0 == 0) {
+    if (tid == 0) *D.chol_fail = 0;
+  } else if (*D.chol_fail) {
+    return;
+  }
+  const int rows = n + 1 - j0, ld = nbw | 1;
+  double* A = s_mem;                       // [rows][ld]
+  double* rinv = s_mem + (size_t)rows * ld;  // [nbw]
+  int* s_flag = reinterpret_cast<int*>(rinv + nbw);
+  for (int e = tid; e < rows * nbw; e += kPanelThreads) {
+    const int r = e / nbw, c = e - r * nbw;
+    A[r * ld + c] = chol_row(D, j0 + r)[j0 + c];
+  }
+  if (tid == 0) *s_flag = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < nbw; b0 += 6) {
+    if (tid == 0) {
+      double L[6][6], ri[6];
+      int good = 1;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) L[r][c] = A[(b0 + r) * ld + b0 + c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double d = L[c][c];
+        if (!(d > 0.0)) good = 0;
+        double r = __builtin_amdgcn_rsq(d);
+        r = r * (1.5 - 0.5 * d * r * r);
+        r = r * (1.5 - 0.5 * d * r * r);
+        double l = d * r;
+        l = l + 0.5 * r * (d - l * l);
+        L[c][c] = l;
+        ri[c] = r;
+#pragma unroll
+        for (int i = c + 1; i < 6; ++i) L[i][c] = L[i][c] * r;
+#pragma unroll
+        for (int i = c + 1; i < 6; ++i)
+#pragma unroll
+          for (int k = c + 1; k <= i; ++k) L[i][k] -= L[i][c] * L[k][c];
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+#pragma unroll
+        for (int c = 0; c <= r; ++c) A[(b0 + r) * ld + b0 + c] = L[r][c];
+        rinv[b0 + r] = ri[r];
+      }
+      if (!good) *s_flag = 1;
+    }
+    __syncthreads();
+    if (*s_flag) break;  // uniform
+    for (int r = b0 + 6 + tid; r < rows; r += kPanelThreads) {
+      double a[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) a[c] = A[r * ld + b0 + c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double v = a[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) v -= a[k] * A[(b0 + c) * ld + b0 + k];
+        a[c] = v * rinv[b0 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) A[r * ld + b0 + c] = a[c];
+    }
+    __syncthreads();
+    // update of the panel's remaining columns: thread = (row, column), 6-term dot product
+    const int wc = nbw - b0 - 6;
+    if (wc > 0) {
+      for (int e = tid; e < (rows - b0 - 6) * wc; e += kPanelThreads) {
+        const int r = b0 + 6 + e / wc, c = b0 + 6 + e % wc;
+        if (c > r && r < rows - 1) continue;  // strictly upper part of the matrix rows (the rhs row keeps all columns)
+        double acc = A[r * ld + c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc -= A[r * ld + b0 + k] * A[c * ld + b0 + k];
+        A[r * ld + c] = acc;
+      }
+      __syncthreads();
+    }
+  }
+  if (*s_flag) {
+    if (tid == 0) *D.chol_fail = 1;
+    return;
+  }
+  for (int e = tid; e < rows * nbw; e += kPanelThreads) {
+    const int r = e / nbw, c = e - r * nbw;
+    if (c <= r || r == rows - 1) chol_row(D, j0 + r)[j0 + c] = A[r * ld + c];
+  }
+  for (int c = tid; c < nbw; c += kPanelThreads) D.rinv[j0 + c] = rinv[c];
+}
+
+// grid (T, T) over the trailing block starting at c0 = j0 + nbw; tiles above the diagonal exit
+__global__ __launch_bounds__(256) void ba_chol_update(ba_dev D, int j0, int nbw) {
+  __shared__ double sR[kUpdTile][25], sC[kUpdTile][25];
+  if (D.st->done || *D.chol_fail) return;
+  if (blockIdx.x > blockIdx.y) return;
+  const int n = D.np, c0 = j0 + nbw, tid = threadIdx.x;
+  const int r_base = c0 + blockIdx.y * kUpdTile, c_base = c0 + blockIdx.x * kUpdTile;
+  for (int e = tid; e < kUpdTile * nbw; e += 256) {
+    const int r = e / nbw, k = e - r * nbw;
+    sR[r][k] = r_base + r <= n ? chol_row(D, r_base + r)[j0 + k] : 0.0;
+    sC[r][k] = c_base + r < n ? D.S[(size_t)(c_base + r) * n + j0 + k] : 0.0;
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int lr = ty + 16 * a, lc = tx + 16 * b;
+      const int r = r_base + lr, c = c_base + lc;
+      if (r > n || c >= n || (c > r)) continue;
+      double* dst = chol_row(D, r) + c;
+      double acc = *dst;
+      for (int k = 0; k < nbw; ++k) acc -= sR[lr][k] * sC[lc][k];
+      *dst = acc;
+    }
+}
+
+__global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nbw) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  lm_state* st = D.st;
+  if (st->done) return;
+  const int n = D.np, tid = threadIdx.x;
+  double* x = s_mem;  // [n]
+  const int ok = !*D.chol_fail;
+  if (ok) {
+    for (int i = tid; i < n; i += kPanelThreads) x[i] = D.bs[i];
+    __syncthreads();
+    // blocks of nbw rows from the bottom: triangular solve inside the block (wave 0), then one matvec for the rows above
+    for (int k1 = n; k1 > 0;) {
+      const int k0 = k1 - ((k1 % nbw) ? (k1 % nbw) : nbw);
+      if (tid < 64) {
+        for (int k = k1 - 1; k >= k0; --k) {
+          const double xk = x[k] * D.rinv[k];
+          wave_lds_sync();
+          if (tid == 0) x[k] = xk;
+          for (int i = k0 + tid; i < k; i += 64) x[i] -= D.S[(size_t)k * n + i] * xk;
+          wave_lds_sync();
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < k0; i += kPanelThreads) {
+        double v = x[i];
+        for (int k = k1 - 1; k >= k0; --k) v -= D.S[(size_t)k * n + i] * x[k];
+        x[i] = v;
+      }
+      __syncthreads();
+      k1 = k0;
+    }
+    for (int i = tid; i < n; i += kPanelThreads) D.xp[i] = x[i];
+  }
+  __syncthreads();
+  const int cur = st->cur;
+  const double* c0 = D.cam[cur];
+  double* c1 = D.cam[cur ^ 1];
+  for (int p = tid; p < D.n_poses; p += kPanelThreads) {
+    const double* src = c0 + (size_t)p * kCamStride;
+    double* dst = c1 + (size_t)p * kCamStride;
+    const int cs = D.pose_slot[p];
+    if (cs < 0 || !ok) {
+      for (int k = 0; k < kCamStride; ++k) dst[k] = src[k];
+    } else {
+      const double* d = x + 6 * cs;
+      double t[3] = {src[0] + d[0], src[1] + d[1], src[2] + d[2]};
+      const double bx = d[3], by = d[4], bz = d[5];
+      const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));
       const double ax = src[3], ay = src[4], az = src[5], aw = src[6];
       const double w = aw * bw - ax * bx - ay * by - az * bz;
       const double xx = aw * bx + ax * bw + ay * bz - az * by;
@@ -1611,7 +1818,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   size_t need = (1u << 20) + sizeof(int) * ((size_t)F + P + 3 * (size_t)n_act + 4 * (size_t)n_obs + 2 * (size_t)nfp +
                                             cam_obs.size() + 2 * (size_t)q.n_scale + nfl + 64) +
                 sizeof(double) * (5 * (size_t)n_obs + (size_t)q.n_scale + 2 * (size_t)F * kCamStride + 6 * (size_t)P +
-                                  2 * (size_t)np * np + 4 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
+                                  2 * (size_t)np * np + 8 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
                                   9 * (size_t)nfl + (size_t)(ns ? ns : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
                                   2 * (size_t)q.max_iterations + 64) +
                 256 * 64 + sizeof(int) * (2 * (size_t)n_obs + nfl + 16) + (motion_only ? sizeof(double) * (8 * cam_obs.size() + 50 * (size_t)nfp + 64) : 0);
@@ -1697,6 +1904,8 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.S = A.take<double>((size_t)np * np);
   D.bs = A.take<double>(np);
   D.xp = A.take<double>(np);
+  D.rinv = A.take<double>(np);
+  D.chol_fail = A.take<int>(4);
   D.part_chi = A.take<double>(nb_pt);
   D.part_scale = A.take<double>(nb_pt);
   D.part_maxd = A.take<double>((size_t)nb_pt + nfp);
@@ -1780,6 +1989,23 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     if (lds_slab) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
     else VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
   }
+  // blocked HBM factorisation for larger systems: widest panel (24 / 12 / 6 columns) whose rows j0..n fit in LDS
+  int chol_nbw = 0;
+  size_t chol_panel_lds = 0;
+  if (!solve_lds) {
+    for (int w : {24, 12, 6}) {
+      const size_t b = sizeof(double) * ((size_t)(np + 1) * (w | 1) + w) + 64;
+      if (b <= 150 * 1024 && sizeof(double) * (size_t)np + 64 <= 150 * 1024) {
+        chol_nbw = w;
+        chol_panel_lds = b;
+        break;
+      }
+    }
+    if (chol_nbw) {
+      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_panel_lds));
+      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (size_t)np + 64)));
+    }
+  }
   if (solve_lds_bytes > 64 * 1024)
     VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes));
   if (schur_lds > 160 * 1024) return vs_fail(ctx, VS_EINVAL, "%s: a point is observed by too many free cameras for the LDS staging", "vs_ba_solve");
@@ -1802,8 +2028,22 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 255) / 256)), dim3(256), 0, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_reduce");
     }
-    if (solve_lds) hipLaunchKernelGGL(ba_solve_block, dim3(1), dim3(kSolveBlock), solve_lds_bytes, s, D);
-    else hipLaunchKernelGGL(ba_solve<false>, dim3(1), dim3(kSolveThreads), solve_lds_bytes, s, D);
+    if (solve_lds) {
+      hipLaunchKernelGGL(ba_solve_block, dim3(1), dim3(kSolveBlock), solve_lds_bytes, s, D);
+    } else if (chol_nbw > 0) {
+      for (int j0 = 0; j0 < np; j0 += chol_nbw) {
+        const int w = std::min(chol_nbw, np - j0);
+        hipLaunchKernelGGL(ba_chol_panel, dim3(1), dim3(kPanelThreads), chol_panel_lds, s, D, j0, w);
+        const int rem = np + 1 - (j0 + w);  // trailing rows incl. the rhs row
+        if (rem > 0) {
+          const unsigned T = (unsigned)((rem + kUpdTile - 1) / kUpdTile);
+          hipLaunchKernelGGL(ba_chol_update, dim3(T, T), dim3(256), 0, s, D, j0, w);
+        }
+      }
+      hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * (size_t)np + 64, s, D, chol_nbw);
+    } else {
+      hipLaunchKernelGGL(ba_solve<false>, dim3(1), dim3(kSolveThreads), solve_lds_bytes, s, D);
+    }
     VS_LAUNCH_CHECK(ctx, "ba_solve");
     hipLaunchKernelGGL(ba_point_trial, dim3(nb_pt), dim3(kPtThreads), 0, s, D);
     VS_LAUNCH_CHECK(ctx, "ba_point_trial");
