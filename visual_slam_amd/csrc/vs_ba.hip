@@ -66,6 +66,9 @@ struct ba_dev {
   double* cam[2];
   double* pts[2];
   double *Hpp, *bp, *Hll, *bl, *Hpl, *Dinv, *slab, *S, *bs, *xp;
+  const unsigned long long* fp_mask;  // per free point: bit t set iff it is observed by a camera of tile row t
+  double* Dbl;     // [nfl][3] (Hll + lambda I)^-1 bl (tiled Schur)
+  int ntile;       // tiles of kTileCams cameras per side (tiled Schur), 0 otherwise
   double* rinv;    // [np] reciprocal Cholesky pivots (large systems)
   int* chol_fail;  // set by a panel kernel that met a non-positive pivot
   double *part_chi, *part_scale, *part_maxd;  // per point-block partials; part_maxd has nb_pt + nfp entries
@@ -77,6 +80,12 @@ struct ba_dev {
 };
 
 // ------------------------------------------------------------------------------------------------ small math
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __host__ inline void quat_to_w2n(const double* t, const double* q, double* w /*[12]*/) {
   const double x = q[0], y = q[1], z = q[2], ww = q[3];
   const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
@@ -545,6 +554,205 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur(ba_dev D) {
   }
 }
 
+// Tiled variant for windows beyond 15 free cameras (the slab no longer fits in LDS).  The slab is cut into tiles of
+// kTileCams x kTileCams camera blocks; workgroup (s, tr, tc) walks slab s's points, keeps those that are seen from both
+// camera ranges (one 64-bit mask per point, written by the host) and accumulates its tile IN REGISTERS: wave w owns the
+// local row cameras w, w+4, w+8 and lane (block row a, column camera c) owns the 6 elements [a][0..5] of block (row, c)
+// for each of them - fixed ownership, so no atomics, no LDS read-modify-write and no barrier between points; per
+// element the points arrive in the same order as in the kernel above, so the sums are identical.  Hpl blocks are staged
+// for kTileBatch points per barrier, all loads issued before the first use, and the camera maps of batch b+1 are
+// scattered while batch b is staged (three map buffers: read / being filled / being cleared).
+constexpr int kTileCams = 10, kTileN = 6 * kTileCams, kTileBatch = 8, kTileChunk = 512, kTileRows = (kTileCams + 3) / 4;
+
+__global__ __launch_bounds__(256) void ba_dinv(ba_dev D) {
+  const lm_state st = *D.st;
+  if (st.done) return;
+  const int l = blockIdx.x * 256 + threadIdx.x;
+  if (l >= D.nfl) return;
+  double Dm[9], inv[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[9 * (size_t)l + k];
+  Dm[0] += st.lambda;
+  Dm[4] += st.lambda;
+  Dm[8] += st.lambda;
+  inv3(Dm, inv);
+  const double b0 = D.bl[3 * (size_t)l], b1 = D.bl[3 * (size_t)l + 1], b2 = D.bl[3 * (size_t)l + 2];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) D.Dinv[9 * (size_t)l + k] = inv[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) D.Dbl[3 * (size_t)l + k] = inv[3 * k] * b0 + inv[3 * k + 1] * b1 + inv[3 * k + 2] * b2;
+}
+
+__global__ __launch_bounds__(256) void ba_schur_tile(ba_dev D) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  if (D.st->done) return;
+  const int np = D.np, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tr = blockIdx.y / D.ntile, tc = blockIdx.y - tr * D.ntile;
+  const int per = (D.nfl + D.ns - 1) / D.ns;
+  const int l0 = blockIdx.x * per, l1 = min(l0 + per, D.nfl);
+  double* sD = s_mem;                                 // [2][batch][12]   Dinv, Dinv bl (double-buffered)
+  double* sY = sD + 2 * kTileBatch * 12;              // [batch][cams][18]
+  double* sB = sY + kTileBatch * kTileCams * 18;      // [batch][cams][18]
+  int* sMap = reinterpret_cast<int*>(sB + kTileBatch * kTileCams * 18);  // [3][batch][2][16]: Hpl block of a local camera, -1
+  int* sList = sMap + 3 * kTileBatch * 32;            // [kTileChunk][3]: point, first Hpl block, blocks
+  int* sCnt = sList + 3 * kTileChunk;                 // [8]: wave counts
+  const int arow = lane / kTileCams, ccam = lane - arow * kTileCams;  // lanes 60..63 (arow == 6) idle in the products
+  double acc[kTileRows][6], racc[kTileRows];
+#pragma unroll
+  for (int r = 0; r < kTileRows; ++r) {
+    racc[r] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[r][c] = 0.0;
+  }
+  const unsigned long long want = (1ull << tr) | (1ull << tc);
+  constexpr int kPerThread = kTileChunk / 256, kScat = 256 / kTileBatch;
+  auto scatter = [&](int b0, int nb, int mbuf, int dbuf) {
+    const int pb = tid / kScat, i0 = tid - pb * kScat;  // kScat threads per point of the batch
+    if (pb < nb) {
+      const int base = sList[3 * (b0 + pb) + 1], m = sList[3 * (b0 + pb) + 2];
+      for (int i = i0; i < m; i += kScat) {
+        const int slot = D.fp_slot[base + i];
+        const int t = slot / kTileCams, ls = slot - t * kTileCams;
+        if (t == tr) sMap[(mbuf * kTileBatch + pb) * 32 + ls] = base + i;
+        if (t == tc) sMap[(mbuf * kTileBatch + pb) * 32 + 16 + ls] = base + i;
+      }
+    }
+    for (int i = tid; i < nb * 12; i += 256) {
+      const int q = i / 12, k = i - q * 12;
+      const int l = sList[3 * (b0 + q)];
+      sD[dbuf * kTileBatch * 12 + i] = k < 9 ? D.Dinv[9 * (size_t)l + k] : D.Dbl[3 * (size_t)l + k - 9];
+    }
+  };
+  for (int c0 = l0; c0 < l1; c0 += kTileChunk) {
+    // ---- ordered list of this chunk's points that touch both camera ranges (thread = kPerThread consecutive points)
+    const int cn = min(kTileChunk, l1 - c0);
+    unsigned keep = 0;
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+      const int i = tid * kPerThread + k;
+      if (i < cn && (D.fp_mask[c0 + i] & want) == want) keep |= 1u << k;
+    }
+    const int cnt = __popc(keep);
+    int scan = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(scan, d);
+      if (lane >= d) scan += v;
+    }
+    __syncthreads();  // the previous chunk's readers of sList / sCnt / sMap are done
+    if (lane == 63) sCnt[wv] = scan;
+    for (int i = tid; i < 3 * kTileBatch * 32; i += 256) sMap[i] = -1;
+    __syncthreads();
+    int off = scan - cnt;
+    for (int w = 0; w < wv; ++w) off += sCnt[w];
+    const int total = sCnt[0] + sCnt[1] + sCnt[2] + sCnt[3];
+    for (int k = 0; k < kPerThread; ++k)
+      if (keep >> k & 1) {
+        const int l = c0 + tid * kPerThread + k;
+        const int base = D.fp_start[l];
+        sList[3 * off] = l;
+        sList[3 * off + 1] = base;
+        sList[3 * off + 2] = D.fp_start[l + 1] - base;
+        ++off;
+      }
+    __syncthreads();
+    if (total == 0) continue;  // uniform
+    scatter(0, min(kTileBatch, total), 0, 0);
+    __syncthreads();
+    int bi = 0;
+    for (int b0 = 0; b0 < total; b0 += kTileBatch, ++bi) {
+      const int nb = min(kTileBatch, total - b0);
+      const int mb = bi % 3, db = bi & 1;
+      // P1: stage batch b from its maps; scatter batch b+1
+      {
+        // item = (point, side, local camera, block row): 3 contiguous values of the Hpl block
+        constexpr int kItems = kTileBatch * 2 * kTileCams * 6, kRounds = (kItems + 255) / 256;
+        double v[kRounds][3];
+        int dst[kRounds];
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+          const int i = tid + 256 * r;
+          const int ar = i % 6, q = i / 6;
+          const int ls = q % kTileCams, side = (q / kTileCams) & 1, pb = q / (2 * kTileCams);
+          dst[r] = -1;
+          if (pb < nb) {
+            const int blk = sMap[(mb * kTileBatch + pb) * 32 + side * 16 + ls];
+            if (blk >= 0) {
+              const double* B = D.Hpl + 18 * (size_t)blk + 3 * ar;
+              v[r][0] = B[0];
+              v[r][1] = B[1];
+              v[r][2] = B[2];
+              dst[r] = ((pb * kTileCams + ls) * 18 + 3 * ar) * 2 + side;
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+          if (dst[r] < 0) continue;
+          const int o = dst[r] >> 1;
+          if (dst[r] & 1) {
+            sB[o] = v[r][0];
+            sB[o + 1] = v[r][1];
+            sB[o + 2] = v[r][2];
+          } else {
+            const double* sd = sD + (db * kTileBatch + o / (kTileCams * 18)) * 12;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) sY[o + c] = v[r][0] * sd[c] + v[r][1] * sd[3 + c] + v[r][2] * sd[6 + c];
+          }
+        }
+      }
+      if (b0 + kTileBatch < total) scatter(b0 + kTileBatch, min(kTileBatch, total - b0 - kTileBatch), (bi + 1) % 3, db ^ 1);
+      __syncthreads();
+      // P2: products of batch b into the register accumulators; clear the map buffer of batch b+2
+      for (int i = tid; i < kTileBatch * 32; i += 256) sMap[((bi + 2) % 3) * kTileBatch * 32 + i] = -1;
+      for (int pb = 0; pb < nb; ++pb) {
+        const int* map = sMap + (mb * kTileBatch + pb) * 32;
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < kTileRows; ++r) any |= wv + 4 * r < kTileCams && map[wv + 4 * r] >= 0;
+        if (!any) continue;  // wave-uniform
+        const bool have = arow < 6 && map[16 + ccam] >= 0;
+        double Bv[18];
+        if (have) {
+          const double* B = sB + (pb * kTileCams + ccam) * 18;
+#pragma unroll
+          for (int k = 0; k < 18; ++k) Bv[k] = B[k];
+        }
+        const double* sd = sD + (db * kTileBatch + pb) * 12;
+#pragma unroll
+        for (int r = 0; r < kTileRows; ++r) {
+          const int ls = wv + 4 * r;
+          if (ls >= kTileCams || map[ls] < 0) continue;  // wave-uniform
+          if (have) {
+            const double* Y = sY + (pb * kTileCams + ls) * 18 + 3 * arow;
+            const double y0 = Y[0], y1 = Y[1], y2 = Y[2];
+#pragma unroll
+            for (int bc = 0; bc < 6; ++bc) acc[r][bc] += y0 * Bv[3 * bc] + y1 * Bv[3 * bc + 1] + y2 * Bv[3 * bc + 2];
+          }
+          if (tr == tc && arow < 6 && ccam == 0) {
+            const double* B = sB + (pb * kTileCams + ls) * 18 + 3 * arow;
+            racc[r] += B[0] * sd[9] + B[1] * sd[10] + B[2] * sd[11];
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  double* out = D.slab + (size_t)blockIdx.x * ((size_t)np * np + np);
+  if (arow < 6) {
+#pragma unroll
+    for (int r = 0; r < kTileRows; ++r) {
+      const int ls = wv + 4 * r;
+      if (ls >= kTileCams) continue;
+      const int row = tr * kTileN + 6 * ls + arow, col = tc * kTileN + 6 * ccam;
+      if (row < np && col < np) {
+#pragma unroll
+        for (int bc = 0; bc < 6; ++bc) out[(size_t)row * np + col + bc] = acc[r][bc];
+      }
+      if (tr == tc && ccam == 0 && row < np) out[(size_t)np * np + row] = racc[r];
+    }
+  }
+}
+
 // S = Hpp + lambda I - sum_s slab_s ; bs = bp - sum_s bslab_s
 __global__ __launch_bounds__(256) void ba_reduce(ba_dev D) {
   const lm_state st = *D.st;
@@ -677,11 +885,6 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve(ba_dev D) {
 //     in the dependent chain; the results differ from the oracle's sqrt/divide by <= 2 ulp
 //   * row stride is odd so the 16 row-owners of a tile hit distinct banks
 //   * the backward substitution L^T x = y runs on wave 0 alone, wave-synchronously
-__device__ inline void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 constexpr int kSolveBlock = 256;
 
@@ -1798,6 +2001,15 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   }
   fp_start[nfl] = (int)fp_slot.size();
   const int n_hpl = (int)fp_slot.size();
+  // tiled Schur (windows beyond the LDS slab): per free point the set of camera tiles that observe it
+  const int ntile = (nfp + kTileCams - 1) / kTileCams;
+  const bool tiled = np > kMaxSlabN && !dups && ntile <= 64 && nfl > 0;
+  std::vector<unsigned long long> fp_mask;
+  if (tiled) {
+    fp_mask.assign(nfl, 0ull);
+    for (int l = 0; l < nfl; ++l)
+      for (int i = fp_start[l]; i < fp_start[l + 1]; ++i) fp_mask[l] |= 1ull << (fp_slot[i] / kTileCams);
+  }
 
   // ---- motion-only fast path (block-diagonal problem): one launch per LM trial, one workgroup per free camera
   const bool motion_only = nfl == 0 && p->n_scale == 0 && nfp > 0 && p->max_iterations > 0;
@@ -1810,6 +2022,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   const int nb_pt = std::max(1, (n_act + kPtThreads - 1) / kPtThreads);
   int ns = nfl > 0 && nfp > 0 ? std::min(256, (nfl + 7) / 8) : 0;
   const bool lds_slab = np <= kMaxSlabN;
+  if (tiled) ns = std::max(4, std::min(256, (16384 + ntile * ntile - 1) / (ntile * ntile)));  // >= 16k workgroups: most tiles are empty
   if (!lds_slab && ns > 0) ns = std::min(ns, std::max(1, (int)((512u << 20) / (sizeof(double) * ((size_t)np * np + np)))));
   const size_t slab_elems = (size_t)np * np + np;
 
@@ -1819,7 +2032,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
                                             cam_obs.size() + 2 * (size_t)q.n_scale + nfl + 64) +
                 sizeof(double) * (5 * (size_t)n_obs + (size_t)q.n_scale + 2 * (size_t)F * kCamStride + 6 * (size_t)P +
                                   2 * (size_t)np * np + 8 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
-                                  9 * (size_t)nfl + (size_t)(ns ? ns : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
+                                  9 * (size_t)nfl + (tiled ? 4 * (size_t)nfl : 0) + (size_t)(ns ? ns : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
                                   2 * (size_t)q.max_iterations + 64) +
                 256 * 64 + sizeof(int) * (2 * (size_t)n_obs + nfl + 16) + (motion_only ? sizeof(double) * (8 * cam_obs.size() + 50 * (size_t)nfp + 64) : 0);
   VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
@@ -1871,6 +2084,12 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.o_hpl = A.take<int>(n_obs, &h_ohpl);
   D.fp_start = A.take<int>(nfl + 1, &h_fps);
   D.fp_slot = A.take<int>(n_hpl, &h_fpl);
+  if (tiled) {
+    unsigned long long* h_mask;
+    D.fp_mask = A.take<unsigned long long>(nfl, &h_mask);
+    memcpy(h_mask, fp_mask.data(), sizeof(unsigned long long) * (size_t)nfl);
+    D.ntile = ntile;
+  }
   memcpy(h_ohpl, o_hpl.data(), sizeof(int) * (size_t)n_obs);
   memcpy(h_fps, fp_start.data(), sizeof(int) * ((size_t)nfl + 1));
   if (n_hpl) memcpy(h_fpl, fp_slot.data(), sizeof(int) * (size_t)n_hpl);
@@ -1905,6 +2124,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.bs = A.take<double>(np);
   D.xp = A.take<double>(np);
   D.rinv = A.take<double>(np);
+  if (tiled) D.Dbl = A.take<double>(3 * (size_t)nfl);
   D.chol_fail = A.take<int>(4);
   D.part_chi = A.take<double>(nb_pt);
   D.part_scale = A.take<double>(nb_pt);
@@ -1985,7 +2205,10 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   const size_t schur_lds = sizeof(double) * ((lds_slab ? slab_elems : 0) + 12 * (size_t)schur_per + 36 * (size_t)mmax) + sizeof(int) * ((size_t)mmax + 1) + 16;
   const bool solve_lds = np <= kMaxLdsN;
   const size_t solve_lds_bytes = 32 + (solve_lds ? sizeof(double) * ((size_t)(np + 1) * ((np + 1) | 1) + np + 2) : 0);
-  if (schur_lds > 64 * 1024) {
+  const size_t tile_lds = sizeof(double) * (2 * kTileBatch * 12 + 2 * kTileBatch * kTileCams * 18) +
+                          sizeof(int) * (3 * kTileBatch * 32 + 3 * kTileChunk + 8) + 64;
+  if (tiled) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
+  if (!tiled && schur_lds > 64 * 1024) {
     if (lds_slab) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
     else VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
   }
@@ -2008,7 +2231,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   }
   if (solve_lds_bytes > 64 * 1024)
     VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes));
-  if (schur_lds > 160 * 1024) return vs_fail(ctx, VS_EINVAL, "%s: a point is observed by too many free cameras for the LDS staging", "vs_ba_solve");
+  if (!tiled && schur_lds > 160 * 1024) return vs_fail(ctx, VS_EINVAL, "%s: a point is observed by too many free cameras for the LDS staging", "vs_ba_solve");
 
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + sizeof(mo_state) + 128));
   lm_state* hst = reinterpret_cast<lm_state*>((uint8_t*)ctx->h_pin.p + 128);
@@ -2019,7 +2242,11 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       hipLaunchKernelGGL(ba_lambda_init, dim3(1), dim3(64), 0, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_lambda_init");
     }
-    if (ns > 0) {
+    if (ns > 0 && tiled) {
+      hipLaunchKernelGGL(ba_dinv, dim3((unsigned)((nfl + 255) / 256)), dim3(256), 0, s, D);
+      hipLaunchKernelGGL(ba_schur_tile, dim3(ns, ntile * ntile), dim3(256), tile_lds, s, D);
+      VS_LAUNCH_CHECK(ctx, "ba_schur_tile");
+    } else if (ns > 0) {
       if (lds_slab) hipLaunchKernelGGL(ba_schur<true>, dim3(ns), dim3(kSchurThreads), schur_lds, s, D);
       else hipLaunchKernelGGL(ba_schur<false>, dim3(ns), dim3(kSchurThreads), schur_lds, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_schur");
