@@ -78,7 +78,7 @@ def cpu_baseline(nq, nt):
 
 
 def frames_leg(ctx, cpu=True):
-    """frames/s of the 640x480 ICL-NUIM stream (detect+describe -> match -> motion-only BA), GPU path and -- as the
+    """frames/s of the 640x480 ICL-NUIM stream (detect+describe -> match -> PnP-RANSAC -> motion-only BA), GPU path and -- as the
     checker/baseline only -- the CPU oracle through the same harness."""
     from visual_slam_amd.harness import HUBER, bench_frames, load_sequence, track_sequence
     out, poses = bench_frames(ctx)
@@ -99,7 +99,10 @@ def frames_leg(ctx, cpu=True):
 
         frames, depth0 = load_sequence(20)
         t0 = time.perf_counter()
-        cposes, cstages, _ = track_sequence(detect, match, ba, frames, depth0)
+        def pnp(obj, img, K4, pose0, seed=0):
+            return oracle.pnp_ransac(obj, img, K4, pose0, seed=seed)
+
+        cposes, cstages, _ = track_sequence(detect, match, ba, frames, depth0, pnp=pnp)
         cdt = time.perf_counter() - t0
         out["cpu_frames_per_s"] = len(frames) / cdt
         out["cpu_stage_ms_per_frame"] = {k: v / len(frames) * 1e3 for k, v in cstages.items()}
@@ -121,7 +124,7 @@ def frames_leg(ctx, cpu=True):
             best = dt if best is None or dt < best else best
         out["driver"] = {"frames_per_s": len(frames) / best, "keyframes": r["keyframes"], "map_points": r["n_points"],
                          "note": "visual_slam_amd/slam.py: main.py:150-348 control flow, key frame every 5th frame, "
-                                 "init from depth of frame 0, no PnP"}
+                                 "init from depth of frame 0"}
     except Exception as e:
         out["driver"] = {"error": repr(e)}
     return out

@@ -69,13 +69,20 @@ def test_tracking_harness_gpu_equals_oracle(vs, oracle):
         return oracle.ba_solve(*p, huber_delta=harness.HUBER, max_iterations=10)
 
     frames, depth0 = harness.load_sequence(20)
-    gposes, _, gn = harness.track_sequence(*harness.gpu_callables(vs), frames, depth0)
-    cposes, _, cn = harness.track_sequence(odetect, omatch, oba, frames, depth0)
-    assert gn == cn and min(gn) > 100
-    rel = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(gposes, cposes))
-    assert rel < 1e-4, rel
-    step = np.linalg.norm(np.diff(gposes[:, :3, 3], axis=0), axis=1)
-    assert step.max() < 0.05  # consecutive ICL-NUIM frames are millimetres apart: the tracker must not jump
+    def opnp(obj, img, K4, pose0, seed=0):
+        return oracle.pnp_ransac(obj, img, K4, pose0, seed=seed)
+
+    for gp, cp in ((None, None), (harness.gpu_pnp(vs), opnp)):   # without and with the PnP-RANSAC stage (main.py:196)
+        gposes, _, gn = harness.track_sequence(*harness.gpu_callables(vs), frames, depth0, pnp=gp)
+        cposes, _, cn = harness.track_sequence(odetect, omatch, oba, frames, depth0, pnp=cp)
+        assert gn == cn and min(gn) > 100
+        rel = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(gposes, cposes))
+        assert rel < 1e-4, rel
+        step = np.linalg.norm(np.diff(gposes[:, :3, 3], axis=0), axis=1)
+        assert step.max() < 0.05  # consecutive ICL-NUIM frames are millimetres apart: the tracker must not jump
+    # the class-API period (Frame / Map / FeatureMatcher / solvePnPRansac / BundleAdjustment) tracks the same poses
+    aposes, _ = harness.track_sequence_api(frames, depth0, context=vs)
+    assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(aposes, gposes)) < 1e-6
 
 
 def test_sharded_matcher_world1_hip_path(vs, oracle):

@@ -1,0 +1,29 @@
+"""Timing of Context.pnp_ransac on a tracking-sized problem (420 correspondences, few outliers)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from test_pnp import scene  # noqa: E402
+from visual_slam_amd.context import Context  # noqa: E402
+from visual_slam_amd.workloads import ICL_NUIM_K  # noqa: E402
+
+ctx = Context()
+for n, frac, motion in ((420, 0.02, 0.003), (420, 0.3, 0.03), (3000, 0.3, 0.03)):
+    X, uv, T, _ = scene(n, frac, 0.3, 1, motion)
+    for _ in range(3):
+        r = ctx.pnp_ransac(X, uv, ICL_NUIM_K, np.eye(4), seed=1)
+    t0 = time.perf_counter()
+    for k in range(50):
+        r = ctx.pnp_ransac(X, uv, ICL_NUIM_K, np.eye(4), seed=k)
+    dt = (time.perf_counter() - t0) / 50
+    print("n=%d outliers=%.2f: %.1f us per call, %d inliers" % (n, frac, dt * 1e6, len(r["inliers"])))
+    if "--oracle" in sys.argv:
+        from oracle import oracle
+        t0 = time.perf_counter()
+        for k in range(20):
+            c = oracle.pnp_ransac(X, uv, ICL_NUIM_K, np.eye(4), seed=k)
+        print("   oracle %.1f us per call, used %d hypotheses" % ((time.perf_counter() - t0) / 20 * 1e6, c["used"]))

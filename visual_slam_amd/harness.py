@@ -1,10 +1,10 @@
-"""Headless tracking harness: the call pattern of the reference's tracking loop (src/v2/main.py:173-214) restricted to
-the hot path -- detect+describe -> match against the last key frame's map points -> motion-only BA over the local map.
+"""Headless tracking harness: the call pattern of the reference's tracking loop (src/v2/main.py:173-214) -- detect+describe
+-> match against the last key frame's map points -> PnP-RANSAC from the previous pose -> motion-only BA over the local
+map.  (Key-frame insertion with triangulation + local BA lives in slam.py.)
 
-What is NOT reproduced (out of scope this round): two-view essential-matrix initialisation, PnP-RANSAC
-and new-point triangulation.  The harness therefore initialises the map from frame 0's keypoints back-projected with
-the dataset's depth image (camera 0 = world) and starts every frame's pose at the previous frame's optimised pose
-(the motion between consecutive ICL-NUIM frames is millimetres); no ground-truth pose is used.
+What is NOT reproduced: the two-view essential-matrix initialisation.  The harness initialises the
+map from frame 0's keypoints back-projected with the dataset's depth image (camera 0 = world); no ground-truth pose is
+used.
 
 Data: the first 20 RGB frames of ICL-NUIM living-room trajectory 3 (the trajectory present in the reference's data/;
 BASELINE.json names traj0, which is not there -- SURVEY.md 0) committed under tests/golden/icl_nuim/.
@@ -62,10 +62,11 @@ class LocalMapArrays:
                 np.concatenate(self.obs_pose), np.concatenate(self.obs_point), np.concatenate(self.obs_uv), ICL_NUIM_K)
 
 
-def track_sequence(detect, match, ba, frames, depth0, max_kp=3000):
-    """One tracking period.  detect(bgr) -> (xy, desc); match(q, t) -> (mq, mt); ba(*problem) -> dict(poses=...).
+def track_sequence(detect, match, ba, frames, depth0, max_kp=3000, pnp=None):
+    """One tracking period.  detect(bgr) -> (xy, desc); match(q, t) -> (mq, mt); pnp(obj, img, K4, pose0, seed=) ->
+    dict(found, pose, inliers) or None to start BA from the previous pose; ba(*problem) -> dict(poses=...).
     Returns (poses [n,4,4], stage seconds dict, per-frame match counts)."""
-    t_det = t_match = t_ba = 0.0
+    t_det = t_match = t_pnp = t_ba = 0.0
     t0 = time.perf_counter()
     xy0, desc0 = detect(frames[0])
     t_det += time.perf_counter() - t0
@@ -77,19 +78,27 @@ def track_sequence(detect, match, ba, frames, depth0, max_kp=3000):
         t1 = time.perf_counter()
         mq, mt = match(desc0, desc)
         t2 = time.perf_counter()
-        lm.add_frame(lm.poses[-1], mq, xy[mt])
+        pose = lm.poses[-1]
+        if pnp is not None and len(mq) >= 5:  # main.py:191-204: previous pose as the extrinsic guess
+            r = pnp(lm.points[mq], xy[mt], ICL_NUIM_K, pose, seed=k)
+            if r["found"]:
+                pose = r["pose"]
+        t3 = time.perf_counter()
+        lm.add_frame(pose, mq, xy[mt])
         res = ba(*lm.problem())
         for i in range(1, len(lm.poses)):
             lm.poses[i] = res["poses"][i]
-        t3 = time.perf_counter()
+        t4 = time.perf_counter()
         t_det += t1 - t0
         t_match += t2 - t1
-        t_ba += t3 - t2
+        t_pnp += t3 - t2
+        t_ba += t4 - t3
         n_matches.append(len(mq))
-    return np.stack(lm.poses), {"detect_describe": t_det, "match": t_match, "motion_ba": t_ba}, n_matches
+    stages = {"detect_describe": t_det, "match": t_match, "pnp_ransac": t_pnp, "motion_ba": t_ba}
+    return np.stack(lm.poses), stages, n_matches
 
 
-def track_sequence_api(frames, depth0, context=None, ba_solver=None):
+def track_sequence_api(frames, depth0, context=None, ba_solver=None, pnp=True, pnp_solver=None):
     """The same tracking period written against the reference's class API exactly as src/v2/main.py:173-214 uses it:
     Frame.process_frame -> Map.GetImagePointsWithFrameID -> FeatureMatcher.match_features ->
     Map.AddParentAndPose / AddPointToFrameCorrespondences -> BundleAdjustment.motionOnlyBundleAdjustement.
@@ -98,8 +107,11 @@ def track_sequence_api(frames, depth0, context=None, ba_solver=None):
     from .frame import FeatureExtractor, FeatureMatcher, Frame
     from .map import Map
     from .point import Point
+    from . import helper_functions as hf
     extractor, matcher = FeatureExtractor(context=context), FeatureMatcher(context=context)
     camera = Camera(*ICL_NUIM_K)
+    fx, fy, cx, cy = ICL_NUIM_K
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
     t0 = time.perf_counter()
     key = Frame(frames[0], None, 0)
     key.AddPose(np.eye(4))
@@ -116,7 +128,14 @@ def track_sequence_api(frames, depth0, context=None, ba_solver=None):
         kp_cur, ft_cur, _ = cur.process_frame(extractor)
         kp_prev, ft_prev, known_3d, point_ids = local_map.GetImagePointsWithFrameID(0)
         matches, _, _, cur_pts, cur_fts = matcher.match_features(kp_prev, ft_prev, kp_cur, ft_cur)
-        prev_pose = local_map.GetFrame(k - 1).GetPose()
+        prev_pose = np.asarray(local_map.GetFrame(k - 1).GetPose(), np.float64)
+        if pnp and len(matches) >= 5:  # main.py:189-204
+            known = known_3d[matches.query_idx]
+            c_T_w = np.linalg.inv(prev_pose)
+            ok, rvec, tvec, _ = hf.solvePnPRansac(known, cur_pts, K, None, hf.Rtorvec(c_T_w[:3, :3]), c_T_w[:3, 3],
+                                                  useExtrinsicGuess=True, context=context, seed=k, solver=pnp_solver)
+            if ok:
+                prev_pose = np.linalg.inv(np.asarray(hf.transformMatrix(rvec, tvec)))
         local_map.AddParentAndPose(parent_id=k - 1, frame_id=k, frame_obj=cur, rel_pose_trans=np.eye(4), pose=prev_pose)
         local_map.AddPointToFrameCorrespondences(point_ids=[point_ids[m[0].queryIdx] for m in matches],
                                                  image_points=cur_pts, descriptors=cur_fts, frame_obj=cur)
@@ -140,17 +159,25 @@ def gpu_callables(ctx):
     return detect, match, ba
 
 
+def gpu_pnp(ctx):
+    def pnp(obj, img, K4, pose0, seed=0):
+        return ctx.pnp_ransac(obj, img, K4, pose0, seed=seed)
+
+    return pnp
+
+
 def bench_frames(ctx, repeats=5):
     """frames/s of the 20-frame ICL-NUIM stream through the host C ABI (PNG decode excluded, H2D copies included).
     Returns (report dict, poses) -- bench.py times the CPU oracle through track_sequence() for the comparison."""
     frames, depth0 = load_sequence(20)
     frames = [ctx.pin(f) for f in frames]  # decoded frames live in pinned memory: H2D is a plain DMA
     det, mat, ba = gpu_callables(ctx)
-    track_sequence(det, mat, ba, frames[:4], depth0)  # warm-up (allocations, code objects)
+    pnp = gpu_pnp(ctx)
+    track_sequence(det, mat, ba, frames[:4], depth0, pnp=pnp)  # warm-up (allocations, code objects)
     best = None
     for _ in range(repeats):
         t0 = time.perf_counter()
-        poses, stages, nm = track_sequence(det, mat, ba, frames, depth0)
+        poses, stages, nm = track_sequence(det, mat, ba, frames, depth0, pnp=pnp)
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
             best = (dt, stages, poses, nm)
@@ -164,9 +191,10 @@ def bench_frames(ctx, repeats=5):
             api_dt, api_poses = adt, ap
     out = {"frames_per_s": len(frames) / dt, "n_frames": len(frames), "seconds": dt,
            "class_api_frames_per_s": len(frames) / api_dt,
-           "class_api_equals_array_path": bool(np.array_equal(api_poses, poses)),
+           "class_api_vs_array_path": float(max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(api_poses, poses))),
            "stage_ms_per_frame": {k: v / len(frames) * 1e3 for k, v in stages.items()},
            "mean_matches": float(np.mean(nm)), "resolution": "640x480",
            "data": "ICL-NUIM living-room traj3 frames 0-19 (fixtures)",
-           "note": "host C-ABI path incl. H2D/D2H copies; map initialised from depth of frame 0, no PnP (SURVEY 8f)"}
+           "note": "host C-ABI path incl. H2D/D2H copies; detect+describe -> match -> PnP-RANSAC -> motion-only BA per "
+                   "frame; map initialised from depth of frame 0"}
     return out, poses
