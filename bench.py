@@ -122,7 +122,12 @@ def frames_leg(ctx, cpu=True):
             r = slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=4)
             dt = time.perf_counter() - t0
             best = dt if best is None or dt < best else best
+        from visual_slam_amd import dataset
+        from visual_slam_amd.harness import ICL_DIR
+        _, gt = dataset.read_trajectory(os.path.join(ICL_DIR, "traj3.gt.freiburg.head20"))
+        ate = dataset.ate_rmse(r["poses"], gt)
         out["driver"] = {"frames_per_s": len(frames) / best, "keyframes": r["keyframes"], "map_points": r["n_points"],
+                         "ate_rmse_m": ate["rmse"], "gt_path_length_m": ate["path_length"],
                          "note": "visual_slam_amd/slam.py: main.py:150-348 control flow, key frame every 5th frame, "
                                  "init from depth of frame 0"}
     except Exception as e:

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def test_extractor_and_matcher_drop_in(vs, oracle):
     from visual_slam_amd.frame import FeatureExtractor, FeatureMatcher, Frame
     ex, ma = FeatureExtractor(context=vs), FeatureMatcher(context=vs)
-    f0 = Frame(os.path.join(GOLDEN, "icl_nuim", "rgb", "0.png"), os.path.join(GOLDEN, "icl_nuim", "depth0.png"), 0)
+    f0 = Frame(os.path.join(GOLDEN, "icl_nuim", "rgb", "0.png"), os.path.join(GOLDEN, "icl_nuim", "depth", "0.png"), 0)
     f1 = Frame(icl_frame(1), None, 1)
     assert f0.rgb.shape == (480, 640, 3) and np.array_equal(f0.rgb, icl_frame(0))
     kp0, ft0, rgb0 = f0.process_frame(ex)

@@ -27,7 +27,7 @@ def load_sequence(n_frames=20):
     if any(f is None for f in frames):
         raise FileNotFoundError("ICL-NUIM fixture frames missing under %s" % ICL_DIR)
     from PIL import Image
-    depth0 = np.asarray(Image.open(os.path.join(ICL_DIR, "depth0.png"))).astype(np.float64) / 5000.0  # metres
+    depth0 = np.asarray(Image.open(os.path.join(ICL_DIR, "depth", "0.png"))).astype(np.float64) / 5000.0  # metres
     return frames, depth0
 
 
