@@ -137,12 +137,25 @@ int vs_triangulate_dlt(vs_ctx* ctx, const double* P1, const double* P2, const do
  * Structure of OpenCV's routine with its defaults (ITERATIVE, 100 iterations, 8 px, confidence 0.99): hypothesis h =
  * LM refinement of the extrinsic guess on 5 sampled correspondences; inliers: squared reprojection error <= thr^2;
  * iteration budget updated by RANSACUpdateNumIters after every improvement; best model refined on its inliers.
- * Own specification where OpenCV cannot be pinned: samples from splitmix64(seed ^ (h << 20 + k)), LM = the g2o-style
+ * Own specification where OpenCV cannot be pinned: samples from splitmix64(splitmix64(seed) ^ ((h << 20) + k)), LM = the g2o-style
  * LM of vs_ba_solve (one free camera, fixed points, no robust kernel, `refine_iters` iterations).
  * pose0 / pose_out: 4x4 camera-to-world row-major (invert for rvec/tvec); inliers: indices, ascending. */
 int vs_pnp_ransac(vs_ctx* ctx, const double* obj /*[n][3]*/, const double* img /*[n][2]*/, int n, double fx, double fy,
                   double cx, double cy, const double* pose0, int iterations, double reproj_err, double confidence,
                   uint64_t seed, int refine_iters, double* pose_out, int32_t* inliers /*[n]*/, int* n_inliers, int* found);
+
+/* ---- next row: two-view initialisation ------------------------------------------------------------
+ * vs_essential_ransac replaces cv2.findEssentialMat(pts1, pts2, method=RANSAC, prob=0.999, threshold) on K-normalised
+ * points (src/v2/helper_functions.py:47-52, called from main.py:102); vs_recover_pose replaces
+ * cv2.recoverPose(E, pts1, pts2, cameraMatrix=K, distanceThresh=50) (helper_functions.py:175-176, main.py:109).
+ * OpenCV's structure (Sampson error vs threshold^2, RANSACUpdateNumIters; decomposeEssentialMat's four
+ * candidates and the cheirality vote z*w > 0, z < dist in both cameras) with an 8-point minimal solver, counter-based
+ * sampling, Jacobi SVDs and one linear re-fit of the winner to its inliers, of this library's own specification.  x1/x2: K-normalised [n][2]; E row-major, x2^T E x1 = 0;
+ * mask of vs_essential_ransac: 1/0; of vs_recover_pose: 255/0 (main.py checks == 255); X: homogeneous [n][4], w >= 0. */
+int vs_essential_ransac(vs_ctx* ctx, const double* x1, const double* x2, int n, double threshold, double prob,
+                        int max_iters, uint64_t seed, double* E /*[9]*/, uint8_t* mask /*[n]*/, int* n_inliers, int* found);
+int vs_recover_pose(vs_ctx* ctx, const double* E, const double* x1, const double* x2, int n, double dist_thresh,
+                    double* R /*[9]*/, double* t /*[3]*/, uint8_t* mask /*[n]*/, double* X /*[n][4]*/, int* n_good);
 
 /* ---- A9-A16: bundle adjustment ------------------------------------------------------------------------------
  * replaces the g2o graph the reference builds and optimises          (src/v2/LocalBA.py:20-94,115-131,39-42)

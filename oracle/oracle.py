@@ -75,6 +75,16 @@ def load(lib_path=None):
                                    C.POINTER(C.c_int)]
     lib.vo_cholesky_lower.argtypes = [c_f64p, C.c_int]
     lib.vo_ba_solve.argtypes = [C.POINTER(BAProblem), C.POINTER(BAResult)]
+    lib.vo_sample_distinct.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, c_i32p]
+    lib.vo_sample_distinct.restype = None
+    lib.vo_eight_point.argtypes = [c_f64p, c_f64p, c_i32p, c_f64p]
+    lib.vo_essential_ransac.argtypes = [c_f64p, c_f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64, c_f64p,
+                                        c_u8p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                        C.POINTER(C.c_int)]
+    lib.vo_decompose_essential.argtypes = [c_f64p, c_f64p, c_f64p, c_f64p]
+    lib.vo_decompose_essential.restype = None
+    lib.vo_recover_pose.argtypes = [c_f64p, c_f64p, c_f64p, C.c_int, C.c_double, c_f64p, c_f64p, c_u8p, c_f64p,
+                                    C.POINTER(C.c_int)]
     lib.vo_pnp_sample.argtypes = [C.c_uint64, C.c_int, C.c_int, c_i32p]
     lib.vo_pnp_sample.restype = None
     lib.vo_pnp_ransac.argtypes = [c_f64p, c_f64p, C.c_int, c_f64p, c_f64p, C.c_int, C.c_double, C.c_double, C.c_uint64,
@@ -297,3 +307,54 @@ def pnp_sample(seed, h, n, lib=None):
     idx = np.zeros(5, np.int32)
     lib.vo_pnp_sample(seed, h, n, _p(idx, c_i32p))
     return idx
+
+
+def eight_point(x1, x2, idx8, lib=None):
+    """K-normalised correspondences + 8 indices -> essential matrix [3,3] (x2^T E x1 = 0) or None if degenerate."""
+    lib = lib or load()
+    x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 2)
+    x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 2)
+    idx = np.ascontiguousarray(idx8, np.int32)
+    E = np.zeros(9)
+    ok = lib.vo_eight_point(_p(x1, c_f64p), _p(x2, c_f64p), _p(idx, c_i32p), _p(E, c_f64p))
+    return E.reshape(3, 3) if ok else None
+
+
+def essential_ransac(x1, x2, threshold, prob=0.999, max_iters=1000, seed=0, lib=None):
+    """x1, x2 K-normalised [N,2] -> dict(found, E [3,3], mask uint8[N] (0/1), best_h, used)."""
+    lib = lib or load()
+    x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 2)
+    x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 2)
+    n = x1.shape[0]
+    E = np.zeros(9)
+    mask = np.zeros(max(n, 1), np.uint8)
+    ni, found, bh, used = C.c_int(0), C.c_int(0), C.c_int(-1), C.c_int(0)
+    _chk(lib.vo_essential_ransac(_p(x1, c_f64p), _p(x2, c_f64p), n, threshold, prob, max_iters, seed, _p(E, c_f64p),
+                                 _p(mask, c_u8p), C.byref(ni), C.byref(found), C.byref(bh), C.byref(used)),
+         "essential_ransac")
+    return dict(found=bool(found.value), E=E.reshape(3, 3), mask=mask[:n].copy(), n_inliers=ni.value, best_h=bh.value,
+                used=used.value)
+
+
+def decompose_essential(E, lib=None):
+    lib = lib or load()
+    E = np.ascontiguousarray(E, np.float64).reshape(9)
+    R1, R2, t = np.zeros(9), np.zeros(9), np.zeros(3)
+    lib.vo_decompose_essential(_p(E, c_f64p), _p(R1, c_f64p), _p(R2, c_f64p), _p(t, c_f64p))
+    return R1.reshape(3, 3), R2.reshape(3, 3), t
+
+
+def recover_pose(E, x1, x2, dist_thresh=50.0, lib=None):
+    """-> dict(R [3,3], t [3], mask uint8[N] (255/0), X [N,4] homogeneous, n_good)."""
+    lib = lib or load()
+    E = np.ascontiguousarray(E, np.float64).reshape(9)
+    x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 2)
+    x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 2)
+    n = x1.shape[0]
+    R, t = np.zeros(9), np.zeros(3)
+    mask = np.zeros(max(n, 1), np.uint8)
+    X = np.zeros((max(n, 1), 4))
+    ng = C.c_int(0)
+    _chk(lib.vo_recover_pose(_p(E, c_f64p), _p(x1, c_f64p), _p(x2, c_f64p), n, dist_thresh, _p(R, c_f64p), _p(t, c_f64p),
+                             _p(mask, c_u8p), _p(X, c_f64p), C.byref(ng)), "recover_pose")
+    return dict(R=R.reshape(3, 3), t=t, mask=mask[:n].copy(), X=X[:n].copy(), n_good=ng.value)

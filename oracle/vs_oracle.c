@@ -942,7 +942,8 @@ VO_EXPORT int vo_ba_pose_update(const double* pose16, const double* d6, double* 
  * default flag ITERATIVE, 100 iterations, reprojection error 8 px, confidence 0.99): every hypothesis refines the
  * extrinsic guess on a random minimal set of 5 correspondences, inliers are counted with err^2 <= thr^2, the iteration
  * budget shrinks with RANSACUpdateNumIters, the best model is refined on its inliers.  PARITY UNPINNED against OpenCV:
- * its RNG stream and CvLevMarq are not available; here the sample comes from a counter-based splitmix64 and the
+ * its RNG stream and CvLevMarq are not available; here the sample comes from a counter-based splitmix64
+ * (value k of hypothesis h = splitmix64(splitmix64(seed) ^ ((h << 20) + k)) mod n, first distinct ones) and the
  * refinement is this file's own LM (vo_ba_solve with one free camera, fixed points, no robust kernel). */
 static uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -954,8 +955,9 @@ static uint64_t splitmix64(uint64_t x) {
 /* 5 distinct indices of hypothesis h */
 VO_EXPORT void vo_pnp_sample(uint64_t seed, int h, int n, int32_t* idx5) {
   int got = 0;
+  const uint64_t base = splitmix64(seed); /* unrelated streams for neighbouring seeds */
   for (uint64_t k = 0; got < 5; ++k) {
-    int32_t c = (int32_t)(splitmix64(seed ^ (((uint64_t)h << 20) + k)) % (uint64_t)n);
+    int32_t c = (int32_t)(splitmix64(base ^ (((uint64_t)h << 20) + k)) % (uint64_t)n);
     int dup = 0;
     for (int j = 0; j < got; ++j) dup |= idx5[j] == c;
     if (!dup) idx5[got++] = c;
@@ -1087,5 +1089,343 @@ VO_EXPORT int vo_pnp_ransac(const double* obj, const double* img, int n, const d
       memcpy(pose_out, best_pose, sizeof best_pose);
   }
   free(err2);
+  return VS_OK;
+}
+
+/* ------------------------------------------------------------------------ two-view initialisation */
+/* Restates the structure of estimateEssential / estimateRelativePose (src/v2/helper_functions.py:47-70,164-195), i.e. of
+ * cv2.findEssentialMat(RANSAC, prob 0.999, threshold) on K-normalised points and cv2.recoverPose(E, ..., distanceThresh).
+ * PARITY UNPINNED against OpenCV.  Kept from OpenCV: Sampson error against threshold^2, the budget rule
+ * (RANSACUpdateNumIters after every strictly better model, at most 1000 iterations);
+ * decomposeEssentialMat's R1 = U W V^T, R2 = U W^T V^T, t = u3; recoverPose's four-candidate cheirality vote
+ * (z*w > 0, z < dist in both cameras; first candidate with the most votes in the order (R1,t),(R2,t),(R1,-t),(R2,-t)).
+ * Own specification: the minimal solver is the 8-point algorithm (null vector of the 8x9 system by Gaussian elimination
+ * with full pivoting, then the closest matrix with singular values (1,1,0)) instead of Nister's 5-point solver; samples
+ * come from the counter-based splitmix64 of the PnP section; SVDs are one-sided Jacobi; the winner is re-fitted once to
+ * all its inliers (linear 8-point) and the re-fit is adopted if it has at least as many inliers. */
+static void jacobi_svd(int n, double* A /* n x n row-major, becomes U*Sigma */, double* V /* n x n */) {
+  for (int r = 0; r < n; ++r)
+    for (int c = 0; c < n; ++c) V[r * n + c] = r == c ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int r = 0; r < n; ++r) {
+          alpha += A[r * n + p] * A[r * n + p];
+          beta += A[r * n + q] * A[r * n + q];
+          gamma += A[r * n + p] * A[r * n + q];
+        }
+        const double lim = sqrt(alpha * beta);
+        if (lim > 0.0) off = fmax(off, fabs(gamma) / lim);
+        if (fabs(gamma) > 1e-300 && fabs(gamma) > 1e-17 * lim) {
+          const double zeta = (beta - alpha) / (2.0 * gamma);
+          const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+          const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+          for (int r = 0; r < n; ++r) {
+            const double ap = A[r * n + p], aq = A[r * n + q];
+            A[r * n + p] = cs * ap - sn * aq;
+            A[r * n + q] = sn * ap + cs * aq;
+            const double vp = V[r * n + p], vq = V[r * n + q];
+            V[r * n + p] = cs * vp - sn * vq;
+            V[r * n + q] = sn * vp + cs * vq;
+          }
+        }
+      }
+    if (off < 1e-15) break;
+  }
+}
+
+/* E = U diag(s) V^T of a 3x3 matrix with s0 >= s1 >= s2, U and V proper rotations (third columns by cross product) */
+static void svd3_sorted(const double* E, double* U, double* s, double* V) {
+  double A[9], W[9];
+  memcpy(A, E, sizeof A);
+  jacobi_svd(3, A, W);
+  double nn[3];
+  int ord[3] = {0, 1, 2};
+  for (int c = 0; c < 3; ++c) nn[c] = A[c] * A[c] + A[3 + c] * A[3 + c] + A[6 + c] * A[6 + c];
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2 - a; ++b)
+      if (nn[ord[b]] < nn[ord[b + 1]]) {
+        int t = ord[b];
+        ord[b] = ord[b + 1];
+        ord[b + 1] = t;
+      }
+  for (int k = 0; k < 2; ++k) {
+    const int c = ord[k];
+    s[k] = sqrt(nn[c]);
+    for (int r = 0; r < 3; ++r) {
+      U[3 * r + k] = s[k] > 0 ? A[3 * r + c] / s[k] : 0.0;
+      V[3 * r + k] = W[3 * r + c];
+    }
+  }
+  s[2] = sqrt(nn[ord[2]]);
+  U[2] = U[3] * U[7] - U[6] * U[4];
+  U[5] = U[6] * U[1] - U[0] * U[7];
+  U[8] = U[0] * U[4] - U[3] * U[1];
+  V[2] = V[3] * V[7] - V[6] * V[4];
+  V[5] = V[6] * V[1] - V[0] * V[7];
+  V[8] = V[0] * V[4] - V[3] * V[1];
+}
+
+/* 8 correspondences -> essential matrix (row-major, x2^T E x1 = 0), 0 if the sample is degenerate */
+static int eight_point(const double* x1, const double* x2, const int32_t* idx, double* E) {
+  double A[8][9];
+  int perm[9];
+  for (int k = 0; k < 8; ++k) {
+    const double a = x1[2 * idx[k]], b = x1[2 * idx[k] + 1], c = x2[2 * idx[k]], d = x2[2 * idx[k] + 1];
+    const double row[9] = {c * a, c * b, c, d * a, d * b, d, a, b, 1.0};
+    memcpy(A[k], row, sizeof row);
+  }
+  for (int j = 0; j < 9; ++j) perm[j] = j;
+  for (int k = 0; k < 8; ++k) {
+    int pi = k, pj = k;
+    double best = -1.0;
+    for (int i = k; i < 8; ++i)
+      for (int j = k; j < 9; ++j)
+        if (fabs(A[i][j]) > best) {
+          best = fabs(A[i][j]);
+          pi = i;
+          pj = j;
+        }
+    if (!(best > 1e-12)) return 0;
+    for (int j = 0; j < 9; ++j) {
+      const double t = A[k][j];
+      A[k][j] = A[pi][j];
+      A[pi][j] = t;
+    }
+    for (int i = 0; i < 8; ++i) {
+      const double t = A[i][k];
+      A[i][k] = A[i][pj];
+      A[i][pj] = t;
+    }
+    const int tp = perm[k];
+    perm[k] = perm[pj];
+    perm[pj] = tp;
+    for (int i = k + 1; i < 8; ++i) {
+      const double f = A[i][k] / A[k][k];
+      for (int j = k; j < 9; ++j) A[i][j] -= f * A[k][j];
+    }
+  }
+  double x[9], e[9];
+  x[8] = 1.0;
+  for (int k = 7; k >= 0; --k) {
+    double sacc = 0.0;
+    for (int j = k + 1; j < 9; ++j) sacc += A[k][j] * x[j];
+    x[k] = -sacc / A[k][k];
+  }
+  double nrm = 0.0;
+  for (int j = 0; j < 9; ++j) nrm += x[j] * x[j];
+  nrm = sqrt(nrm);
+  for (int j = 0; j < 9; ++j) e[perm[j]] = x[j] / nrm;
+  double U[9], s[3], V[9];
+  svd3_sorted(e, U, s, V);
+  if (!(s[1] > 1e-12)) return 0;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) E[3 * r + c] = U[3 * r] * V[3 * c] + U[3 * r + 1] * V[3 * c + 1];
+  return 1;
+}
+
+/* least-squares 8-point over the correspondences with mask != 0: smallest eigenvector of A^T A (9x9, Jacobi), then the
+ * same projection onto the essential manifold */
+static int eight_point_lsq(const double* x1, const double* x2, const uint8_t* mask, int n, double* E) {
+  double M[81], V[81];
+  memset(M, 0, sizeof M);
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!mask[i]) continue;
+    const double a = x1[2 * i], b = x1[2 * i + 1], c = x2[2 * i], d = x2[2 * i + 1];
+    const double row[9] = {c * a, c * b, c, d * a, d * b, d, a, b, 1.0};
+    for (int r = 0; r < 9; ++r)
+      for (int q = 0; q < 9; ++q) M[9 * r + q] += row[r] * row[q];
+    ++cnt;
+  }
+  if (cnt < 8) return 0;
+  jacobi_svd(9, M, V);
+  double best = DBL_MAX;
+  int bc = 8;
+  for (int k = 0; k < 9; ++k) {
+    double nn = 0;
+    for (int r = 0; r < 9; ++r) nn += M[9 * r + k] * M[9 * r + k];
+    if (nn < best) {
+      best = nn;
+      bc = k;
+    }
+  }
+  double e[9], U[9], sv[3], W[9];
+  for (int r = 0; r < 9; ++r) e[r] = V[9 * r + bc];
+  svd3_sorted(e, U, sv, W);
+  if (!(sv[1] > 1e-12)) return 0;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) E[3 * r + c] = U[3 * r] * W[3 * c] + U[3 * r + 1] * W[3 * c + 1];
+  return 1;
+}
+
+static double sampson(const double* E, double a, double b, double c, double d) {
+  const double l0 = E[0] * a + E[1] * b + E[2], l1 = E[3] * a + E[4] * b + E[5], l2 = E[6] * a + E[7] * b + E[8];
+  const double m0 = E[0] * c + E[3] * d + E[6], m1 = E[1] * c + E[4] * d + E[7];
+  const double r = c * l0 + d * l1 + l2;
+  return r * r / (l0 * l0 + l1 * l1 + m0 * m0 + m1 * m1);
+}
+
+VO_EXPORT void vo_sample_distinct(uint64_t seed, int h, int n, int m, int32_t* idx) {
+  int got = 0;
+  const uint64_t base = splitmix64(seed);
+  for (uint64_t k = 0; got < m; ++k) {
+    int32_t c = (int32_t)(splitmix64(base ^ (((uint64_t)h << 20) + k)) % (uint64_t)n);
+    int dup = 0;
+    for (int j = 0; j < got; ++j) dup |= idx[j] == c;
+    if (!dup) idx[got++] = c;
+  }
+}
+
+VO_EXPORT int vo_eight_point(const double* x1, const double* x2, const int32_t* idx8, double* E) {
+  return eight_point(x1, x2, idx8, E);
+}
+
+/* x1, x2: K-normalised [n][2]; mask[n] 0/1; *found = 1 if a model with >= 8 inliers exists */
+VO_EXPORT int vo_essential_ransac(const double* x1, const double* x2, int n, double threshold, double prob, int max_iters,
+                                  uint64_t seed, double* E_out, uint8_t* mask, int* n_inliers, int* found, int* best_h,
+                                  int* used) {
+  if (!x1 || !x2 || !E_out || !mask || !n_inliers || !found || n < 0 || max_iters < 0) return VS_EINVAL;
+  *found = 0;
+  *n_inliers = 0;
+  if (best_h) *best_h = -1;
+  if (used) *used = 0;
+  memset(E_out, 0, 9 * sizeof(double));
+  memset(mask, 0, (size_t)n);
+  if (n < 8) return VS_OK;
+  const double thr2 = threshold * threshold;
+  int max_good = 0, niters = max_iters, bh = -1, h = 0;
+  double best[9];
+  for (; h < niters; ++h) {
+    int32_t idx[8];
+    double E[9];
+    if (n == 8)
+      for (int k = 0; k < 8; ++k) idx[k] = k;
+    else
+      vo_sample_distinct(seed, h, n, 8, idx);
+    if (!eight_point(x1, x2, idx, E)) continue;
+    int good = 0;
+    for (int i = 0; i < n; ++i) good += sampson(E, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]) <= thr2;
+    if (good > (max_good > 7 ? max_good : 7)) {
+      max_good = good;
+      bh = h;
+      memcpy(best, E, sizeof best);
+      niters = ransac_update_iters(prob, (double)(n - good) / n, 8, niters);
+    }
+  }
+  if (used) *used = h;
+  if (bh >= 0) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+      mask[i] = sampson(best, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]) <= thr2;
+      m += mask[i];
+    }
+    /* local optimisation (own addition, OpenCV keeps the minimal-sample model): linear 8-point fit to all inliers,
+     * adopted if it explains at least as many correspondences */
+    double Els[9];
+    if (eight_point_lsq(x1, x2, mask, n, Els)) {
+      int m2 = 0;
+      for (int i = 0; i < n; ++i) m2 += sampson(Els, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]) <= thr2;
+      if (m2 >= m) {
+        memcpy(best, Els, sizeof best);
+        m = 0;
+        for (int i = 0; i < n; ++i) {
+          mask[i] = sampson(best, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]) <= thr2;
+          m += mask[i];
+        }
+      }
+    }
+    memcpy(E_out, best, sizeof best);
+    *n_inliers = m;
+    *found = 1;
+    if (best_h) *best_h = bh;
+  }
+  return VS_OK;
+}
+
+VO_EXPORT void vo_decompose_essential(const double* E, double* R1, double* R2, double* t) {
+  double U[9], s[3], V[9];
+  svd3_sorted(E, U, s, V);
+  /* W = [0 -1 0; 1 0 0; 0 0 1]:  U W = [u1, -u0, u2],  U W^T = [-u1, u0, u2] */
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      R1[3 * r + c] = U[3 * r + 1] * V[3 * c] - U[3 * r] * V[3 * c + 1] + U[3 * r + 2] * V[3 * c + 2];
+      R2[3 * r + c] = -U[3 * r + 1] * V[3 * c] + U[3 * r] * V[3 * c + 1] + U[3 * r + 2] * V[3 * c + 2];
+    }
+  for (int r = 0; r < 3; ++r) t[r] = U[3 * r + 2];
+}
+
+/* DLT of one correspondence against P0 = [I|0], P1 = [R|t]: homogeneous point with w >= 0 */
+static void triangulate_rt(const double* R, const double* t, double a, double b, double c, double d, double* Q) {
+  double A[16], V[16];
+  const double P1[12] = {R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2]};
+  const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  for (int k = 0; k < 4; ++k) {
+    A[k] = a * P0[8 + k] - P0[k];
+    A[4 + k] = b * P0[8 + k] - P0[4 + k];
+    A[8 + k] = c * P1[8 + k] - P1[k];
+    A[12 + k] = d * P1[8 + k] - P1[4 + k];
+  }
+  jacobi_svd(4, A, V);
+  double best = DBL_MAX;
+  int bc = 3;
+  for (int k = 0; k < 4; ++k) {
+    double nn = 0;
+    for (int r = 0; r < 4; ++r) nn += A[4 * r + k] * A[4 * r + k];
+    if (nn < best) {
+      best = nn;
+      bc = k;
+    }
+  }
+  double nrm = 0;
+  for (int r = 0; r < 4; ++r) {
+    Q[r] = V[4 * r + bc];
+    nrm += Q[r] * Q[r];
+  }
+  nrm = sqrt(nrm);
+  if (Q[3] < 0) nrm = -nrm;
+  if (nrm != 0.0)
+    for (int r = 0; r < 4; ++r) Q[r] /= nrm;
+}
+
+/* cv2.recoverPose(E, pts1, pts2, K, distanceThresh): x1, x2 K-normalised; mask[n] 255/0; X [n][4] homogeneous */
+VO_EXPORT int vo_recover_pose(const double* E, const double* x1, const double* x2, int n, double dist, double* R_out,
+                              double* t_out, uint8_t* mask, double* X, int* n_good) {
+  if (!E || !R_out || !t_out || !n_good || n < 0 || (n > 0 && (!x1 || !x2 || !mask || !X))) return VS_EINVAL;
+  double R1[9], R2[9], t[3], tn[3];
+  vo_decompose_essential(E, R1, R2, t);
+  for (int k = 0; k < 3; ++k) tn[k] = -t[k];
+  const double* Rs[4] = {R1, R2, R1, R2};
+  const double* ts[4] = {t, t, tn, tn};
+  uint8_t* m4 = (uint8_t*)malloc(4 * (size_t)(n ? n : 1));
+  double* q4 = (double*)malloc(sizeof(double) * 16 * (size_t)(n ? n : 1));
+  int good[4] = {0, 0, 0, 0};
+  for (int c = 0; c < 4; ++c)
+    for (int i = 0; i < n; ++i) {
+      double* Q = q4 + ((size_t)c * n + i) * 4;
+      triangulate_rt(Rs[c], ts[c], x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1], Q);
+      int ok = Q[2] * Q[3] > 0;
+      const double X0 = Q[0] / Q[3], X1 = Q[1] / Q[3], X2 = Q[2] / Q[3];
+      ok = ok && X2 < dist;
+      const double z2 = Rs[c][6] * X0 + Rs[c][7] * X1 + Rs[c][8] * X2 + ts[c][2];
+      ok = ok && z2 > 0 && z2 < dist;
+      m4[(size_t)c * n + i] = ok ? 255 : 0;
+      good[c] += ok;
+    }
+  int pick = 3;
+  if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) pick = 0;
+  else if (good[1] >= good[0] && good[1] >= good[2] && good[1] >= good[3]) pick = 1;
+  else if (good[2] >= good[0] && good[2] >= good[1] && good[2] >= good[3]) pick = 2;
+  memcpy(R_out, Rs[pick], 9 * sizeof(double));
+  memcpy(t_out, ts[pick], 3 * sizeof(double));
+  if (n) {
+    memcpy(mask, m4 + (size_t)pick * n, (size_t)n);
+    memcpy(X, q4 + (size_t)pick * n * 4, sizeof(double) * 4 * (size_t)n);
+  }
+  *n_good = good[pick];
+  free(m4);
+  free(q4);
   return VS_OK;
 }

@@ -2,6 +2,8 @@
 the 20 ICL-NUIM fixture frames: BASELINE.json configs[0] (traj3 instead of traj0).  CPU: the driver on
 the oracle back ends.  GPU: the same driver on the HIP back ends must take the same decisions (key frames, new
 points) and end within the BA contract of the CPU run."""
+import os
+
 import numpy as np
 import pytest
 
@@ -31,7 +33,8 @@ class OracleMatcher:
 def oracle_backends(oracle):
     from oracle import np_reference
     return slam.Backends(ba_solver=oracle.ba_solve, extractor=OracleExtractor(oracle), matcher=OracleMatcher(oracle),
-                         triangulate=np_reference.triangulate, pnp_solver=oracle.pnp_ransac)
+                         triangulate=np_reference.triangulate, pnp_solver=oracle.pnp_ransac,
+                         essential_solver=oracle.essential_ransac, recover_solver=oracle.recover_pose)
 
 
 def _run(be, n=20, gap=4):
@@ -65,3 +68,46 @@ def test_driver_gpu_equals_oracle(vs, oracle):
     pc = np.array([p.location_3d for p in c["map"].points_3d.values()])
     # new points come out of local BA started from PnP poses that agree to ~1e-9: low-parallax points amplify that
     assert np.abs(pg - pc).max() < 1e-5, np.abs(pg - pc).max()
+
+
+def _two_view(be):
+    """main.py:78-148 on the two committed frames with enough parallax (ICL-NUIM traj3 images 0 and 150, ~0.45 m and 33
+    degrees apart; consecutive frames are millimetres apart and cannot initialise, as in the reference)."""
+    import os
+    from visual_slam_amd.LocalBA import Camera
+    from visual_slam_amd.frame import imread
+    from visual_slam_amd.map import Map
+    g = os.path.join(os.path.dirname(__file__), "golden", "icl_nuim", "rgb")
+    frames = [imread(os.path.join(g, "0.png")), imread(os.path.join(g, "150.png"))]
+    K = np.array([[ICL_NUIM_K[0], 0, ICL_NUIM_K[2]], [0, ICL_NUIM_K[1], ICL_NUIM_K[3]], [0, 0, 1.0]])
+    m = Map()
+    i, next_id = slam.two_view_init(frames, K, Camera(*ICL_NUIM_K), be, m, min_valid=0.75)
+    return m, i, next_id
+
+
+def test_two_view_initialisation_on_the_oracle_back_ends(oracle):
+    from visual_slam_amd import dataset
+    m, i, next_id = _two_view(oracle_backends(oracle))
+    assert i == 1 and len(m.frames) == 2 and len(m.points_3d) == next_id - 1 >= 50
+    assert all(p.GetNVisibleFrames() == 2 for p in m.points_3d.values())
+    P1 = np.asarray(m.GetFrame(1).GetPose())
+    assert np.allclose(P1[:3, :3] @ P1[:3, :3].T, np.eye(3), atol=1e-9)
+    X = np.array([p.location_3d for p in m.points_3d.values()])
+    assert abs(np.median(np.linalg.norm(X, axis=1)) - 1.0) < 1e-9          # scale=True: median point norm 1
+    # against the data set's ground truth (lines 1 and 151): direction of motion and amount of rotation
+    g = os.path.join(os.path.dirname(__file__), "golden", "icl_nuim")
+    _, g0 = dataset.read_trajectory(os.path.join(g, "traj3.gt.freiburg.head20"))
+    _, g1 = dataset.read_trajectory(os.path.join(g, "traj3.gt.freiburg.line151"))
+    rel = np.linalg.inv(g0[0]) @ g1[0]
+    from scipy.spatial.transform import Rotation
+    ang_gt = np.linalg.norm(Rotation.from_matrix(rel[:3, :3]).as_rotvec())
+    ang = np.linalg.norm(Rotation.from_matrix(P1[:3, :3]).as_rotvec())
+    assert abs(ang - ang_gt) < np.radians(5), (np.degrees(ang), np.degrees(ang_gt))
+
+
+@pytest.mark.gpu
+def test_two_view_initialisation_gpu_equals_oracle(vs, oracle):
+    g, _, gn = _two_view(slam.Backends(context=vs))
+    c, _, cn = _two_view(oracle_backends(oracle))
+    assert gn == cn
+    assert np.linalg.norm(g.GetFrame(1).GetPose() - c.GetFrame(1).GetPose()) < 1e-6

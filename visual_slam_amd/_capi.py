@@ -75,6 +75,10 @@ SIGNATURES = {
                                      c_f64p]),
     "vs_pnp_ransac": (C.c_int, [C.c_void_p, c_f64p, c_f64p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, c_f64p,
                                 C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_int, c_f64p, c_i32p, c_intp, c_intp]),
+    "vs_essential_ransac": (C.c_int, [C.c_void_p, c_f64p, c_f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64,
+                                      c_f64p, c_u8p, c_intp, c_intp]),
+    "vs_recover_pose": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p, C.c_int, C.c_double, c_f64p, c_f64p, c_u8p, c_f64p,
+                                  c_intp]),
     "vs_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(BAResult)]),
 }
 

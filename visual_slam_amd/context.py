@@ -195,6 +195,38 @@ class Context:
                                           C.byref(ni), C.byref(found)))
         return dict(found=bool(found.value), pose=pose.reshape(4, 4), inliers=inl[:ni.value].copy())
 
+    # ------------------------------------------------------------------ two-view initialisation
+    def essential_ransac(self, x1, x2, threshold, prob=0.999, max_iters=1000, seed=0):
+        """x1, x2 K-normalised [N,2] -> dict(found, E [3,3] with x2^T E x1 = 0, mask uint8[N] (0/1), n_inliers)."""
+        x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 2)
+        x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 2)
+        n = x1.shape[0]
+        if x2.shape[0] != n:
+            raise ValueError("essential_ransac: x1 and x2 differ in length")
+        E = np.zeros(9)
+        mask = np.zeros(max(n, 1), np.uint8)
+        ni, found = C.c_int(0), C.c_int(0)
+        self._chk(self._lib.vs_essential_ransac(self._h, ptr(x1, c_f64p), ptr(x2, c_f64p), n, float(threshold), float(prob),
+                                                int(max_iters), int(seed), ptr(E, c_f64p), ptr(mask, c_u8p), C.byref(ni),
+                                                C.byref(found)))
+        return dict(found=bool(found.value), E=E.reshape(3, 3), mask=mask[:n].copy(), n_inliers=ni.value)
+
+    def recover_pose(self, E, x1, x2, dist_thresh=50.0):
+        """-> dict(R [3,3], t [3], mask uint8[N] (255/0), X [N,4] homogeneous, n_good)."""
+        E = np.ascontiguousarray(E, np.float64).reshape(9)
+        x1 = np.ascontiguousarray(x1, np.float64).reshape(-1, 2)
+        x2 = np.ascontiguousarray(x2, np.float64).reshape(-1, 2)
+        n = x1.shape[0]
+        if x2.shape[0] != n:
+            raise ValueError("recover_pose: x1 and x2 differ in length")
+        R, t = np.zeros(9), np.zeros(3)
+        mask = np.zeros(max(n, 1), np.uint8)
+        X = np.zeros((max(n, 1), 4))
+        ng = C.c_int(0)
+        self._chk(self._lib.vs_recover_pose(self._h, ptr(E, c_f64p), ptr(x1, c_f64p), ptr(x2, c_f64p), n, float(dist_thresh),
+                                            ptr(R, c_f64p), ptr(t, c_f64p), ptr(mask, c_u8p), ptr(X, c_f64p), C.byref(ng)))
+        return dict(R=R.reshape(3, 3), t=t, mask=mask[:n].copy(), X=X[:n].copy(), n_good=ng.value)
+
     # ------------------------------------------------------------------ bundle adjustment (A9-A16)
     def ba_solve(self, poses, pose_fixed, points, point_fixed, obs_pose, obs_point, obs_uv, K,
                  huber_delta=float(np.sqrt(5.991)), max_iterations=10, scale_edges=None, obs_info=None, dcs_phi=1.0):

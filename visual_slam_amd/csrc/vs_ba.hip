@@ -1930,8 +1930,9 @@ __global__ __launch_bounds__(64) void pnp_hypothesis_kernel(pnp_args P) {
       for (int k = 0; k < 5; ++k) s_idx[k] = k;
     } else {
       int got = 0;
+      const unsigned long long base = splitmix64(P.seed);  // unrelated streams for neighbouring seeds
       for (unsigned long long k = 0; got < 5; ++k) {
-        const int c = (int)(splitmix64(P.seed ^ (((unsigned long long)h << 20) + k)) % (unsigned long long)P.n);
+        const int c = (int)(splitmix64(base ^ (((unsigned long long)h << 20) + k)) % (unsigned long long)P.n);
         bool dup = false;
         for (int j = 0; j < got; ++j) dup |= s_idx[j] == c;
         if (!dup) s_idx[got++] = c;

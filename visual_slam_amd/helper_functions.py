@@ -106,3 +106,63 @@ def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rve
     R = w_T_c[:3, :3].T
     t = -R @ w_T_c[:3, 3]
     return bool(r["found"]), Rtorvec(R), t.reshape(3, 1), r["inliers"].astype(np.int32).reshape(-1, 1)
+
+
+def _normalise(pts, K):
+    """cv2.undistortPoints(pts, K, None) without distortion: pixel -> K-normalised coordinates."""
+    K = np.asarray(K, np.float64)
+    pts = np.asarray(pts, np.float64).reshape(-1, 2)
+    return np.stack([(pts[:, 0] - K[0, 2]) / K[0, 0], (pts[:, 1] - K[1, 2]) / K[1, 1]], 1)
+
+
+def matlab_max(v, s):
+    """helper_functions.py:43-44."""
+    return [max(v[i], s) for i in range(len(v))]
+
+
+def estimateEssential(pts1, pts2, K, essTh, context=None, seed=0, solver=None):
+    """helper_functions.py:47-70 -> (E, inliers uint8 [N,1] (1/0), score).
+
+    cv2.findEssentialMat(RANSAC, prob=0.999, threshold=essTh) on the K-normalised points is replaced by
+    Context.essential_ransac (8-point hypotheses); the score is the reference's own NumPy: squared distances
+    to the epipolar lines (cv2.computeCorrespondEpilines == l = E^T x2 resp. E x1, scaled to a^2 + b^2 = 1) of the
+    inliers in both images against outlierThreshold = 4.  `solver(x1, x2, threshold, seed=)` injects the CPU oracle."""
+    x1, x2 = _normalise(pts1, K), _normalise(pts2, K)
+    run = solver or (context or default_context()).essential_ransac
+    r = run(x1, x2, float(essTh), seed=int(seed))
+    E = r["E"]
+    inliers = r["mask"].astype(np.uint8).reshape(-1, 1)
+    sel = inliers[:, 0] == 1
+    p1, p2 = x1[sel], x2[sel]
+    loc1 = np.concatenate((p1, np.ones((len(p1), 1))), axis=1)
+    loc2 = np.concatenate((p2, np.ones((len(p2), 1))), axis=1)
+
+    def epilines(E_, pts_h):  # computeCorrespondEpilines: l = E_ x, normalised so that a^2 + b^2 = 1
+        l = pts_h @ E_.T
+        nrm = np.sqrt(l[:, 0] ** 2 + l[:, 1] ** 2)
+        nrm[nrm == 0] = 1.0
+        return l / nrm[:, None]
+
+    line_in_1 = epilines(E.T, loc2)  # whichImage=2 -> lines in image 1
+    err_2in1 = np.sum(loc1 * line_in_1, axis=1) ** 2 / np.sum(line_in_1[:, :3] ** 2, axis=1)
+    line_in_2 = epilines(E.T, loc1)  # the reference passes whichImage=2 for this direction as well (:66)
+    err_1in2 = np.sum(loc2 * line_in_2, axis=1) ** 2 / np.sum(line_in_2[:, :3] ** 2, axis=1)
+    outlier_threshold = 4
+    score = np.sum(matlab_max(outlier_threshold - err_1in2, 0)) + sum(matlab_max(outlier_threshold - err_2in1, 0))
+    return E, inliers, score
+
+
+def estimateRelativePose(tform, inlier_pts1, inlier_pts2, inlier_fts1, inlier_fts2, K, tform_type="Essential",
+                         context=None, solver=None):
+    """helper_functions.py:164-191 (Essential branch): cv2.recoverPose(E, pts1, pts2, K, distanceThresh=50) and the
+    gather of the points it accepted -> (R, t [3,1], validFraction, X [4,M], pts1, pts2, fts1, fts2)."""
+    if tform_type != "Essential":
+        raise NotImplementedError("estimateRelativePose: only the Essential branch is live in the reference (main.py:109)")
+    x1, x2 = _normalise(inlier_pts1, K), _normalise(inlier_pts2, K)
+    run = solver or (context or default_context()).recover_pose
+    r = run(np.asarray(tform, np.float64), x1, x2, 50.0)
+    good = np.where(r["mask"] == 255)[0]
+    n = max(len(x1), 1)
+    X = r["X"][good].T if len(good) else np.zeros((4, 0))
+    return (r["R"], r["t"].reshape(3, 1), len(good) / n, X, [inlier_pts1[i] for i in good],
+            [inlier_pts2[i] for i in good], [inlier_fts1[i] for i in good], [inlier_fts2[i] for i in good])

@@ -9,10 +9,12 @@ on the CPU oracle (tests, bench baseline):
     triangulation    helper_functions.triangulate main.py:284
     local BA         BundleAdjustment            main.py:322-323
     PnP-RANSAC       helper_functions.solvePnPRansac  main.py:196-204
-One stage of main.py has no counterpart yet: the two-view initialisation (findEssentialMat /
-recoverPose, main.py:88-148).  It is replaced by initialisation from the first frame's keypoints back-projected with the
-dataset's depth image, followed by the same normalisation main.py applies after its first BA (everything divided by the
-median point norm, LocalBA.py:178-190).
+    two-view init    helper_functions.estimateEssential / estimateRelativePose  main.py:88-148 (init="two_view")
+Initialisation: `init="depth"` (default) back-projects the first frame's keypoints with the dataset's depth image and
+applies the normalisation main.py applies after its first BA (everything divided by the median point norm,
+LocalBA.py:178-190); `init="two_view"` is main.py:78-148 - essential matrix + recoverPose between frame 0 and the first
+later frame with >= 100 matches and >= 90 % cheirality-valid inliers, then local BA with scale=True.  The frames consumed
+by the initialisation get the second key frame's pose in the returned trajectory.
 main.py:193-194 hands solvePnPRansac the previous camera-to-world pose as if it were world-to-camera; here the guess is
 the previous world-to-camera transform (`pnp_guess="w2c"`); `pnp_guess="reference"` reproduces the reference's call,
 `pnp_guess=None` skips PnP and starts motion-only BA from the previous pose.
@@ -32,15 +34,23 @@ from .point import Point
 class Backends:
     """extractor / matcher objects and factories for BundleAdjustment and triangulate."""
 
-    def __init__(self, context=None, ba_solver=None, extractor=None, matcher=None, triangulate=None, pnp_solver=None):
+    def __init__(self, context=None, ba_solver=None, extractor=None, matcher=None, triangulate=None, pnp_solver=None,
+                 essential_solver=None, recover_solver=None):
         self.extractor = extractor or FeatureExtractor(context=context)
         self.matcher = matcher or FeatureMatcher(context=context)
         self._ctx, self._solver, self._pnp = context, ba_solver, pnp_solver
+        self._ess, self._rec = essential_solver, recover_solver
         self.triangulate = triangulate or (lambda P1, P2, x1, x2: hf.triangulate(P1, P2, x1, x2, context=context))
 
     def pnp(self, obj, img, K, rvec, tvec, seed):
         return hf.solvePnPRansac(obj, img, K, None, rvec, tvec, useExtrinsicGuess=True, context=self._ctx, seed=seed,
                                  solver=self._pnp)
+
+    def essential(self, pts1, pts2, K, essTh, seed=0):
+        return hf.estimateEssential(pts1, pts2, K, essTh, context=self._ctx, seed=seed, solver=self._ess)
+
+    def relative_pose(self, E, p1, p2, f1, f2, K):
+        return hf.estimateRelativePose(E, p1, p2, f1, f2, K, "Essential", context=self._ctx, solver=self._rec)
 
     def ba(self, camera):
         return BundleAdjustment(camera, context=self._ctx, solver=self._solver)
@@ -50,8 +60,52 @@ def _inv(pose):
     return Isometry3d(R=pose[0:3, 0:3], t=np.asarray(pose[:3, -1]).squeeze()).inverse().matrix()
 
 
+def two_view_init(frames, K, camera, be, map, min_matches=100, min_valid=0.9, log=None):
+    """main.py:78-148: returns (index of the second key frame, next point id); the map then holds two key frames, the
+    triangulated points and has been bundle-adjusted with scale=True."""
+    id_frame, id_point = 0, 1
+    cur_frame = Frame(frames[0], None, id_frame)
+    cur_frame.AddPose(init_pose=np.eye(4))
+    cur_frame.SetAsKeyFrame()
+    cur_frame.AddParent(None, None)
+    kp_prev, features_prev, _ = cur_frame.process_frame(be.extractor)
+    map.AddFrame(frame_id=id_frame, frame=cur_frame)
+    id_frame += 1
+    for i in range(1, len(frames)):
+        prev_frame = map.GetFrame(id_frame - 1)
+        cur_frame = Frame(frames[i], None, id_frame)
+        kp_cur, features_cur, _ = cur_frame.process_frame(be.extractor)
+        matches, p1, f1, p2, f2 = be.matcher.match_features(kp_prev, features_prev, kp_cur, features_cur)
+        if len(matches) < min_matches:
+            continue
+        E, inliers, score = be.essential(p1, p2, K, essTh=3.0 / K[0, 0], seed=i)
+        sel = inliers[:, 0] == 1
+        if sel.sum() < 8:
+            continue
+        R, t, valid, X, q1, q2, g1, g2 = be.relative_pose(E, p1[sel], p2[sel], f1[sel], f2[sel], K)
+        if log:
+            log("two-view init, image %d: %d matches, %d inliers, valid fraction %.2f" % (i, len(matches), sel.sum(), valid))
+        if valid < min_valid:
+            continue
+        rel = Isometry3d(R=R, t=np.squeeze(t)).inverse().matrix()
+        pose = rel @ prev_frame.GetPose()
+        map.AddParentAndPose(parent_id=id_frame - 1, frame_id=id_frame, frame_obj=cur_frame, rel_pose_trans=rel, pose=pose)
+        pts = (np.linalg.inv(prev_frame.GetPose()) @ X).T
+        pts = pts[:, :3] / np.asarray(pts[:, -1]).reshape(-1, 1)
+        for pt, uv1, uv2, ft1, ft2 in zip(pts, q1, q2, g1, g2):
+            pt_object = Point(location=pt, id=id_point)
+            pt_object.AddFrame(frame=prev_frame, uv=uv1, descriptor=ft1)
+            pt_object.AddFrame(frame=cur_frame, uv=uv2, descriptor=ft2)
+            map.AddPoint3D(point_id=id_point, point_3d=pt_object)
+            id_point += 1
+        cur_frame.SetAsKeyFrame()
+        be.ba(camera).localBundleAdjustement(map, scale=True)  # main.py:146-148
+        return i, id_point
+    raise RuntimeError("two-view initialisation failed: no frame pair with enough parallax")
+
+
 def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, max_depth=1.0, log=None,
-                 pnp_guess="w2c"):
+                 pnp_guess="w2c", init="depth"):
     """frames: list of BGR images; depth0: metric depth of frames[0]; K4 = (fx, fy, cx, cy).
     Returns dict(poses [n,4,4] camera-to-world, keyframes [indices], n_points, map, tracked [per frame])."""
     fx, fy, cx, cy = K4
@@ -60,32 +114,42 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
     be = backends
     map = Map()
     id_frame, id_point = 0, 1
-    # ---- initialisation (replaces main.py:78-148)
-    cur_frame = Frame(frames[0], None, id_frame)
-    cur_frame.AddPose(init_pose=np.eye(4))
-    cur_frame.SetAsKeyFrame()
-    cur_frame.AddParent(None, None)
-    kp0, ft0, _ = cur_frame.process_frame(be.extractor)
-    map.AddFrame(frame_id=id_frame, frame=cur_frame)
-    z = depth0[kp0[:, 1].astype(int), kp0[:, 0].astype(int)]
-    pts = np.stack([(kp0[:, 0] - cx) * z / fx, (kp0[:, 1] - cy) * z / fy, z], 1)
-    pts = pts / np.median(np.linalg.norm(pts, axis=1))  # LocalBA.py:178-190 (scale=True): median point norm = 1
-    for X, uv, ft in zip(pts, kp0, ft0):
-        pt_object = Point(location=X, id=id_point)
-        pt_object.AddFrame(frame=cur_frame, uv=uv, descriptor=ft)
-        map.AddPoint3D(point_id=id_point, point_3d=pt_object)
-        id_point += 1
-    id_frame += 1
-    last_keyframe = copy.copy(map.GetFrame(frame_id=0))
+    start = 1
+    if init == "two_view":
+        start, id_point = two_view_init(frames, K, camera, be, map, log=log)
+        id_frame = 2
+        start += 1
+    else:
+        # ---- initialisation from the depth image of frame 0
+        cur_frame = Frame(frames[0], None, id_frame)
+        cur_frame.AddPose(init_pose=np.eye(4))
+        cur_frame.SetAsKeyFrame()
+        cur_frame.AddParent(None, None)
+        kp0, ft0, _ = cur_frame.process_frame(be.extractor)
+        map.AddFrame(frame_id=id_frame, frame=cur_frame)
+        z = depth0[kp0[:, 1].astype(int), kp0[:, 0].astype(int)]
+        pts = np.stack([(kp0[:, 0] - cx) * z / fx, (kp0[:, 1] - cy) * z / fy, z], 1)
+        pts = pts / np.median(np.linalg.norm(pts, axis=1))  # LocalBA.py:178-190 (scale=True): median point norm = 1
+        for X, uv, ft in zip(pts, kp0, ft0):
+            pt_object = Point(location=X, id=id_point)
+            pt_object.AddFrame(frame=cur_frame, uv=uv, descriptor=ft)
+            map.AddPoint3D(point_id=id_point, point_3d=pt_object)
+            id_point += 1
+        id_frame += 1
+    last_keyframe = copy.copy(map.GetFrame(frame_id=id_frame - 1))  # main.py:153
     local_map = Map()
     local_map.AddFrame(last_keyframe.GetID(), last_keyframe)
     local_map.Store3DPoints(map.GetCopyOfPointObjects(last_keyframe.GetID()))
     id_frame_local = id_frame
-    loop_idx = 0
-    all_poses = {0: np.eye(4)}
+    loop_idx = start - 1
+    all_poses = {0: np.array(map.GetFrame(0).GetPose(), dtype=np.float64)}
     keyframes, tracked, pnp_inliers = [0], [], []
+    if init == "two_view":
+        for k in range(1, start):
+            all_poses[k] = np.array(map.GetFrame(1).GetPose(), dtype=np.float64)
+        keyframes.append(start - 1)
     # ---- tracking loop (main.py:173-348)
-    for i in range(1, len(frames)):
+    for i in range(start, len(frames)):
         cur_frame = Frame(frames[i], None, id_frame_local)
         kp_cur, features_cur, _ = cur_frame.process_frame(be.extractor)
         kp_prev, features_prev, known_3d, point_IDs = local_map.GetImagePointsWithFrameID(last_keyframe.GetID())
