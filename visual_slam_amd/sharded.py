@@ -31,21 +31,31 @@ class RcclAllGather:
         import torch.distributed as dist
         self._C = C
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        self.lib = C.CDLL(path if os.path.exists(path) else "librccl.so")
+        dev = torch.device("cuda", torch.cuda.current_device())
 
         class UniqueId(C.Structure):
             _fields_ = [("internal", C.c_byte * 128)]
 
-        self.lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
-        self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-        self.lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
-        self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
-        self.lib.ncclGetErrorString.restype = C.c_char_p
+        # every step that can fail on one rank alone is followed by an agreement, so that no rank is ever left alone
+        # inside a collective: (1) the library loads everywhere, (2) rank 0 obtained an id, then the collective init
+        ok = 1
+        try:
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            self.lib = C.CDLL(path if os.path.exists(path) else "librccl.so")
+            self.lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+            self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            self.lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+            self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            self.lib.ncclGetErrorString.restype = C.c_char_p
+        except (OSError, AttributeError):
+            ok = 0
         uid = UniqueId()
-        if self.rank == 0:
-            self._chk(self.lib.ncclGetUniqueId(C.byref(uid)))
-        dev = torch.device("cuda", torch.cuda.current_device())
+        if ok and self.rank == 0 and self.lib.ncclGetUniqueId(C.byref(uid)) != 0:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            raise RuntimeError("RCCL library / unique id not available on every rank")
         t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=dev)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
@@ -168,8 +178,9 @@ class ShardedMatcher:
                 and os.environ.get("VS_SHARDED_TORCH_COLLECTIVE", "0") != "1":
             try:
                 if self._rccl is None:
-                    self._rccl = RcclAllGather(self.group)
-                    self._events = {}
+                    self._init_direct(packed.device)
+                if self._rccl_failed:
+                    raise RuntimeError("direct RCCL path disabled by agreement of the ranks")
                 key = packed.data_ptr()
                 if key not in self._events:               # one (ready, done) event pair per rotating buffer
                     self._events[key] = (torch.cuda.Event(), torch.cuda.Event())
@@ -182,6 +193,24 @@ class ShardedMatcher:
             except (OSError, AttributeError, RuntimeError):
                 self._rccl_failed = True                   # fall back to torch.distributed below
         return ("work", self._dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True))
+
+    def _init_direct(self, device):
+        """Create the direct communicator on every rank, then agree on the outcome: if any rank failed, all ranks use
+        torch.distributed's collective (a rank alone in ncclAllGather would wait for ever)."""
+        import torch
+        ok = 1
+        try:
+            self._rccl = RcclAllGather(self.group)
+            self._events = {}
+        except (OSError, AttributeError, RuntimeError):
+            self._rccl, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            self._rccl_failed = True
+            if self._rccl is not None:
+                self._rccl.close()
+                self._rccl = None
 
     def collect(self, ticket):
         """Wait for a ticket's all-gather; returns (idx [Q,2], dist [Q,2]).  With the ceil partition only trailing ranks
