@@ -69,6 +69,32 @@ def main():
     r = oracle.ba_solve(*args, max_iterations=10)
     out.update(ba_cfg4_poses=r["poses"], ba_cfg4_chi2=r["chi2_trace"], ba_cfg4_lambda=r["lambda_trace"],
                ba_cfg4_chi2_initial=np.array([r["chi2_initial"]]), ba_cfg4_points_head=r["points"][:16])
+    # (5) the rows around the path: PnP-RANSAC, essential RANSAC, pose recovery -- seeded synthetic scenes;
+    # cross-checks against independent NumPy where one exists (SVD of E, DLT triangulation, projection of the inliers)
+    from test_pnp import scene as pnp_scene
+    from test_twoview import scene as tv_scene, true_E
+    from visual_slam_amd.workloads import ICL_NUIM_K
+    X, uv, T, bad = pnp_scene(300, 0.25, 0.4, 12)
+    r = oracle.pnp_ransac(X, uv, ICL_NUIM_K, np.eye(4), seed=12)
+    assert r["found"] and not set(r["inliers"].tolist()) & set(bad.tolist())
+    fx, fy, cx, cy = ICL_NUIM_K
+    Xc = (X[r["inliers"]] - r["pose"][:3, 3]) @ r["pose"][:3, :3]
+    err = np.hypot(fx * Xc[:, 0] / Xc[:, 2] + cx - uv[r["inliers"], 0], fy * Xc[:, 1] / Xc[:, 2] + cy - uv[r["inliers"], 1])
+    assert err.max() < 8.5 and np.linalg.norm(r["pose"][:3] - T[:3]) < 5e-3
+    out.update(pnp_obj=X, pnp_img=uv, pnp_pose=r["pose"], pnp_inliers=r["inliers"])
+    x1, x2, R, t, _, _ = tv_scene(400, 100, 0.5, 13)
+    e = oracle.essential_ransac(x1, x2, 3.0 / 480, seed=13)
+    sv = np.linalg.svd(e["E"])[1]
+    assert e["found"] and abs(sv[0] - 1) < 1e-9 and abs(sv[1] - 1) < 1e-9 and sv[2] < 1e-9
+    sel = e["mask"] == 1
+    rp = oracle.recover_pose(e["E"], x1[sel], x2[sel])
+    P0, P1 = np.eye(4)[:3], np.hstack([rp["R"], rp["t"][:, None]])
+    from oracle import np_reference
+    tri = np_reference.triangulate(P0, P1, np.c_[x1[sel], np.ones(sel.sum())], np.c_[x2[sel], np.ones(sel.sum())])
+    tri = tri / np.linalg.norm(tri, axis=1, keepdims=True) * np.sign(tri[:, 3:])
+    assert np.abs(tri - rp["X"]).max() < 1e-9 and np.abs(rp["R"] - R).max() < 0.05
+    out.update(tv_x1=x1, tv_x2=x2, tv_E=e["E"], tv_mask=e["mask"], tv_R=rp["R"], tv_t=rp["t"], tv_pose_mask=rp["mask"],
+               tv_X=rp["X"])
     np.savez_compressed(os.path.join(HERE, "oracle_golden.npz"), **out)
     print("wrote oracle_golden.npz:", {k: v.shape for k, v in out.items()})
 
