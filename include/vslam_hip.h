@@ -157,6 +157,25 @@ int vs_essential_ransac(vs_ctx* ctx, const double* x1, const double* x2, int n, 
 int vs_recover_pose(vs_ctx* ctx, const double* E, const double* x1, const double* x2, int n, double dist_thresh,
                     double* R /*[9]*/, double* t /*[3]*/, uint8_t* mask /*[n]*/, double* X /*[n][4]*/, int* n_good);
 
+/* ---- one tracking period resident on the device ----------------------------------------------------
+ * replaces the body of the per-frame tracking loop (src/v2/main.py:181-214): process_frame, GetImagePointsWithFrameID,
+ * match_features, solvePnPRansac, AddPointToFrameCorrespondences, motionOnlyBundleAdjustement.
+ * vs_track_begin uploads the last key frame's map points (xyz, descriptors, in Map.GetImagePointsWithFrameID order) and
+ * its pose once; every vs_track_frame uploads only the image and runs detect+describe -> match (map = query, frame =
+ * train, Lowe ratio) -> PnP-RANSAC from the previous pose -> append the observations -> motion-only BA over all poses of
+ * the period (LocalBA.py:195-229 re-optimises all of them every frame), without the host rebuilding or re-uploading the
+ * period's observations.  Same kernels and arithmetic as vs_detect_describe_bgr / vs_match_ratio / vs_pnp_ransac /
+ * vs_ba_solve.  poses_out: [n_frames+1][16] camera-to-world, pose 0 = the key frame.  Optional outputs may be NULL. */
+int vs_track_begin(vs_ctx* ctx, const double* xyz /*[n][3]*/, const uint8_t* desc /*[n][32]*/, int n_points,
+                   const double* key_pose /*4x4*/, double fx, double fy, double cx, double cy, int max_frames, int max_kp,
+                   int pnp_iterations /*0: start BA from the previous pose*/);
+int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int thr, double ratio,
+                   double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations, double huber_delta,
+                   double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found, float* xy_out /*[max_kp][2]*/,
+                   uint8_t* desc_out /*[max_kp][32]*/, int* n_kp_out, int32_t* match_q /*[n_points]*/,
+                   int32_t* match_t /*[n_points]*/);
+int vs_track_end(vs_ctx* ctx);
+
 /* ---- A9-A16: bundle adjustment ------------------------------------------------------------------------------
  * replaces the g2o graph the reference builds and optimises          (src/v2/LocalBA.py:20-94,115-131,39-42)
  *   solver      : Levenberg-Marquardt( BlockSolverSE3( Cholesky ) ), points marginalised (Schur complement)

@@ -80,6 +80,10 @@ def test_tracking_harness_gpu_equals_oracle(vs, oracle):
         assert rel < 1e-4, rel
         step = np.linalg.norm(np.diff(gposes[:, :3, 3], axis=0), axis=1)
         assert step.max() < 0.05  # consecutive ICL-NUIM frames are millimetres apart: the tracker must not jump
+    # the device-resident session (map uploaded once, one image upload per frame) runs the same kernels
+    rposes, _, rn = harness.track_sequence_resident(vs, frames, depth0)
+    assert rn == gn
+    assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(rposes, gposes)) < 1e-9
     # the class-API period (Frame / Map / FeatureMatcher / solvePnPRansac / BundleAdjustment) tracks the same poses
     aposes, _ = harness.track_sequence_api(frames, depth0, context=vs)
     assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(aposes, gposes)) < 1e-6
@@ -130,3 +134,29 @@ def test_pinned_frames_and_resident_descriptors(vs, oracle):
     mq, mt, md = vs.match_ratio(a[2], a2[2], 0.8)   # both descriptor sets are already resident on the device
     oq, ot, od = oracle.match_ratio(b[2], oracle.detect_describe_bgr(icl_frame(3), 20, 3000)[2], 0.8)
     assert np.array_equal(mq, oq) and np.array_equal(mt, ot) and np.array_equal(md, od)
+
+
+def test_tracking_session_details(vs, oracle):
+    """vs_track_*: optional outputs equal the stand-alone entry points, no-PnP mode, capacity and misuse errors."""
+    from visual_slam_amd import harness
+    from visual_slam_amd.context import VsError
+    frames, depth0 = harness.load_sequence(4)
+    xy0, _, d0 = vs.detect_describe_bgr(frames[0], 20, 3000)
+    X = harness.backproject(xy0, depth0)
+    with pytest.raises(VsError):
+        vs.track_end() or vs.track_frame(frames[1])           # no period open
+    vs.track_begin(X, d0, np.eye(4), ICL_NUIM_K, max_frames=2, pnp_iterations=0)
+    r = vs.track_frame(frames[1], want_keypoints=True)
+    xy1, _, d1 = vs.detect_describe_bgr(frames[1], 20, 3000)
+    mq, mt, _ = vs.match_ratio(d0, d1, 0.8)
+    assert np.array_equal(r["xy"], xy1) and np.array_equal(r["desc"], d1) and r["n_keypoints"] == len(xy1)
+    assert np.array_equal(r["match_q"], mq) and np.array_equal(r["match_t"], mt) and not r["pnp_found"]
+    # without PnP the session is motion-only BA from the previous pose: identical to the stand-alone solve
+    lm = harness.LocalMapArrays(X)
+    lm.add_frame(np.eye(4), mq, xy1[mt])
+    ref = vs.ba_solve(*lm.problem(), huber_delta=harness.HUBER, max_iterations=10)
+    assert r["poses"].shape == (2, 4, 4) and np.abs(r["poses"][1] - ref["poses"][1]).max() < 1e-12
+    vs.track_frame(frames[2])
+    with pytest.raises(VsError):
+        vs.track_frame(frames[3])                               # max_frames = 2
+    vs.track_end()

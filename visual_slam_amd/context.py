@@ -195,6 +195,46 @@ class Context:
                                           C.byref(ni), C.byref(found)))
         return dict(found=bool(found.value), pose=pose.reshape(4, 4), inliers=inl[:ni.value].copy())
 
+    # ------------------------------------------------------------------ tracking period on the device
+    def track_begin(self, xyz, desc, key_pose, K, max_frames=64, max_kp=3000, pnp_iterations=100):
+        """Upload the last key frame's map points (xyz [P,3], desc uint8 [P,32]) and pose; starts a tracking period."""
+        xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        if xyz.shape[0] != desc.shape[0]:
+            raise ValueError("track_begin: xyz and desc differ in length")
+        key_pose = np.ascontiguousarray(key_pose, np.float64).reshape(16)
+        fx, fy, cx, cy = (float(v) for v in K)
+        self._chk(self._lib.vs_track_begin(self._h, ptr(xyz, c_f64p), ptr(desc, c_u8p), xyz.shape[0], ptr(key_pose, c_f64p),
+                                           fx, fy, cx, cy, int(max_frames), int(max_kp), int(pnp_iterations)))
+        self._track = dict(P=xyz.shape[0], max_frames=int(max_frames), max_kp=int(max_kp),
+                           poses=np.zeros((int(max_frames) + 1, 16)), xy=np.zeros((int(max_kp), 2), np.float32),
+                           desc=np.zeros((int(max_kp), 32), np.uint8), mq=np.zeros(xyz.shape[0], np.int32),
+                           mt=np.zeros(xyz.shape[0], np.int32))
+
+    def track_frame(self, bgr, thr=20, ratio=0.8, reproj_err=8.0, confidence=0.99, seed=0, lm_iterations=10,
+                    huber_delta=float(np.sqrt(5.991)), want_keypoints=False, want_matches=True):
+        """One frame of the period -> dict(poses [n+1,4,4] (pose 0 = key frame), n_matches, pnp_found, match_q, match_t
+        [, xy, desc])."""
+        t = self._track
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w, _ = bgr.shape
+        npo, nm, found, nk = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self._lib.vs_track_frame(
+            self._h, ptr(bgr, c_u8p), w, h, 3 * w, int(thr), float(ratio), float(reproj_err), float(confidence), int(seed),
+            int(lm_iterations), float(huber_delta), ptr(t["poses"], c_f64p), C.byref(npo), C.byref(nm), C.byref(found),
+            ptr(t["xy"], c_f32p) if want_keypoints else None, ptr(t["desc"], c_u8p) if want_keypoints else None,
+            C.byref(nk), ptr(t["mq"], c_i32p) if want_matches else None, ptr(t["mt"], c_i32p) if want_matches else None))
+        out = dict(poses=t["poses"][:npo.value].reshape(-1, 4, 4).copy(), n_matches=nm.value, pnp_found=bool(found.value),
+                   n_keypoints=nk.value)
+        if want_matches:
+            out["match_q"], out["match_t"] = t["mq"][:nm.value].copy(), t["mt"][:nm.value].copy()
+        if want_keypoints:
+            out["xy"], out["desc"] = t["xy"][:nk.value].copy(), t["desc"][:nk.value].copy()
+        return out
+
+    def track_end(self):
+        self._chk(self._lib.vs_track_end(self._h))
+
     # ------------------------------------------------------------------ two-view initialisation (SURVEY 8f rank 4)
     def essential_ransac(self, x1, x2, threshold, prob=0.999, max_iters=1000, seed=0):
         """x1, x2 K-normalised [N,2] -> dict(found, E [3,3] with x2^T E x1 = 0, mask uint8[N] (0/1), n_inliers)."""

@@ -43,6 +43,16 @@ struct vs_ctx {
   vs_buf h_pin_big; // pinned staging (frames, descriptors)
   vs_desc_entry desc_cache[VS_DESC_CACHE];
   uint64_t desc_stamp = 0;
+  // tracking session (vs_track_*): one key-frame period resident on the device
+  vs_buf d_track, h_track;
+  struct {
+    int active = 0, n_points = 0, cap_frames = 0, max_kp = 0, pnp_iters = 0;
+    int n_frames = 0;   // frames tracked so far in this period (pose index of the newest one)
+    int obs_used = 0;   // observations appended so far
+    int cur = 0;        // state buffer holding the accepted estimate
+    double K[4] = {0, 0, 0, 0};
+    double last_rec[19];  // camera record of the newest pose (the PnP guess of the next frame)
+  } track;
 };
 
 uint64_t vs_fingerprint(const void* p, size_t bytes);

@@ -98,6 +98,23 @@ def track_sequence(detect, match, ba, frames, depth0, max_kp=3000, pnp=None):
     return np.stack(lm.poses), stages, n_matches
 
 
+def track_sequence_resident(ctx, frames, depth0, pnp=True):
+    """The same tracking period through the device-resident session (vs_track_begin / vs_track_frame): the key frame's
+    map is uploaded once, every frame uploads only its image.  Returns (poses [n,4,4], seconds, per-frame match counts)."""
+    t0 = time.perf_counter()
+    xy0, _, desc0 = ctx.detect_describe_bgr(frames[0], 20, 3000)
+    ctx.track_begin(backproject(xy0, depth0), desc0, np.eye(4), ICL_NUIM_K, max_frames=max(len(frames) - 1, 1),
+                    pnp_iterations=100 if pnp else 0)
+    n_matches, r = [], None
+    for k in range(1, len(frames)):
+        r = ctx.track_frame(frames[k], seed=k, want_matches=False)
+        n_matches.append(r["n_matches"])
+    ctx.track_end()
+    dt = time.perf_counter() - t0
+    poses = r["poses"] if r is not None else np.eye(4)[None]
+    return poses, dt, n_matches
+
+
 def track_sequence_api(frames, depth0, context=None, ba_solver=None, pnp=True, pnp_solver=None):
     """The same tracking period written against the reference's class API exactly as src/v2/main.py:173-214 uses it:
     Frame.process_frame -> Map.GetImagePointsWithFrameID -> FeatureMatcher.match_features ->
@@ -189,7 +206,16 @@ def bench_frames(ctx, repeats=5):
         ap, adt = track_sequence_api(frames, depth0, context=ctx)
         if api_dt is None or adt < api_dt:
             api_dt, api_poses = adt, ap
+    # the same period with the map resident on the device (one image upload per frame)
+    track_sequence_resident(ctx, frames[:4], depth0)
+    res_dt, res_poses = None, None
+    for _ in range(repeats):
+        rp, rdt, _ = track_sequence_resident(ctx, frames, depth0)
+        if res_dt is None or rdt < res_dt:
+            res_dt, res_poses = rdt, rp
     out = {"frames_per_s": len(frames) / dt, "n_frames": len(frames), "seconds": dt,
+           "resident_frames_per_s": len(frames) / res_dt,
+           "resident_vs_array_path": float(max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(res_poses, poses))),
            "class_api_frames_per_s": len(frames) / api_dt,
            "class_api_vs_array_path": float(max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(api_poses, poses))),
            "stage_ms_per_frame": {k: v / len(frames) * 1e3 for k, v in stages.items()},
