@@ -944,7 +944,8 @@ VO_EXPORT int vo_ba_pose_update(const double* pose16, const double* d6, double* 
  * budget shrinks with RANSACUpdateNumIters, the best model is refined on its inliers.  PARITY UNPINNED against OpenCV:
  * its RNG stream and CvLevMarq are not available; here the sample comes from a counter-based splitmix64
  * (value k of hypothesis h = splitmix64(splitmix64(seed) ^ ((h << 20) + k)) mod n, first distinct ones) and the
- * refinement is this file's own LM (vo_ba_solve with one free camera, fixed points, no robust kernel). */
+ * refinement is this file's own LM (pnp_refine below: one camera, fixed points, no robust kernel, g2o's LM schedule plus
+ * a stop on a numerically zero step). */
 static uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -996,49 +997,128 @@ static void pnp_errors(const double* pose16, const double* obj, const double* im
   }
 }
 
+/* One-camera LM on fixed points, identity information, no robust kernel: OptimizationAlgorithmLevenberg's schedule
+ * (lambda_0 = 1e-5 max diag, gain ratio with the 1e-3 guard, at most 10 trials per iteration) plus a convergence stop -
+ * OpenCV's iterative solver stops on a small parameter change as well - : once a solved step is below the numerical
+ * resolution of chi2 (|x|^2 < 1e-18) that trial is the last one. */
+static void pnp_edge_acc(const cam_t* c, const double* X, const double* uv, const double* K4, int jac, double* H /*[6][6]*/,
+                         double* b /*[6]*/, double* chi) {
+  double pc[3];
+  for (int i = 0; i < 3; ++i) pc[i] = c->w2n[i][0] * X[0] + c->w2n[i][1] * X[1] + c->w2n[i][2] * X[2] + c->w2n[i][3];
+  const double eu = (K4[0] * pc[0] + K4[2] * pc[2]) / pc[2] - uv[0];
+  const double ev = (K4[1] * pc[1] + K4[3] * pc[2]) / pc[2] - uv[1];
+  *chi += eu * eu + ev * ev;
+  if (!jac) return;
+  const double px = pc[0], py = pc[1], pz = pc[2];
+  const double ipz2 = 1.0 / (pz * pz);
+  const double ipz2fx = ipz2 * K4[0], ipz2fy = ipz2 * K4[1];
+  const double pwt[3] = {X[0] - c->t[0], X[1] - c->t[1], X[2] - c->t[2]};
+  double J[2][6];
+  for (int a = 0; a < 3; ++a) {
+    double dp[3];
+    for (int i = 0; i < 3; ++i) dp[i] = c->dR[a][i][0] * pwt[0] + c->dR[a][i][1] * pwt[1] + c->dR[a][i][2] * pwt[2];
+    J[0][3 + a] = (pz * dp[0] - px * dp[2]) * ipz2fx;
+    J[1][3 + a] = (pz * dp[1] - py * dp[2]) * ipz2fy;
+    J[0][a] = -((pz * c->w2n[0][a] - px * c->w2n[2][a]) * ipz2fx);
+    J[1][a] = -((pz * c->w2n[1][a] - py * c->w2n[2][a]) * ipz2fy);
+  }
+  for (int a = 0; a < 6; ++a) {
+    b[a] += J[0][a] * (-eu) + J[1][a] * (-ev);
+    for (int cc = 0; cc < 6; ++cc) H[6 * a + cc] += J[0][a] * J[0][cc] + J[1][a] * J[1][cc];
+  }
+}
+
 static int pnp_refine(const double* pose_in, const double* obj, const double* img, const int32_t* sel, int m,
                       const double* K4, int iters, double* pose_out) {
-  double* pts = (double*)malloc(sizeof(double) * 3 * (size_t)m);
-  double* uv = (double*)malloc(sizeof(double) * 2 * (size_t)m);
-  int32_t* op = (int32_t*)calloc((size_t)m, sizeof(int32_t));
-  int32_t* oq = (int32_t*)malloc(sizeof(int32_t) * (size_t)m);
-  uint8_t* pf = (uint8_t*)malloc((size_t)m);
-  for (int j = 0; j < m; ++j) {
-    memcpy(pts + 3 * j, obj + 3 * (size_t)sel[j], 3 * sizeof(double));
-    memcpy(uv + 2 * j, img + 2 * (size_t)sel[j], 2 * sizeof(double));
-    oq[j] = j;
-    pf[j] = 1;
+  cam_t cam, trial;
+  memset(&cam, 0, sizeof cam);
+  quat_from_R(pose_in, cam.q);
+  cam.t[0] = pose_in[3];
+  cam.t[1] = pose_in[7];
+  cam.t[2] = pose_in[11];
+  cam_refresh(&cam);
+  double lambda = 0.0, ni = 2.0;
+  for (int it = 0; it < iters; ++it) {
+    double H[36], b[6], cur = 0.0;
+    memset(H, 0, sizeof H);
+    memset(b, 0, sizeof b);
+    for (int j = 0; j < m; ++j) pnp_edge_acc(&cam, obj + 3 * (size_t)sel[j], img + 2 * (size_t)sel[j], K4, 1, H, b, &cur);
+    if (it == 0) {
+      double mx = 0.0;
+      for (int a = 0; a < 6; ++a) mx = fmax(mx, fabs(H[7 * a]));
+      lambda = 1e-5 * mx;
+      ni = 2.0;
+    }
+    double rho = 0.0;
+    int qmax = 0, stop = 0, conv = 0;
+    do {
+      double A[36], x[6];
+      memcpy(A, H, sizeof A);
+      for (int a = 0; a < 6; ++a) {
+        A[7 * a] += lambda;
+        x[a] = b[a];
+      }
+      int ok = 1;
+      for (int j = 0; j < 6; ++j) {
+        double sdiag = A[7 * j];
+        for (int k = 0; k < j; ++k) sdiag -= A[6 * j + k] * A[6 * j + k];
+        if (!(sdiag > 0.0)) ok = 0;
+        const double l = sqrt(sdiag);
+        A[7 * j] = l;
+        for (int i = j + 1; i < 6; ++i) {
+          double v = A[6 * i + j];
+          for (int k = 0; k < j; ++k) v -= A[6 * i + k] * A[6 * j + k];
+          A[6 * i + j] = v / l;
+        }
+      }
+      double temp = DBL_MAX;
+      if (ok) {
+        for (int i = 0; i < 6; ++i) {
+          double v = x[i];
+          for (int k = 0; k < i; ++k) v -= A[6 * i + k] * x[k];
+          x[i] = v / A[7 * i];
+        }
+        for (int i = 5; i >= 0; --i) {
+          double v = x[i];
+          for (int k = i + 1; k < 6; ++k) v -= A[6 * k + i] * x[k];
+          x[i] = v / A[7 * i];
+        }
+        trial = cam;
+        cam_update(&trial, x);
+        temp = 0.0;
+        for (int j = 0; j < m; ++j) pnp_edge_acc(&trial, obj + 3 * (size_t)sel[j], img + 2 * (size_t)sel[j], K4, 0, NULL, NULL, &temp);
+        double step2 = 0.0;
+        for (int a = 0; a < 6; ++a) step2 += x[a] * x[a];
+        conv = step2 < 1e-18;
+      } else {
+        for (int a = 0; a < 6; ++a) x[a] = 0.0;
+      }
+      rho = cur - temp;
+      double scale = 0.0;
+      for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && isfinite(temp)) {
+        double alpha = 1.0 - pow(2 * rho - 1, 3);
+        alpha = fmin(alpha, 2.0 / 3.0);
+        lambda *= fmax(1.0 / 3.0, alpha);
+        ni = 2.0;
+        cur = temp;
+        cam = trial;
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        if (!isfinite(lambda)) {
+          stop = 1;
+          break;
+        }
+      }
+      ++qmax;
+    } while (rho < 0 && qmax < 10 && !conv);
+    if (qmax == 10 || rho == 0 || stop || conv) break;
   }
-  uint8_t pose_free = 0;
-  vs_ba_problem p;
-  memset(&p, 0, sizeof p);
-  p.n_poses = 1;
-  p.n_points = m;
-  p.n_obs = m;
-  p.poses = pose_in;
-  p.pose_fixed = &pose_free;
-  p.points = pts;
-  p.point_fixed = pf;
-  p.obs_pose = op;
-  p.obs_point = oq;
-  p.obs_uv = uv;
-  p.fx = K4[0];
-  p.fy = K4[1];
-  p.cx = K4[2];
-  p.cy = K4[3];
-  p.huber_delta = 0;
-  p.dcs_phi = 1;
-  p.max_iterations = iters;
-  vs_ba_result r;
-  memset(&r, 0, sizeof r);
-  r.poses_out = pose_out;
-  int rc = vo_ba_solve(&p, &r);
-  free(pts);
-  free(uv);
-  free(op);
-  free(oq);
-  free(pf);
-  return rc;
+  pose_matrix(&cam, pose_out);
+  return VS_OK;
 }
 
 /* returns VS_OK; *found = 1 if a model with >= 5 inliers exists.  pose0/pose_out: camera-to-world 4x4 row-major. */

@@ -31,7 +31,7 @@ def test_sequence_directory():
     d = seq.depth(0)                                            # only depth/0.png is committed (the initialisation frame)
     assert d.shape == (480, 640) and 0.5 < np.median(d) < 10
     bare = dataset.Sequence(ICL, associations="missing.txt")   # falls back to the rgb directory in numeric order
-    assert [f[2] for f in bare.frames] == list(range(20))
+    assert [f[2] for f in bare.frames] == list(range(20)) + [150]   # 150: the wide-baseline frame of the two-view test
 
 
 def test_umeyama_recovers_a_similarity_and_ate_is_zero_for_it():

@@ -1798,8 +1798,9 @@ __device__ inline void pnp_reduce(double* v, double* s_red) {
   }
 }
 
-// Levenberg-Marquardt as OptimizationAlgorithmLevenberg drives it (one camera, fixed points, no robust kernel), run
-// redundantly by every thread on identical sums.  Edge e of the thread: e = first, first + stride, ... < m; sel maps to
+// Levenberg-Marquardt as OptimizationAlgorithmLevenberg drives it (one camera, fixed points, no robust kernel) plus a
+// stop once a solved step is numerically zero (|x|^2 < 1e-18; OpenCV's iterative solver stops on a small parameter change
+// too), run redundantly by every thread on identical sums.  Edge e of the thread: e = first, first + stride, ... < m; sel maps to
 // the correspondence (nullptr: identity).
 template <int STEPS, int NWAVES>
 __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int first, int stride, double* cam, double* s_red) {
@@ -1839,7 +1840,7 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
       ni = 2.0;
     }
     double rho = 0.0;
-    int qmax = 0, stop = 0;
+    int qmax = 0, stop = 0, conv = 0;
     do {
       double A[6][6], x[6];
 #pragma unroll
@@ -1883,6 +1884,10 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
           x[i] = v / A[i][i];
         }
         cam_apply(cam, x, trial);
+        double step2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) step2 += x[a] * x[a];
+        conv = step2 < 1e-18;  // below the numerical resolution of chi2: this trial is the last one
       } else {
 #pragma unroll
         for (int a = 0; a < 6; ++a) x[a] = 0.0;
@@ -1921,8 +1926,8 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
         }
       }
       ++qmax;
-    } while (rho < 0 && qmax < 10);
-    if (qmax == 10 || rho == 0 || stop) break;
+    } while (rho < 0 && qmax < 10 && !conv);
+    if (qmax == 10 || rho == 0 || stop || conv) break;
   }
 }
 
