@@ -2674,7 +2674,7 @@ VS_API int vs_pnp_ransac(vs_ctx* ctx, const double* obj, const double* img, int 
 namespace {
 struct track_layout {
   size_t xyz, mapdesc, fxy, fscore, fdesc, fn, mq, mt, md, M, flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part,
-      H, mst, pnp_cam, pnp_pose, pnp_good, pnp_res, pnp_inl, total;
+      H, mst, pnp_cam, pnp_pose, pnp_good, pnp_res, pnp_inl, rb_end, total;
   int cap_obs;
 };
 
@@ -2698,20 +2698,22 @@ track_layout track_layout_of(int P, int F, int max_kp, int H) {
   L.mt = take(sizeof(int) * (size_t)P);
   L.md = take(sizeof(int) * (size_t)P);
   L.M = take(sizeof(int));
+  // read-back block: [LM state x2 | flags | PnP result | both camera buffers] is fetched with one copy per frame
+  L.mst = take(2 * sizeof(mo_state));
   L.flags = take(4 * sizeof(int));
+  L.pnp_res = take(sizeof(double) * 20);
   L.cam0 = take(sizeof(double) * kCamStride * (size_t)(F + 1));
   L.cam1 = take(sizeof(double) * kCamStride * (size_t)(F + 1));
+  L.rb_end = off;
   L.moX = take(sizeof(double) * 3 * (size_t)L.cap_obs);
   L.moUV = take(sizeof(double) * 2 * (size_t)L.cap_obs);
   L.cam_start = take(sizeof(int) * (size_t)(F + 2));
   L.slot_pose = take(sizeof(int) * (size_t)(F + 1));
   L.part = take(sizeof(double) * 8 * (size_t)F);
   L.H = take(sizeof(double) * 42 * (size_t)F);
-  L.mst = take(2 * sizeof(mo_state));
   L.pnp_cam = take(sizeof(double) * kCamStride * (size_t)H);
   L.pnp_pose = take(sizeof(double) * 12 * (size_t)H);
   L.pnp_good = take(sizeof(int) * (size_t)H);
-  L.pnp_res = take(sizeof(double) * 20);
   L.pnp_inl = take(sizeof(int) * (size_t)(per > 0 ? per : 1));
   L.total = off;
   return L;
@@ -2809,10 +2811,11 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   else VS_HIP(ctx, hipMemcpy2DAsync(ctx->d_bgr.p, pitch, bgr, stride, 3 * (size_t)w, h_img, hipMemcpyHostToDevice, s));
   VS_TRY(vs_detect_describe_bgr_dev(ctx, ctx->d_bgr.p, w, h_img, pitch, thr, T.max_kp, d + L.fxy, d + L.fscore, d + L.fdesc,
                                     d + L.fn, s));
-  const size_t pin_need = 4096 + sizeof(double) * kCamStride * 2 * (size_t)(T.cap_frames + 1);
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, pin_need));
+  const size_t rb_bytes = L.rb_end - L.mst;  // the read-back block is mirrored at hp + 4096
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, 4096 + rb_bytes));
   uint8_t* hp = (uint8_t*)ctx->h_track.p;
-  int* h_n = (int*)hp;  // [0]: keypoints, [1..4]: flags, [8]: M
+  uint8_t* rb = hp + 4096;
+  int* h_n = (int*)hp;  // [0]: keypoints
   VS_HIP(ctx, hipMemcpyAsync(h_n, d + L.fn, sizeof(int), hipMemcpyDeviceToHost, s));
   VS_HIP(ctx, hipStreamSynchronize(s));
   const int n_kp = h_n[0];
@@ -2889,8 +2892,8 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   D.mo_H = (double*)(d + L.H);
   mo_state* d_mst = (mo_state*)(d + L.mst);
   D.st = reinterpret_cast<lm_state*>(d_mst);
-  mo_state* h_st = (mo_state*)(hp + 1024);  // [0..1] initial, [2..3] read-back
-  memset(h_st, 0, 4 * sizeof(mo_state));
+  mo_state* h_st = (mo_state*)(hp + 1024);  // initial state (uploaded)
+  memset(h_st, 0, 2 * sizeof(mo_state));
   h_st[1].need_lin = 1;
   h_st[1].ni = 2.0;
   h_st[1].cur = T.cur;
@@ -2898,6 +2901,7 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   mo_state fin;
   memset(&fin, 0, sizeof fin);
   fin.cur = T.cur;
+  const mo_state* rb_st = (const mo_state*)(rb + (L.mst - L.mst));
   if (lm_iterations > 0) {
     VS_HIP(ctx, hipMemcpyAsync(d_mst, h_st, 2 * sizeof(mo_state), hipMemcpyHostToDevice, s));
     const int max_steps = 1 + lm_iterations * 10;
@@ -2908,30 +2912,20 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
         hipLaunchKernelGGL(ba_motion_step, dim3(k), dim3(kMoThreads), 0, s, D, step);
         VS_LAUNCH_CHECK(ctx, "ba_motion_step");
       }
-      VS_HIP(ctx, hipMemcpyAsync(h_st + 2, d_mst + ((step - 1) & 1), sizeof(mo_state), hipMemcpyDeviceToHost, s));
-      // everything the host wants is requested before the one synchronisation; if the solve needs another batch the
-      // state copies are simply repeated
-      double* h_cam = (double*)(hp + 4096);
-      VS_HIP(ctx, hipMemcpyAsync(h_cam, cam0, sizeof(double) * kCamStride * (size_t)(k + 1), hipMemcpyDeviceToHost, s));
-      VS_HIP(ctx, hipMemcpyAsync(h_cam + (size_t)(T.cap_frames + 1) * kCamStride, cam1,
-                                 sizeof(double) * kCamStride * (size_t)(k + 1), hipMemcpyDeviceToHost, s));
-      VS_HIP(ctx, hipMemcpyAsync(h_n + 1, d + L.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-      VS_HIP(ctx, hipMemcpyAsync(hp + 512, d + L.pnp_res, 20 * sizeof(double), hipMemcpyDeviceToHost, s));
+      // one copy brings back everything the host wants; if the solve needs another batch it is simply repeated
+      VS_HIP(ctx, hipMemcpyAsync(rb, d + L.mst, rb_bytes, hipMemcpyDeviceToHost, s));
       VS_HIP(ctx, hipStreamSynchronize(s));
-      if (h_st[2].done || step > max_steps) break;
+      if (rb_st[(step - 1) & 1].done || step > max_steps) break;
     }
-    fin = h_st[2];
+    fin = rb_st[(step - 1) & 1];
   } else {
-    double* h_cam = (double*)(hp + 4096);
-    VS_HIP(ctx, hipMemcpyAsync(h_cam, cam0, sizeof(double) * kCamStride * (size_t)(k + 1), hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipMemcpyAsync(h_cam + (size_t)(T.cap_frames + 1) * kCamStride, cam1,
-                               sizeof(double) * kCamStride * (size_t)(k + 1), hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipMemcpyAsync(h_n + 1, d + L.flags, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipMemcpyAsync(hp + 512, d + L.pnp_res, 20 * sizeof(double), hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipMemcpyAsync(rb, d + L.mst, rb_bytes, hipMemcpyDeviceToHost, s));
     VS_HIP(ctx, hipStreamSynchronize(s));
   }
-  const int M = h_n[2];
-  if (h_n[1]) return vs_fail(ctx, VS_ENOMEM, "%s: observation capacity of the period exceeded", "vs_track_frame");
+  const int* rb_flags = (const int*)(rb + (L.flags - L.mst));
+  const double* rb_res = (const double*)(rb + (L.pnp_res - L.mst));
+  const int M = rb_flags[1];
+  if (rb_flags[0]) return vs_fail(ctx, VS_ENOMEM, "%s: observation capacity of the period exceeded", "vs_track_frame");
   if (match_q && match_t && M > 0) {
     VS_HIP(ctx, hipMemcpyAsync(match_q, d + L.mq, sizeof(int) * (size_t)M, hipMemcpyDeviceToHost, s));
     VS_HIP(ctx, hipMemcpyAsync(match_t, d + L.mt, sizeof(int) * (size_t)M, hipMemcpyDeviceToHost, s));
@@ -2940,13 +2934,13 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
     VS_HIP(ctx, hipStreamSynchronize(s));
   }
   T.cur = fin.cur;
-  const double* h_cam = (const double*)(hp + 4096) + (size_t)T.cur * (T.cap_frames + 1) * kCamStride;
+  const double* h_cam = (const double*)(rb + ((T.cur ? L.cam1 : L.cam0) - L.mst));
   for (int i = 0; i <= k; ++i) pose_from_rec(h_cam + (size_t)i * kCamStride, poses_out + 16 * (size_t)i);
   memcpy(T.last_rec, h_cam + (size_t)k * kCamStride, sizeof T.last_rec);
   T.n_frames = k;
   T.obs_used += M;
   *n_poses_out = k + 1;
   *n_matches = M;
-  if (pnp_found) *pnp_found = T.pnp_iters > 0 && ((const double*)(hp + 512))[16] != 0.0;
+  if (pnp_found) *pnp_found = T.pnp_iters > 0 && rb_res[16] != 0.0;
   return VS_OK;
 }
