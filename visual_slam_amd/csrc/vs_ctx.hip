@@ -25,7 +25,7 @@ VS_API int vs_create(vs_ctx** out, int device) {
   }
   if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
     vs_fail(nullptr, VS_EHIP, "vs_create: this library is built for gfx950 only, device is %s", ctx->prop.gcnArchName);
-    hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return VS_EHIP;
   }
@@ -34,25 +34,25 @@ VS_API int vs_create(vs_ctx** out, int device) {
 }
 
 static void free_dev(vs_buf* b) {
-  if (b->p) hipFree(b->p);
+  if (b->p) (void)hipFree(b->p);  // teardown: nothing useful can be done with an error here
   b->p = nullptr;
   b->cap = 0;
 }
 
 VS_API int vs_destroy(vs_ctx* ctx) {
   if (!ctx) return VS_OK;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
   vs_buf* dev[] = {&ctx->d_q,   &ctx->d_t,    &ctx->d_idx,     &ctx->d_dist, &ctx->d_partial, &ctx->d_mq,
                    &ctx->d_mt,  &ctx->d_md,   &ctx->d_cnt,     &ctx->d_bgr,  &ctx->d_gray,    &ctx->d_box,
                    &ctx->d_raw, &ctx->d_bandcnt, &ctx->d_hist, &ctx->d_xy,   &ctx->d_score,   &ctx->d_desc,
                    &ctx->d_n,   &ctx->d_xy_in, &ctx->d_keep,   &ctx->d_ba,  &ctx->d_track};
   for (vs_buf* b : dev) free_dev(b);
   for (vs_desc_entry& e : ctx->desc_cache) free_dev(&e.dev);
-  if (ctx->h_pin.p) hipHostFree(ctx->h_pin.p);
-  if (ctx->h_pin_big.p) hipHostFree(ctx->h_pin_big.p);
-  if (ctx->h_track.p) hipHostFree(ctx->h_track.p);
-  hipStreamDestroy(ctx->stream);
+  if (ctx->h_pin.p) (void)hipHostFree(ctx->h_pin.p);
+  if (ctx->h_pin_big.p) (void)hipHostFree(ctx->h_pin_big.p);
+  if (ctx->h_track.p) (void)hipHostFree(ctx->h_track.p);
+  (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return VS_OK;
 }
