@@ -29,6 +29,7 @@ BYTES_PER_MATCH = 32           # SURVEY.md 8d streamed-operand model: one 32-byt
 VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9  # 3.93e13: integer VALU issues a wave64 op every 4 cycles per SIMD (measured
                                       # 36-38e12 with tools/valu_probe.hip; only f32 FMA-class ops run at twice that)
 OPS_PER_MATCH = 19             # 8 v_xor + 8 v_bcnt + v_lshl_or + v_med3 + v_min
+VALU_LANE_OPS_MEASURED = 37.0e12  # tools/valu_probe.hip on this GPU (profiles/r01_valu_probe.log): 4.2-4.4 cycles per op
 
 
 def parse():
@@ -133,6 +134,30 @@ def frames_leg(ctx, cpu=True):
     except Exception as e:
         out["driver"] = {"error": repr(e)}
     return out
+
+
+def frames_replicas(ctx, dist, world, dev):
+    """frames/s with one independent replica of the tracker per GPU (north_star: detection and BA stay single-GPU, so
+    N GPUs track N streams): every rank runs the device-resident tracking period on the 20 fixture frames between two
+    barriers; the aggregate is ranks x frames / slowest rank."""
+    import torch
+    from visual_slam_amd.harness import load_sequence, track_sequence_resident
+    frames, depth0 = load_sequence(20)
+    frames = [ctx.pin(f) for f in frames]
+    track_sequence_resident(ctx, frames[:4], depth0)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        track_sequence_resident(ctx, frames, depth0)
+        dt = time.perf_counter() - t0
+        te = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        dt = float(te.item())
+        best = dt if best is None or dt < best else best
+    return {"replicas": world, "frames_per_s": world * len(frames) / best, "seconds_slowest_rank": best,
+            "note": "one tracker replica per GPU on the same 20 frames (device-resident tracking period)"}
 
 
 def main():
@@ -250,8 +275,16 @@ def main():
                                   "FETCH_SIZE doubled per the gfx950 correction)",
                 "valu_ceiling_gmatches": valu_ceiling,
                 "valu_frac": (float(nq) * nt / (kernel_ms * 1e-3) / 1e9) / valu_ceiling,
+                "valu_frac_of_measured_issue_rate": (float(nq) * nt / (kernel_ms * 1e-3) / 1e9) /
+                                                    (VALU_LANE_OPS_MEASURED / OPS_PER_MATCH / 1e9),
                 "note": "tiles are reused from SGPRs/VGPRs, so real HBM traffic is ~1000x below the streamed-operand "
                         "model and frac exceeds 1; the binding limit is integer VALU issue (valu_frac)"}
+    replicas = None
+    if use_dist and not args.no_frames:
+        try:
+            replicas = frames_replicas(ctx, dist, world, dev)
+        except Exception as e:  # all ranks take the same path: the collectives inside stay matched
+            replicas = {"error": repr(e)}
     if rank == 0:
         line = {
             "metric": "10k x 10k 256-bit Hamming 2-NN brute-force match throughput", "value": value,
@@ -271,6 +304,8 @@ def main():
         if not args.no_frames:
             try:
                 line["frames"] = frames_leg(ctx, cpu=(world == 1 and not args.no_cpu_baseline))
+                if replicas is not None:
+                    line["frames"]["replicas"] = replicas
                 if world > 1:
                     line["frames"]["parallelism"] = ("replica: detection, the 600 x 600 per-frame match and BA run on "
                                                      "rank 0's GPU only (north_star: detection and BA stay single-GPU)")
