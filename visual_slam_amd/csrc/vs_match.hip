@@ -273,7 +273,7 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 //     ceil(workgroups / 256 CUs) * chunk_len  +  merge cost per chunk
 // over plans with 1000..4600 workgroups -- the first term is the busiest CU's share of train rows (workgroups are
 // spread round-robin, 4..16 resident per CU), the second the extra partial rows the merge kernel folds.  At 10k x 10k
-// this gives 25 chunks x 40 query tiles = 1000 workgroups, at 100k x 100k 11 x 391 = 4301 (98.8 % balanced; a fixed
+// this gives 32 chunks x 40 query tiles = 1280 workgroups (25 chunks cost 0.2 % more), at 100k x 100k 11 x 391 = 4301 (98.8 % balanced; a fixed
 // 1024-workgroup plan loses 25 % there to 4-vs-3 workgroups per CU).
 void plan_chunks(int nq, int nt, int* chunk_len, int* sub_len, int* nchunks) {
   const variant_t& v = kVariants[g_variant];
