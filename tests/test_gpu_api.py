@@ -160,3 +160,23 @@ def test_tracking_session_details(vs, oracle):
     with pytest.raises(VsError):
         vs.track_frame(frames[3])                               # max_frames = 2
     vs.track_end()
+
+
+def test_tracking_session_survives_frames_without_features(vs):
+    """A black frame has no keypoints: no matches, PnP finds nothing, the pose stays at the previous one and the period
+    continues with the next real frame (the reference would raise in knnMatch; the session reports 0 matches)."""
+    from visual_slam_amd import harness
+    frames, depth0 = harness.load_sequence(3)
+    xy0, _, d0 = vs.detect_describe_bgr(frames[0], 20, 3000)
+    vs.track_begin(harness.backproject(xy0, depth0), d0, np.eye(4), ICL_NUIM_K, max_frames=4)
+    black = np.zeros_like(frames[0])
+    r = vs.track_frame(black, want_keypoints=True)
+    assert r["n_keypoints"] == 0 and r["n_matches"] == 0 and not r["pnp_found"]
+    assert np.allclose(r["poses"][1], np.eye(4), atol=1e-12)
+    r1 = vs.track_frame(frames[1])
+    assert r1["n_matches"] > 100 and r1["pnp_found"] and r1["poses"].shape == (3, 4, 4)
+    assert np.allclose(r1["poses"][1], np.eye(4), atol=1e-12)            # the empty camera is untouched by the BA
+    assert np.linalg.norm(r1["poses"][2][:3, 3]) < 0.05 and np.isfinite(r1["poses"]).all()
+    r2 = vs.track_frame(black)
+    assert r2["n_matches"] == 0 and np.abs(r2["poses"][3] - r2["poses"][2]).max() < 1e-9
+    vs.track_end()

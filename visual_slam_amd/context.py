@@ -17,6 +17,7 @@ class Context:
         if rc != 0:
             raise VsError(rc, self._lib.vs_last_error(None).decode())
         self._h = h
+        self._track = None
         self._pinned = []
         self.device = int(device)
 
@@ -216,6 +217,8 @@ class Context:
         """One frame of the period -> dict(poses [n+1,4,4] (pose 0 = key frame), n_matches, pnp_found, match_q, match_t
         [, xy, desc])."""
         t = self._track
+        if t is None:
+            raise VsError(-1, "track_frame: no tracking period (call track_begin)")
         bgr = np.ascontiguousarray(bgr, np.uint8)
         h, w, _ = bgr.shape
         npo, nm, found, nk = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
@@ -234,6 +237,7 @@ class Context:
 
     def track_end(self):
         self._chk(self._lib.vs_track_end(self._h))
+        self._track = None
 
     # ------------------------------------------------------------------ two-view initialisation
     def essential_ransac(self, x1, x2, threshold, prob=0.999, max_iters=1000, seed=0):
