@@ -27,16 +27,17 @@
 //   ba_decide         one thread: gain ratio, accept (flip the state buffer index) or reject, lambda update, stop rules
 //  motion-only problem (no free points, no scale edges => block diagonal): ba_motion_step, see below.
 // Trial states are written to the OTHER of two state buffers, so a rejected step needs no restore.
-#include "vs_internal.h"
+#include "vs_ba_internal.h"
 
 #include <math.h>
 
 #include <algorithm>
 #include <vector>
 
+using namespace vsba;
+
 namespace {
 
-constexpr int kCamStride = 19;  // t[3] q[4] w2n[12]
 constexpr int kPtThreads = 128; // threads per point block
 constexpr int kCamThreads = 256;
 constexpr int kSchurThreads = 256;
@@ -44,100 +45,11 @@ constexpr int kSolveThreads = 512;
 constexpr int kMaxLdsN = 126;   // reduced systems up to 126 x 126 (21 free cameras) are factorised in LDS by one wave
 constexpr int kMaxSlabN = 90;   // Schur slabs up to 90 x 90 (15 free cameras) live in LDS
 
-struct lm_state {
-  double lambda, ni, current_chi, temp_chi, rho, scale_pose, chi0;
-  int cur;       // index of the state buffer holding the accepted estimate
-  int it;        // outer iterations finished
-  int trials, qmax, not_pd;
-  int need_lin;  // 1: the next slot starts with a linearisation
-  int done, terminated, solve_ok;
-  int pad;
-};
 
-struct ba_dev {
-  int n_poses, n_points, n_obs, n_scale, nfp, nfl, np, n_act;  // n_act: points with >= 1 active observation
-  int ns, nb_pt, mmax, has_info, dups, max_it, lds_slab, pad0;
-  double fx, fy, cx, cy, huber, dcs;
-  const int *pose_slot, *pt_slot, *act_pt, *pt_start, *o_cam, *o_pt, *cam_start, *cam_obs;
-  const int *o_hpl, *fp_start, *fp_slot, *slot_pose;  // slot_pose[free camera slot] = pose index  // Hpl block index of an observation (-1: none); per free point: its blocks
-  const double *o_uv, *o_info;
-  const int *sc_parent, *sc_child;
-  const double* sc_meas;
-  double* cam[2];
-  double* pts[2];
-  double *Hpp, *bp, *Hll, *bl, *Hpl, *Dinv, *slab, *S, *bs, *xp;
-  const unsigned long long* fp_mask;  // per free point: bit t set iff it is observed by a camera of tile row t
-  double* Dbl;     // [nfl][3] (Hll + lambda I)^-1 bl (tiled Schur)
-  int ntile;       // tiles of kTileCams cameras per side (tiled Schur), 0 otherwise
-  double* rinv;    // [np] reciprocal Cholesky pivots (large systems)
-  int* chol_fail;  // set by a panel kernel that met a non-positive pivot
-  double *part_chi, *part_scale, *part_maxd;  // per point-block partials; part_maxd has nb_pt + nfp entries
-  double *chi_trace, *lambda_trace;
-  lm_state* st;
-  // motion-only kernel: camera-major observation copy cut into chunks of 64
-  const double *mo_X, *mo_uv, *mo_info;  // [n_obs_free_cam][3|2|3] in camera-major (cam_start) order
-  double *mo_part, *mo_H;                // [2][nfp][4] per-camera partials by step parity; [nfp][42] H upper + b
-};
 
 // ------------------------------------------------------------------------------------------------ small math
-__device__ inline void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
-__device__ __host__ inline void quat_to_w2n(const double* t, const double* q, double* w /*[12]*/) {
-  const double x = q[0], y = q[1], z = q[2], ww = q[3];
-  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-  const double twx = tx * ww, twy = ty * ww, twz = tz * ww, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
-               tyz = tz * y, tzz = tz * z;
-  double R[3][3];
-  R[0][0] = 1 - (tyy + tzz);
-  R[0][1] = txy - twz;
-  R[0][2] = txz + twy;
-  R[1][0] = txy + twz;
-  R[1][1] = 1 - (txx + tzz);
-  R[1][2] = tyz - twx;
-  R[2][0] = txz - twy;
-  R[2][1] = tyz + twx;
-  R[2][2] = 1 - (txx + tyy);
-  for (int i = 0; i < 3; ++i) {
-    w[4 * i + 0] = R[0][i];
-    w[4 * i + 1] = R[1][i];
-    w[4 * i + 2] = R[2][i];
-    w[4 * i + 3] = -(w[4 * i + 0] * t[0] + w[4 * i + 1] * t[1] + w[4 * i + 2] * t[2]);
-  }
-}
 
-// Eigen's matrix -> quaternion, then SE3Quat::normalizeRotation (w >= 0, unit norm)   [setup only]
-__device__ __host__ inline void quat_from_pose(const double* m, double* q) {
-#define M(r, c) m[(r)*4 + (c)]
-  const double tr = M(0, 0) + M(1, 1) + M(2, 2);
-  if (tr > 0.0) {
-    double s = sqrt(tr + 1.0);
-    q[3] = 0.5 * s;
-    s = 0.5 / s;
-    q[0] = (M(2, 1) - M(1, 2)) * s;
-    q[1] = (M(0, 2) - M(2, 0)) * s;
-    q[2] = (M(1, 0) - M(0, 1)) * s;
-  } else {
-    int i = 0;
-    if (M(1, 1) > M(0, 0)) i = 1;
-    if (M(2, 2) > M(i, i)) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    double s = sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
-    q[i] = 0.5 * s;
-    s = 0.5 / s;
-    q[3] = (M(k, j) - M(j, k)) * s;
-    q[j] = (M(j, i) + M(i, j)) * s;
-    q[k] = (M(k, i) + M(i, k)) * s;
-  }
-#undef M
-  if (q[3] < 0.0)
-    for (int a = 0; a < 4; ++a) q[a] = -q[a];
-  const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  for (int a = 0; a < 4; ++a) q[a] /= nrm;
-}
 
 __device__ inline void huber_rho(double delta, double e2, double& rho0, double& rho1) {
   const double dsqr = delta * delta;
@@ -1353,14 +1265,7 @@ __global__ void ba_decide(ba_dev D) {
 //   step s >= 1      : decide(step s-1) -> [re-linearise if a step was accepted] -> solve -> trial state -> trial chi2
 // State and partials are double buffered by step parity; observations are read from a camera-major copy
 // (mo_X / mo_uv / mo_info) so every load is coalesced and index-free.
-constexpr int kMoThreads = 256;
 
-struct mo_state {
-  double lambda, ni, current_chi, chi0;
-  int cur, it, trials, qmax, not_pd, need_lin, done, terminated;
-  int stage;  // 0: nothing yet, 1: the previous launch only linearised (iteration 0), 2: it ran a trial
-  int seq;
-};
 
 // sums 28 doubles per thread over the workgroup in a fixed order; result in s_out[0..27]
 __device__ inline void block_reduce28(double (&acc)[28], double (*s_all)[28], double* s_out, int tid) {
@@ -1385,6 +1290,9 @@ __device__ inline void block_reduce28(double (&acc)[28], double (*s_all)[28], do
   __syncthreads();
 }
 
+}  // namespace
+
+namespace vsba {
 __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step) {
   __shared__ double s_all[kMoThreads / 2][28];
   __shared__ double s_sum[28];
@@ -1676,448 +1584,9 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
   }
 }
 
-// ------------------------------------------------------------------------------------------------ PnP-RANSAC
-// cv2.solvePnPRansac as the reference calls it (src/v2/main.py:196-197; useExtrinsicGuess, ITERATIVE, 100 iterations,
-// 8 px, 0.99): hypothesis h refines the extrinsic guess on 5 sampled correspondences, inliers are counted over all
-// points, RANSACUpdateNumIters shrinks the budget, the best model is refined on its inliers.
-//   pnp_hypothesis_kernel: one wave per hypothesis.  The 5 sampled edges sit on lanes 0..4 of every group of 8 lanes;
-//     the 28 sums of a linearisation (21 H, 6 b, chi2) are butterfly-reduced inside the group, so every lane holds the
-//     same normal equations and runs the same LM step redundantly in registers - no LDS, no broadcast.  Then the 64
-//     lanes score the n points and a ballot counts the inliers.
-//   pnp_finish_kernel: one workgroup replays the sequential budget rule over the per-hypothesis counts (which yields
-//     exactly the sequential algorithm's winner), lists the winner's inliers in order and refines the pose on them
-//     with the same cooperative LM (edges strided over 256 threads), all inside the one launch.
-struct pnp_args {
-  const double* obj;   // [n][3]
-  const double* img;   // [n][2]
-  int n, iters_lm, iterations, pad;
-  double fx, fy, cx, cy, thr2, confidence;
-  unsigned long long seed;
-  double cam0[kCamStride];
-  double* cam_out;     // [H][19] record re-derived from the 4x4 model
-  double* pose_out;    // [H][12] the model itself: rows of [R|t], camera-to-world
-  int* good_out;       // [H]
-  double* result;      // [20]: pose 4x4, found, inliers, best hypothesis, hypotheses used
-  int* inl_out;        // [n]
-  const int* n_dev;    // tracking session: the number of correspondences lives on the device (nullptr: use n)
-  double* rec_out[2];  // tracking session: camera record of the result (the guess if nothing was found), or nullptr
-};
+}  // namespace vsba
 
-__device__ inline int pnp_count(const pnp_args& P) { return P.n_dev ? *P.n_dev : P.n; }
-
-__device__ inline unsigned long long splitmix64(unsigned long long x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
-
-__device__ inline void pnp_err(const pnp_args& P, const double* cam, const double* X, const double* uv, double& eu,
-                               double& ev, double* pc) {
-  const double* w = cam + 7;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) pc[i] = w[4 * i] * X[0] + w[4 * i + 1] * X[1] + w[4 * i + 2] * X[2] + w[4 * i + 3];
-  eu = (P.fx * pc[0] + P.cx * pc[2]) / pc[2] - uv[0];
-  ev = (P.fy * pc[1] + P.cy * pc[2]) / pc[2] - uv[1];
-}
-
-// one edge into acc[28] = H upper triangle row-major (21), b (6), chi2 (identity information, no robust kernel)
-template <bool JAC>
-__device__ inline void pnp_edge(const pnp_args& P, const double* cam, const double* X, const double* uv, double* acc) {
-  double pc[3], eu, ev;
-  pnp_err(P, cam, X, uv, eu, ev, pc);
-  acc[27] += eu * eu + ev * ev;
-  if (!JAC) return;
-  const double* w = cam + 7;
-  const double px = pc[0], py = pc[1], pz = pc[2];
-  const double ipz2 = 1.0 / (pz * pz);
-  const double ipz2fx = ipz2 * P.fx, ipz2fy = ipz2 * P.fy;
-  const double p0 = X[0] - cam[0], p1 = X[1] - cam[1], p2 = X[2] - cam[2];
-  double r[3], J[2][6];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) r[k] = w[4 * k] * p0 + w[4 * k + 1] * p1 + w[4 * k + 2] * p2;
-  const double dpx[3] = {0.0, 2 * r[2], -2 * r[1]}, dpy[3] = {-2 * r[2], 0.0, 2 * r[0]}, dpz[3] = {2 * r[1], -2 * r[0], 0.0};
-  J[0][3] = (pz * dpx[0] - px * dpx[2]) * ipz2fx;
-  J[1][3] = (pz * dpx[1] - py * dpx[2]) * ipz2fy;
-  J[0][4] = (pz * dpy[0] - px * dpy[2]) * ipz2fx;
-  J[1][4] = (pz * dpy[1] - py * dpy[2]) * ipz2fy;
-  J[0][5] = (pz * dpz[0] - px * dpz[2]) * ipz2fx;
-  J[1][5] = (pz * dpz[1] - py * dpz[2]) * ipz2fy;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    J[0][a] = -((pz * w[a] - px * w[8 + a]) * ipz2fx);
-    J[1][a] = -((pz * w[4 + a] - py * w[8 + a]) * ipz2fy);
-  }
-  int k = 0;
-#pragma unroll
-  for (int a = 0; a < 6; ++a) {
-#pragma unroll
-    for (int c = a; c < 6; ++c) acc[k++] += J[0][a] * J[0][c] + J[1][a] * J[1][c];
-  }
-#pragma unroll
-  for (int a = 0; a < 6; ++a) acc[21 + a] += J[0][a] * (-eu) + J[1][a] * (-ev);
-}
-
-__device__ inline void cam_apply(const double* src, const double* x, double* dst) {
-  double t[3] = {src[0] + x[0], src[1] + x[1], src[2] + x[2]};
-  const double bx = x[3], by = x[4], bz = x[5];
-  const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));
-  const double ax = src[3], ay = src[4], az = src[5], aw = src[6];
-  const double w = aw * bw - ax * bx - ay * by - az * bz;
-  const double xx = aw * bx + ax * bw + ay * bz - az * by;
-  const double yy = aw * by + ay * bw + az * bx - ax * bz;
-  const double zz = aw * bz + az * bw + ax * by - ay * bx;
-  const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
-  double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
-  for (int k = 0; k < 3; ++k) dst[k] = t[k];
-  for (int k = 0; k < 4; ++k) dst[3 + k] = q[k];
-  quat_to_w2n(t, q, dst + 7);
-}
-
-// sum of v[0..NV) over the lanes of aligned groups of 2^STEPS lanes (butterfly: every lane of the group ends with the
-// same bits), then - for workgroups of several waves - over the waves through LDS in wave order
-template <int NV, int STEPS, int NWAVES>
-__device__ inline void pnp_reduce(double* v, double* s_red) {
-#pragma unroll
-  for (int d = 1; d < (1 << STEPS); d <<= 1) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] += __shfl_xor(v[k], d);
-  }
-  if (NWAVES > 1) {
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __syncthreads();  // previous readers of s_red are done
-    if (lane == 0)
-      for (int k = 0; k < NV; ++k) s_red[wv * NV + k] = v[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      double a = s_red[k];
-      for (int w = 1; w < NWAVES; ++w) a += s_red[w * NV + k];
-      v[k] = a;
-    }
-  }
-}
-
-// Levenberg-Marquardt as OptimizationAlgorithmLevenberg drives it (one camera, fixed points, no robust kernel) plus a
-// stop once a solved step is numerically zero (|x|^2 < 1e-18; OpenCV's iterative solver stops on a small parameter change
-// too), run redundantly by every thread on identical sums.  Edge e of the thread: e = first, first + stride, ... < m; sel maps to
-// the correspondence (nullptr: identity).
-template <int STEPS, int NWAVES>
-__device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int first, int stride, double* cam, double* s_red) {
-  double trial[kCamStride];
-  double lambda = 0.0, ni = 2.0;
-  for (int it = 0; it < P.iters_lm; ++it) {
-    double acc[28];
-#pragma unroll
-    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-    for (int e = first; e < m; e += stride) {
-      const int i = sel ? sel[e] : e;
-      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
-      pnp_edge<true>(P, cam, X, uv, acc);
-    }
-    pnp_reduce<28, STEPS, NWAVES>(acc, s_red);
-    double H[6][6], b[6];
-    {
-      int k = 0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-#pragma unroll
-        for (int c = a; c < 6; ++c) {
-          H[a][c] = acc[k];
-          H[c][a] = acc[k];
-          ++k;
-        }
-        b[a] = acc[21 + a];
-      }
-    }
-    double cur = acc[27];
-    if (it == 0) {
-      double mx = 0.0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) mx = fmax(mx, fabs(H[a][a]));
-      lambda = 1e-5 * mx;
-      ni = 2.0;
-    }
-    double rho = 0.0;
-    int qmax = 0, stop = 0, conv = 0;
-    do {
-      double A[6][6], x[6];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) A[a][c] = H[a][c];
-        A[a][a] += lambda;
-        x[a] = b[a];
-      }
-      int ok = 1;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        double sdiag = A[j][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) sdiag -= A[j][k] * A[j][k];
-        if (!(sdiag > 0.0)) ok = 0;
-        const double l = sqrt(sdiag);
-        A[j][j] = l;
-#pragma unroll
-        for (int i = j + 1; i < 6; ++i) {
-          double v = A[i][j];
-#pragma unroll
-          for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k];
-          A[i][j] = v / l;
-        }
-      }
-      double temp = 1.7976931348623157e308;
-      if (ok) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          double v = x[i];
-#pragma unroll
-          for (int k = 0; k < i; ++k) v -= A[i][k] * x[k];
-          x[i] = v / A[i][i];
-        }
-#pragma unroll
-        for (int i = 5; i >= 0; --i) {
-          double v = x[i];
-#pragma unroll
-          for (int k = i + 1; k < 6; ++k) v -= A[k][i] * x[k];
-          x[i] = v / A[i][i];
-        }
-        cam_apply(cam, x, trial);
-        double step2 = 0.0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) step2 += x[a] * x[a];
-        conv = step2 < 1e-18;  // below the numerical resolution of chi2: this trial is the last one
-      } else {
-#pragma unroll
-        for (int a = 0; a < 6; ++a) x[a] = 0.0;
-      }
-      // the trial chi2 is reduced in any case: the reduction is a workgroup-wide rendezvous
-      double tacc[28];
-      tacc[27] = 0.0;
-      if (ok)
-        for (int e = first; e < m; e += stride) {
-          const int i = sel ? sel[e] : e;
-          const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-          const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
-          pnp_edge<false>(P, trial, X, uv, tacc);
-        }
-      pnp_reduce<1, STEPS, NWAVES>(tacc + 27, s_red);
-      if (ok) temp = tacc[27];
-      rho = cur - temp;
-      double scale = 0.0;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
-      scale += 1e-3;
-      rho /= scale;
-      if (rho > 0 && isfinite(temp)) {
-        double alpha = 1.0 - pow(2 * rho - 1, 3);
-        alpha = fmin(alpha, 2.0 / 3.0);
-        lambda *= fmax(1.0 / 3.0, alpha);
-        ni = 2.0;
-        cur = temp;
-        for (int k = 0; k < kCamStride; ++k) cam[k] = trial[k];
-      } else {
-        lambda *= ni;
-        ni *= 2;
-        if (!isfinite(lambda)) {
-          stop = 1;
-          break;
-        }
-      }
-      ++qmax;
-    } while (rho < 0 && qmax < 10 && !conv);
-    if (qmax == 10 || rho == 0 || stop || conv) break;
-  }
-}
-
-__global__ __launch_bounds__(64) void pnp_hypothesis_kernel(pnp_args P) {
-  __shared__ int s_idx[8];
-  const int h = blockIdx.x, lane = threadIdx.x;
-  P.n = pnp_count(P);
-  if (P.n < 5) {
-    if (lane == 0) P.good_out[h] = 0;
-    return;
-  }
-  if (lane == 0) {
-    if (P.n == 5) {
-      for (int k = 0; k < 5; ++k) s_idx[k] = k;
-    } else {
-      int got = 0;
-      const unsigned long long base = splitmix64(P.seed);  // unrelated streams for neighbouring seeds
-      for (unsigned long long k = 0; got < 5; ++k) {
-        const int c = (int)(splitmix64(base ^ (((unsigned long long)h << 20) + k)) % (unsigned long long)P.n);
-        bool dup = false;
-        for (int j = 0; j < got; ++j) dup |= s_idx[j] == c;
-        if (!dup) s_idx[got++] = c;
-      }
-    }
-  }
-  __syncthreads();
-  double cam[kCamStride];
-  for (int k = 0; k < kCamStride; ++k) cam[k] = P.cam0[k];
-  pnp_lm<3, 1>(P, s_idx, 5, lane & 7, 8, cam, nullptr);
-  // the model is handed on as a 4x4 pose (as the sequential algorithm does): re-derive the record from that matrix
-  double m[16];
-  for (int r = 0; r < 3; ++r) {
-    for (int k = 0; k < 3; ++k) m[4 * r + k] = cam[7 + 4 * k + r];
-    m[4 * r + 3] = cam[r];
-  }
-  quat_from_pose(m, cam + 3);
-  quat_to_w2n(cam, cam + 3, cam + 7);
-  if (lane == 0) {
-    for (int k = 0; k < 12; ++k) P.pose_out[(size_t)h * 12 + k] = m[k];
-    for (int k = 0; k < kCamStride; ++k) P.cam_out[(size_t)h * kCamStride + k] = cam[k];
-  }
-  int good = 0;
-  for (int i0 = 0; i0 < P.n; i0 += 64) {
-    const int i = i0 + lane;
-    bool in = false;
-    if (i < P.n) {
-      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
-      double eu, ev, pc[3];
-      pnp_err(P, cam, X, uv, eu, ev, pc);
-      in = eu * eu + ev * ev <= P.thr2;
-    }
-    good += __popcll(__ballot(in));
-  }
-  if (lane == 0) P.good_out[h] = good;
-}
-
-__device__ inline int ransac_update_iters_dev(double p, double ep, int model_points, int max_iters) {
-  p = fmin(fmax(p, 0.0), 1.0);
-  ep = fmin(fmax(ep, 0.0), 1.0);
-  double num = fmax(1 - p, 2.2250738585072014e-308);
-  double denom = 1 - pow(1 - ep, (double)model_points);
-  if (denom < 2.2250738585072014e-308) return 0;
-  num = log(num);
-  denom = log(denom);
-  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
-}
-
-constexpr int kPnpFinish = 256;
-
-__global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
-  __shared__ double s_red[4 * 28];
-  __shared__ int s_best[2], s_cnt[4], s_base;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  P.n = pnp_count(P);
-  if (tid == 0) {
-    // replay of the sequential RANSAC loop (budget update after every improvement) over the per-hypothesis counts
-    int max_good = 0, niters = P.n >= 5 ? P.iterations : 0, best = -1, k = 0;
-    for (; k < niters && k < P.iterations; ++k) {
-      const int g = P.good_out[k];
-      if (g > (max_good > 4 ? max_good : 4)) {
-        max_good = g;
-        best = k;
-        niters = ransac_update_iters_dev(P.confidence, (double)(P.n - g) / P.n, 5, niters);
-      }
-    }
-    s_best[0] = best;
-    s_best[1] = k;
-    s_base = 0;
-  }
-  __syncthreads();
-  const int best = s_best[0];
-  if (best < 0) {
-    if (tid == 0) {
-      P.result[16] = 0.0;
-      P.result[17] = 0.0;
-      P.result[18] = -1.0;
-      P.result[19] = (double)s_best[1];
-    }
-    if (P.rec_out[0] && tid < kCamStride) {
-      P.rec_out[0][tid] = P.cam0[tid];
-      P.rec_out[1][tid] = P.cam0[tid];
-    }
-    return;
-  }
-  double cam[kCamStride];
-  for (int k = 0; k < kCamStride; ++k) cam[k] = P.cam_out[(size_t)best * kCamStride + k];
-  // ordered inlier list of the best model
-  for (int i0 = 0; i0 < P.n; i0 += kPnpFinish) {
-    const int i = i0 + tid;
-    bool in = false;
-    if (i < P.n) {
-      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
-      double eu, ev, pc[3];
-      pnp_err(P, cam, X, uv, eu, ev, pc);
-      in = eu * eu + ev * ev <= P.thr2;
-    }
-    const unsigned long long bal = __ballot(in);
-    if (lane == 0) s_cnt[wv] = __popcll(bal);
-    __syncthreads();
-    int off = s_base + __popcll(bal & ((1ull << lane) - 1));
-    for (int w = 0; w < wv; ++w) off += s_cnt[w];
-    if (in) P.inl_out[off] = i;
-    __syncthreads();
-    if (tid == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    __syncthreads();
-  }
-  const int m = s_base;
-  double pose[12];
-  for (int k = 0; k < 12; ++k) pose[k] = P.pose_out[(size_t)best * 12 + k];
-  if (m >= 1 && P.iters_lm > 0) {
-    // final refinement on the inliers (solvePnP(inliers, useExtrinsicGuess) in OpenCV)
-    __threadfence_block();
-    pnp_lm<6, kPnpFinish / 64>(P, P.inl_out, m, tid, kPnpFinish, cam, s_red);
-    for (int r = 0; r < 3; ++r) {
-      for (int k = 0; k < 3; ++k) pose[4 * r + k] = cam[7 + 4 * k + r];
-      pose[4 * r + 3] = cam[r];
-    }
-  }
-  if (P.rec_out[0] && tid == 0) {
-    // the record is re-derived from the 4x4 result, as a caller that passes the pose matrix on would do
-    double m[16], rec[kCamStride];
-    for (int k = 0; k < 12; ++k) m[k] = pose[k];
-    rec[0] = m[3];
-    rec[1] = m[7];
-    rec[2] = m[11];
-    quat_from_pose(m, rec + 3);
-    quat_to_w2n(rec, rec + 3, rec + 7);
-    for (int k = 0; k < kCamStride; ++k) {
-      P.rec_out[0][k] = rec[k];
-      P.rec_out[1][k] = rec[k];
-    }
-  }
-  if (tid == 0) {
-    for (int k = 0; k < 12; ++k) P.result[k] = pose[k];
-    P.result[12] = P.result[13] = P.result[14] = 0.0;
-    P.result[15] = 1.0;
-    P.result[16] = 1.0;
-    P.result[17] = (double)m;
-    P.result[18] = (double)best;
-    P.result[19] = (double)s_best[1];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ tracking session
-// appends the new frame's observations to the period's camera-major arrays: obs i = (map point mq[i], keypoint mt[i])
-__global__ __launch_bounds__(256) void track_append_kernel(const double* xyz, const float* fxy, const int* mq, const int* mt,
-                                                           const int* d_M, double* mo_X, double* mo_uv, int* cam_start,
-                                                           int slot, int cap_obs, int* flags) {
-  const int base = cam_start[slot];
-  int M = *d_M;
-  if (base + M > cap_obs) {
-    M = max(0, cap_obs - base);
-    if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 1;  // capacity exceeded: the host reports it
-  }
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) {
-    const int q = mq[i], t = mt[i];
-    mo_X[3 * (size_t)(base + i)] = xyz[3 * (size_t)q];
-    mo_X[3 * (size_t)(base + i) + 1] = xyz[3 * (size_t)q + 1];
-    mo_X[3 * (size_t)(base + i) + 2] = xyz[3 * (size_t)q + 2];
-    mo_uv[2 * (size_t)(base + i)] = (double)fxy[2 * (size_t)t];
-    mo_uv[2 * (size_t)(base + i) + 1] = (double)fxy[2 * (size_t)t + 1];
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    cam_start[slot + 1] = base + M;
-    flags[1] = M;  // the count PnP and the host see (clamped)
-  }
-}
-
+namespace {
 // ------------------------------------------------------------------------------------------------ host
 struct arena {
   uint8_t* base = nullptr;  // device
@@ -2589,358 +2058,5 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       o[15] = 1.0;
     }
   if (res->points_out) memcpy(res->points_out, h_pts, sizeof(double) * 3 * (size_t)P);
-  return VS_OK;
-}
-
-VS_API int vs_pnp_ransac(vs_ctx* ctx, const double* obj, const double* img, int n, double fx, double fy, double cx,
-                         double cy, const double* pose0, int iterations, double reproj_err, double confidence,
-                         uint64_t seed, int refine_iters, double* pose_out, int32_t* inliers, int* n_inliers,
-                         int* found) {
-  if (!ctx) return VS_EINVAL;
-  if (!pose0 || !pose_out || !n_inliers || !found || n < 0 || iterations < 0 || refine_iters < 0 ||
-      (n > 0 && (!obj || !img || !inliers)))
-    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_pnp_ransac");
-  *found = 0;
-  *n_inliers = 0;
-  memcpy(pose_out, pose0, 16 * sizeof(double));
-  if (n < 5 || iterations == 0) return VS_OK;
-  VS_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  const int H = iterations;
-  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  // [obj | img] uploaded; [result | inliers] read back; [cam | pose | good] stay on the device
-  const size_t off_img = up(sizeof(double) * 3 * (size_t)n);
-  const size_t off_res = off_img + up(sizeof(double) * 2 * (size_t)n);
-  const size_t off_inl = off_res + 256;
-  const size_t off_cam = off_inl + up(sizeof(int) * (size_t)n);
-  const size_t off_pose = off_cam + up(sizeof(double) * kCamStride * (size_t)H);
-  const size_t off_good = off_pose + up(sizeof(double) * 12 * (size_t)H);
-  const size_t total = off_good + up(sizeof(int) * (size_t)H);
-  VS_TRY(vs_reserve(ctx, &ctx->d_xy_in, total));
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, off_cam));
-  VS_HIP(ctx, hipStreamSynchronize(s));
-  uint8_t* h = (uint8_t*)ctx->h_pin_big.p;
-  uint8_t* d = (uint8_t*)ctx->d_xy_in.p;
-  memcpy(h, obj, sizeof(double) * 3 * (size_t)n);
-  memcpy(h + off_img, img, sizeof(double) * 2 * (size_t)n);
-  VS_HIP(ctx, hipMemcpyAsync(d, h, off_res, hipMemcpyHostToDevice, s));
-  pnp_args P;
-  memset(&P, 0, sizeof P);
-  P.obj = (const double*)d;
-  P.img = (const double*)(d + off_img);
-  P.n = n;
-  P.iters_lm = refine_iters;
-  P.iterations = H;
-  P.fx = fx;
-  P.fy = fy;
-  P.cx = cx;
-  P.cy = cy;
-  P.thr2 = reproj_err * reproj_err;
-  P.confidence = confidence;
-  P.seed = seed;
-  P.cam0[0] = pose0[3];
-  P.cam0[1] = pose0[7];
-  P.cam0[2] = pose0[11];
-  quat_from_pose(pose0, P.cam0 + 3);
-  quat_to_w2n(P.cam0, P.cam0 + 3, P.cam0 + 7);
-  P.result = (double*)(d + off_res);
-  P.inl_out = (int*)(d + off_inl);
-  P.cam_out = (double*)(d + off_cam);
-  P.pose_out = (double*)(d + off_pose);
-  P.good_out = (int*)(d + off_good);
-  hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(H), dim3(64), 0, s, P);
-  VS_LAUNCH_CHECK(ctx, "pnp_hypothesis_kernel");
-  hipLaunchKernelGGL(pnp_finish_kernel, dim3(1), dim3(kPnpFinish), 0, s, P);
-  VS_LAUNCH_CHECK(ctx, "pnp_finish_kernel");
-  VS_HIP(ctx, hipMemcpyAsync(h + off_res, d + off_res, off_cam - off_res, hipMemcpyDeviceToHost, s));
-  VS_HIP(ctx, hipStreamSynchronize(s));
-  const double* res = (const double*)(h + off_res);
-  if (res[16] != 0.0) {
-    const int m = (int)res[17];
-    *found = 1;
-    *n_inliers = m;
-    memcpy(pose_out, res, 16 * sizeof(double));
-    memcpy(inliers, h + off_inl, sizeof(int32_t) * (size_t)m);
-  }
-  return VS_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ tracking session
-// One key-frame period of the reference's tracking loop (src/v2/main.py:173-214) kept resident on the device: the key
-// frame's map points and descriptors are uploaded once (vs_track_begin); every vs_track_frame uploads only the image
-// and runs detect+describe -> match against the map -> PnP-RANSAC from the previous pose -> append the observations
-// -> motion-only BA over all poses of the period, with one host synchronisation for the keypoint count (the matcher's
-// launch geometry needs it) and one at the end.  Same kernels, same arithmetic as the separate entry points.
-namespace {
-struct track_layout {
-  size_t xyz, mapdesc, fxy, fscore, fdesc, fn, mq, mt, md, M, flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part,
-      H, mst, pnp_cam, pnp_pose, pnp_good, pnp_res, pnp_inl, rb_end, total;
-  int cap_obs;
-};
-
-track_layout track_layout_of(int P, int F, int max_kp, int H) {
-  track_layout L;
-  size_t off = 0;
-  auto take = [&](size_t bytes) {
-    const size_t o = off;
-    off += (bytes + 255) & ~(size_t)255;
-    return o;
-  };
-  const int per = P < max_kp ? P : max_kp;
-  L.cap_obs = F * (per > 0 ? per : 1);
-  L.xyz = take(sizeof(double) * 3 * (size_t)P);
-  L.mapdesc = take(32 * (size_t)P + 32);
-  L.fxy = take(sizeof(float) * 2 * (size_t)max_kp);
-  L.fscore = take((size_t)max_kp);
-  L.fdesc = take(32 * (size_t)max_kp + 32);
-  L.fn = take(sizeof(int));
-  L.mq = take(sizeof(int) * (size_t)P);
-  L.mt = take(sizeof(int) * (size_t)P);
-  L.md = take(sizeof(int) * (size_t)P);
-  L.M = take(sizeof(int));
-  // read-back block: [LM state x2 | flags | PnP result | both camera buffers] is fetched with one copy per frame
-  L.mst = take(2 * sizeof(mo_state));
-  L.flags = take(4 * sizeof(int));
-  L.pnp_res = take(sizeof(double) * 20);
-  L.cam0 = take(sizeof(double) * kCamStride * (size_t)(F + 1));
-  L.cam1 = take(sizeof(double) * kCamStride * (size_t)(F + 1));
-  L.rb_end = off;
-  L.moX = take(sizeof(double) * 3 * (size_t)L.cap_obs);
-  L.moUV = take(sizeof(double) * 2 * (size_t)L.cap_obs);
-  L.cam_start = take(sizeof(int) * (size_t)(F + 2));
-  L.slot_pose = take(sizeof(int) * (size_t)(F + 1));
-  L.part = take(sizeof(double) * 8 * (size_t)F);
-  L.H = take(sizeof(double) * 42 * (size_t)F);
-  L.pnp_cam = take(sizeof(double) * kCamStride * (size_t)H);
-  L.pnp_pose = take(sizeof(double) * 12 * (size_t)H);
-  L.pnp_good = take(sizeof(int) * (size_t)H);
-  L.pnp_inl = take(sizeof(int) * (size_t)(per > 0 ? per : 1));
-  L.total = off;
-  return L;
-}
-
-void rec_from_pose(const double* pose16, double* rec) {
-  rec[0] = pose16[3];
-  rec[1] = pose16[7];
-  rec[2] = pose16[11];
-  quat_from_pose(pose16, rec + 3);
-  quat_to_w2n(rec, rec + 3, rec + 7);
-}
-
-void pose_from_rec(const double* c, double* o) {
-  for (int r = 0; r < 3; ++r) {
-    for (int k = 0; k < 3; ++k) o[4 * r + k] = c[7 + 4 * k + r];
-    o[4 * r + 3] = c[r];
-  }
-  o[12] = o[13] = o[14] = 0.0;
-  o[15] = 1.0;
-}
-}  // namespace
-
-VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, int n_points, const double* key_pose,
-                          double fx, double fy, double cx, double cy, int max_frames, int max_kp, int pnp_iterations) {
-  if (!ctx) return VS_EINVAL;
-  if (!xyz || !desc || !key_pose || n_points < 1 || max_frames < 1 || max_kp < 2 || pnp_iterations < 0 || pnp_iterations > 4096)
-    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_begin");
-  VS_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  const track_layout L = track_layout_of(n_points, max_frames, max_kp, pnp_iterations > 0 ? pnp_iterations : 1);
-  VS_TRY(vs_reserve(ctx, &ctx->d_track, L.total));
-  const size_t up = L.fxy;  // [xyz | mapdesc] are uploaded
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(up, (size_t)1 << 16)));
-  VS_HIP(ctx, hipStreamSynchronize(s));
-  uint8_t* h = (uint8_t*)ctx->h_track.p;
-  uint8_t* d = (uint8_t*)ctx->d_track.p;
-  memcpy(h + L.xyz, xyz, sizeof(double) * 3 * (size_t)n_points);
-  memcpy(h + L.mapdesc, desc, 32 * (size_t)n_points);
-  VS_HIP(ctx, hipMemcpyAsync(d, h, up, hipMemcpyHostToDevice, s));
-  VS_HIP(ctx, hipMemsetAsync(d + L.cam_start, 0, sizeof(int) * (size_t)(max_frames + 2), s));
-  VS_HIP(ctx, hipMemsetAsync(d + L.flags, 0, 4 * sizeof(int), s));
-  double rec[kCamStride];
-  rec_from_pose(key_pose, rec);
-  VS_HIP(ctx, hipStreamSynchronize(s));  // the pinned mirror is reused below
-  memcpy(h, rec, sizeof rec);
-  int* sp = (int*)(h + 1024);
-  for (int c = 0; c < max_frames; ++c) sp[c] = c + 1;  // free-camera slot c = pose c + 1 (pose 0 is the fixed key frame)
-  VS_HIP(ctx, hipMemcpyAsync(d + L.cam0, h, sizeof rec, hipMemcpyHostToDevice, s));
-  VS_HIP(ctx, hipMemcpyAsync(d + L.cam1, h, sizeof rec, hipMemcpyHostToDevice, s));
-  if (sizeof(int) * (size_t)max_frames + 1024 > ctx->h_track.cap) return vs_fail(ctx, VS_ENOMEM, "%s: staging too small", "vs_track_begin");
-  VS_HIP(ctx, hipMemcpyAsync(d + L.slot_pose, sp, sizeof(int) * (size_t)max_frames, hipMemcpyHostToDevice, s));
-  VS_HIP(ctx, hipStreamSynchronize(s));
-  ctx->track.active = 1;
-  ctx->track.n_points = n_points;
-  ctx->track.cap_frames = max_frames;
-  ctx->track.max_kp = max_kp;
-  ctx->track.pnp_iters = pnp_iterations;
-  ctx->track.n_frames = 0;
-  ctx->track.obs_used = 0;
-  ctx->track.cur = 0;
-  ctx->track.K[0] = fx;
-  ctx->track.K[1] = fy;
-  ctx->track.K[2] = cx;
-  ctx->track.K[3] = cy;
-  memcpy(ctx->track.last_rec, rec, sizeof rec);
-  return VS_OK;
-}
-
-VS_API int vs_track_end(vs_ctx* ctx) {
-  if (!ctx) return VS_EINVAL;
-  ctx->track.active = 0;
-  return VS_OK;
-}
-
-VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
-                          double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations,
-                          double huber_delta, double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found,
-                          float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t) {
-  if (!ctx) return VS_EINVAL;
-  if (!ctx->track.active) return vs_fail(ctx, VS_EINVAL, "%s: no tracking period (call vs_track_begin)", "vs_track_frame");
-  if (!bgr || w < 31 || h_img < 31 || stride < 3 * w || !poses_out || !n_poses_out || !n_matches || lm_iterations < 0)
-    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_frame");
-  auto& T = ctx->track;
-  if (T.n_frames >= T.cap_frames) return vs_fail(ctx, VS_ENOMEM, "%s: the period holds max_frames frames already", "vs_track_frame");
-  VS_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  const int P = T.n_points, H = T.pnp_iters > 0 ? T.pnp_iters : 1;
-  const track_layout L = track_layout_of(P, T.cap_frames, T.max_kp, H);
-  uint8_t* d = (uint8_t*)ctx->d_track.p;
-  // ---- image upload (pitch = 3w rounded up to 4 bytes, 16 bytes of slack after the last row)
-  const int pitch = (3 * w + 3) & ~3;
-  VS_TRY(vs_reserve(ctx, &ctx->d_bgr, (size_t)pitch * h_img + 16));
-  if (stride == pitch) VS_HIP(ctx, hipMemcpyAsync(ctx->d_bgr.p, bgr, (size_t)pitch * h_img, hipMemcpyHostToDevice, s));
-  else VS_HIP(ctx, hipMemcpy2DAsync(ctx->d_bgr.p, pitch, bgr, stride, 3 * (size_t)w, h_img, hipMemcpyHostToDevice, s));
-  VS_TRY(vs_detect_describe_bgr_dev(ctx, ctx->d_bgr.p, w, h_img, pitch, thr, T.max_kp, d + L.fxy, d + L.fscore, d + L.fdesc,
-                                    d + L.fn, s));
-  const size_t rb_bytes = L.rb_end - L.mst;  // the read-back block is mirrored at hp + 4096
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, 4096 + rb_bytes));
-  uint8_t* hp = (uint8_t*)ctx->h_track.p;
-  uint8_t* rb = hp + 4096;
-  int* h_n = (int*)hp;  // [0]: keypoints
-  VS_HIP(ctx, hipMemcpyAsync(h_n, d + L.fn, sizeof(int), hipMemcpyDeviceToHost, s));
-  VS_HIP(ctx, hipStreamSynchronize(s));
-  const int n_kp = h_n[0];
-  if (n_kp_out) *n_kp_out = n_kp;
-  if (xy_out && n_kp > 0) VS_HIP(ctx, hipMemcpyAsync(xy_out, d + L.fxy, sizeof(float) * 2 * (size_t)n_kp, hipMemcpyDeviceToHost, s));
-  if (desc_out && n_kp > 0) VS_HIP(ctx, hipMemcpyAsync(desc_out, d + L.fdesc, 32 * (size_t)n_kp, hipMemcpyDeviceToHost, s));
-  // ---- match the map's descriptors (query) against the frame's (train), Lowe ratio, ordered compaction
-  if (n_kp >= 2) {
-    VS_TRY(vs_match_ratio_dev(ctx, d + L.mapdesc, P, d + L.fdesc, n_kp, ratio, d + L.mq, d + L.mt, d + L.md, d + L.M, s));
-  } else {
-    VS_HIP(ctx, hipMemsetAsync(d + L.M, 0, sizeof(int), s));
-  }
-  const int slot = T.n_frames, k = T.n_frames + 1;  // new free-camera slot / pose index
-  hipLaunchKernelGGL(track_append_kernel, dim3(8), dim3(256), 0, s, (const double*)(d + L.xyz), (const float*)(d + L.fxy),
-                     (const int*)(d + L.mq), (const int*)(d + L.mt), (const int*)(d + L.M), (double*)(d + L.moX),
-                     (double*)(d + L.moUV), (int*)(d + L.cam_start), slot, L.cap_obs, (int*)(d + L.flags));
-  VS_LAUNCH_CHECK(ctx, "track_append_kernel");
-  double* cam0 = (double*)(d + L.cam0);
-  double* cam1 = (double*)(d + L.cam1);
-  // ---- PnP-RANSAC from the previous pose; its result becomes the new pose's record in both state buffers
-  pnp_args A;
-  memset(&A, 0, sizeof A);
-  A.obj = (const double*)(d + L.moX) + 3 * (size_t)T.obs_used;
-  A.img = (const double*)(d + L.moUV) + 2 * (size_t)T.obs_used;
-  A.n = 0;
-  A.n_dev = (const int*)(d + L.flags) + 1;
-  A.iters_lm = lm_iterations;
-  A.iterations = T.pnp_iters;
-  A.fx = T.K[0];
-  A.fy = T.K[1];
-  A.cx = T.K[2];
-  A.cy = T.K[3];
-  A.thr2 = pnp_reproj_err * pnp_reproj_err;
-  A.confidence = pnp_confidence;
-  A.seed = seed;
-  memcpy(A.cam0, T.last_rec, sizeof A.cam0);
-  A.cam_out = (double*)(d + L.pnp_cam);
-  A.pose_out = (double*)(d + L.pnp_pose);
-  A.good_out = (int*)(d + L.pnp_good);
-  A.result = (double*)(d + L.pnp_res);
-  A.inl_out = (int*)(d + L.pnp_inl);
-  A.rec_out[0] = cam0 + (size_t)k * kCamStride;
-  A.rec_out[1] = cam1 + (size_t)k * kCamStride;
-  if (T.pnp_iters > 0) {
-    hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(H), dim3(64), 0, s, A);
-    VS_LAUNCH_CHECK(ctx, "pnp_hypothesis_kernel");
-    hipLaunchKernelGGL(pnp_finish_kernel, dim3(1), dim3(kPnpFinish), 0, s, A);
-    VS_LAUNCH_CHECK(ctx, "pnp_finish_kernel");
-  } else {  // no PnP: the previous pose is the start (pinned staging: h_track + 2048)
-    memcpy(hp + 2048, T.last_rec, sizeof T.last_rec);
-    VS_HIP(ctx, hipMemcpyAsync(A.rec_out[0], hp + 2048, sizeof T.last_rec, hipMemcpyHostToDevice, s));
-    VS_HIP(ctx, hipMemcpyAsync(A.rec_out[1], hp + 2048, sizeof T.last_rec, hipMemcpyHostToDevice, s));
-  }
-  // ---- motion-only BA over the k free poses of the period
-  ba_dev D;
-  memset(&D, 0, sizeof D);
-  D.n_poses = k + 1;
-  D.nfp = k;
-  D.np = 6 * k;
-  D.max_it = lm_iterations;
-  D.fx = T.K[0];
-  D.fy = T.K[1];
-  D.cx = T.K[2];
-  D.cy = T.K[3];
-  D.huber = huber_delta;
-  D.dcs = 1.0;
-  D.slot_pose = (const int*)(d + L.slot_pose);
-  D.cam_start = (const int*)(d + L.cam_start);
-  D.cam[0] = cam0;
-  D.cam[1] = cam1;
-  D.mo_X = (const double*)(d + L.moX);
-  D.mo_uv = (const double*)(d + L.moUV);
-  D.mo_part = (double*)(d + L.part);
-  D.mo_H = (double*)(d + L.H);
-  mo_state* d_mst = (mo_state*)(d + L.mst);
-  D.st = reinterpret_cast<lm_state*>(d_mst);
-  mo_state* h_st = (mo_state*)(hp + 1024);  // initial state (uploaded)
-  memset(h_st, 0, 2 * sizeof(mo_state));
-  h_st[1].need_lin = 1;
-  h_st[1].ni = 2.0;
-  h_st[1].cur = T.cur;
-  h_st[0].cur = T.cur;
-  mo_state fin;
-  memset(&fin, 0, sizeof fin);
-  fin.cur = T.cur;
-  const mo_state* rb_st = (const mo_state*)(rb + (L.mst - L.mst));
-  if (lm_iterations > 0) {
-    VS_HIP(ctx, hipMemcpyAsync(d_mst, h_st, 2 * sizeof(mo_state), hipMemcpyHostToDevice, s));
-    const int max_steps = 1 + lm_iterations * 10;
-    int step = 0;
-    for (;;) {
-      const int batch = std::min(max_steps + 1 - step, lm_iterations + 2);
-      for (int b = 0; b < batch; ++b, ++step) {
-        hipLaunchKernelGGL(ba_motion_step, dim3(k), dim3(kMoThreads), 0, s, D, step);
-        VS_LAUNCH_CHECK(ctx, "ba_motion_step");
-      }
-      // one copy brings back everything the host wants; if the solve needs another batch it is simply repeated
-      VS_HIP(ctx, hipMemcpyAsync(rb, d + L.mst, rb_bytes, hipMemcpyDeviceToHost, s));
-      VS_HIP(ctx, hipStreamSynchronize(s));
-      if (rb_st[(step - 1) & 1].done || step > max_steps) break;
-    }
-    fin = rb_st[(step - 1) & 1];
-  } else {
-    VS_HIP(ctx, hipMemcpyAsync(rb, d + L.mst, rb_bytes, hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipStreamSynchronize(s));
-  }
-  const int* rb_flags = (const int*)(rb + (L.flags - L.mst));
-  const double* rb_res = (const double*)(rb + (L.pnp_res - L.mst));
-  const int M = rb_flags[1];
-  if (rb_flags[0]) return vs_fail(ctx, VS_ENOMEM, "%s: observation capacity of the period exceeded", "vs_track_frame");
-  if (match_q && match_t && M > 0) {
-    VS_HIP(ctx, hipMemcpyAsync(match_q, d + L.mq, sizeof(int) * (size_t)M, hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipMemcpyAsync(match_t, d + L.mt, sizeof(int) * (size_t)M, hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipStreamSynchronize(s));
-  } else if ((xy_out || desc_out) && lm_iterations == 0) {
-    VS_HIP(ctx, hipStreamSynchronize(s));
-  }
-  T.cur = fin.cur;
-  const double* h_cam = (const double*)(rb + ((T.cur ? L.cam1 : L.cam0) - L.mst));
-  for (int i = 0; i <= k; ++i) pose_from_rec(h_cam + (size_t)i * kCamStride, poses_out + 16 * (size_t)i);
-  memcpy(T.last_rec, h_cam + (size_t)k * kCamStride, sizeof T.last_rec);
-  T.n_frames = k;
-  T.obs_used += M;
-  *n_poses_out = k + 1;
-  *n_matches = M;
-  if (pnp_found) *pnp_found = T.pnp_iters > 0 && rb_res[16] != 0.0;
   return VS_OK;
 }

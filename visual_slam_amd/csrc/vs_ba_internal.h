@@ -1,0 +1,137 @@
+// vs_ba_internal.h -- types, small math and kernel prototypes shared by the bundle-adjustment, PnP and tracking-session
+// translation units of libvslam_hip.so (gfx950 only).
+#pragma once
+#include "vs_internal.h"
+
+#include <math.h>
+
+namespace vsba {
+
+constexpr int kCamStride = 19;  // t[3] q[4] w2n[12]
+constexpr int kMoThreads = 256;
+constexpr int kPnpFinish = 256;
+
+struct lm_state {
+  double lambda, ni, current_chi, temp_chi, rho, scale_pose, chi0;
+  int cur;       // index of the state buffer holding the accepted estimate
+  int it;        // outer iterations finished
+  int trials, qmax, not_pd;
+  int need_lin;  // 1: the next slot starts with a linearisation
+  int done, terminated, solve_ok;
+  int pad;
+};
+
+struct ba_dev {
+  int n_poses, n_points, n_obs, n_scale, nfp, nfl, np, n_act;  // n_act: points with >= 1 active observation
+  int ns, nb_pt, mmax, has_info, dups, max_it, lds_slab, pad0;
+  double fx, fy, cx, cy, huber, dcs;
+  const int *pose_slot, *pt_slot, *act_pt, *pt_start, *o_cam, *o_pt, *cam_start, *cam_obs;
+  const int *o_hpl, *fp_start, *fp_slot, *slot_pose;  // slot_pose[free camera slot] = pose index  // Hpl block index of an observation (-1: none); per free point: its blocks
+  const double *o_uv, *o_info;
+  const int *sc_parent, *sc_child;
+  const double* sc_meas;
+  double* cam[2];
+  double* pts[2];
+  double *Hpp, *bp, *Hll, *bl, *Hpl, *Dinv, *slab, *S, *bs, *xp;
+  const unsigned long long* fp_mask;  // per free point: bit t set iff it is observed by a camera of tile row t
+  double* Dbl;     // [nfl][3] (Hll + lambda I)^-1 bl (tiled Schur)
+  int ntile;       // tiles of kTileCams cameras per side (tiled Schur), 0 otherwise
+  double* rinv;    // [np] reciprocal Cholesky pivots (large systems)
+  int* chol_fail;  // set by a panel kernel that met a non-positive pivot
+  double *part_chi, *part_scale, *part_maxd;  // per point-block partials; part_maxd has nb_pt + nfp entries
+  double *chi_trace, *lambda_trace;
+  lm_state* st;
+  // motion-only kernel: camera-major observation copy cut into chunks of 64
+  const double *mo_X, *mo_uv, *mo_info;  // [n_obs_free_cam][3|2|3] in camera-major (cam_start) order
+  double *mo_part, *mo_H;                // [2][nfp][4] per-camera partials by step parity; [nfp][42] H upper + b
+};
+
+// motion-only LM state (double-buffered by launch parity, see vs_ba.hip)
+struct mo_state {
+  double lambda, ni, current_chi, chi0;
+  int cur, it, trials, qmax, not_pd, need_lin, done, terminated;
+  int stage;  // 0: nothing yet, 1: the previous launch only linearised (iteration 0), 2: it ran a trial
+  int seq;
+};
+
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __host__ inline void quat_to_w2n(const double* t, const double* q, double* w /*[12]*/) {
+  const double x = q[0], y = q[1], z = q[2], ww = q[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * ww, twy = ty * ww, twz = tz * ww, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y,
+               tyz = tz * y, tzz = tz * z;
+  double R[3][3];
+  R[0][0] = 1 - (tyy + tzz);
+  R[0][1] = txy - twz;
+  R[0][2] = txz + twy;
+  R[1][0] = txy + twz;
+  R[1][1] = 1 - (txx + tzz);
+  R[1][2] = tyz - twx;
+  R[2][0] = txz - twy;
+  R[2][1] = tyz + twx;
+  R[2][2] = 1 - (txx + tyy);
+  for (int i = 0; i < 3; ++i) {
+    w[4 * i + 0] = R[0][i];
+    w[4 * i + 1] = R[1][i];
+    w[4 * i + 2] = R[2][i];
+    w[4 * i + 3] = -(w[4 * i + 0] * t[0] + w[4 * i + 1] * t[1] + w[4 * i + 2] * t[2]);
+  }
+}
+
+// Eigen's matrix -> quaternion, then SE3Quat::normalizeRotation (w >= 0, unit norm)   [setup only]
+__device__ __host__ inline void quat_from_pose(const double* m, double* q) {
+#define M(r, c) m[(r)*4 + (c)]
+  const double tr = M(0, 0) + M(1, 1) + M(2, 2);
+  if (tr > 0.0) {
+    double s = sqrt(tr + 1.0);
+    q[3] = 0.5 * s;
+    s = 0.5 / s;
+    q[0] = (M(2, 1) - M(1, 2)) * s;
+    q[1] = (M(0, 2) - M(2, 0)) * s;
+    q[2] = (M(1, 0) - M(0, 1)) * s;
+  } else {
+    int i = 0;
+    if (M(1, 1) > M(0, 0)) i = 1;
+    if (M(2, 2) > M(i, i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
+    q[i] = 0.5 * s;
+    s = 0.5 / s;
+    q[3] = (M(k, j) - M(j, k)) * s;
+    q[j] = (M(j, i) + M(i, j)) * s;
+    q[k] = (M(k, i) + M(i, k)) * s;
+  }
+#undef M
+  if (q[3] < 0.0)
+    for (int a = 0; a < 4; ++a) q[a] = -q[a];
+  const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int a = 0; a < 4; ++a) q[a] /= nrm;
+}
+
+// arguments of the PnP-RANSAC kernels (vs_pnp.hip); also launched by the tracking session (vs_track.hip)
+struct pnp_args {
+  const double* obj;   // [n][3]
+  const double* img;   // [n][2]
+  int n, iters_lm, iterations, pad;
+  double fx, fy, cx, cy, thr2, confidence;
+  unsigned long long seed;
+  double cam0[kCamStride];
+  double* cam_out;     // [H][19] record re-derived from the 4x4 model
+  double* pose_out;    // [H][12] the model itself: rows of [R|t], camera-to-world
+  int* good_out;       // [H]
+  double* result;      // [20]: pose 4x4, found, inliers, best hypothesis, hypotheses used
+  int* inl_out;        // [n]
+  const int* n_dev;    // tracking session: the number of correspondences lives on the device (nullptr: use n)
+  double* rec_out[2];  // tracking session: camera record of the result (the guess if nothing was found), or nullptr
+};
+
+__global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step);
+__global__ __launch_bounds__(64) void pnp_hypothesis_kernel(pnp_args P);
+__global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P);
+
+}  // namespace vsba

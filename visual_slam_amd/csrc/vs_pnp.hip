@@ -1,0 +1,491 @@
+// vs_pnp.hip -- PnP-RANSAC (gfx950).
+#include "vs_ba_internal.h"
+
+using namespace vsba;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ PnP-RANSAC
+// cv2.solvePnPRansac as the reference calls it (src/v2/main.py:196-197; useExtrinsicGuess, ITERATIVE, 100 iterations,
+// 8 px, 0.99): hypothesis h refines the extrinsic guess on 5 sampled correspondences, inliers are counted over all
+// points, RANSACUpdateNumIters shrinks the budget, the best model is refined on its inliers.
+//   pnp_hypothesis_kernel: one wave per hypothesis.  The 5 sampled edges sit on lanes 0..4 of every group of 8 lanes;
+//     the 28 sums of a linearisation (21 H, 6 b, chi2) are butterfly-reduced inside the group, so every lane holds the
+//     same normal equations and runs the same LM step redundantly in registers - no LDS, no broadcast.  Then the 64
+//     lanes score the n points and a ballot counts the inliers.
+//   pnp_finish_kernel: one workgroup replays the sequential budget rule over the per-hypothesis counts (which yields
+//     exactly the sequential algorithm's winner), lists the winner's inliers in order and refines the pose on them
+//     with the same cooperative LM (edges strided over 256 threads), all inside the one launch.
+
+
+__device__ inline int pnp_count(const pnp_args& P) { return P.n_dev ? *P.n_dev : P.n; }
+
+__device__ inline unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__device__ inline void pnp_err(const pnp_args& P, const double* cam, const double* X, const double* uv, double& eu,
+                               double& ev, double* pc) {
+  const double* w = cam + 7;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) pc[i] = w[4 * i] * X[0] + w[4 * i + 1] * X[1] + w[4 * i + 2] * X[2] + w[4 * i + 3];
+  eu = (P.fx * pc[0] + P.cx * pc[2]) / pc[2] - uv[0];
+  ev = (P.fy * pc[1] + P.cy * pc[2]) / pc[2] - uv[1];
+}
+
+// one edge into acc[28] = H upper triangle row-major (21), b (6), chi2 (identity information, no robust kernel)
+template <bool JAC>
+__device__ inline void pnp_edge(const pnp_args& P, const double* cam, const double* X, const double* uv, double* acc) {
+  double pc[3], eu, ev;
+  pnp_err(P, cam, X, uv, eu, ev, pc);
+  acc[27] += eu * eu + ev * ev;
+  if (!JAC) return;
+  const double* w = cam + 7;
+  const double px = pc[0], py = pc[1], pz = pc[2];
+  const double ipz2 = 1.0 / (pz * pz);
+  const double ipz2fx = ipz2 * P.fx, ipz2fy = ipz2 * P.fy;
+  const double p0 = X[0] - cam[0], p1 = X[1] - cam[1], p2 = X[2] - cam[2];
+  double r[3], J[2][6];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r[k] = w[4 * k] * p0 + w[4 * k + 1] * p1 + w[4 * k + 2] * p2;
+  const double dpx[3] = {0.0, 2 * r[2], -2 * r[1]}, dpy[3] = {-2 * r[2], 0.0, 2 * r[0]}, dpz[3] = {2 * r[1], -2 * r[0], 0.0};
+  J[0][3] = (pz * dpx[0] - px * dpx[2]) * ipz2fx;
+  J[1][3] = (pz * dpx[1] - py * dpx[2]) * ipz2fy;
+  J[0][4] = (pz * dpy[0] - px * dpy[2]) * ipz2fx;
+  J[1][4] = (pz * dpy[1] - py * dpy[2]) * ipz2fy;
+  J[0][5] = (pz * dpz[0] - px * dpz[2]) * ipz2fx;
+  J[1][5] = (pz * dpz[1] - py * dpz[2]) * ipz2fy;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    J[0][a] = -((pz * w[a] - px * w[8 + a]) * ipz2fx);
+    J[1][a] = -((pz * w[4 + a] - py * w[8 + a]) * ipz2fy);
+  }
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+#pragma unroll
+    for (int c = a; c < 6; ++c) acc[k++] += J[0][a] * J[0][c] + J[1][a] * J[1][c];
+  }
+#pragma unroll
+  for (int a = 0; a < 6; ++a) acc[21 + a] += J[0][a] * (-eu) + J[1][a] * (-ev);
+}
+
+__device__ inline void cam_apply(const double* src, const double* x, double* dst) {
+  double t[3] = {src[0] + x[0], src[1] + x[1], src[2] + x[2]};
+  const double bx = x[3], by = x[4], bz = x[5];
+  const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));
+  const double ax = src[3], ay = src[4], az = src[5], aw = src[6];
+  const double w = aw * bw - ax * bx - ay * by - az * bz;
+  const double xx = aw * bx + ax * bw + ay * bz - az * by;
+  const double yy = aw * by + ay * bw + az * bx - ax * bz;
+  const double zz = aw * bz + az * bw + ax * by - ay * bx;
+  const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
+  double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
+  for (int k = 0; k < 3; ++k) dst[k] = t[k];
+  for (int k = 0; k < 4; ++k) dst[3 + k] = q[k];
+  quat_to_w2n(t, q, dst + 7);
+}
+
+// sum of v[0..NV) over the lanes of aligned groups of 2^STEPS lanes (butterfly: every lane of the group ends with the
+// same bits), then - for workgroups of several waves - over the waves through LDS in wave order
+template <int NV, int STEPS, int NWAVES>
+__device__ inline void pnp_reduce(double* v, double* s_red) {
+#pragma unroll
+  for (int d = 1; d < (1 << STEPS); d <<= 1) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] += __shfl_xor(v[k], d);
+  }
+  if (NWAVES > 1) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();  // previous readers of s_red are done
+    if (lane == 0)
+      for (int k = 0; k < NV; ++k) s_red[wv * NV + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double a = s_red[k];
+      for (int w = 1; w < NWAVES; ++w) a += s_red[w * NV + k];
+      v[k] = a;
+    }
+  }
+}
+
+// Levenberg-Marquardt as OptimizationAlgorithmLevenberg drives it (one camera, fixed points, no robust kernel) plus a
+// stop once a solved step is numerically zero (|x|^2 < 1e-18; OpenCV's iterative solver stops on a small parameter change
+// too), run redundantly by every thread on identical sums.  Edge e of the thread: e = first, first + stride, ... < m; sel maps to
+// the correspondence (nullptr: identity).
+template <int STEPS, int NWAVES>
+__device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int first, int stride, double* cam, double* s_red) {
+  double trial[kCamStride];
+  double lambda = 0.0, ni = 2.0;
+  for (int it = 0; it < P.iters_lm; ++it) {
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+    for (int e = first; e < m; e += stride) {
+      const int i = sel ? sel[e] : e;
+      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
+      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+      pnp_edge<true>(P, cam, X, uv, acc);
+    }
+    pnp_reduce<28, STEPS, NWAVES>(acc, s_red);
+    double H[6][6], b[6];
+    {
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c = a; c < 6; ++c) {
+          H[a][c] = acc[k];
+          H[c][a] = acc[k];
+          ++k;
+        }
+        b[a] = acc[21 + a];
+      }
+    }
+    double cur = acc[27];
+    if (it == 0) {
+      double mx = 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) mx = fmax(mx, fabs(H[a][a]));
+      lambda = 1e-5 * mx;
+      ni = 2.0;
+    }
+    double rho = 0.0;
+    int qmax = 0, stop = 0, conv = 0;
+    do {
+      double A[6][6], x[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) A[a][c] = H[a][c];
+        A[a][a] += lambda;
+        x[a] = b[a];
+      }
+      int ok = 1;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        double sdiag = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) sdiag -= A[j][k] * A[j][k];
+        if (!(sdiag > 0.0)) ok = 0;
+        const double l = sqrt(sdiag);
+        A[j][j] = l;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+          double v = A[i][j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k];
+          A[i][j] = v / l;
+        }
+      }
+      double temp = 1.7976931348623157e308;
+      if (ok) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double v = x[i];
+#pragma unroll
+          for (int k = 0; k < i; ++k) v -= A[i][k] * x[k];
+          x[i] = v / A[i][i];
+        }
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+          double v = x[i];
+#pragma unroll
+          for (int k = i + 1; k < 6; ++k) v -= A[k][i] * x[k];
+          x[i] = v / A[i][i];
+        }
+        cam_apply(cam, x, trial);
+        double step2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) step2 += x[a] * x[a];
+        conv = step2 < 1e-18;  // below the numerical resolution of chi2: this trial is the last one
+      } else {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) x[a] = 0.0;
+      }
+      // the trial chi2 is reduced in any case: the reduction is a workgroup-wide rendezvous
+      double tacc[28];
+      tacc[27] = 0.0;
+      if (ok)
+        for (int e = first; e < m; e += stride) {
+          const int i = sel ? sel[e] : e;
+          const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
+          const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+          pnp_edge<false>(P, trial, X, uv, tacc);
+        }
+      pnp_reduce<1, STEPS, NWAVES>(tacc + 27, s_red);
+      if (ok) temp = tacc[27];
+      rho = cur - temp;
+      double scale = 0.0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && isfinite(temp)) {
+        double alpha = 1.0 - pow(2 * rho - 1, 3);
+        alpha = fmin(alpha, 2.0 / 3.0);
+        lambda *= fmax(1.0 / 3.0, alpha);
+        ni = 2.0;
+        cur = temp;
+        for (int k = 0; k < kCamStride; ++k) cam[k] = trial[k];
+      } else {
+        lambda *= ni;
+        ni *= 2;
+        if (!isfinite(lambda)) {
+          stop = 1;
+          break;
+        }
+      }
+      ++qmax;
+    } while (rho < 0 && qmax < 10 && !conv);
+    if (qmax == 10 || rho == 0 || stop || conv) break;
+  }
+}
+
+}  // namespace
+
+namespace vsba {
+__global__ __launch_bounds__(64) void pnp_hypothesis_kernel(pnp_args P) {
+  __shared__ int s_idx[8];
+  const int h = blockIdx.x, lane = threadIdx.x;
+  P.n = pnp_count(P);
+  if (P.n < 5) {
+    if (lane == 0) P.good_out[h] = 0;
+    return;
+  }
+  if (lane == 0) {
+    if (P.n == 5) {
+      for (int k = 0; k < 5; ++k) s_idx[k] = k;
+    } else {
+      int got = 0;
+      const unsigned long long base = splitmix64(P.seed);  // unrelated streams for neighbouring seeds
+      for (unsigned long long k = 0; got < 5; ++k) {
+        const int c = (int)(splitmix64(base ^ (((unsigned long long)h << 20) + k)) % (unsigned long long)P.n);
+        bool dup = false;
+        for (int j = 0; j < got; ++j) dup |= s_idx[j] == c;
+        if (!dup) s_idx[got++] = c;
+      }
+    }
+  }
+  __syncthreads();
+  double cam[kCamStride];
+  for (int k = 0; k < kCamStride; ++k) cam[k] = P.cam0[k];
+  pnp_lm<3, 1>(P, s_idx, 5, lane & 7, 8, cam, nullptr);
+  // the model is handed on as a 4x4 pose (as the sequential algorithm does): re-derive the record from that matrix
+  double m[16];
+  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) m[4 * r + k] = cam[7 + 4 * k + r];
+    m[4 * r + 3] = cam[r];
+  }
+  quat_from_pose(m, cam + 3);
+  quat_to_w2n(cam, cam + 3, cam + 7);
+  if (lane == 0) {
+    for (int k = 0; k < 12; ++k) P.pose_out[(size_t)h * 12 + k] = m[k];
+    for (int k = 0; k < kCamStride; ++k) P.cam_out[(size_t)h * kCamStride + k] = cam[k];
+  }
+  int good = 0;
+  for (int i0 = 0; i0 < P.n; i0 += 64) {
+    const int i = i0 + lane;
+    bool in = false;
+    if (i < P.n) {
+      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
+      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+      double eu, ev, pc[3];
+      pnp_err(P, cam, X, uv, eu, ev, pc);
+      in = eu * eu + ev * ev <= P.thr2;
+    }
+    good += __popcll(__ballot(in));
+  }
+  if (lane == 0) P.good_out[h] = good;
+}
+
+}  // namespace vsba
+
+namespace {
+__device__ inline int ransac_update_iters_dev(double p, double ep, int model_points, int max_iters) {
+  p = fmin(fmax(p, 0.0), 1.0);
+  ep = fmin(fmax(ep, 0.0), 1.0);
+  double num = fmax(1 - p, 2.2250738585072014e-308);
+  double denom = 1 - pow(1 - ep, (double)model_points);
+  if (denom < 2.2250738585072014e-308) return 0;
+  num = log(num);
+  denom = log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+
+}  // namespace
+
+namespace vsba {
+__global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
+  __shared__ double s_red[4 * 28];
+  __shared__ int s_best[2], s_cnt[4], s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  P.n = pnp_count(P);
+  if (tid == 0) {
+    // replay of the sequential RANSAC loop (budget update after every improvement) over the per-hypothesis counts
+    int max_good = 0, niters = P.n >= 5 ? P.iterations : 0, best = -1, k = 0;
+    for (; k < niters && k < P.iterations; ++k) {
+      const int g = P.good_out[k];
+      if (g > (max_good > 4 ? max_good : 4)) {
+        max_good = g;
+        best = k;
+        niters = ransac_update_iters_dev(P.confidence, (double)(P.n - g) / P.n, 5, niters);
+      }
+    }
+    s_best[0] = best;
+    s_best[1] = k;
+    s_base = 0;
+  }
+  __syncthreads();
+  const int best = s_best[0];
+  if (best < 0) {
+    if (tid == 0) {
+      P.result[16] = 0.0;
+      P.result[17] = 0.0;
+      P.result[18] = -1.0;
+      P.result[19] = (double)s_best[1];
+    }
+    if (P.rec_out[0] && tid < kCamStride) {
+      P.rec_out[0][tid] = P.cam0[tid];
+      P.rec_out[1][tid] = P.cam0[tid];
+    }
+    return;
+  }
+  double cam[kCamStride];
+  for (int k = 0; k < kCamStride; ++k) cam[k] = P.cam_out[(size_t)best * kCamStride + k];
+  // ordered inlier list of the best model
+  for (int i0 = 0; i0 < P.n; i0 += kPnpFinish) {
+    const int i = i0 + tid;
+    bool in = false;
+    if (i < P.n) {
+      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
+      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+      double eu, ev, pc[3];
+      pnp_err(P, cam, X, uv, eu, ev, pc);
+      in = eu * eu + ev * ev <= P.thr2;
+    }
+    const unsigned long long bal = __ballot(in);
+    if (lane == 0) s_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = s_base + __popcll(bal & ((1ull << lane) - 1));
+    for (int w = 0; w < wv; ++w) off += s_cnt[w];
+    if (in) P.inl_out[off] = i;
+    __syncthreads();
+    if (tid == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+  }
+  const int m = s_base;
+  double pose[12];
+  for (int k = 0; k < 12; ++k) pose[k] = P.pose_out[(size_t)best * 12 + k];
+  if (m >= 1 && P.iters_lm > 0) {
+    // final refinement on the inliers (solvePnP(inliers, useExtrinsicGuess) in OpenCV)
+    __threadfence_block();
+    pnp_lm<6, kPnpFinish / 64>(P, P.inl_out, m, tid, kPnpFinish, cam, s_red);
+    for (int r = 0; r < 3; ++r) {
+      for (int k = 0; k < 3; ++k) pose[4 * r + k] = cam[7 + 4 * k + r];
+      pose[4 * r + 3] = cam[r];
+    }
+  }
+  if (P.rec_out[0] && tid == 0) {
+    // the record is re-derived from the 4x4 result, as a caller that passes the pose matrix on would do
+    double m[16], rec[kCamStride];
+    for (int k = 0; k < 12; ++k) m[k] = pose[k];
+    rec[0] = m[3];
+    rec[1] = m[7];
+    rec[2] = m[11];
+    quat_from_pose(m, rec + 3);
+    quat_to_w2n(rec, rec + 3, rec + 7);
+    for (int k = 0; k < kCamStride; ++k) {
+      P.rec_out[0][k] = rec[k];
+      P.rec_out[1][k] = rec[k];
+    }
+  }
+  if (tid == 0) {
+    for (int k = 0; k < 12; ++k) P.result[k] = pose[k];
+    P.result[12] = P.result[13] = P.result[14] = 0.0;
+    P.result[15] = 1.0;
+    P.result[16] = 1.0;
+    P.result[17] = (double)m;
+    P.result[18] = (double)best;
+    P.result[19] = (double)s_best[1];
+  }
+}
+}  // namespace vsba
+
+VS_API int vs_pnp_ransac(vs_ctx* ctx, const double* obj, const double* img, int n, double fx, double fy, double cx,
+                         double cy, const double* pose0, int iterations, double reproj_err, double confidence,
+                         uint64_t seed, int refine_iters, double* pose_out, int32_t* inliers, int* n_inliers,
+                         int* found) {
+  if (!ctx) return VS_EINVAL;
+  if (!pose0 || !pose_out || !n_inliers || !found || n < 0 || iterations < 0 || refine_iters < 0 ||
+      (n > 0 && (!obj || !img || !inliers)))
+    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_pnp_ransac");
+  *found = 0;
+  *n_inliers = 0;
+  memcpy(pose_out, pose0, 16 * sizeof(double));
+  if (n < 5 || iterations == 0) return VS_OK;
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int H = iterations;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  // [obj | img] uploaded; [result | inliers] read back; [cam | pose | good] stay on the device
+  const size_t off_img = up(sizeof(double) * 3 * (size_t)n);
+  const size_t off_res = off_img + up(sizeof(double) * 2 * (size_t)n);
+  const size_t off_inl = off_res + 256;
+  const size_t off_cam = off_inl + up(sizeof(int) * (size_t)n);
+  const size_t off_pose = off_cam + up(sizeof(double) * kCamStride * (size_t)H);
+  const size_t off_good = off_pose + up(sizeof(double) * 12 * (size_t)H);
+  const size_t total = off_good + up(sizeof(int) * (size_t)H);
+  VS_TRY(vs_reserve(ctx, &ctx->d_xy_in, total));
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, off_cam));
+  VS_HIP(ctx, hipStreamSynchronize(s));
+  uint8_t* h = (uint8_t*)ctx->h_pin_big.p;
+  uint8_t* d = (uint8_t*)ctx->d_xy_in.p;
+  memcpy(h, obj, sizeof(double) * 3 * (size_t)n);
+  memcpy(h + off_img, img, sizeof(double) * 2 * (size_t)n);
+  VS_HIP(ctx, hipMemcpyAsync(d, h, off_res, hipMemcpyHostToDevice, s));
+  pnp_args P;
+  memset(&P, 0, sizeof P);
+  P.obj = (const double*)d;
+  P.img = (const double*)(d + off_img);
+  P.n = n;
+  P.iters_lm = refine_iters;
+  P.iterations = H;
+  P.fx = fx;
+  P.fy = fy;
+  P.cx = cx;
+  P.cy = cy;
+  P.thr2 = reproj_err * reproj_err;
+  P.confidence = confidence;
+  P.seed = seed;
+  P.cam0[0] = pose0[3];
+  P.cam0[1] = pose0[7];
+  P.cam0[2] = pose0[11];
+  quat_from_pose(pose0, P.cam0 + 3);
+  quat_to_w2n(P.cam0, P.cam0 + 3, P.cam0 + 7);
+  P.result = (double*)(d + off_res);
+  P.inl_out = (int*)(d + off_inl);
+  P.cam_out = (double*)(d + off_cam);
+  P.pose_out = (double*)(d + off_pose);
+  P.good_out = (int*)(d + off_good);
+  hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(H), dim3(64), 0, s, P);
+  VS_LAUNCH_CHECK(ctx, "pnp_hypothesis_kernel");
+  hipLaunchKernelGGL(pnp_finish_kernel, dim3(1), dim3(kPnpFinish), 0, s, P);
+  VS_LAUNCH_CHECK(ctx, "pnp_finish_kernel");
+  VS_HIP(ctx, hipMemcpyAsync(h + off_res, d + off_res, off_cam - off_res, hipMemcpyDeviceToHost, s));
+  VS_HIP(ctx, hipStreamSynchronize(s));
+  const double* res = (const double*)(h + off_res);
+  if (res[16] != 0.0) {
+    const int m = (int)res[17];
+    *found = 1;
+    *n_inliers = m;
+    memcpy(pose_out, res, 16 * sizeof(double));
+    memcpy(inliers, h + off_inl, sizeof(int32_t) * (size_t)m);
+  }
+  return VS_OK;
+}
