@@ -180,3 +180,28 @@ def test_tracking_session_survives_frames_without_features(vs):
     r2 = vs.track_frame(black)
     assert r2["n_matches"] == 0 and np.abs(r2["poses"][3] - r2["poses"][2]).max() < 1e-9
     vs.track_end()
+
+
+def test_argument_errors_of_the_widened_entry_points(vs):
+    """Status codes instead of crashes: mismatched lengths, negative counts, capacities (C ABI returns VS_EINVAL / VS_ENOMEM,
+    the Python layer raises VsError / ValueError)."""
+    from visual_slam_amd.context import VsError
+    x = np.zeros((10, 2))
+    with pytest.raises(ValueError):
+        vs.essential_ransac(x, x[:5], 1e-3)
+    with pytest.raises(ValueError):
+        vs.recover_pose(np.eye(3), x, x[:5])
+    with pytest.raises(VsError):
+        vs.essential_ransac(x, x, 1e-3, max_iters=-1)
+    with pytest.raises(VsError):
+        vs.pnp_ransac(np.zeros((10, 3)), x, ICL_NUIM_K, np.eye(4), refine_iters=-1)
+    with pytest.raises(ValueError):
+        vs.track_begin(np.zeros((10, 3)), np.zeros((9, 32), np.uint8), np.eye(4), ICL_NUIM_K)
+    with pytest.raises(VsError):
+        vs.track_begin(np.zeros((10, 3)), np.zeros((10, 32), np.uint8), np.eye(4), ICL_NUIM_K, max_frames=0)
+    with pytest.raises(VsError):
+        vs.track_begin(np.zeros((10, 3)), np.zeros((10, 32), np.uint8), np.eye(4), ICL_NUIM_K, pnp_iterations=100000)
+    # degenerate but legal inputs give "not found", not an error
+    assert not vs.essential_ransac(np.zeros((20, 2)), np.zeros((20, 2)), 1e-3)["found"]          # all points coincide
+    r = vs.pnp_ransac(np.zeros((20, 3)), np.zeros((20, 2)), ICL_NUIM_K, np.eye(4))              # points at the centre
+    assert isinstance(r["found"], bool) and np.isfinite(r["pose"]).all() or not r["found"]
