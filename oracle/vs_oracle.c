@@ -1059,16 +1059,18 @@ static int pnp_refine(const double* pose_in, const double* obj, const double* im
         x[a] = b[a];
       }
       int ok = 1;
+      double rinv[6]; /* one division per pivot, multiplications elsewhere: the arithmetic the HIP kernel uses */
       for (int j = 0; j < 6; ++j) {
         double sdiag = A[7 * j];
         for (int k = 0; k < j; ++k) sdiag -= A[6 * j + k] * A[6 * j + k];
         if (!(sdiag > 0.0)) ok = 0;
         const double l = sqrt(sdiag);
         A[7 * j] = l;
+        rinv[j] = 1.0 / l;
         for (int i = j + 1; i < 6; ++i) {
           double v = A[6 * i + j];
           for (int k = 0; k < j; ++k) v -= A[6 * i + k] * A[6 * j + k];
-          A[6 * i + j] = v / l;
+          A[6 * i + j] = v * rinv[j];
         }
       }
       double temp = DBL_MAX;
@@ -1076,12 +1078,12 @@ static int pnp_refine(const double* pose_in, const double* obj, const double* im
         for (int i = 0; i < 6; ++i) {
           double v = x[i];
           for (int k = 0; k < i; ++k) v -= A[6 * i + k] * x[k];
-          x[i] = v / A[7 * i];
+          x[i] = v * rinv[i];
         }
         for (int i = 5; i >= 0; --i) {
           double v = x[i];
           for (int k = i + 1; k < 6; ++k) v -= A[6 * k + i] * x[k];
-          x[i] = v / A[7 * i];
+          x[i] = v * rinv[i];
         }
         trial = cam;
         cam_update(&trial, x);
@@ -1099,7 +1101,8 @@ static int pnp_refine(const double* pose_in, const double* obj, const double* im
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && isfinite(temp)) {
-        double alpha = 1.0 - pow(2 * rho - 1, 3);
+        const double g = 2 * rho - 1;
+        double alpha = 1.0 - g * g * g;
         alpha = fmin(alpha, 2.0 / 3.0);
         lambda *= fmax(1.0 / 3.0, alpha);
         ni = 2.0;

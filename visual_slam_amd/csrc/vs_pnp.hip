@@ -166,6 +166,7 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
         x[a] = b[a];
       }
       int ok = 1;
+      double rinv[6];  // one division per pivot; every other division by a pivot is a multiplication (oracle alike)
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         double sdiag = A[j][j];
@@ -174,12 +175,13 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
         if (!(sdiag > 0.0)) ok = 0;
         const double l = sqrt(sdiag);
         A[j][j] = l;
+        rinv[j] = 1.0 / l;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
           double v = A[i][j];
 #pragma unroll
           for (int k = 0; k < j; ++k) v -= A[i][k] * A[j][k];
-          A[i][j] = v / l;
+          A[i][j] = v * rinv[j];
         }
       }
       double temp = 1.7976931348623157e308;
@@ -189,14 +191,14 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
           double v = x[i];
 #pragma unroll
           for (int k = 0; k < i; ++k) v -= A[i][k] * x[k];
-          x[i] = v / A[i][i];
+          x[i] = v * rinv[i];
         }
 #pragma unroll
         for (int i = 5; i >= 0; --i) {
           double v = x[i];
 #pragma unroll
           for (int k = i + 1; k < 6; ++k) v -= A[k][i] * x[k];
-          x[i] = v / A[i][i];
+          x[i] = v * rinv[i];
         }
         cam_apply(cam, x, trial);
         double step2 = 0.0;
@@ -226,7 +228,8 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
       scale += 1e-3;
       rho /= scale;
       if (rho > 0 && isfinite(temp)) {
-        double alpha = 1.0 - pow(2 * rho - 1, 3);
+        const double g = 2 * rho - 1;
+        double alpha = 1.0 - g * g * g;
         alpha = fmin(alpha, 2.0 / 3.0);
         lambda *= fmax(1.0 / 3.0, alpha);
         ni = 2.0;
