@@ -174,6 +174,15 @@ int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, in
                    double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found, float* xy_out /*[max_kp][2]*/,
                    uint8_t* desc_out /*[max_kp][32]*/, int* n_kp_out, int32_t* match_q /*[n_points]*/,
                    int32_t* match_t /*[n_points]*/);
+/* Pipelined variant for recorded streams: the call for frame k+1 first enqueues the back half (append, PnP, BA) of frame
+ * k on the context's stream, then prepares frame k+1's front half (upload, detect, match) on a second stream while that
+ * runs, and finally returns frame k's results (*has_result = 1; 0 on the first call).  bgr == NULL flushes the pending
+ * frame.  The parameters given with a frame are the ones used for it.  Results are identical to vs_track_frame. */
+int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int thr, double ratio,
+                             double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations,
+                             double huber_delta, int* has_result, double* poses_out, int* n_poses_out, int* n_matches,
+                             int* pnp_found, float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q,
+                             int32_t* match_t);
 int vs_track_end(vs_ctx* ctx);
 
 /* ---- A9-A16: bundle adjustment ------------------------------------------------------------------------------

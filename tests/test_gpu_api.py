@@ -84,6 +84,9 @@ def test_tracking_harness_gpu_equals_oracle(vs, oracle):
     rposes, _, rn = harness.track_sequence_resident(vs, frames, depth0)
     assert rn == gn
     assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(rposes, gposes)) < 1e-9
+    # ... and pipelining frame k+1's upload / detection / match with frame k's PnP + BA changes nothing
+    pposes, _, pn = harness.track_sequence_resident(vs, frames, depth0, pipelined=True)
+    assert pn == rn and np.array_equal(pposes, rposes)
     # the class-API period (Frame / Map / FeatureMatcher / solvePnPRansac / BundleAdjustment) tracks the same poses
     aposes, _ = harness.track_sequence_api(frames, depth0, context=vs)
     assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(aposes, gposes)) < 1e-6
@@ -159,6 +162,17 @@ def test_tracking_session_details(vs, oracle):
     vs.track_frame(frames[2])
     with pytest.raises(VsError):
         vs.track_frame(frames[3])                               # max_frames = 2
+    vs.track_end()
+    # pipelined entry point: result of frame k arrives with the submission of frame k+1; flush with None; optional outputs
+    vs.track_begin(X, d0, np.eye(4), ICL_NUIM_K, max_frames=3, pnp_iterations=0)
+    assert vs.track_frame_pipelined(frames[1], want_keypoints=True) is None
+    with pytest.raises(VsError):
+        vs.track_frame(frames[2])                               # a pipelined frame is pending
+    p1 = vs.track_frame_pipelined(frames[2], want_keypoints=True)
+    assert np.array_equal(p1["xy"], xy1) and np.array_equal(p1["match_q"], mq) and np.array_equal(p1["match_t"], mt)
+    assert np.abs(p1["poses"][1] - ref["poses"][1]).max() < 1e-12
+    p2 = vs.track_frame_pipelined(None)
+    assert p2["poses"].shape == (3, 4, 4) and vs.track_frame_pipelined(None) is None
     vs.track_end()
 
 

@@ -235,6 +235,36 @@ class Context:
             out["xy"], out["desc"] = t["xy"][:nk.value].copy(), t["desc"][:nk.value].copy()
         return out
 
+    def track_frame_pipelined(self, bgr, thr=20, ratio=0.8, reproj_err=8.0, confidence=0.99, seed=0, lm_iterations=10,
+                              huber_delta=float(np.sqrt(5.991)), want_keypoints=False, want_matches=True):
+        """Submit `bgr` (None: flush) and return the result of the PREVIOUS submitted frame (None on the first call): that
+        frame's PnP + BA run on the GPU while this frame is uploaded, detected and matched."""
+        t = self._track
+        if t is None:
+            raise VsError(-1, "track_frame_pipelined: no tracking period (call track_begin)")
+        if bgr is not None:
+            bgr = np.ascontiguousarray(bgr, np.uint8)
+            h, w, _ = bgr.shape
+            t["keep"] = bgr  # the upload may still be in flight when this call returns
+        else:
+            h = w = 0
+        has, npo, nm, found, nk = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        self._chk(self._lib.vs_track_frame_pipelined(
+            self._h, ptr(bgr, c_u8p) if bgr is not None else None, w, h, 3 * w, int(thr), float(ratio), float(reproj_err),
+            float(confidence), int(seed), int(lm_iterations), float(huber_delta), C.byref(has), ptr(t["poses"], c_f64p),
+            C.byref(npo), C.byref(nm), C.byref(found), ptr(t["xy"], c_f32p) if want_keypoints else None,
+            ptr(t["desc"], c_u8p) if want_keypoints else None, C.byref(nk), ptr(t["mq"], c_i32p) if want_matches else None,
+            ptr(t["mt"], c_i32p) if want_matches else None))
+        if not has.value:
+            return None
+        out = dict(poses=t["poses"][:npo.value].reshape(-1, 4, 4).copy(), n_matches=nm.value, pnp_found=bool(found.value),
+                   n_keypoints=nk.value)
+        if want_matches:
+            out["match_q"], out["match_t"] = t["mq"][:nm.value].copy(), t["mt"][:nm.value].copy()
+        if want_keypoints:
+            out["xy"], out["desc"] = t["xy"][:nk.value].copy(), t["desc"][:nk.value].copy()
+        return out
+
     def track_end(self):
         self._chk(self._lib.vs_track_end(self._h))
         self._track = None

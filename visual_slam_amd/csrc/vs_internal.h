@@ -52,7 +52,20 @@ struct vs_ctx {
     int cur = 0;        // state buffer holding the accepted estimate
     double K[4] = {0, 0, 0, 0};
     double last_rec[19];  // camera record of the newest pose (the PnP guess of the next frame)
+    // pipelined use (vs_track_frame_pipelined): the front half (upload, detect, match) of frame k+1 runs on its own
+    // stream while the back half (PnP, BA) of frame k runs on the context's stream; two sets of per-frame buffers
+    hipStream_t front_stream = nullptr;
+    hipEvent_t ev_front[2] = {nullptr, nullptr};
+    int pending = -1;   // buffer set of the frame whose front half is done and whose back half is not, or -1
+    int next_set = 0;
+    int front_nkp[2] = {0, 0};
+    struct {
+      double reproj_err, confidence, huber;
+      unsigned long long seed;
+      int lm_iterations;
+    } params[2];
   } track;
+  vs_buf d_bgr2;  // image buffer of the second set
 };
 
 uint64_t vs_fingerprint(const void* p, size_t bytes);

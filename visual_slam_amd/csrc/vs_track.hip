@@ -41,9 +41,14 @@ __global__ __launch_bounds__(256) void track_append_kernel(const double* xyz, co
 // -> motion-only BA over all poses of the period, with one host synchronisation for the keypoint count (the matcher's
 // launch geometry needs it) and one at the end.  Same kernels, same arithmetic as the separate entry points.
 namespace {
+struct track_front {
+  size_t fxy, fscore, fdesc, fn, mq, mt, md, M;
+};
 struct track_layout {
-  size_t xyz, mapdesc, fxy, fscore, fdesc, fn, mq, mt, md, M, flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part,
-      H, mst, pnp_cam, pnp_pose, pnp_good, pnp_res, pnp_inl, rb_end, total;
+  size_t xyz, mapdesc;
+  track_front f[2];  // two sets of per-frame buffers (the synchronous entry point uses set 0 only)
+  size_t flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part, H, mst, pnp_cam, pnp_pose, pnp_good, pnp_res, pnp_inl,
+      rb_end, total;
   int cap_obs;
 };
 
@@ -59,14 +64,16 @@ track_layout track_layout_of(int P, int F, int max_kp, int H) {
   L.cap_obs = F * (per > 0 ? per : 1);
   L.xyz = take(sizeof(double) * 3 * (size_t)P);
   L.mapdesc = take(32 * (size_t)P + 32);
-  L.fxy = take(sizeof(float) * 2 * (size_t)max_kp);
-  L.fscore = take((size_t)max_kp);
-  L.fdesc = take(32 * (size_t)max_kp + 32);
-  L.fn = take(sizeof(int));
-  L.mq = take(sizeof(int) * (size_t)P);
-  L.mt = take(sizeof(int) * (size_t)P);
-  L.md = take(sizeof(int) * (size_t)P);
-  L.M = take(sizeof(int));
+  for (track_front& f : L.f) {
+    f.fxy = take(sizeof(float) * 2 * (size_t)max_kp);
+    f.fscore = take((size_t)max_kp);
+    f.fdesc = take(32 * (size_t)max_kp + 32);
+    f.fn = take(sizeof(int));
+    f.mq = take(sizeof(int) * (size_t)P);
+    f.mt = take(sizeof(int) * (size_t)P);
+    f.md = take(sizeof(int) * (size_t)P);
+    f.M = take(sizeof(int));
+  }
   // read-back block: [LM state x2 | flags | PnP result | both camera buffers] is fetched with one copy per frame
   L.mst = take(2 * sizeof(mo_state));
   L.flags = take(4 * sizeof(int));
@@ -104,102 +111,57 @@ void pose_from_rec(const double* c, double* o) {
   o[12] = o[13] = o[14] = 0.0;
   o[15] = 1.0;
 }
-}  // namespace
 
-VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, int n_points, const double* key_pose,
-                          double fx, double fy, double cx, double cy, int max_frames, int max_kp, int pnp_iterations) {
-  if (!ctx) return VS_EINVAL;
-  if (!xyz || !desc || !key_pose || n_points < 1 || max_frames < 1 || max_kp < 2 || pnp_iterations < 0 || pnp_iterations > 4096)
-    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_begin");
-  VS_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  const track_layout L = track_layout_of(n_points, max_frames, max_kp, pnp_iterations > 0 ? pnp_iterations : 1);
-  VS_TRY(vs_reserve(ctx, &ctx->d_track, L.total));
-  const size_t up = L.fxy;  // [xyz | mapdesc] are uploaded
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(up, (size_t)1 << 16)));
-  VS_HIP(ctx, hipStreamSynchronize(s));
-  uint8_t* h = (uint8_t*)ctx->h_track.p;
-  uint8_t* d = (uint8_t*)ctx->d_track.p;
-  memcpy(h + L.xyz, xyz, sizeof(double) * 3 * (size_t)n_points);
-  memcpy(h + L.mapdesc, desc, 32 * (size_t)n_points);
-  VS_HIP(ctx, hipMemcpyAsync(d, h, up, hipMemcpyHostToDevice, s));
-  VS_HIP(ctx, hipMemsetAsync(d + L.cam_start, 0, sizeof(int) * (size_t)(max_frames + 2), s));
-  VS_HIP(ctx, hipMemsetAsync(d + L.flags, 0, 4 * sizeof(int), s));
-  double rec[kCamStride];
-  rec_from_pose(key_pose, rec);
-  VS_HIP(ctx, hipStreamSynchronize(s));  // the pinned mirror is reused below
-  memcpy(h, rec, sizeof rec);
-  int* sp = (int*)(h + 1024);
-  for (int c = 0; c < max_frames; ++c) sp[c] = c + 1;  // free-camera slot c = pose c + 1 (pose 0 is the fixed key frame)
-  VS_HIP(ctx, hipMemcpyAsync(d + L.cam0, h, sizeof rec, hipMemcpyHostToDevice, s));
-  VS_HIP(ctx, hipMemcpyAsync(d + L.cam1, h, sizeof rec, hipMemcpyHostToDevice, s));
-  if (sizeof(int) * (size_t)max_frames + 1024 > ctx->h_track.cap) return vs_fail(ctx, VS_ENOMEM, "%s: staging too small", "vs_track_begin");
-  VS_HIP(ctx, hipMemcpyAsync(d + L.slot_pose, sp, sizeof(int) * (size_t)max_frames, hipMemcpyHostToDevice, s));
-  VS_HIP(ctx, hipStreamSynchronize(s));
-  ctx->track.active = 1;
-  ctx->track.n_points = n_points;
-  ctx->track.cap_frames = max_frames;
-  ctx->track.max_kp = max_kp;
-  ctx->track.pnp_iters = pnp_iterations;
-  ctx->track.n_frames = 0;
-  ctx->track.obs_used = 0;
-  ctx->track.cur = 0;
-  ctx->track.K[0] = fx;
-  ctx->track.K[1] = fy;
-  ctx->track.K[2] = cx;
-  ctx->track.K[3] = cy;
-  memcpy(ctx->track.last_rec, rec, sizeof rec);
-  return VS_OK;
+track_layout layout_of(const vs_ctx* ctx) {
+  const auto& T = ctx->track;
+  return track_layout_of(T.n_points, T.cap_frames, T.max_kp, T.pnp_iters > 0 ? T.pnp_iters : 1);
 }
 
-VS_API int vs_track_end(vs_ctx* ctx) {
-  if (!ctx) return VS_EINVAL;
-  ctx->track.active = 0;
-  return VS_OK;
-}
+constexpr size_t kPinRb = 4096;  // pinned staging: [0,64) keypoint counts, 1024 LM start state, 2048 record, 4096 read-back
 
-VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
-                          double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations,
-                          double huber_delta, double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found,
-                          float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t) {
-  if (!ctx) return VS_EINVAL;
-  if (!ctx->track.active) return vs_fail(ctx, VS_EINVAL, "%s: no tracking period (call vs_track_begin)", "vs_track_frame");
-  if (!bgr || w < 31 || h_img < 31 || stride < 3 * w || !poses_out || !n_poses_out || !n_matches || lm_iterations < 0)
-    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_frame");
+// Front half of a frame on stream `s`: image upload, detect+describe, (host reads the keypoint count), match against the
+// map.  Ends with ev_front[set] recorded on `s`.
+int track_front_half(vs_ctx* ctx, int set, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
+                     hipStream_t s) {
   auto& T = ctx->track;
-  if (T.n_frames >= T.cap_frames) return vs_fail(ctx, VS_ENOMEM, "%s: the period holds max_frames frames already", "vs_track_frame");
-  VS_HIP(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  const int P = T.n_points, H = T.pnp_iters > 0 ? T.pnp_iters : 1;
-  const track_layout L = track_layout_of(P, T.cap_frames, T.max_kp, H);
+  const track_layout L = layout_of(ctx);
+  const track_front& F = L.f[set];
   uint8_t* d = (uint8_t*)ctx->d_track.p;
-  // ---- image upload (pitch = 3w rounded up to 4 bytes, 16 bytes of slack after the last row)
-  const int pitch = (3 * w + 3) & ~3;
-  VS_TRY(vs_reserve(ctx, &ctx->d_bgr, (size_t)pitch * h_img + 16));
-  if (stride == pitch) VS_HIP(ctx, hipMemcpyAsync(ctx->d_bgr.p, bgr, (size_t)pitch * h_img, hipMemcpyHostToDevice, s));
-  else VS_HIP(ctx, hipMemcpy2DAsync(ctx->d_bgr.p, pitch, bgr, stride, 3 * (size_t)w, h_img, hipMemcpyHostToDevice, s));
-  VS_TRY(vs_detect_describe_bgr_dev(ctx, ctx->d_bgr.p, w, h_img, pitch, thr, T.max_kp, d + L.fxy, d + L.fscore, d + L.fdesc,
-                                    d + L.fn, s));
-  const size_t rb_bytes = L.rb_end - L.mst;  // the read-back block is mirrored at hp + 4096
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, 4096 + rb_bytes));
-  uint8_t* hp = (uint8_t*)ctx->h_track.p;
-  uint8_t* rb = hp + 4096;
-  int* h_n = (int*)hp;  // [0]: keypoints
-  VS_HIP(ctx, hipMemcpyAsync(h_n, d + L.fn, sizeof(int), hipMemcpyDeviceToHost, s));
+  vs_buf* img = set ? &ctx->d_bgr2 : &ctx->d_bgr;
+  const int pitch = (3 * w + 3) & ~3;  // 3w rounded up to 4 bytes, 16 bytes of slack after the last row
+  VS_TRY(vs_reserve(ctx, img, (size_t)pitch * h_img + 16));
+  if (stride == pitch) VS_HIP(ctx, hipMemcpyAsync(img->p, bgr, (size_t)pitch * h_img, hipMemcpyHostToDevice, s));
+  else VS_HIP(ctx, hipMemcpy2DAsync(img->p, pitch, bgr, stride, 3 * (size_t)w, h_img, hipMemcpyHostToDevice, s));
+  VS_TRY(vs_detect_describe_bgr_dev(ctx, img->p, w, h_img, pitch, thr, T.max_kp, d + F.fxy, d + F.fscore, d + F.fdesc, d + F.fn, s));
+  int* h_n = (int*)ctx->h_track.p + 4 * set;
+  VS_HIP(ctx, hipMemcpyAsync(h_n, d + F.fn, sizeof(int), hipMemcpyDeviceToHost, s));
   VS_HIP(ctx, hipStreamSynchronize(s));
   const int n_kp = h_n[0];
-  if (n_kp_out) *n_kp_out = n_kp;
-  if (xy_out && n_kp > 0) VS_HIP(ctx, hipMemcpyAsync(xy_out, d + L.fxy, sizeof(float) * 2 * (size_t)n_kp, hipMemcpyDeviceToHost, s));
-  if (desc_out && n_kp > 0) VS_HIP(ctx, hipMemcpyAsync(desc_out, d + L.fdesc, 32 * (size_t)n_kp, hipMemcpyDeviceToHost, s));
-  // ---- match the map's descriptors (query) against the frame's (train), Lowe ratio, ordered compaction
+  T.front_nkp[set] = n_kp;
   if (n_kp >= 2) {
-    VS_TRY(vs_match_ratio_dev(ctx, d + L.mapdesc, P, d + L.fdesc, n_kp, ratio, d + L.mq, d + L.mt, d + L.md, d + L.M, s));
+    VS_TRY(vs_match_ratio_dev(ctx, d + L.mapdesc, T.n_points, d + F.fdesc, n_kp, ratio, d + F.mq, d + F.mt, d + F.md, d + F.M, s));
   } else {
-    VS_HIP(ctx, hipMemsetAsync(d + L.M, 0, sizeof(int), s));
+    VS_HIP(ctx, hipMemsetAsync(d + F.M, 0, sizeof(int), s));
   }
+  VS_HIP(ctx, hipEventRecord(T.ev_front[set], s));
+  return VS_OK;
+}
+
+// Back half, enqueue only (context stream): wait for the front half, append the observations, PnP-RANSAC from the
+// previous pose, motion-only BA over the k free poses, one read-back copy.  *steps_out = LM launches enqueued.
+int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
+  auto& T = ctx->track;
+  const auto& Q = T.params[set];
+  const track_layout L = layout_of(ctx);
+  const track_front& F = L.f[set];
+  hipStream_t s = ctx->stream;
+  uint8_t* d = (uint8_t*)ctx->d_track.p;
+  uint8_t* hp = (uint8_t*)ctx->h_track.p;
+  const int H = T.pnp_iters > 0 ? T.pnp_iters : 1;
   const int slot = T.n_frames, k = T.n_frames + 1;  // new free-camera slot / pose index
-  hipLaunchKernelGGL(track_append_kernel, dim3(8), dim3(256), 0, s, (const double*)(d + L.xyz), (const float*)(d + L.fxy),
-                     (const int*)(d + L.mq), (const int*)(d + L.mt), (const int*)(d + L.M), (double*)(d + L.moX),
+  VS_HIP(ctx, hipStreamWaitEvent(s, T.ev_front[set], 0));
+  hipLaunchKernelGGL(track_append_kernel, dim3(8), dim3(256), 0, s, (const double*)(d + L.xyz), (const float*)(d + F.fxy),
+                     (const int*)(d + F.mq), (const int*)(d + F.mt), (const int*)(d + F.M), (double*)(d + L.moX),
                      (double*)(d + L.moUV), (int*)(d + L.cam_start), slot, L.cap_obs, (int*)(d + L.flags));
   VS_LAUNCH_CHECK(ctx, "track_append_kernel");
   double* cam0 = (double*)(d + L.cam0);
@@ -211,15 +173,15 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   A.img = (const double*)(d + L.moUV) + 2 * (size_t)T.obs_used;
   A.n = 0;
   A.n_dev = (const int*)(d + L.flags) + 1;
-  A.iters_lm = lm_iterations;
+  A.iters_lm = Q.lm_iterations;
   A.iterations = T.pnp_iters;
   A.fx = T.K[0];
   A.fy = T.K[1];
   A.cx = T.K[2];
   A.cy = T.K[3];
-  A.thr2 = pnp_reproj_err * pnp_reproj_err;
-  A.confidence = pnp_confidence;
-  A.seed = seed;
+  A.thr2 = Q.reproj_err * Q.reproj_err;
+  A.confidence = Q.confidence;
+  A.seed = Q.seed;
   memcpy(A.cam0, T.last_rec, sizeof A.cam0);
   A.cam_out = (double*)(d + L.pnp_cam);
   A.pose_out = (double*)(d + L.pnp_pose);
@@ -233,75 +195,115 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
     VS_LAUNCH_CHECK(ctx, "pnp_hypothesis_kernel");
     hipLaunchKernelGGL(pnp_finish_kernel, dim3(1), dim3(kPnpFinish), 0, s, A);
     VS_LAUNCH_CHECK(ctx, "pnp_finish_kernel");
-  } else {  // no PnP: the previous pose is the start (pinned staging: h_track + 2048)
+  } else {  // no PnP: the previous pose is the start
     memcpy(hp + 2048, T.last_rec, sizeof T.last_rec);
     VS_HIP(ctx, hipMemcpyAsync(A.rec_out[0], hp + 2048, sizeof T.last_rec, hipMemcpyHostToDevice, s));
     VS_HIP(ctx, hipMemcpyAsync(A.rec_out[1], hp + 2048, sizeof T.last_rec, hipMemcpyHostToDevice, s));
   }
-  // ---- motion-only BA over the k free poses of the period
+  *steps_out = 0;
+  if (Q.lm_iterations > 0) {
+    mo_state* h_st = (mo_state*)(hp + 1024);
+    memset(h_st, 0, 2 * sizeof(mo_state));
+    h_st[1].need_lin = 1;
+    h_st[1].ni = 2.0;
+    h_st[1].cur = T.cur;
+    h_st[0].cur = T.cur;
+    VS_HIP(ctx, hipMemcpyAsync(d + L.mst, h_st, 2 * sizeof(mo_state), hipMemcpyHostToDevice, s));
+  }
+  return VS_OK;
+}
+
+ba_dev track_ba_dev(vs_ctx* ctx, int set) {
+  auto& T = ctx->track;
+  const track_layout L = layout_of(ctx);
+  uint8_t* d = (uint8_t*)ctx->d_track.p;
+  const int k = T.n_frames + 1;
   ba_dev D;
   memset(&D, 0, sizeof D);
   D.n_poses = k + 1;
   D.nfp = k;
   D.np = 6 * k;
-  D.max_it = lm_iterations;
+  D.max_it = T.params[set].lm_iterations;
   D.fx = T.K[0];
   D.fy = T.K[1];
   D.cx = T.K[2];
   D.cy = T.K[3];
-  D.huber = huber_delta;
+  D.huber = T.params[set].huber;
   D.dcs = 1.0;
   D.slot_pose = (const int*)(d + L.slot_pose);
   D.cam_start = (const int*)(d + L.cam_start);
-  D.cam[0] = cam0;
-  D.cam[1] = cam1;
+  D.cam[0] = (double*)(d + L.cam0);
+  D.cam[1] = (double*)(d + L.cam1);
   D.mo_X = (const double*)(d + L.moX);
   D.mo_uv = (const double*)(d + L.moUV);
   D.mo_part = (double*)(d + L.part);
   D.mo_H = (double*)(d + L.H);
-  mo_state* d_mst = (mo_state*)(d + L.mst);
-  D.st = reinterpret_cast<lm_state*>(d_mst);
-  mo_state* h_st = (mo_state*)(hp + 1024);  // initial state (uploaded)
-  memset(h_st, 0, 2 * sizeof(mo_state));
-  h_st[1].need_lin = 1;
-  h_st[1].ni = 2.0;
-  h_st[1].cur = T.cur;
-  h_st[0].cur = T.cur;
+  D.st = reinterpret_cast<lm_state*>(d + L.mst);
+  return D;
+}
+
+// enqueues up to one batch of LM launches followed by the read-back copy; returns the number of launches so far
+int track_ba_batch(vs_ctx* ctx, int set, int* step) {
+  auto& T = ctx->track;
+  const track_layout L = layout_of(ctx);
+  hipStream_t s = ctx->stream;
+  uint8_t* d = (uint8_t*)ctx->d_track.p;
+  uint8_t* rb = (uint8_t*)ctx->h_track.p + kPinRb;
+  const int lm = T.params[set].lm_iterations, k = T.n_frames + 1;
+  if (lm > 0) {
+    const ba_dev D = track_ba_dev(ctx, set);
+    const int max_steps = 1 + lm * 10;
+    const int batch = std::min(max_steps + 1 - *step, lm + 2);
+    for (int b = 0; b < batch; ++b, ++*step) {
+      hipLaunchKernelGGL(ba_motion_step, dim3(k), dim3(kMoThreads), 0, s, D, *step);
+      VS_LAUNCH_CHECK(ctx, "ba_motion_step");
+    }
+  }
+  // one copy brings back everything the host wants; if the solve needs another batch it is simply repeated
+  VS_HIP(ctx, hipMemcpyAsync(rb, d + L.mst, L.rb_end - L.mst, hipMemcpyDeviceToHost, s));
+  return VS_OK;
+}
+
+// Back half, completion: synchronise, run further LM batches if the solve is not finished, hand out the results.
+int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found,
+                      float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t) {
+  auto& T = ctx->track;
+  const track_layout L = layout_of(ctx);
+  const track_front& F = L.f[set];
+  hipStream_t s = ctx->stream;
+  uint8_t* d = (uint8_t*)ctx->d_track.p;
+  const uint8_t* rb = (const uint8_t*)ctx->h_track.p + kPinRb;
+  const mo_state* rb_st = (const mo_state*)rb;
+  const int lm = T.params[set].lm_iterations, k = T.n_frames + 1;
   mo_state fin;
   memset(&fin, 0, sizeof fin);
   fin.cur = T.cur;
-  const mo_state* rb_st = (const mo_state*)(rb + (L.mst - L.mst));
-  if (lm_iterations > 0) {
-    VS_HIP(ctx, hipMemcpyAsync(d_mst, h_st, 2 * sizeof(mo_state), hipMemcpyHostToDevice, s));
-    const int max_steps = 1 + lm_iterations * 10;
-    int step = 0;
-    for (;;) {
-      const int batch = std::min(max_steps + 1 - step, lm_iterations + 2);
-      for (int b = 0; b < batch; ++b, ++step) {
-        hipLaunchKernelGGL(ba_motion_step, dim3(k), dim3(kMoThreads), 0, s, D, step);
-        VS_LAUNCH_CHECK(ctx, "ba_motion_step");
-      }
-      // one copy brings back everything the host wants; if the solve needs another batch it is simply repeated
-      VS_HIP(ctx, hipMemcpyAsync(rb, d + L.mst, rb_bytes, hipMemcpyDeviceToHost, s));
-      VS_HIP(ctx, hipStreamSynchronize(s));
-      if (rb_st[(step - 1) & 1].done || step > max_steps) break;
-    }
-    fin = rb_st[(step - 1) & 1];
-  } else {
-    VS_HIP(ctx, hipMemcpyAsync(rb, d + L.mst, rb_bytes, hipMemcpyDeviceToHost, s));
+  for (;;) {
     VS_HIP(ctx, hipStreamSynchronize(s));
+    if (lm == 0) break;
+    fin = rb_st[(*step - 1) & 1];
+    if (fin.done || *step > 1 + lm * 10) break;
+    VS_TRY(track_ba_batch(ctx, set, step));
   }
   const int* rb_flags = (const int*)(rb + (L.flags - L.mst));
   const double* rb_res = (const double*)(rb + (L.pnp_res - L.mst));
-  const int M = rb_flags[1];
+  const int M = rb_flags[1], n_kp = T.front_nkp[set];
   if (rb_flags[0]) return vs_fail(ctx, VS_ENOMEM, "%s: observation capacity of the period exceeded", "vs_track_frame");
-  if (match_q && match_t && M > 0) {
-    VS_HIP(ctx, hipMemcpyAsync(match_q, d + L.mq, sizeof(int) * (size_t)M, hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipMemcpyAsync(match_t, d + L.mt, sizeof(int) * (size_t)M, hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipStreamSynchronize(s));
-  } else if ((xy_out || desc_out) && lm_iterations == 0) {
-    VS_HIP(ctx, hipStreamSynchronize(s));
+  bool copies = false;
+  if (xy_out && n_kp > 0) {
+    VS_HIP(ctx, hipMemcpyAsync(xy_out, d + F.fxy, sizeof(float) * 2 * (size_t)n_kp, hipMemcpyDeviceToHost, s));
+    copies = true;
   }
+  if (desc_out && n_kp > 0) {
+    VS_HIP(ctx, hipMemcpyAsync(desc_out, d + F.fdesc, 32 * (size_t)n_kp, hipMemcpyDeviceToHost, s));
+    copies = true;
+  }
+  if (match_q && match_t && M > 0) {
+    VS_HIP(ctx, hipMemcpyAsync(match_q, d + F.mq, sizeof(int) * (size_t)M, hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipMemcpyAsync(match_t, d + F.mt, sizeof(int) * (size_t)M, hipMemcpyDeviceToHost, s));
+    copies = true;
+  }
+  if (copies) VS_HIP(ctx, hipStreamSynchronize(s));
   T.cur = fin.cur;
   const double* h_cam = (const double*)(rb + ((T.cur ? L.cam1 : L.cam0) - L.mst));
   for (int i = 0; i <= k; ++i) pose_from_rec(h_cam + (size_t)i * kCamStride, poses_out + 16 * (size_t)i);
@@ -310,6 +312,132 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   T.obs_used += M;
   *n_poses_out = k + 1;
   *n_matches = M;
+  if (n_kp_out) *n_kp_out = n_kp;
   if (pnp_found) *pnp_found = T.pnp_iters > 0 && rb_res[16] != 0.0;
+  return VS_OK;
+}
+
+int track_check_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int lm_iterations, const char* who) {
+  if (!ctx->track.active) return vs_fail(ctx, VS_EINVAL, "%s: no tracking period (call vs_track_begin)", who);
+  if (!bgr || w < 31 || h_img < 31 || stride < 3 * w || lm_iterations < 0) return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", who);
+  if (ctx->track.n_frames + (ctx->track.pending >= 0 ? 1 : 0) >= ctx->track.cap_frames)
+    return vs_fail(ctx, VS_ENOMEM, "%s: the period holds max_frames frames already", who);
+  return VS_OK;
+}
+}  // namespace
+
+VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, int n_points, const double* key_pose,
+                          double fx, double fy, double cx, double cy, int max_frames, int max_kp, int pnp_iterations) {
+  if (!ctx) return VS_EINVAL;
+  if (!xyz || !desc || !key_pose || n_points < 1 || max_frames < 1 || max_kp < 2 || pnp_iterations < 0 || pnp_iterations > 4096)
+    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_begin");
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  auto& T = ctx->track;
+  if (!T.front_stream) {
+    VS_HIP(ctx, hipStreamCreateWithFlags(&T.front_stream, hipStreamNonBlocking));
+    for (hipEvent_t& e : T.ev_front) VS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  VS_HIP(ctx, hipStreamSynchronize(T.front_stream));
+  const track_layout L = track_layout_of(n_points, max_frames, max_kp, pnp_iterations > 0 ? pnp_iterations : 1);
+  VS_TRY(vs_reserve(ctx, &ctx->d_track, L.total));
+  const size_t up = L.f[0].fxy;  // [xyz | mapdesc] are uploaded
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(std::max(up, (size_t)1 << 16), kPinRb + (L.rb_end - L.mst))));
+  VS_HIP(ctx, hipStreamSynchronize(s));
+  uint8_t* h = (uint8_t*)ctx->h_track.p;
+  uint8_t* d = (uint8_t*)ctx->d_track.p;
+  memcpy(h + L.xyz, xyz, sizeof(double) * 3 * (size_t)n_points);
+  memcpy(h + L.mapdesc, desc, 32 * (size_t)n_points);
+  VS_HIP(ctx, hipMemcpyAsync(d, h, up, hipMemcpyHostToDevice, s));
+  VS_HIP(ctx, hipMemsetAsync(d + L.cam_start, 0, sizeof(int) * (size_t)(max_frames + 2), s));
+  VS_HIP(ctx, hipMemsetAsync(d + L.flags, 0, 4 * sizeof(int), s));
+  double rec[kCamStride];
+  rec_from_pose(key_pose, rec);
+  VS_HIP(ctx, hipStreamSynchronize(s));  // the pinned mirror is reused below
+  if (sizeof(int) * (size_t)max_frames + 1024 > ctx->h_track.cap) return vs_fail(ctx, VS_ENOMEM, "%s: staging too small", "vs_track_begin");
+  memcpy(h, rec, sizeof rec);
+  int* sp = (int*)(h + 1024);
+  for (int c = 0; c < max_frames; ++c) sp[c] = c + 1;  // free-camera slot c = pose c + 1 (pose 0 is the fixed key frame)
+  VS_HIP(ctx, hipMemcpyAsync(d + L.cam0, h, sizeof rec, hipMemcpyHostToDevice, s));
+  VS_HIP(ctx, hipMemcpyAsync(d + L.cam1, h, sizeof rec, hipMemcpyHostToDevice, s));
+  VS_HIP(ctx, hipMemcpyAsync(d + L.slot_pose, sp, sizeof(int) * (size_t)max_frames, hipMemcpyHostToDevice, s));
+  VS_HIP(ctx, hipStreamSynchronize(s));
+  T.active = 1;
+  T.n_points = n_points;
+  T.cap_frames = max_frames;
+  T.max_kp = max_kp;
+  T.pnp_iters = pnp_iterations;
+  T.n_frames = 0;
+  T.obs_used = 0;
+  T.cur = 0;
+  T.pending = -1;
+  T.next_set = 0;
+  T.K[0] = fx;
+  T.K[1] = fy;
+  T.K[2] = cx;
+  T.K[3] = cy;
+  memcpy(T.last_rec, rec, sizeof rec);
+  return VS_OK;
+}
+
+VS_API int vs_track_end(vs_ctx* ctx) {
+  if (!ctx) return VS_EINVAL;
+  if (ctx->track.front_stream) (void)hipStreamSynchronize(ctx->track.front_stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  ctx->track.active = 0;
+  ctx->track.pending = -1;
+  return VS_OK;
+}
+
+VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
+                          double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations,
+                          double huber_delta, double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found,
+                          float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t) {
+  if (!ctx) return VS_EINVAL;
+  VS_TRY(track_check_frame(ctx, bgr, w, h_img, stride, lm_iterations, "vs_track_frame"));
+  if (!poses_out || !n_poses_out || !n_matches) return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_frame");
+  if (ctx->track.pending >= 0) return vs_fail(ctx, VS_EINVAL, "%s: a pipelined frame is pending (flush it first)", "vs_track_frame");
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  auto& T = ctx->track;
+  T.params[0] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
+  VS_TRY(track_front_half(ctx, 0, bgr, w, h_img, stride, thr, ratio, ctx->stream));
+  int step = 0;
+  VS_TRY(track_back_enqueue(ctx, 0, &step));
+  VS_TRY(track_ba_batch(ctx, 0, &step));
+  return track_back_finish(ctx, 0, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out, match_q, match_t);
+}
+
+VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
+                                    double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations,
+                                    double huber_delta, int* has_result, double* poses_out, int* n_poses_out,
+                                    int* n_matches, int* pnp_found, float* xy_out, uint8_t* desc_out, int* n_kp_out,
+                                    int32_t* match_q, int32_t* match_t) {
+  if (!ctx) return VS_EINVAL;
+  if (!has_result || !poses_out || !n_poses_out || !n_matches)
+    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_frame_pipelined");
+  *has_result = 0;
+  auto& T = ctx->track;
+  if (!T.active) return vs_fail(ctx, VS_EINVAL, "%s: no tracking period (call vs_track_begin)", "vs_track_frame_pipelined");
+  if (bgr) VS_TRY(track_check_frame(ctx, bgr, w, h_img, stride, lm_iterations, "vs_track_frame_pipelined"));
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  const int solve = T.pending;
+  int step = 0;
+  if (solve >= 0) {  // back half of the previous frame: enqueued first, it runs while this frame's front half is prepared
+    VS_TRY(track_back_enqueue(ctx, solve, &step));
+    VS_TRY(track_ba_batch(ctx, solve, &step));
+  }
+  int submitted = -1;
+  if (bgr) {
+    submitted = T.next_set;
+    T.next_set ^= 1;
+    T.params[submitted] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
+    VS_TRY(track_front_half(ctx, submitted, bgr, w, h_img, stride, thr, ratio, T.front_stream));
+  }
+  if (solve >= 0) {
+    VS_TRY(track_back_finish(ctx, solve, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out,
+                             match_q, match_t));
+    *has_result = 1;
+  }
+  T.pending = submitted;
   return VS_OK;
 }

@@ -98,17 +98,26 @@ def track_sequence(detect, match, ba, frames, depth0, max_kp=3000, pnp=None):
     return np.stack(lm.poses), stages, n_matches
 
 
-def track_sequence_resident(ctx, frames, depth0, pnp=True):
+def track_sequence_resident(ctx, frames, depth0, pnp=True, pipelined=False):
     """The same tracking period through the device-resident session (vs_track_begin / vs_track_frame): the key frame's
-    map is uploaded once, every frame uploads only its image.  Returns (poses [n,4,4], seconds, per-frame match counts)."""
+    map is uploaded once, every frame uploads only its image.  pipelined=True (recorded streams): frame k+1 is uploaded,
+    detected and matched on a second stream while frame k's PnP + BA run.  Returns (poses [n,4,4], seconds, per-frame
+    match counts)."""
     t0 = time.perf_counter()
     xy0, _, desc0 = ctx.detect_describe_bgr(frames[0], 20, 3000)
     ctx.track_begin(backproject(xy0, depth0), desc0, np.eye(4), ICL_NUIM_K, max_frames=max(len(frames) - 1, 1),
                     pnp_iterations=100 if pnp else 0)
     n_matches, r = [], None
-    for k in range(1, len(frames)):
-        r = ctx.track_frame(frames[k], seed=k, want_matches=False)
-        n_matches.append(r["n_matches"])
+    if pipelined:
+        for k in list(range(1, len(frames))) + [None]:
+            out = ctx.track_frame_pipelined(frames[k] if k is not None else None, seed=k or 0, want_matches=False)
+            if out is not None:
+                r = out
+                n_matches.append(r["n_matches"])
+    else:
+        for k in range(1, len(frames)):
+            r = ctx.track_frame(frames[k], seed=k, want_matches=False)
+            n_matches.append(r["n_matches"])
     ctx.track_end()
     dt = time.perf_counter() - t0
     poses = r["poses"] if r is not None else np.eye(4)[None]
@@ -213,8 +222,16 @@ def bench_frames(ctx, repeats=5):
         rp, rdt, _ = track_sequence_resident(ctx, frames, depth0)
         if res_dt is None or rdt < res_dt:
             res_dt, res_poses = rdt, rp
+    track_sequence_resident(ctx, frames[:4], depth0, pipelined=True)
+    pipe_dt, pipe_poses = None, None
+    for _ in range(repeats):
+        pp, pdt, _ = track_sequence_resident(ctx, frames, depth0, pipelined=True)
+        if pipe_dt is None or pdt < pipe_dt:
+            pipe_dt, pipe_poses = pdt, pp
     out = {"frames_per_s": len(frames) / dt, "n_frames": len(frames), "seconds": dt,
            "resident_frames_per_s": len(frames) / res_dt,
+           "resident_pipelined_frames_per_s": len(frames) / pipe_dt,
+           "resident_pipelined_equals_resident": bool(np.array_equal(pipe_poses, res_poses)),
            "resident_vs_array_path": float(max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(res_poses, poses))),
            "class_api_frames_per_s": len(frames) / api_dt,
            "class_api_vs_array_path": float(max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(api_poses, poses))),
