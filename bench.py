@@ -127,7 +127,15 @@ def frames_leg(ctx, cpu=True):
         from visual_slam_amd.harness import ICL_DIR
         _, gt = dataset.read_trajectory(os.path.join(ICL_DIR, "traj3.gt.freiburg.head20"))
         ate = dataset.ate_rmse(r["poses"], gt)
-        out["driver"] = {"frames_per_s": len(frames) / best, "keyframes": r["keyframes"], "map_points": r["n_points"],
+        slam.run_sequence(frames[:7], depth0, ICL_NUIM_K, be, keyframe_gap=4, resident_ctx=ctx)
+        best_res = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=4, resident_ctx=ctx)
+            dt = time.perf_counter() - t0
+            best_res = dt if best_res is None or dt < best_res else best_res
+        out["driver"] = {"frames_per_s": len(frames) / best, "resident_frames_per_s": len(frames) / best_res,
+                         "keyframes": r["keyframes"], "map_points": r["n_points"],
                          "ate_rmse_m": ate["rmse"], "gt_path_length_m": ate["path_length"],
                          "note": "visual_slam_amd/slam.py: main.py:150-348 control flow, key frame every 5th frame, "
                                  "init from depth of frame 0"}

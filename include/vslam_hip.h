@@ -165,7 +165,8 @@ int vs_recover_pose(vs_ctx* ctx, const double* E, const double* x1, const double
  * train, Lowe ratio) -> PnP-RANSAC from the previous pose -> append the observations -> motion-only BA over all poses of
  * the period (LocalBA.py:195-229 re-optimises all of them every frame), without the host rebuilding or re-uploading the
  * period's observations.  Same kernels and arithmetic as vs_detect_describe_bgr / vs_match_ratio / vs_pnp_ransac /
- * vs_ba_solve.  poses_out: [n_frames+1][16] camera-to-world, pose 0 = the key frame.  Optional outputs may be NULL. */
+ * vs_ba_solve.  poses_out: [n_frames+1][16] camera-to-world, pose 0 = the key frame; *pnp_found = number of inliers of the
+ * PnP model (0: none found, the previous pose was the start).  Optional outputs may be NULL. */
 int vs_track_begin(vs_ctx* ctx, const double* xyz /*[n][3]*/, const uint8_t* desc /*[n][32]*/, int n_points,
                    const double* key_pose /*4x4*/, double fx, double fy, double cx, double cy, int max_frames, int max_kp,
                    int pnp_iterations /*0: start BA from the previous pose*/);

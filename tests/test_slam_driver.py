@@ -70,6 +70,22 @@ def test_driver_gpu_equals_oracle(vs, oracle):
     assert np.abs(pg - pc).max() < 1e-5, np.abs(pg - pc).max()
 
 
+@pytest.mark.gpu
+def test_driver_with_the_resident_tracking_period_equals_the_class_api_driver(vs):
+    """run_sequence(resident_ctx=...): the frames between key frames go through vs_track_frame, key frames through the
+    class API - same decisions, same map, same trajectory."""
+    frames, depth0 = harness.load_sequence(20)
+    a = slam.run_sequence(frames, depth0, ICL_NUIM_K, slam.Backends(context=vs), keyframe_gap=4, min_tracked=80)
+    b = slam.run_sequence(frames, depth0, ICL_NUIM_K, slam.Backends(context=vs), keyframe_gap=4, min_tracked=80,
+                          resident_ctx=vs)
+    assert a["keyframes"] == b["keyframes"] and a["tracked"] == b["tracked"] and a["n_points"] == b["n_points"]
+    assert a["pnp_inliers"] == b["pnp_inliers"]
+    assert max(np.linalg.norm(x - y) / np.linalg.norm(y) for x, y in zip(a["poses"], b["poses"])) < 1e-7
+    pa = np.array([p.location_3d for p in a["map"].points_3d.values()])
+    pb = np.array([p.location_3d for p in b["map"].points_3d.values()])
+    assert np.abs(pa - pb).max() < 1e-5    # low-parallax points amplify pose differences of ~1e-9 (see above)
+
+
 def _two_view(be):
     """main.py:78-148 on the two committed frames with enough parallax (ICL-NUIM traj3 images 0 and 150, ~0.45 m and 33
     degrees apart; consecutive frames are millimetres apart and cannot initialise, as in the reference)."""

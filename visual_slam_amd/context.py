@@ -228,7 +228,7 @@ class Context:
             ptr(t["xy"], c_f32p) if want_keypoints else None, ptr(t["desc"], c_u8p) if want_keypoints else None,
             C.byref(nk), ptr(t["mq"], c_i32p) if want_matches else None, ptr(t["mt"], c_i32p) if want_matches else None))
         out = dict(poses=t["poses"][:npo.value].reshape(-1, 4, 4).copy(), n_matches=nm.value, pnp_found=bool(found.value),
-                   n_keypoints=nk.value)
+                   pnp_inliers=found.value, n_keypoints=nk.value)
         if want_matches:
             out["match_q"], out["match_t"] = t["mq"][:nm.value].copy(), t["mt"][:nm.value].copy()
         if want_keypoints:
@@ -258,7 +258,7 @@ class Context:
         if not has.value:
             return None
         out = dict(poses=t["poses"][:npo.value].reshape(-1, 4, 4).copy(), n_matches=nm.value, pnp_found=bool(found.value),
-                   n_keypoints=nk.value)
+                   pnp_inliers=found.value, n_keypoints=nk.value)
         if want_matches:
             out["match_q"], out["match_t"] = t["mq"][:nm.value].copy(), t["mt"][:nm.value].copy()
         if want_keypoints:

@@ -313,7 +313,7 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   *n_poses_out = k + 1;
   *n_matches = M;
   if (n_kp_out) *n_kp_out = n_kp;
-  if (pnp_found) *pnp_found = T.pnp_iters > 0 && rb_res[16] != 0.0;
+  if (pnp_found) *pnp_found = T.pnp_iters > 0 && rb_res[16] != 0.0 ? (int)rb_res[17] : 0;  // inliers of the PnP model
   return VS_OK;
 }
 

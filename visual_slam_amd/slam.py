@@ -105,8 +105,10 @@ def two_view_init(frames, K, camera, be, map, min_matches=100, min_valid=0.9, lo
 
 
 def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, max_depth=1.0, log=None,
-                 pnp_guess="w2c", init="depth"):
+                 pnp_guess="w2c", init="depth", resident_ctx=None):
     """frames: list of BGR images; depth0: metric depth of frames[0]; K4 = (fx, fy, cx, cy).
+    resident_ctx: a Context -> the frames between two key frames run on the device-resident tracking period
+    (Context.track_begin / track_frame: main.py:181-214 as one call); key-frame insertion stays on the class API.
     Returns dict(poses [n,4,4] camera-to-world, keyframes [indices], n_points, map, tracked [per frame])."""
     fx, fy, cx, cy = K4
     K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
@@ -149,42 +151,68 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             all_poses[k] = np.array(map.GetFrame(1).GetPose(), dtype=np.float64)
         keyframes.append(start - 1)
     # ---- tracking loop (main.py:173-348)
+    resident = resident_ctx is not None
+
+    def open_period():
+        """resident mode: the local map of the new period (the last key frame's points) goes to the device once"""
+        _, ft, xyz, ids = local_map.GetImagePointsWithFrameID(last_keyframe.GetID())
+        resident_ctx.track_begin(xyz, ft, last_keyframe.GetPose(), K4, max_frames=max(len(frames), 1),
+                                 pnp_iterations=100 if pnp_guess is not None else 0)
+        return ids, len(xyz)
+
+    if resident:
+        point_IDs, n_known = open_period()
     for i in range(start, len(frames)):
         cur_frame = Frame(frames[i], None, id_frame_local)
-        kp_cur, features_cur, _ = cur_frame.process_frame(be.extractor)
-        kp_prev, features_prev, known_3d, point_IDs = local_map.GetImagePointsWithFrameID(last_keyframe.GetID())
-        matches, _, _, curMatchedPoints, curMatchedFeatures = be.matcher.match_features(kp_prev, features_prev, kp_cur,
-                                                                                         features_cur)
-        known_3d_matched_ids = [point_IDs[m[0].queryIdx] for m in matches]
-        known_3d_matched = np.array([known_3d[m[0].queryIdx] for m in matches]).reshape(-1, 3)
-        # pose from PnP-RANSAC with the previous frame as extrinsic guess (main.py:191-204)
-        W_T_prev = np.array(local_map.GetFrame(id_frame_local - 1).GetPose(), dtype=np.float64)
-        W_T_curr = W_T_prev.copy()
-        if pnp_guess is not None and len(known_3d_matched) >= 5:
-            guess = W_T_prev if pnp_guess == "reference" else _inv(W_T_prev)
-            retval, rvec, tvec, inl = be.pnp(known_3d_matched, curMatchedPoints, K, hf.Rtorvec(guess[:3, :3]),
-                                             np.array(guess[:3, 3]), seed=i)
-            if retval:
-                T = hf.transformMatrix(rvec, tvec)
-                W_T_curr = np.asarray(_inv(np.asarray(T)))
-            pnp_inliers.append(len(inl))
+        if resident:
+            # main.py:181-214 as one call on the device-resident period (vs_track_frame)
+            r = resident_ctx.track_frame(frames[i], seed=i, want_keypoints=True, want_matches=True)
+            cur_frame.keypoints, cur_frame.features = r["xy"], r["desc"]
+            known_3d_matched_ids = [point_IDs[q] for q in r["match_q"]]
+            curMatchedPoints, curMatchedFeatures = r["xy"][r["match_t"]], r["desc"][r["match_t"]]
+            W_T_cur = r["poses"][-1]
+            pnp_inliers.append(r["pnp_inliers"])
         else:
-            pnp_inliers.append(0)
-        RelativePoseTransformation = _inv(W_T_prev) @ W_T_curr
-        local_map.AddParentAndPose(parent_id=id_frame_local - 1, frame_id=id_frame_local, frame_obj=cur_frame,
-                                   rel_pose_trans=RelativePoseTransformation, pose=W_T_curr)
-        local_map.AddPointToFrameCorrespondences(point_ids=known_3d_matched_ids, image_points=curMatchedPoints,
-                                                 descriptors=curMatchedFeatures, frame_obj=cur_frame)
-        be.ba(camera).motionOnlyBundleAdjustement(local_map, scale=False, save=True)
-        all_poses[i] = np.array(local_map.GetFrame(id_frame_local).GetPose())
+            kp_cur, features_cur, _ = cur_frame.process_frame(be.extractor)
+            kp_prev, features_prev, known_3d, point_IDs = local_map.GetImagePointsWithFrameID(last_keyframe.GetID())
+            n_known = len(known_3d)
+            matches, _, _, curMatchedPoints, curMatchedFeatures = be.matcher.match_features(kp_prev, features_prev, kp_cur,
+                                                                                             features_cur)
+            known_3d_matched_ids = [point_IDs[m[0].queryIdx] for m in matches]
+            known_3d_matched = np.array([known_3d[m[0].queryIdx] for m in matches]).reshape(-1, 3)
+            # pose from PnP-RANSAC with the previous frame as extrinsic guess (main.py:191-204)
+            W_T_prev = np.array(local_map.GetFrame(id_frame_local - 1).GetPose(), dtype=np.float64)
+            W_T_curr = W_T_prev.copy()
+            if pnp_guess is not None and len(known_3d_matched) >= 5:
+                guess = W_T_prev if pnp_guess == "reference" else _inv(W_T_prev)
+                retval, rvec, tvec, inl = be.pnp(known_3d_matched, curMatchedPoints, K, hf.Rtorvec(guess[:3, :3]),
+                                                 np.array(guess[:3, 3]), seed=i)
+                if retval:
+                    T = hf.transformMatrix(rvec, tvec)
+                    W_T_curr = np.asarray(_inv(np.asarray(T)))
+                pnp_inliers.append(len(inl))
+            else:
+                pnp_inliers.append(0)
+            RelativePoseTransformation = _inv(W_T_prev) @ W_T_curr
+            local_map.AddParentAndPose(parent_id=id_frame_local - 1, frame_id=id_frame_local, frame_obj=cur_frame,
+                                       rel_pose_trans=RelativePoseTransformation, pose=W_T_curr)
+            local_map.AddPointToFrameCorrespondences(point_ids=known_3d_matched_ids, image_points=curMatchedPoints,
+                                                     descriptors=curMatchedFeatures, frame_obj=cur_frame)
+            be.ba(camera).motionOnlyBundleAdjustement(local_map, scale=False, save=True)
+            W_T_cur = np.array(local_map.GetFrame(id_frame_local).GetPose())
+        all_poses[i] = np.array(W_T_cur)
         tracked.append(len(curMatchedPoints))
         # key-frame rule (main.py:221)
         if (i - loop_idx > keyframe_gap or len(curMatchedPoints) < min_tracked) and (
-                len(curMatchedPoints) < 0.9 * len(known_3d)):
+                len(curMatchedPoints) < 0.9 * n_known):
             loop_idx = i
             cur_frame.SetAsKeyFrame()
             W_T_prev_key = map.GetFrame(id_frame - 1).GetPose()
-            W_T_cur_key = local_map.GetFrame(id_frame_local).GetPose()
+            W_T_cur_key = W_T_cur
+            if resident:
+                resident_ctx.track_end()
+                cur_frame.AddPose(W_T_cur_key)
+                cur_frame.AddID(id_frame)
             cur_frame.ClearParent()
             map.AddParentAndPose(parent_id=id_frame - 1, frame_id=id_frame, frame_obj=cur_frame,
                                  rel_pose_trans=_inv(W_T_prev_key) @ W_T_cur_key, pose=W_T_cur_key)
@@ -235,8 +263,12 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             id_frame += 1
             id_frame_local = id_frame
             local_map.Store3DPoints(map.GetCopyOfPointObjects(last_keyframe.GetID()))
+            if resident:
+                point_IDs, n_known = open_period()
         else:
             id_frame_local += 1
+    if resident:
+        resident_ctx.track_end()
     poses = np.stack([all_poses[i] for i in range(len(frames))])
     return dict(poses=poses, keyframes=keyframes, n_points=len(map.points_3d), map=map, tracked=tracked,
                 pnp_inliers=pnp_inliers)
