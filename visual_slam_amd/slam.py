@@ -138,10 +138,12 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             map.AddPoint3D(point_id=id_point, point_3d=pt_object)
             id_point += 1
         id_frame += 1
+    resident = resident_ctx is not None
     last_keyframe = copy.copy(map.GetFrame(frame_id=id_frame - 1))  # main.py:153
     local_map = Map()
     local_map.AddFrame(last_keyframe.GetID(), last_keyframe)
-    local_map.Store3DPoints(map.GetCopyOfPointObjects(last_keyframe.GetID()))
+    if not resident:  # the resident period reads the key frame's points straight from the global map (it never edits them)
+        local_map.Store3DPoints(map.GetCopyOfPointObjects(last_keyframe.GetID()))
     id_frame_local = id_frame
     loop_idx = start - 1
     all_poses = {0: np.array(map.GetFrame(0).GetPose(), dtype=np.float64)}
@@ -151,11 +153,9 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             all_poses[k] = np.array(map.GetFrame(1).GetPose(), dtype=np.float64)
         keyframes.append(start - 1)
     # ---- tracking loop (main.py:173-348)
-    resident = resident_ctx is not None
-
     def open_period():
         """resident mode: the local map of the new period (the last key frame's points) goes to the device once"""
-        _, ft, xyz, ids = local_map.GetImagePointsWithFrameID(last_keyframe.GetID())
+        _, ft, xyz, ids = map.GetImagePointsWithFrameID(last_keyframe.GetID())
         resident_ctx.track_begin(xyz, ft, last_keyframe.GetPose(), K4, max_frames=max(len(frames), 1),
                                  pnp_iterations=100 if pnp_guess is not None else 0)
         return ids, len(xyz)
@@ -262,9 +262,10 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             local_map.AddFrame(last_keyframe.GetID(), last_keyframe)
             id_frame += 1
             id_frame_local = id_frame
-            local_map.Store3DPoints(map.GetCopyOfPointObjects(last_keyframe.GetID()))
             if resident:
                 point_IDs, n_known = open_period()
+            else:
+                local_map.Store3DPoints(map.GetCopyOfPointObjects(last_keyframe.GetID()))
         else:
             id_frame_local += 1
     if resident:
