@@ -665,24 +665,32 @@ __global__ __launch_bounds__(256) void ba_schur_tile(ba_dev D) {
   }
 }
 
-// S = Hpp + lambda I - sum_s slab_s ; bs = bp - sum_s bslab_s
+// S = Hpp + lambda I - sum_s slab_s ; bs = bp - sum_s bslab_s.  Workgroup = 64 elements x 4 slab groups: group g sums the
+// slabs g, g+4, ... (loads batched by 8), the four partial sums are added in group order - fixed order, deterministic.
 __global__ __launch_bounds__(256) void ba_reduce(ba_dev D) {
+  __shared__ double s_part[4][64];
   const lm_state st = *D.st;
   if (st.done) return;
   const int np = D.np;
   const int slab_elems = np * np + np;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= slab_elems) return;
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e;
   double acc = 0.0;
-  int s = 0;
-  for (; s + 8 <= D.ns; s += 8) {
-    double v[8];
+  if (i < slab_elems) {
+    int s = g;
+    for (; s + 28 < D.ns; s += 32) {
+      double v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = D.slab[(size_t)(s + u) * slab_elems + i];
+      for (int u = 0; u < 8; ++u) v[u] = D.slab[(size_t)(s + 4 * u) * slab_elems + i];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc += v[u];
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < D.ns; s += 4) acc += D.slab[(size_t)s * slab_elems + i];
   }
-  for (; s < D.ns; ++s) acc += D.slab[(size_t)s * slab_elems + i];
+  s_part[g][e] = acc;
+  __syncthreads();
+  if (g != 0 || i >= slab_elems) return;
+  acc = ((s_part[0][e] + s_part[1][e]) + s_part[2][e]) + s_part[3][e];
   if (i < np * np) {
     const int r = i / np, c = i - r * np;
     double v = D.Hpp[i];
@@ -1939,7 +1947,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       VS_LAUNCH_CHECK(ctx, "ba_schur");
     }
     if (np > 0) {
-      hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 255) / 256)), dim3(256), 0, s, D);
+      hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 63) / 64)), dim3(256), 0, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_reduce");
     }
     if (solve_lds) {
