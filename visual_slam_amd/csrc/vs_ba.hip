@@ -38,7 +38,9 @@ using namespace vsba;
 
 namespace {
 
-constexpr int kPtThreads = 128; // threads per point block
+constexpr int kPtThreads = 256; // threads per point block
+constexpr int kPtLanes = 8;     // lanes that share one point's observations (linearisation and trial)
+constexpr int kPtPerBlock = kPtThreads / kPtLanes;
 constexpr int kCamThreads = 256;
 constexpr int kSchurThreads = 256;
 constexpr int kSolveThreads = 512;
@@ -164,6 +166,22 @@ __device__ inline double block_reduce_max(double v, double* s_red) {
   return s_red[0];
 }
 
+// sum / max of the per-block partials by one wave: lane l takes entries l, l + 64, ... in order, then an xor-butterfly
+__device__ inline double wave_sum_partials(const double* v, int n) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) a += v[i];
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) a += __shfl_xor(a, d);
+  return a;
+}
+__device__ inline double wave_max_partials(const double* v, int n) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) a = fmax(a, v[i]);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) a = fmax(a, __shfl_xor(a, d));
+  return a;
+}
+
 // ------------------------------------------------------------------------------------------------ linearize
 __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
   __shared__ double s_red[kCamThreads];
@@ -174,15 +192,16 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
   const double* pts = D.pts[st.cur];
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < D.nb_pt) {
-    // ---- point role (kPtThreads active threads)
-    const int a = blockIdx.x * kPtThreads + tid;
+    // ---- point role: kPtLanes lanes share a point, lane s takes its observations s, s + kPtLanes, ...; the 3x3 block
+    // and the right-hand side are summed over the lanes with xor-shuffles (every lane ends with the same bits)
+    const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;
     double chi = 0.0, maxd = 0.0;
-    if (tid < kPtThreads && a < D.n_act) {
+    if (a < D.n_act) {
       const int p = D.act_pt[a];
       const int ls = D.pt_slot[p];
       const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
       double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-      for (int o = D.pt_start[a]; o < D.pt_start[a + 1]; ++o) {
+      for (int o = D.pt_start[a] + sub; o < D.pt_start[a + 1]; o += kPtLanes) {
         const int ci = D.o_cam[o];
         const int cs = D.pose_slot[ci];
         edge_t E;
@@ -213,12 +232,21 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
           }
         }
       }
-      if (ls >= 0) {
+      if (ls >= 0) {  // uniform inside the lane group
 #pragma unroll
-        for (int k = 0; k < 9; ++k) D.Hll[9 * (size_t)ls + k] = H[k];
+        for (int d = 1; d < kPtLanes; d <<= 1) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) D.bl[3 * (size_t)ls + k] = b[k];
-        maxd = fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8])));
+          for (int k = 0; k < 9; ++k) H[k] += __shfl_xor(H[k], d);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) b[k] += __shfl_xor(b[k], d);
+        }
+        if (sub == 0) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) D.Hll[9 * (size_t)ls + k] = H[k];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) D.bl[3 * (size_t)ls + k] = b[k];
+          maxd = fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8])));
+        }
       }
     }
     const double csum = block_reduce_sum<kCamThreads>(chi, s_red);
@@ -356,13 +384,13 @@ __device__ inline double scale_edges_chi(const ba_dev& D, const double* cams) {
   return chi;
 }
 
-__global__ void ba_lambda_init(ba_dev D) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void ba_lambda_init(ba_dev D) {
   lm_state* st = D.st;
-  double chi = 0.0, mx = 0.0;
-  for (int i = 0; i < D.nb_pt; ++i) chi += D.part_chi[i];
+  if (blockIdx.x != 0) return;
+  double chi = wave_sum_partials(D.part_chi, D.nb_pt);
+  const double mx = wave_max_partials(D.part_maxd, D.nb_pt + D.nfp);
+  if (threadIdx.x != 0) return;
   chi += scale_edges_chi(D, D.cam[st->cur]);
-  for (int i = 0; i < D.nb_pt + D.nfp; ++i) mx = fmax(mx, D.part_maxd[i]);
   st->current_chi = chi;
   st->chi0 = chi;
   st->lambda = 1e-5 * mx;
@@ -1160,7 +1188,7 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
   const lm_state st = *D.st;
   if (st.done) return;
   const int tid = threadIdx.x;
-  const int a = blockIdx.x * kPtThreads + tid;
+  const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;  // kPtLanes lanes per point, as above
   double chi = 0.0, sc = 0.0;
   if (st.solve_ok && a < D.n_act) {
     const double* cams1 = D.cam[st.cur ^ 1];
@@ -1171,8 +1199,9 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
     double X[3] = {pts0[3 * (size_t)p], pts0[3 * (size_t)p + 1], pts0[3 * (size_t)p + 2]};
     const int o0 = D.pt_start[a], o1 = D.pt_start[a + 1];
     if (ls >= 0) {
-      double cl[3] = {D.bl[3 * (size_t)ls], D.bl[3 * (size_t)ls + 1], D.bl[3 * (size_t)ls + 2]};
-      for (int o = o0; o < o1; ++o) {
+      // back substitution: cl = bl - sum_i Hpl_i^T dx_cam(i); the sum is split over the lanes and shuffle-reduced
+      double part[3] = {0.0, 0.0, 0.0};
+      for (int o = o0 + sub; o < o1; o += kPtLanes) {
         const int cs = D.pose_slot[D.o_cam[o]];
         if (cs < 0) continue;
         const double* B = D.Hpl + 18 * (size_t)D.o_hpl[o];
@@ -1180,19 +1209,26 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
-          for (int k = 0; k < 6; ++k) cl[b] -= B[3 * k + b] * xc[k];
+          for (int k = 0; k < 6; ++k) part[b] += B[3 * k + b] * xc[k];
       }
+#pragma unroll
+      for (int d = 1; d < kPtLanes; d <<= 1)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) part[b] += __shfl_xor(part[b], d);
+      const double cl[3] = {D.bl[3 * (size_t)ls] - part[0], D.bl[3 * (size_t)ls + 1] - part[1], D.bl[3 * (size_t)ls + 2] - part[2]};
       const double* Di = D.Dinv + 9 * (size_t)ls;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const double xl = Di[3 * k] * cl[0] + Di[3 * k + 1] * cl[1] + Di[3 * k + 2] * cl[2];
-        sc += xl * (st.lambda * xl + D.bl[3 * (size_t)ls + k]);
+        if (sub == 0) sc += xl * (st.lambda * xl + D.bl[3 * (size_t)ls + k]);
         X[k] += xl;
       }
     }
+    if (sub == 0) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) pts1[3 * (size_t)p + k] = X[k];
-    for (int o = o0; o < o1; ++o) {
+      for (int k = 0; k < 3; ++k) pts1[3 * (size_t)p + k] = X[k];
+    }
+    for (int o = o0 + sub; o < o1; o += kPtLanes) {
       edge_t E;
       eval_edge<false>(D, cams1 + (size_t)D.o_cam[o] * kCamStride, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
       chi += E.rho0;
@@ -1207,16 +1243,15 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
 }
 
 // OptimizationAlgorithmLevenberg::solve's accept/reject logic and SparseOptimizer::optimize's loop control
-__global__ void ba_decide(ba_dev D) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void ba_decide(ba_dev D) {
   lm_state* st = D.st;
-  if (st->done) return;
+  if (blockIdx.x != 0 || st->done) return;
+  const double psum = wave_sum_partials(D.part_chi, D.nb_pt), ssum = wave_sum_partials(D.part_scale, D.nb_pt);
+  if (threadIdx.x != 0) return;
   double temp = 0.0, scale = st->scale_pose;
   if (st->solve_ok) {
-    for (int i = 0; i < D.nb_pt; ++i) {
-      temp += D.part_chi[i];
-      scale += D.part_scale[i];
-    }
+    temp = psum;
+    scale += ssum;
     temp += scale_edges_chi(D, D.cam[st->cur ^ 1]);
   } else {
     temp = 1.7976931348623157e308;
@@ -1714,7 +1749,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   res->chi2_initial = res->chi2_final = res->lambda_final = 0.0;
 
   // ---- launch geometry
-  const int nb_pt = std::max(1, (n_act + kPtThreads - 1) / kPtThreads);
+  const int nb_pt = std::max(1, (n_act + kPtPerBlock - 1) / kPtPerBlock);
   int ns = nfl > 0 && nfp > 0 ? std::min(256, (nfl + 7) / 8) : 0;
   const bool lds_slab = np <= kMaxSlabN;
   if (tiled) ns = std::max(4, std::min(256, (16384 + ntile * ntile - 1) / (ntile * ntile)));  // >= 16k workgroups: most tiles are empty
