@@ -925,14 +925,33 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
     }
     __syncthreads();
   }
-  // backward substitution on wave 0: x lives in row n
+  // backward substitution L^T x = y on wave 0, by 6x6 blocks from the bottom: lane 0 solves the block's triangular
+  // system in registers (descending k, as the element-wise recurrence does), then the lanes subtract the block's
+  // contribution from the rows above -- nb dependent steps instead of n.  x lives in row n.
   double* x = A + n * ld;
   if (ok && tid < 64) {
-    for (int k = n - 1; k >= 0; --k) {
-      const double xk = x[k] * rinv[k];
-      wave_lds_sync();  // every lane has read x[k] before lane 0 overwrites it
-      if (tid == 0) x[k] = xk;
-      for (int i = tid; i < k; i += 64) x[i] -= A[k * ld + i] * xk;
+    for (int J = nb - 1; J >= 0; --J) {
+      const int j0 = 6 * J;
+      if (tid == 0) {
+        double xb[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) xb[k] = x[j0 + k];
+#pragma unroll
+        for (int k = 5; k >= 0; --k) {
+          xb[k] = xb[k] * rinv[j0 + k];
+#pragma unroll
+          for (int i = 0; i < k; ++i) xb[i] -= A[(j0 + k) * ld + j0 + i] * xb[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) x[j0 + k] = xb[k];
+      }
+      wave_lds_sync();
+      for (int i = tid; i < j0; i += 64) {
+        double v = x[i];
+#pragma unroll
+        for (int k = 5; k >= 0; --k) v -= A[(j0 + k) * ld + i] * x[j0 + k];
+        x[i] = v;
+      }
       wave_lds_sync();
     }
   }
