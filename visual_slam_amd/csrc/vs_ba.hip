@@ -41,7 +41,7 @@ namespace {
 constexpr int kPtThreads = 256; // threads per point block
 constexpr int kPtLanes = 8;     // lanes that share one point's observations (linearisation and trial)
 constexpr int kPtPerBlock = kPtThreads / kPtLanes;
-constexpr int kCamThreads = 256;
+constexpr int kCamThreads = 512;  // ba_linearize: a camera's observations are spread over this many threads
 constexpr int kSchurThreads = 256;
 constexpr int kSolveThreads = 512;
 constexpr int kMaxLdsN = 126;   // reduced systems up to 126 x 126 (21 free cameras) are factorised in LDS by one wave
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
     // and the right-hand side are summed over the lanes with xor-shuffles (every lane ends with the same bits)
     const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;
     double chi = 0.0, maxd = 0.0;
-    if (a < D.n_act) {
+    if (tid < kPtThreads && a < D.n_act) {  // the point role uses the first kPtThreads threads of the workgroup
       const int p = D.act_pt[a];
       const int ls = D.pt_slot[p];
       const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
