@@ -839,16 +839,24 @@ constexpr int kSolveBlock = 256;
 __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   lm_state* st = D.st;
-  if (st->done) return;
+  // the state, the system and everything the epilogue needs are requested together (one round trip); a finished solve
+  // pays for the unused loads, which is rare and cheap
+  const int done = st->done, cur = st->cur;
+  const double lambda = st->lambda;
   const int n = D.np, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int ld = (n + 1) | 1;
   double* A = s_mem;                        // (n + 1) rows of ld: rows 0..n-1 matrix, row n = rhs
   double* rinv = s_mem + (size_t)(n + 1) * ld;  // [n]
-  int* s_flag = reinterpret_cast<int*>(rinv + n + 1);
+  double* s_bp = rinv + n + 1;              // [n] right-hand side before the Schur complement (gain denominator)
+  int* s_flag = reinterpret_cast<int*>(s_bp + n + 1);
   for (int r = ty; r < n; r += 16)
     for (int c = tx; c < n; c += 16) A[r * ld + c] = D.S[(size_t)r * n + c];
-  for (int c = tid; c < n; c += kSolveBlock) A[n * ld + c] = D.bs[c];
+  for (int c = tid; c < n; c += kSolveBlock) {
+    A[n * ld + c] = D.bs[c];
+    s_bp[c] = D.bp[c];
+  }
   if (tid == 0) *s_flag = 0;
+  if (done) return;  // uniform
   __syncthreads();
   // ---- blocked right-looking Cholesky on the 6x6 camera blocks (n = 6 * nb); row n carries the right-hand side
   int ok = 1;
@@ -959,7 +967,6 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   if (ok)
     for (int i = tid; i < n; i += kSolveBlock) D.xp[i] = x[i];
   // trial camera states into the other buffer (SBACam::update), fixed cameras copied
-  const int cur = st->cur;
   const double* c0 = D.cam[cur];
   double* c1 = D.cam[cur ^ 1];
   for (int p = tid; p < D.n_poses; p += kSolveBlock) {
@@ -988,7 +995,7 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   if (tid == 0) {
     double sc = 0.0;
     if (ok)
-      for (int j = 0; j < n; ++j) sc += x[j] * (st->lambda * x[j] + D.bp[j]);
+      for (int j = 0; j < n; ++j) sc += x[j] * (lambda * x[j] + s_bp[j]);
     st->scale_pose = sc;
     st->solve_ok = ok;
     st->trials += 1;
@@ -1953,7 +1960,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   const int schur_per = ns > 0 ? (nfl + ns - 1) / ns : 0;
   const size_t schur_lds = sizeof(double) * ((lds_slab ? slab_elems : 0) + 12 * (size_t)schur_per + 36 * (size_t)mmax) + sizeof(int) * ((size_t)mmax + 1) + 16;
   const bool solve_lds = np <= kMaxLdsN;
-  const size_t solve_lds_bytes = 32 + (solve_lds ? sizeof(double) * ((size_t)(np + 1) * ((np + 1) | 1) + np + 2) : 0);
+  const size_t solve_lds_bytes = 32 + (solve_lds ? sizeof(double) * ((size_t)(np + 1) * ((np + 1) | 1) + 2 * (size_t)np + 4) : 0);
   const size_t tile_lds = sizeof(double) * (2 * kTileBatch * 12 + 2 * kTileBatch * kTileCams * 18) +
                           sizeof(int) * (3 * kTileBatch * 32 + 3 * kTileChunk + 8) + 64;
   if (tiled) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
