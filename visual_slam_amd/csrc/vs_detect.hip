@@ -81,13 +81,18 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // ------------------------------------------------------------------------------------------------- detect
 // LDS carve (dynamic): gray[(kBand+2*kHalo)][P] u8 | score[(kBand+2)][w4] u8 | hsum[(kBand+4)][w4] u16 | ballots u64[nseg]
 // | segoff int[nseg]
+// i / d for 0 <= i < 2^20 with magic = ceil(2^32 / d): one v_mul_hi_u32 instead of the ~40-instruction runtime division
+__device__ __forceinline__ int fast_div(int i, uint32_t magic) { return (int)__umulhi((uint32_t)i, magic); }
+__host__ inline uint32_t div_magic(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
+
 template <bool FROM_BGR, bool DO_BOX, bool WRITE_GRAY>
 __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t* __restrict__ img, int pitch, int w,
                                                                    int h, int thr, int border,
                                                                    uint8_t* __restrict__ gray_out,
                                                                    uint16_t* __restrict__ box_out,
                                                                    uint32_t* __restrict__ raw, int band_cap,
-                                                                   int* __restrict__ bandcnt) {
+                                                                   int* __restrict__ bandcnt, uint32_t magic_w,
+                                                                   uint32_t magic_w4, uint32_t magic_gpr) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int w4 = (w + 3) & ~3;
   const int P = w4;
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
       lds_off[u] = -1;
       d[u][0] = d[u][1] = d[u][2] = 0;
       if (g < ngroups) {
-        const int r = g / groups_per_row, x = (g - r * groups_per_row) << 2;
+        const int r = fast_div(g, magic_gpr), x = (g - r * groups_per_row) << 2;
         const int y = y0 - kHalo + r;
         lds_off[u] = r * P + x;
         if (y >= 0 && y < h) {
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
         packed = d[u][0];
       }
       if (WRITE_GRAY) {
-        const int r = lds_off[u] / P, x = lds_off[u] - r * P;
+        const int r = fast_div(lds_off[u], magic_w4), x = lds_off[u] - r * P;
         const int y = y0 - kHalo + r;
         if (r >= kHalo && r < kHalo + kBand && y < h) {  // interior rows are written exactly once
 #pragma unroll
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
   // ---- 2. 5x5 box sums of the band rows (separable: horizontal 5-sums of rows y0-2..y0+kBand+1, then vertical)
   if (DO_BOX) {
     for (int i = tid; i < (kBand + 4) * w; i += kDetThreads) {
-      const int r = i / w, x = i - r * w;  // r = 0 is image row y0 - 2 = tile row kHalo - 2
+      const int r = fast_div(i, magic_w), x = i - r * w;  // r = 0 is image row y0 - 2 = tile row kHalo - 2
       int s = 0;
       if (x >= 2 && x < w - 2) {
         const uint8_t* g = s_gray + (r + kHalo - 2) * P + x;
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
     }
     __syncthreads();
     for (int i = tid; i < kBand * w; i += kDetThreads) {
-      const int r = i / w, x = i - r * w;
+      const int r = fast_div(i, magic_w), x = i - r * w;
       const int y = y0 + r;
       if (y < h) {
         int s = 0;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
 
   // ---- 3. FAST-9 scores for rows y0-1 .. y0+kBand into LDS
   for (int i = tid; i < (kBand + 2) * w4; i += kDetThreads) {  // w4 % 64 may be != 0: lanes past w idle below
-    const int r = i / w4, x = i - r * w4;
+    const int r = fast_div(i, magic_w4), x = i - r * w4;
     const int y = y0 - 1 + r;
     int score = 0;
     bool cand = false;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
     const int p = seg * 64 + lane;
     bool keep = false;
     if (p < npx) {
-      const int r = p / w, x = p - r * w;
+      const int r = fast_div(p, magic_w), x = p - r * w;
       if (y0 + r < h) {
         const uint8_t* sp = s_score + (r + 1) * w4 + x;
         const int s = sp[0];
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
     const unsigned long long bal = s_ballot[seg];
     if ((bal >> lane) & 1ull) {
       const int p = seg * 64 + lane;
-      const int r = p / w, x = p - r * w;
+      const int r = fast_div(p, magic_w), x = p - r * w;
       const int pos = s_segoff[seg] + __popcll(bal & ((1ull << lane) - 1ull));
       const uint32_t s = s_score[(r + 1) * w4 + x];
       if (pos < band_cap) raw[(size_t)blockIdx.x * band_cap + pos] = ((uint32_t)(y0 + r) << 20) | ((uint32_t)x << 8) | s;
@@ -516,8 +521,9 @@ int launch_detect(vs_ctx* ctx, hipStream_t s, const uint8_t* d_img, int pitch, i
   auto fn = detect_band_kernel<FROM_BGR, DO_BOX, WRITE_GRAY>;
   if (lds > 64 * 1024)
     VS_HIP(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int w4 = (w + 3) & ~3;
   hipLaunchKernelGGL(fn, dim3(nbands), dim3(kDetThreads), lds, s, d_img, pitch, w, h, thr, border, d_gray, d_box, d_raw,
-                     band_cap, d_bandcnt);
+                     band_cap, d_bandcnt, div_magic(w), div_magic(w4), div_magic(w4 >> 2));
   VS_LAUNCH_CHECK(ctx, "detect_band_kernel");
   return VS_OK;
 }
