@@ -22,7 +22,7 @@ namespace {
 
 constexpr int kBand = 2;         // image rows per workgroup
 constexpr int kHalo = 4;         // 3 (circle radius) + 1 (NMS neighbour)
-constexpr int kDetThreads = 512; // 8 waves
+constexpr int kDetThreads = 1024; // 16 waves: 4 per SIMD hide the LDS latency of the box / score phases
 constexpr int kStageUnroll = 2; // staging groups per thread with their loads in flight together
 constexpr int kSelThreads = 256;
 constexpr int kMaxDim = 4096;    // x, y packed in 12 bits each
