@@ -11,20 +11,26 @@
 //  general problem (free points => Schur complement), one "slot" per LM trial, every kernel predicated on the
 //  device-resident LM state:
 //   ba_linearize      grid = point blocks + one block per free camera (one launch, two roles)
-//       point block : thread = point; loops its observations (CSR by point), accumulates Hll / bl in registers, writes
-//                     the 6x3 blocks Hpl (stored contiguously per free point), robust chi2 partial per block
-//       camera block: workgroup = free camera; threads stride over the camera's observation list, 27 register
+//       point block : 8 lanes share a point; each takes every 8th observation (CSR by point), Hll / bl are summed over
+//                     the lanes with xor-shuffles, the 6x3 blocks Hpl are stored contiguously per free point, robust
+//                     chi2 partial per block
+//       camera block: workgroup = free camera; 512 threads stride over the camera's observation list, 27 register
 //                     accumulators (Hpp upper 21 + bp 6), fixed-order LDS tree reduction; also the EdgeSBAScale terms
 //   ba_lambda_init    first slot only: chi2_0 and lambda_0 = 1e-5 * max diag(H)
-//   ba_schur          workgroup = slab of points; (Hll + lambda I)^-1 for the slab's points up front, then per point
-//                     Y_i = Hpl_i Dinv staged in LDS and every thread owns fixed elements of the 6x6 products Y_i Hpl_j^T,
-//                     accumulated into the workgroup's LDS slab of the reduced camera system (no float atomics)
-//   ba_reduce         S = Hpp + lambda I - sum of slabs, rhs likewise (one thread per matrix element)
-//   ba_solve_block    one workgroup: dense Cholesky of [S | rhs] in LDS (n <= 126; ba_solve<false> in HBM beyond), back-substitution,
-//                     trial camera states
-//   ba_point_trial    thread = point: back-substitution x_l = Dinv (bl - sum Hpl^T x_p), trial point, robust chi2 of the
-//                     trial state, fixed-order block reduction
-//   ba_decide         one thread: gain ratio, accept (flip the state buffer index) or reject, lambda update, stop rules
+//   ba_dinv           (Hll + lambda I)^-1 and its product with bl, thread = free point
+//   ba_schur_tile     workgroup = (slab of points, tile of 10 x 10 camera blocks); the tile is accumulated in registers:
+//                     wave w owns the row cameras w, w+4, w+8, lane (block row, column camera) owns 6 elements per row
+//                     camera -- fixed ownership, no atomics, no LDS read-modify-write; Hpl blocks staged 8 points per
+//                     barrier (ba_schur<LDS_SLAB> remains for duplicate observations of one camera: LDS atomics there)
+//   ba_reduce         S = Hpp + lambda I - sum of slabs, rhs likewise (four slab groups per element, fixed order)
+//   dense solve       n <= 126: ba_solve_block, one workgroup, [S | rhs] in LDS, blocked by the 6x6 camera blocks,
+//                     blocked back-substitution, trial camera states;  beyond: ba_chol_panel + ba_chol_update per block
+//                     column in HBM, then ba_chol_finish;  ba_solve<false> (element-wise, one workgroup) is the last
+//                     resort when even a 6-column panel does not fit in LDS
+//   ba_point_trial    8 lanes per point: back-substitution x_l = Dinv (bl - sum Hpl^T x_p) with the sum split over the
+//                     lanes, trial point, robust chi2 of the trial state, fixed-order block reduction
+//   ba_decide         one wave sums the block partials, one thread: gain ratio, accept (flip the state buffer index) or
+//                     reject, lambda update, stop rules
 //  motion-only problem (no free points, no scale edges => block diagonal): ba_motion_step, see below.
 // Trial states are written to the OTHER of two state buffers, so a rejected step needs no restore.
 #include "vs_ba_internal.h"
