@@ -1342,26 +1342,32 @@ __global__ __launch_bounds__(64) void ba_decide(ba_dev D) {
 // (mo_X / mo_uv / mo_info) so every load is coalesced and index-free.
 
 
-// sums 28 doubles per thread over the workgroup in a fixed order; result in s_out[0..27]
-__device__ inline void block_reduce28(double (&acc)[28], double (*s_all)[28], double* s_out, int tid) {
-  if (tid >= kMoThreads / 2) {
+// sums 28 doubles per thread over the workgroup in a fixed order; result in s_out[0..27].  Transposed through LDS: every
+// thread stores its 28 values, then (value k, group g) threads add the 32 rows of their group in row order and 28
+// threads add the 8 group sums in group order -- three barriers instead of the nine of a binary tree over 28-vectors.
+constexpr int kRedGroups = kMoThreads / 32;
+__device__ inline void block_reduce28(double (&acc)[28], double (*s_all)[29], double (*s_grp)[28], double* s_out, int tid) {
 #pragma unroll
-    for (int k = 0; k < 28; ++k) s_all[tid - kMoThreads / 2][k] = acc[k];
-  }
+  for (int k = 0; k < 28; ++k) s_all[tid][k] = acc[k];
   __syncthreads();
-  if (tid < kMoThreads / 2) {
-#pragma unroll
-    for (int k = 0; k < 28; ++k) s_all[tid][k] += acc[k];
-  }
-  __syncthreads();
-  for (int off = kMoThreads / 4; off > 0; off >>= 1) {
-    if (tid < off) {
-#pragma unroll
-      for (int k = 0; k < 28; ++k) s_all[tid][k] += s_all[tid + off][k];
+  {
+    // wave w handles the groups 2w and 2w+1 with its lanes 0..55 (value k = lane % 28)
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane < 56) {
+      const int k = lane % 28, g = 2 * wv + lane / 28;
+      double a = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) a += s_all[g * 32 + j][k];
+      s_grp[g][k] = a;
     }
-    __syncthreads();
   }
-  if (tid < 28) s_out[tid] = s_all[0][tid];
+  __syncthreads();
+  if (tid < 28) {
+    double a = s_grp[0][tid];
+#pragma unroll
+    for (int g = 1; g < kRedGroups; ++g) a += s_grp[g][tid];
+    s_out[tid] = a;
+  }
   __syncthreads();
 }
 
@@ -1369,7 +1375,8 @@ __device__ inline void block_reduce28(double (&acc)[28], double (*s_all)[28], do
 
 namespace vsba {
 __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step) {
-  __shared__ double s_all[kMoThreads / 2][28];
+  __shared__ double s_all[kMoThreads][29];
+  __shared__ double s_grp[kRedGroups][28];
   __shared__ double s_sum[28];
   __shared__ double s_part[3][kMoThreads];  // chi, scale / maxd, ok of up to 256 cameras (strided beyond)
   __shared__ mo_state s_st;
@@ -1526,7 +1533,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
       for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
       acc[27] += E.rho0;
     }
-    block_reduce28(acc, s_all, s_sum, tid);
+    block_reduce28(acc, s_all, s_grp, s_sum, tid);
     if (tid < 27) gH[tid] = s_sum[tid];  // upper triangle (21) + b (6), re-read by retries of this linearisation
     if (lin_only) {
       if (tid == 0) {
