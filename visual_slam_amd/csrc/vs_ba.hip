@@ -191,7 +191,8 @@ __device__ inline double wave_max_partials(const double* v, int n) {
 // ------------------------------------------------------------------------------------------------ linearize
 __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
   __shared__ double s_red[kCamThreads];
-  __shared__ double s_all[kCamThreads / 2][27];  // camera role: upper half of the first tree level lives in registers
+  __shared__ double s_all[kCamThreads / 2][27];  // camera role: upper half of the first level lives in registers
+  __shared__ double s_grp[kCamThreads / 64][27];
   const lm_state st = *D.st;
   if (st.done || !st.need_lin) return;
   const double* cams = D.cam[st.cur];
@@ -293,25 +294,37 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
   }
-  // fixed-order tree over the 256 threads, all 27 sums at once
-  if (tid >= kCamThreads / 2) {
+  // fixed-order reduction of the 27 sums: the upper half of the threads hands its values to the lower half through
+  // LDS, then the 256 rows are added by (value, group-of-32) threads in row order and the 8 group sums in group order
+  constexpr int kHalf = kCamThreads / 2, kGroups = kHalf / 32;
+  if (tid >= kHalf) {
 #pragma unroll
-    for (int k = 0; k < 27; ++k) s_all[tid - kCamThreads / 2][k] = acc[k];
+    for (int k = 0; k < 27; ++k) s_all[tid - kHalf][k] = acc[k];
   }
   __syncthreads();
-  if (tid < kCamThreads / 2) {
+  if (tid < kHalf) {
 #pragma unroll
     for (int k = 0; k < 27; ++k) s_all[tid][k] += acc[k];
   }
   __syncthreads();
-  for (int off = kCamThreads / 4; off > 0; off >>= 1) {
-    if (tid < off) {
-#pragma unroll
-      for (int k = 0; k < 27; ++k) s_all[tid][k] += s_all[tid + off][k];
+  {
+    const int lane = tid & 63, wv = tid >> 6;  // waves 0..kGroups-1: one group each, lanes 0..26 = the 27 values
+    if (wv < kGroups && lane < 27) {
+      double a2 = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) a2 += s_all[wv * 32 + j][lane];
+      s_grp[wv][lane] = a2;
     }
-    __syncthreads();
   }
-  const double* s_acc = s_all[0];
+  __syncthreads();
+  if (tid < 27) {
+    double a2 = s_grp[0][tid];
+#pragma unroll
+    for (int g = 1; g < kGroups; ++g) a2 += s_grp[g][tid];
+    s_grp[0][tid] = a2;
+  }
+  __syncthreads();
+  const double* s_acc = s_grp[0];
   // block row c of Hpp: zero, diagonal block, then the EdgeSBAScale terms of every scale edge touching this camera
   const int np = D.np;
   for (int i = tid; i < 6 * np; i += kCamThreads) D.Hpp[(size_t)(6 * c) * np + i] = 0.0;
