@@ -91,8 +91,42 @@ __device__ inline void cam_apply(const double* src, const double* x, double* dst
 
 // sum of v[0..NV) over the lanes of aligned groups of 2^STEPS lanes (butterfly: every lane of the group ends with the
 // same bits), then - for workgroups of several waves - over the waves through LDS in wave order
+// LDS scratch of the multi-wave reductions: rows of the transposed 28-vector reduction, group sums, totals
+constexpr int kPnpRedRows = kPnpFinish * 29, kPnpRedDoubles = kPnpRedRows + 8 * 28 + 32;
+
 template <int NV, int STEPS, int NWAVES>
 __device__ inline void pnp_reduce(double* v, double* s_red) {
+  if (NWAVES > 1 && NV == 28) {
+    // workgroup-wide sum of 28-vectors through a transposed LDS layout: every thread stores its row, (value, group of
+    // 32 rows) threads add their rows in row order, 28 threads add the group sums in group order, everybody reads the
+    // totals -- fixed order, and far fewer cross-lane operations than 28 butterflies per wave
+    constexpr int kGroups = NWAVES * 2;
+    double* rows = s_red;
+    double* grp = s_red + kPnpRedRows;
+    double* tot = grp + 8 * 28;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __syncthreads();  // previous readers of the scratch are done
+#pragma unroll
+    for (int k = 0; k < NV; ++k) rows[tid * 29 + k] = v[k];
+    __syncthreads();
+    if (lane < 56) {
+      const int k = lane % 28, g = 2 * wv + lane / 28;
+      double a = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) a += rows[(g * 32 + j) * 29 + k];
+      grp[g * 28 + k] = a;
+    }
+    __syncthreads();
+    if (tid < 28) {
+      double a = grp[tid];
+      for (int g = 1; g < kGroups; ++g) a += grp[g * 28 + tid];
+      tot[tid] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = tot[k];
+    return;
+  }
 #pragma unroll
   for (int d = 1; d < (1 << STEPS); d <<= 1) {
 #pragma unroll
@@ -325,7 +359,7 @@ __device__ inline int ransac_update_iters_dev(double p, double ep, int model_poi
 
 namespace vsba {
 __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
-  __shared__ double s_red[4 * 28];
+  __shared__ double s_red[kPnpRedDoubles];
   __shared__ int s_best[2], s_cnt[4], s_base;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   P.n = pnp_count(P);
