@@ -1355,18 +1355,26 @@ __global__ __launch_bounds__(64) void ba_decide(ba_dev D) {
 // (mo_X / mo_uv / mo_info) so every load is coalesced and index-free.
 
 
-// sums 28 doubles per thread over the workgroup in a fixed order; result in s_out[0..27].  Transposed through LDS: every
-// thread stores its 28 values, then (value k, group g) threads add the 32 rows of their group in row order and 28
-// threads add the 8 group sums in group order -- three barriers instead of the nine of a binary tree over 28-vectors.
-constexpr int kRedGroups = kMoThreads / 32;
+// sums 28 doubles per thread over the workgroup in a fixed order; result in s_out[0..27].  The upper half of the threads
+// hands its values to the lower half through LDS; the kMoRows rows are then transposed-reduced: (value k, group g)
+// threads add the 32 rows of their group in row order and 28 threads add the group sums in group order -- four barriers
+// instead of the ten of a binary tree over 28-vectors.
+constexpr int kMoRows = kMoThreads / 2, kRedGroups = kMoRows / 32;
 __device__ inline void block_reduce28(double (&acc)[28], double (*s_all)[29], double (*s_grp)[28], double* s_out, int tid) {
+  if (tid >= kMoRows) {
 #pragma unroll
-  for (int k = 0; k < 28; ++k) s_all[tid][k] = acc[k];
+    for (int k = 0; k < 28; ++k) s_all[tid - kMoRows][k] = acc[k];
+  }
+  __syncthreads();
+  if (tid < kMoRows) {
+#pragma unroll
+    for (int k = 0; k < 28; ++k) s_all[tid][k] += acc[k];
+  }
   __syncthreads();
   {
-    // wave w handles the groups 2w and 2w+1 with its lanes 0..55 (value k = lane % 28)
+    // wave w < kRedGroups / 2 handles the groups 2w and 2w+1 with its lanes 0..55 (value k = lane % 28)
     const int lane = tid & 63, wv = tid >> 6;
-    if (lane < 56) {
+    if (wv < kRedGroups / 2 && lane < 56) {
       const int k = lane % 28, g = 2 * wv + lane / 28;
       double a = 0.0;
 #pragma unroll 8
@@ -1388,7 +1396,7 @@ __device__ inline void block_reduce28(double (&acc)[28], double (*s_all)[29], do
 
 namespace vsba {
 __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step) {
-  __shared__ double s_all[kMoThreads][29];
+  __shared__ double s_all[kMoRows][29];
   __shared__ double s_grp[kRedGroups][28];
   __shared__ double s_sum[28];
   __shared__ double s_part[3][kMoThreads];  // chi, scale / maxd, ok of up to 256 cameras (strided beyond)
@@ -1661,14 +1669,15 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
     }
     chi += E.rho0;
   }
-  s_part[0][tid] = chi;
+  // workgroup sum of chi: xor-butterfly inside each wave, then the wave totals in wave order
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) chi += __shfl_xor(chi, d);
+  if ((tid & 63) == 0) s_part[0][tid >> 6] = chi;
   __syncthreads();
-  for (int off = kMoThreads / 2; off > 0; off >>= 1) {
-    if (tid < off) s_part[0][tid] += s_part[0][tid + off];
-    __syncthreads();
-  }
   if (tid == 0) {
-    my_part[4 * c] = s_part[0][0];
+    double tot = s_part[0][0];
+    for (int wv = 1; wv < kMoThreads / 64; ++wv) tot += s_part[0][wv];
+    my_part[4 * c] = tot;
     my_part[4 * c + 1] = scl;
     my_part[4 * c + 2] = ok ? 0.0 : 1.0;
     my_part[4 * c + 3] = 0.0;

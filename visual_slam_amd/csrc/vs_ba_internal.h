@@ -8,7 +8,7 @@
 namespace vsba {
 
 constexpr int kCamStride = 19;  // t[3] q[4] w2n[12]
-constexpr int kMoThreads = 256;
+constexpr int kMoThreads = 512;  // threads per camera workgroup of the motion-only step (one observation per thread at ~500 matches)
 constexpr int kPnpFinish = 256;
 
 struct lm_state {
