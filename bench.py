@@ -230,9 +230,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import gc
     for _ in range(args.warmup):
         step()
     drain()
+    gc.collect()
+    gc.disable()  # a generation-2 collection of the interpreter (tens of ms with torch loaded) must not land in K steps
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -240,6 +243,7 @@ def main():
     out = drain() or out
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
