@@ -7,6 +7,9 @@ from test_pnp import scene
 from visual_slam_amd.context import Context
 from visual_slam_amd.workloads import ICL_NUIM_K
 ctx = Context()
+if os.environ.get("NOGC"):
+    import gc
+    gc.disable()
 for n, frac, motion in ((420, 0.02, 0.003), (420, 0.3, 0.03), (3000, 0.3, 0.03)):
     X, uv, T, _ = scene(n, frac, 0.3, 1, motion)
     for _ in range(3):
