@@ -853,7 +853,7 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve(ba_dev D) {
 //   * row stride is odd so the 16 row-owners of a tile hit distinct banks
 //   * the backward substitution L^T x = y runs on wave 0 alone, wave-synchronously
 
-constexpr int kSolveBlock = 256;
+constexpr int kSolveBlock = 1024, kSolveTile = 32;  // threads as a kSolveTile x kSolveTile grid over matrix tiles
 
 __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
@@ -862,14 +862,14 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   // pays for the unused loads, which is rare and cheap
   const int done = st->done, cur = st->cur;
   const double lambda = st->lambda;
-  const int n = D.np, tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int n = D.np, tid = threadIdx.x, tx = tid % kSolveTile, ty = tid / kSolveTile;
   const int ld = (n + 1) | 1;
   double* A = s_mem;                        // (n + 1) rows of ld: rows 0..n-1 matrix, row n = rhs
   double* rinv = s_mem + (size_t)(n + 1) * ld;  // [n]
   double* s_bp = rinv + n + 1;              // [n] right-hand side before the Schur complement (gain denominator)
   int* s_flag = reinterpret_cast<int*>(s_bp + n + 1);
-  for (int r = ty; r < n; r += 16)
-    for (int c = tx; c < n; c += 16) A[r * ld + c] = D.S[(size_t)r * n + c];
+  for (int r = ty; r < n; r += kSolveTile)
+    for (int c = tx; c < n; c += kSolveTile) A[r * ld + c] = D.S[(size_t)r * n + c];
   for (int c = tid; c < n; c += kSolveBlock) {
     A[n * ld + c] = D.bs[c];
     s_bp[c] = D.bp[c];
@@ -938,12 +938,12 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
     }
     __syncthreads();
     // (3) trailing update: A[r][c] -= sum_k A[r][j0+k] * A[c][j0+k]  for r > j0+5 (incl. rhs row), j0+5 < c <= min(r, n-1)
-    for (int r = j0 + 6 + ty; r <= n; r += 16) {
+    for (int r = j0 + 6 + ty; r <= n; r += kSolveTile) {
       double ar[6];
 #pragma unroll
       for (int k = 0; k < 6; ++k) ar[k] = A[r * ld + j0 + k];
       const int cmax = r < n ? r : n - 1;
-      for (int c = j0 + 6 + tx; c <= cmax; c += 16) {
+      for (int c = j0 + 6 + tx; c <= cmax; c += kSolveTile) {
         double acc = A[r * ld + c];
 #pragma unroll
         for (int k = 0; k < 6; ++k) acc -= ar[k] * A[c * ld + j0 + k];
