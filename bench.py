@@ -144,6 +144,30 @@ def frames_leg(ctx, cpu=True):
     return out
 
 
+def ba_leg(ctx, cpu=True):
+    """BASELINE.json configs[3]: local BA of 10 key frames x 2000 points (20 000 residuals), 10 LM iterations."""
+    from visual_slam_amd.workloads import ba_workload
+    w = ba_workload()
+    args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
+    for _ in range(5):
+        g = ctx.ba_solve(*args)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        g = ctx.ba_solve(*args)
+    dt = (time.perf_counter() - t0) / 10
+    out = {"workload": "BASELINE.json configs[3]: 10 cameras x 2000 points, 20000 residuals, Huber, 10 LM iterations",
+           "ms_per_solve": dt * 1e3, "lm_trials": int(g["trials"]), "chi2": [float(g["chi2_initial"]), float(g["chi2_final"])]}
+    if cpu:
+        from oracle import oracle
+        t0 = time.perf_counter()
+        c = oracle.ba_solve(*args)
+        out["cpu_ms_per_solve"] = (time.perf_counter() - t0) * 1e3
+        out["cpu_cores_used"] = 1
+        out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
+                                                         for a, b in zip(g["poses"], c["poses"])))
+    return out
+
+
 def frames_replicas(ctx, dist, world, dev):
     """frames/s with one independent replica of the tracker per GPU (north_star: detection and BA stay single-GPU, so
     N GPUs track N streams): every rank runs the device-resident tracking period on the 20 fixture frames between two
@@ -336,6 +360,11 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(nq, nt)
             except Exception as e:  # never lose the GPU numbers to a host-side problem
                 line["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and not args.no_frames:
+            try:
+                line["local_ba"] = ba_leg(ctx, cpu=not args.no_cpu_baseline)
+            except Exception as e:
+                line["local_ba"] = {"error": repr(e)}
         if not args.no_frames:
             try:
                 line["frames"] = frames_leg(ctx, cpu=(world == 1 and not args.no_cpu_baseline))
