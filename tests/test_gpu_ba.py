@@ -97,6 +97,20 @@ def test_mixed_fixed_points_and_unobserved_points(vs, oracle):
     _compare(vs.ba_solve(*_args(w)), oracle.ba_solve(*_args(w)))
 
 
+def test_free_points_seen_by_fixed_cameras_only(vs, oracle):
+    """Key-frame BA fixes frame 0 (LocalBA.py:155-156): points observed by fixed cameras alone are still free points --
+    they get the damped 3x3 update but touch no block of the reduced camera system."""
+    w = ba_workload(n_cams=4, n_points=90, seed=29)
+    w["pose_fixed"][:2] = 1                                       # cameras 0 and 1 fixed
+    only_fixed = (w["obs_point"] % 3 == 0) & (w["obs_pose"] >= 2)  # every third point loses its free-camera observations
+    for k in ("obs_pose", "obs_point", "obs_uv"):
+        w[k] = w[k][~only_fixed]
+    g, o = vs.ba_solve(*_args(w)), oracle.ba_solve(*_args(w))
+    _compare(g, o)
+    moved = np.linalg.norm(g["points"][::3] - w["points"][::3], axis=1)
+    assert moved.min() > 1e-6                                      # those points were optimised, not skipped
+
+
 def test_duplicate_observations_use_the_atomic_path(vs, oracle):
     w = ba_workload(n_cams=3, n_points=30, seed=23)
     for k in ("obs_pose", "obs_point"):

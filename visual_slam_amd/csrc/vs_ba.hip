@@ -545,6 +545,7 @@ __global__ __launch_bounds__(256) void ba_dinv(ba_dev D) {
 __global__ __launch_bounds__(256) void ba_schur_tile(ba_dev D) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   if (D.st->done) return;
+  const double lambda = D.st->lambda;
   const int np = D.np, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int tr = blockIdx.y / D.ntile, tc = blockIdx.y - tr * D.ntile;
   const int per = (D.nfl + D.ns - 1) / D.ns;
@@ -576,10 +577,34 @@ __global__ __launch_bounds__(256) void ba_schur_tile(ba_dev D) {
         if (t == tc) sMap[(mbuf * kTileBatch + pb) * 32 + 16 + ls] = base + i;
       }
     }
-    for (int i = tid; i < nb * 12; i += 256) {
-      const int q = i / 12, k = i - q * 12;
-      const int l = sList[3 * (b0 + q)];
-      sD[dbuf * kTileBatch * 12 + i] = k < 9 ? D.Dinv[9 * (size_t)l + k] : D.Dbl[3 * (size_t)l + k - 9];
+    // (Hll + lambda I)^-1 and its product with bl of the batch's points: the last lane of every point's group
+    // (single-tile windows: nobody else computes it, so it is also stored for ba_point_trial; with several tiles
+    // ba_dinv has run before and the values are only re-read)
+    if (pb < nb && i0 == kScat - 1) {
+      const int l = sList[3 * (b0 + pb)];
+      double* d = sD + (dbuf * kTileBatch + pb) * 12;
+      if (D.ntile == 1) {
+        double Dm[9], inv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[9 * (size_t)l + k];
+        Dm[0] += lambda;
+        Dm[4] += lambda;
+        Dm[8] += lambda;
+        inv3(Dm, inv);
+        const double b0_ = D.bl[3 * (size_t)l], b1_ = D.bl[3 * (size_t)l + 1], b2_ = D.bl[3 * (size_t)l + 2];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          d[k] = inv[k];
+          D.Dinv[9 * (size_t)l + k] = inv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[9 + k] = inv[3 * k] * b0_ + inv[3 * k + 1] * b1_ + inv[3 * k + 2] * b2_;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) d[k] = D.Dinv[9 * (size_t)l + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[9 + k] = D.Dbl[3 * (size_t)l + k];
+      }
     }
   };
   for (int c0 = l0; c0 < l1; c0 += kTileChunk) {
@@ -589,7 +614,8 @@ __global__ __launch_bounds__(256) void ba_schur_tile(ba_dev D) {
 #pragma unroll
     for (int k = 0; k < kPerThread; ++k) {
       const int i = tid * kPerThread + k;
-      if (i < cn && (D.fp_mask[c0 + i] & want) == want) keep |= 1u << k;
+      // single tile: every free point is listed, also one seen by fixed cameras only -- its Dinv is computed here
+      if (i < cn && (D.ntile == 1 || (D.fp_mask[c0 + i] & want) == want)) keep |= 1u << k;
     }
     const int cnt = __popc(keep);
     int scan = cnt;
@@ -2034,7 +2060,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       VS_LAUNCH_CHECK(ctx, "ba_lambda_init");
     }
     if (ns > 0 && tiled) {
-      hipLaunchKernelGGL(ba_dinv, dim3((unsigned)((nfl + 255) / 256)), dim3(256), 0, s, D);
+      if (ntile > 1) hipLaunchKernelGGL(ba_dinv, dim3((unsigned)((nfl + 255) / 256)), dim3(256), 0, s, D);  // single tile: fused
       hipLaunchKernelGGL(ba_schur_tile, dim3(ns, ntile * ntile), dim3(256), tile_lds, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_schur_tile");
     } else if (ns > 0) {
