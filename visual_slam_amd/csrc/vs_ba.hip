@@ -17,7 +17,8 @@
 //       camera block: workgroup = free camera; 512 threads stride over the camera's observation list, 27 register
 //                     accumulators (Hpp upper 21 + bp 6), fixed-order LDS tree reduction; also the EdgeSBAScale terms
 //   ba_lambda_init    first slot only: chi2_0 and lambda_0 = 1e-5 * max diag(H)
-//   ba_dinv           (Hll + lambda I)^-1 and its product with bl, thread = free point
+//   ba_dinv           (Hll + lambda I)^-1 and its product with bl, thread = free point (windows of several tiles only;
+//                     with a single tile ba_schur_tile computes it for its own points)
 //   ba_schur_tile     workgroup = (slab of points, tile of 10 x 10 camera blocks); the tile is accumulated in registers:
 //                     wave w owns the row cameras w, w+4, w+8, lane (block row, column camera) owns 6 elements per row
 //                     camera -- fixed ownership, no atomics, no LDS read-modify-write; Hpl blocks staged 8 points per
