@@ -221,3 +221,19 @@ def test_argument_errors_of_the_widened_entry_points(vs):
     assert not vs.essential_ransac(np.zeros((20, 2)), np.zeros((20, 2)), 1e-3)["found"]          # all points coincide
     r = vs.pnp_ransac(np.zeros((20, 3)), np.zeros((20, 2)), ICL_NUIM_K, np.eye(4))              # points at the centre
     assert isinstance(r["found"], bool) and np.isfinite(r["pose"]).all() or not r["found"]
+
+
+def test_tracking_session_on_an_odd_sized_image(vs):
+    """Width 637: the rows are not a multiple of four bytes, so the session's upload goes through the pitched copy."""
+    from visual_slam_amd import harness
+    frames, depth0 = harness.load_sequence(3)
+    crop = [np.ascontiguousarray(f[3:470, 2:639]) for f in frames]          # 467 x 637
+    xy0, _, d0 = vs.detect_describe_bgr(crop[0], 20, 3000)
+    X = harness.backproject(xy0 + np.array([2, 3], np.float32), depth0)
+    vs.track_begin(X, d0, np.eye(4), ICL_NUIM_K, max_frames=2, pnp_iterations=0)
+    r = vs.track_frame(crop[1], want_keypoints=True)
+    xy1, _, d1 = vs.detect_describe_bgr(crop[1], 20, 3000)
+    mq, mt, _ = vs.match_ratio(d0, d1, 0.8)
+    assert np.array_equal(r["xy"], xy1) and np.array_equal(r["desc"], d1)
+    assert np.array_equal(r["match_q"], mq) and np.array_equal(r["match_t"], mt) and len(mq) > 100
+    vs.track_end()
