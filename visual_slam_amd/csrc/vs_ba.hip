@@ -39,6 +39,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 using namespace vsba;
@@ -1753,6 +1754,13 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   VS_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
 
+  // developer aid (VS_BA_TIMING=1): host phase times on stderr
+  static const bool timing = getenv("VS_BA_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::micro>(b - a).count();
+  };
+  const auto t_begin = now();
   // ---- structure (host): slots, active observations grouped by point (stable), per-camera lists
   const int F = p->n_poses, P = p->n_points;
   std::vector<int> pose_slot(F), pt_slot(P);
@@ -1774,60 +1782,56 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   // active points = free points (even without observations: they still receive the lambda damping) + fixed points
   // that are observed by a free camera.  Skipped points own no active observation, so the sorted observation ranges
   // of consecutive active points are adjacent: pt_start[a] = cnt[act_pt[a]], pt_start[n_act] = n_obs.
+  // One pass over the sorted observations collects everything that follows from (point, camera slot): the active
+  // points, the per-camera counts, the Hpl blocks (observations whose point AND camera are free, stored contiguously per
+  // free point), duplicate cameras per point, and the camera-tile mask of every free point (tiled Schur).
+  const int ntile = (nfp + kTileCams - 1) / kTileCams;
   std::vector<int> act_pt;
+  act_pt.reserve(P);
+  std::vector<int> seen_by(F, -1);  // seen_by[camera] = last free point with an observation from that free camera
+  std::vector<int> cam_start(nfp + 1, 0), cs_sorted(n_obs ? n_obs : 1);  // cs_sorted[i] = camera slot of sorted obs i
+  std::vector<int> o_hpl(n_obs ? n_obs : 1, -1), fp_start(nfl + 1, 0), fp_slot;
+  std::vector<unsigned long long> fp_mask(nfl, 0ull);
+  fp_slot.reserve(n_obs);
   int mmax = 1, dups = 0;
   for (int j = 0; j < P; ++j) {
-    const int m = cnt[j + 1] - cnt[j];
-    if (m == 0 && pt_slot[j] < 0) continue;
-    if (pt_slot[j] >= 0) {
-      int mf = 0;
-      for (int i = cnt[j]; i < cnt[j + 1]; ++i)
-        if (pose_slot[p->obs_pose[order[i]]] >= 0) {
-          ++mf;
-          for (int k = cnt[j]; k < i; ++k)
-            if (p->obs_pose[order[k]] == p->obs_pose[order[i]]) dups = 1;  // same camera twice: LDS atomics
-        }
+    const int m = cnt[j + 1] - cnt[j], ls = pt_slot[j];
+    if (m == 0 && ls < 0) continue;
+    int mf = 0;
+    unsigned long long mask = 0ull;
+    if (ls >= 0) fp_start[ls] = (int)fp_slot.size();
+    for (int i = cnt[j]; i < cnt[j + 1]; ++i) {
+      const int cam = p->obs_pose[order[i]];
+      const int cs = pose_slot[cam];
+      cs_sorted[i] = cs;
+      if (cs < 0) continue;
+      cam_start[cs + 1]++;
+      if (ls >= 0) {
+        ++mf;
+        if (seen_by[cam] == j) dups = 1;  // same camera twice: LDS atomics
+        seen_by[cam] = j;
+        o_hpl[i] = (int)fp_slot.size();
+        fp_slot.push_back(cs);
+        mask |= 1ull << ((cs / kTileCams) & 63);
+      }
+    }
+    if (ls >= 0) {
       mmax = std::max(mmax, mf);
+      fp_mask[ls] = mask;
     }
     act_pt.push_back(j);
   }
+  fp_start[nfl] = (int)fp_slot.size();
+  const int n_hpl = (int)fp_slot.size();
   const int n_act = (int)act_pt.size();
-  std::vector<int> cam_start(nfp + 1, 0);
-  for (int i = 0; i < n_obs; ++i) {
-    const int cs = pose_slot[p->obs_pose[order[i]]];
-    if (cs >= 0) cam_start[cs + 1]++;
-  }
   for (int c = 0; c < nfp; ++c) cam_start[c + 1] += cam_start[c];
   std::vector<int> cam_obs(cam_start[nfp] ? cam_start[nfp] : 1), cfill(cam_start.begin(), cam_start.end() - 1);
   for (int i = 0; i < n_obs; ++i) {
-    const int cs = pose_slot[p->obs_pose[order[i]]];
+    const int cs = cs_sorted[i];
     if (cs >= 0) cam_obs[cfill[cs]++] = i;
   }
-
-  // Hpl blocks exist for observations whose point AND camera are free; they are stored contiguously per free point
-  std::vector<int> o_hpl(n_obs ? n_obs : 1, -1), fp_start(nfl + 1, 0), fp_slot;
-  for (int j = 0; j < P; ++j) {
-    if (pt_slot[j] < 0) continue;
-    fp_start[pt_slot[j]] = (int)fp_slot.size();
-    for (int i = cnt[j]; i < cnt[j + 1]; ++i) {
-      const int cs = pose_slot[p->obs_pose[order[i]]];
-      if (cs >= 0) {
-        o_hpl[i] = (int)fp_slot.size();
-        fp_slot.push_back(cs);
-      }
-    }
-  }
-  fp_start[nfl] = (int)fp_slot.size();
-  const int n_hpl = (int)fp_slot.size();
-  // tiled Schur (windows beyond the LDS slab): per free point the set of camera tiles that observe it
-  const int ntile = (nfp + kTileCams - 1) / kTileCams;
-  const bool tiled = np > 0 && !dups && ntile <= 64 && nfl > 0;  // measured faster than the LDS-slab kernel at every window size
-  std::vector<unsigned long long> fp_mask;
-  if (tiled) {
-    fp_mask.assign(nfl, 0ull);
-    for (int l = 0; l < nfl; ++l)
-      for (int i = fp_start[l]; i < fp_start[l + 1]; ++i) fp_mask[l] |= 1ull << (fp_slot[i] / kTileCams);
-  }
+  // tiled Schur: measured faster than the LDS-slab kernel at every window size
+  const bool tiled = np > 0 && !dups && ntile <= 64 && nfl > 0;
 
   // ---- motion-only fast path (block-diagonal problem): one launch per LM trial, one workgroup per free camera
   const bool motion_only = nfl == 0 && p->n_scale == 0 && nfp > 0 && p->max_iterations > 0;
@@ -1844,6 +1848,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   if (!lds_slab && ns > 0) ns = std::min(ns, std::max(1, (int)((512u << 20) / (sizeof(double) * ((size_t)np * np + np)))));
   const size_t slab_elems = (size_t)np * np + np;
 
+  const auto t_struct = now();
   // ---- arena: [uploaded constants | state | system]
   vs_ba_problem const& q = *p;
   size_t need = (1u << 20) + sizeof(int) * ((size_t)F + P + 3 * (size_t)n_act + 4 * (size_t)n_obs + 2 * (size_t)nfp +
@@ -2013,6 +2018,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   h_st->need_lin = 1;
   h_st->ni = 2.0;
   const bool nothing = (np + 3 * nfl == 0) || q.max_iterations == 0;
+  const auto t_filled = now();
   VS_HIP(ctx, hipMemcpyAsync(A.base, A.host, upload_bytes, hipMemcpyHostToDevice, s));
   // both state buffers start identical (fixed cameras / points are never rewritten in the trial buffer's points)
   VS_HIP(ctx, hipMemcpyAsync(D.cam[1], D.cam[0], sizeof(double) * (size_t)F * kCamStride, hipMemcpyDeviceToDevice, s));
@@ -2152,6 +2158,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     VS_HIP(ctx, hipStreamSynchronize(s));
   }
 
+  const auto t_solved = now();
   // ---- read back the accepted state
   const int cur = hst->cur;
   double* h_cam = reinterpret_cast<double*>(A.host);  // reuse the pinned mirror
@@ -2165,6 +2172,9 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
                                hipMemcpyDeviceToHost, s));
   }
   VS_HIP(ctx, hipStreamSynchronize(s));
+  if (timing)
+    fprintf(stderr, "vs_ba_solve: structure %.1f us, arena fill %.1f us, upload + kernels %.1f us, read-back %.1f us (upload %zu B)\n",
+            us(t_begin, t_struct), us(t_struct, t_filled), us(t_filled, t_solved), us(t_solved, now()), upload_bytes);
   res->iterations = hst->it;
   res->trials = hst->trials;
   res->not_pd = hst->not_pd;
