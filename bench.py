@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X tracking hot path (contract: see the task description / DESIGN.md).
+"""bench.py -- headline benchmark of the MI355X tracking hot path (contract: see the task description / DESIGN.md 5).
 
 A "step" is one pass of the brute-force Hamming 2-NN match (the reference's knnMatch, src/v2/frame.py:23) over one
 batch of synthetic descriptors already resident in HBM:
   N = 1 : BASELINE.json configs[2] -- 10 000 x 10 000 x 256-bit, k = 2 (the configuration the metric is quoted on)
-  N > 1 : weak scaling -- every rank matches its own 10 000-query shard against the replicated 10 000-row train set,
-          then one RCCL all-gather of the per-shard best matches (16 B per query) assembles the N*10 000 results.
+  N > 1 : weak scaling of the same -- every rank matches its own 10 000-query shard against the replicated 10 000-row
+          train set, then one RCCL all-gather of the per-shard best matches (16 B per query) assembles N*10 000 results.
 value = distance evaluations (Q*T) of all ranks / wall time of the K timed steps, in Gmatches/s.
 
-Rank 0 prints ONE JSON line.  Extra objects on the line: roofline (dominant kernel, HIP-event timed in this run),
-cpu_baseline (the CPU oracle timed on this box's host cores), frames (the 640x480 detect+describe -> match -> motion
-BA stream, frames/s), config.
+Rank 0 prints ONE JSON line.  Extra objects on the line:
+  roofline      dominant kernel (hamming_knn2_kernel), HIP-event timed in this run.  bound = "valu": the kernel is bound
+                by integer VALU issue, not by HBM; the SURVEY 8d streamed-operand HBM model and the
+                MEASURED HBM traffic are carried as labelled secondary entries; per-kernel entries for the detector and
+                the local BA sit under roofline.kernels
+  cpu_baseline  the CPU oracle timed on this box's host cores (1 thread and all threads)
+  cfg5          BASELINE.json configs[4]: 100 000 x 100 000 query-split over the N ranks (strong scaling), with the
+                all-gather, the compute-only time beside it
+  cfg2 / local_ba / frames   the single-frame detector, the 10 x 2000 local BA and the 640x480 ICL-NUIM stream
 """
 import argparse
 import json
@@ -23,13 +29,18 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("VS_DATASET_DIR", os.path.join(ROOT, "tests", "golden", "icl_nuim"))  # fixture frames
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_MATCH = 32           # SURVEY.md 8d streamed-operand model: one 32-byte train descriptor per evaluation
-VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9  # 3.93e13: integer VALU issues a wave64 op every 4 cycles per SIMD (measured
-                                      # 36-38e12 with tools/valu_probe.hip; only f32 FMA-class ops run at twice that)
-OPS_PER_MATCH = 19             # 8 v_xor + 8 v_bcnt + v_lshl_or + v_med3 + v_min
-VALU_LANE_OPS_MEASURED = 37.0e12  # tools/valu_probe.hip on this GPU (profiles/r01_valu_probe.log): 4.2-4.4 cycles per op
+# integer VALU: one wave64 op per 4 cycles per SIMD = 16 lanes/clk (tools/valu_probe*.hip: xor/bcnt/min/med3 4.2-4.4 cycles
+# at the clock the chip holds; only f32 FMA-class ops issue at twice that) x 4 SIMD x 256 CU x 2.4 GHz
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # 3.93e13 lane-ops/s
+# main loop of hamming_knn2_kernel (train rows staged through LDS), from its ISA: per 8 distances 64 v_xor + 64 v_bcnt +
+# 8 v_lshl_or + 4 v_med3 + 4 v_min3 + 4 v_min = 148 VALU instructions
+OPS_PER_MATCH = 148.0 / 8.0
+LAUNCH_BOUNDARY_US = 1.45      # dependent kernel boundary on MI355X (MI355X_MICROARCH.md price list, row "boundary")
+PCIE_GBS = 63.0
 
 
 def parse():
@@ -40,11 +51,45 @@ def parse():
     ap.add_argument("--nq", type=int, default=10000, help="queries per rank")
     ap.add_argument("--nt", type=int, default=10000, help="train descriptors (replicated)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-frames", action="store_true")
+    ap.add_argument("--no-frames", action="store_true", help="skip the cfg2 / local BA / frames legs")
+    ap.add_argument("--no-cfg5", action="store_true")
     ap.add_argument("--target-blocks", type=int, default=0, help="tuning: workgroups per launch of the match kernel")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the RCCL all-gather even at world size 1 (exercises the N>1 code path)")
     return ap.parse_args()
+
+
+def median_time(fn, reps, warm=3):
+    """Median wall seconds of fn() over `reps` calls after `warm` untimed ones."""
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), ts
+
+
+def all_threads_rate(fn, threads, seconds=6.0):
+    """Calls per second with `threads` host threads calling fn() concurrently (ctypes releases the GIL inside the C
+    oracle): the all-cores figure of a sequential CPU algorithm = independent instances side by side."""
+    import threading
+    stop = time.perf_counter() + seconds
+    counts = [0] * threads
+
+    def work(i):
+        while time.perf_counter() < stop:
+            fn()
+            counts[i] += 1
+
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    return sum(counts) / (time.perf_counter() - t0)
 
 
 def cpu_baseline(nq, nt):
@@ -78,11 +123,103 @@ def cpu_baseline(nq, nt):
             "single_thread_value": nq * nt / t1 / 1e9}
 
 
+def detector_leg(ctx, torch, stream, cpu=True):
+    """BASELINE.json configs[1] / SURVEY 8d cfg2: one 640x480 frame, detect + describe.  Kernel-only time from HIP events
+    on the launch stream around the two launches (frame resident in HBM), end-to-end through the host ABI (H2D + D2H
+    included), on the synthetic frame SURVEY prescribes and on ICL-NUIM frame 0."""
+    from visual_slam_amd.harness import load_sequence
+    from visual_slam_amd.workloads import synthetic_frame
+    out = {}
+    frames, _ = load_sequence(1)
+    cases = {"synthetic_rng2_blur5": synthetic_frame(640, 480, 2), "icl_nuim_rgb0": frames[0]}
+    max_kp = 3000
+    for name, bgr in cases.items():
+        h, w, _ = bgr.shape
+        with torch.cuda.stream(stream):
+            d_img = torch.from_numpy(np.ascontiguousarray(bgr)).cuda()
+            d_xy = torch.empty((max_kp, 2), dtype=torch.float32, device="cuda")
+            d_sc = torch.empty((max_kp + 16,), dtype=torch.uint8, device="cuda")
+            d_desc = torch.empty((max_kp, 32), dtype=torch.uint8, device="cuda")
+            d_n = torch.zeros((4,), dtype=torch.int32, device="cuda")
+
+            def launch():
+                ctx._chk(ctx._lib.vs_detect_describe_bgr_dev(ctx._h, d_img.data_ptr(), w, h, 3 * w, 20, max_kp,
+                                                             d_xy.data_ptr(), d_sc.data_ptr(), d_desc.data_ptr(),
+                                                             d_n.data_ptr(), None))
+            for _ in range(20):
+                launch()
+            reps = []
+            for _ in range(20):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for _ in range(10):
+                    launch()
+                e1.record(stream)
+                stream.synchronize()
+                reps.append(e0.elapsed_time(e1) / 10 * 1e3)
+            n_kp = int(d_n.cpu()[0])
+        kernel_us = statistics.median(reps)
+        pinned = ctx.pin(bgr)
+        med, _ = median_time(lambda: ctx.detect_describe_bgr(pinned, 20, max_kp), 30, warm=5)
+        # compulsory bytes (SURVEY 8d): BGR in + box sums out and in again + results out
+        alg_bytes = 3 * w * h + 2 * (2 * w * h) + n_kp * (8 + 1 + 32)
+        entry = {"keypoints": n_kp, "kernel_only_us": kernel_us, "end_to_end_host_abi_us": med * 1e6,
+                 "frames_per_s_kernel_only": 1e6 / kernel_us, "frames_per_s_host_abi": 1.0 / med,
+                 "algorithmic_bytes": alg_bytes, "hbm_GBps": alg_bytes / (kernel_us * 1e-6) / 1e9,
+                 "hbm_frac_of_8TBps": alg_bytes / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                 "launch_floor_us": 2 * LAUNCH_BOUNDARY_US,
+                 "host_floor_us": 2 * LAUNCH_BOUNDARY_US + 3 * w * h / (PCIE_GBS * 1e3)}
+        if cpu:
+            from oracle import oracle
+            cm, _ = median_time(lambda: oracle.detect_describe_bgr(bgr, 20, max_kp), 20, warm=2)
+            entry["cpu_us_1_thread"] = cm * 1e6
+        out[name] = entry
+    out["note"] = ("kernels: detect_band_kernel + select_describe_kernel (two launches per frame); latency-bound as SURVEY 8d "
+                   "predicts -- bytes / time is a tiny HBM fraction, the floor is two kernel boundaries (+ the 921 KB H2D "
+                   "at PCIe rate on the host path); the per-kernel split is in profiles/ (rocprofv3 --kernel-trace --stats)")
+    return out
+
+
+def ba_leg(ctx, cpu=True):
+    """BASELINE.json configs[3]: local BA of 10 key frames x 2000 points (20 000 residuals), 10 LM iterations."""
+    from visual_slam_amd.workloads import ba_workload
+    w = ba_workload()
+    args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
+    g = ctx.ba_solve(*args)
+    med, ts = median_time(lambda: ctx.ba_solve(*args), 30, warm=5)
+    n_res = len(w["obs_pose"])
+    trials = int(g["trials"])
+    out = {"workload": "BASELINE.json configs[3]: 10 cameras x 2000 points, 20000 residuals, Huber, 10 LM iterations",
+           "ms_per_solve": med * 1e3, "ms_per_solve_min": min(ts) * 1e3, "repetitions": len(ts), "statistic": "median",
+           "lm_trials": trials, "us_per_trial": med * 1e6 / max(trials, 1),
+           "chi2": [float(g["chi2_initial"]), float(g["chi2_final"])],
+           # SURVEY 8d: ~178 B and ~150 flop per residual per linearisation
+           "algorithmic_bytes_per_trial": 178 * n_res,
+           "hbm_GBps": 178.0 * n_res * trials / med / 1e9,
+           "hbm_frac_of_8TBps": 178.0 * n_res * trials / med / 1e9 / HBM_PEAK_GBS,
+           "note": "latency-bound (SURVEY 8d): 3.6 MB and 30 MFLOP per LM trial are ~1 us at either roof; the time is "
+                   "dependent launches + one host structure pass + upload + read-back"}
+    if cpu:
+        from oracle import oracle
+        c = oracle.ba_solve(*args)
+        cmed, _ = median_time(lambda: oracle.ba_solve(*args), 5, warm=1)
+        out["cpu_ms_per_solve_1_thread"] = cmed * 1e3
+        cores = os.cpu_count() or 1
+        thr = min(cores, 64)
+        rate = all_threads_rate(lambda: oracle.ba_solve(*args), thr, seconds=5.0)
+        out["cpu_all_threads"] = {"threads": thr, "solves_per_s": rate, "ms_per_solve_equivalent": 1e3 / rate,
+                                  "note": "the LM solve is sequential; all-threads = independent solves side by side"}
+        out["gpu_solves_per_s"] = 1.0 / med
+        out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
+                                                         for a, b in zip(g["poses"], c["poses"])))
+    return out
+
+
 def frames_leg(ctx, cpu=True):
     """frames/s of the 640x480 ICL-NUIM stream (detect+describe -> match -> PnP-RANSAC -> motion-only BA), GPU path and -- as the
-    checker/baseline only -- the CPU oracle through the same harness."""
-    from visual_slam_amd.harness import HUBER, bench_frames, load_sequence, track_sequence
-    out, poses = bench_frames(ctx)
+    checker/baseline only -- the CPU oracle through the same harness.  Medians over >= 20 repetitions."""
+    from visual_slam_amd.harness import HUBER, bench_frames, dataset_dir, load_sequence, track_sequence
+    out, poses = bench_frames(ctx, repeats=20)
     if cpu:
         from oracle import oracle
         oracle.load()
@@ -98,73 +235,44 @@ def frames_leg(ctx, cpu=True):
         def ba(*problem):
             return oracle.ba_solve(*problem, huber_delta=HUBER, max_iterations=10)
 
-        frames, depth0 = load_sequence(20)
-        t0 = time.perf_counter()
         def pnp(obj, img, K4, pose0, seed=0):
             return oracle.pnp_ransac(obj, img, K4, pose0, seed=seed)
 
+        frames, depth0 = load_sequence(20)
+        t0 = time.perf_counter()
         cposes, cstages, _ = track_sequence(detect, match, ba, frames, depth0, pnp=pnp)
         cdt = time.perf_counter() - t0
         out["cpu_frames_per_s"] = len(frames) / cdt
         out["cpu_stage_ms_per_frame"] = {k: v / len(frames) * 1e3 for k, v in cstages.items()}
         out["cpu_cores_used"] = 1
+        cores = os.cpu_count() or 1
+        thr = min(cores, 32)
+        rate = all_threads_rate(lambda: track_sequence(detect, match, ba, frames, depth0, pnp=pnp), thr, seconds=8.0)
+        out["cpu_all_threads"] = {"threads": thr, "frames_per_s": rate * len(frames),
+                                  "note": "one sequential tracker per host thread on the same 20 frames (streams side by side)"}
         out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
                                                          for a, b in zip(poses, cposes)))
     # the full headless driver (main.py's tracking loop + key-frame insertion: triangulation + local BA), class API
     try:
-        from visual_slam_amd import slam
+        from visual_slam_amd import dataset, slam
         from visual_slam_amd.workloads import ICL_NUIM_K
         frames, depth0 = load_sequence(20)
         be = slam.Backends(context=ctx)
-        slam.run_sequence(frames[:7], depth0, ICL_NUIM_K, be, keyframe_gap=4)
-        best = None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            r = slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=4)
-            dt = time.perf_counter() - t0
-            best = dt if best is None or dt < best else best
-        from visual_slam_amd import dataset
-        from visual_slam_amd.harness import ICL_DIR
-        _, gt = dataset.read_trajectory(os.path.join(ICL_DIR, "traj3.gt.freiburg.head20"))
+        res = {}
+        med, _ = median_time(lambda: res.__setitem__("r", slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=4)),
+                             20, warm=2)
+        r = res["r"]
+        _, gt = dataset.read_trajectory(os.path.join(dataset_dir(), "traj3.gt.freiburg.head20"))
         ate = dataset.ate_rmse(r["poses"], gt)
-        slam.run_sequence(frames[:7], depth0, ICL_NUIM_K, be, keyframe_gap=4, resident_ctx=ctx)
-        best_res = None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=4, resident_ctx=ctx)
-            dt = time.perf_counter() - t0
-            best_res = dt if best_res is None or dt < best_res else best_res
-        out["driver"] = {"frames_per_s": len(frames) / best, "resident_frames_per_s": len(frames) / best_res,
-                         "keyframes": r["keyframes"], "map_points": r["n_points"],
+        med_res, _ = median_time(lambda: slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=4, resident_ctx=ctx),
+                                 20, warm=2)
+        out["driver"] = {"frames_per_s": len(frames) / med, "resident_frames_per_s": len(frames) / med_res,
+                         "statistic": "median of 20", "keyframes": r["keyframes"], "map_points": r["n_points"],
                          "ate_rmse_m": ate["rmse"], "gt_path_length_m": ate["path_length"],
                          "note": "visual_slam_amd/slam.py: main.py:150-348 control flow, key frame every 5th frame, "
                                  "init from depth of frame 0"}
     except Exception as e:
         out["driver"] = {"error": repr(e)}
-    return out
-
-
-def ba_leg(ctx, cpu=True):
-    """BASELINE.json configs[3]: local BA of 10 key frames x 2000 points (20 000 residuals), 10 LM iterations."""
-    from visual_slam_amd.workloads import ba_workload
-    w = ba_workload()
-    args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
-    for _ in range(5):
-        g = ctx.ba_solve(*args)
-    t0 = time.perf_counter()
-    for _ in range(10):
-        g = ctx.ba_solve(*args)
-    dt = (time.perf_counter() - t0) / 10
-    out = {"workload": "BASELINE.json configs[3]: 10 cameras x 2000 points, 20000 residuals, Huber, 10 LM iterations",
-           "ms_per_solve": dt * 1e3, "lm_trials": int(g["trials"]), "chi2": [float(g["chi2_initial"]), float(g["chi2_final"])]}
-    if cpu:
-        from oracle import oracle
-        t0 = time.perf_counter()
-        c = oracle.ba_solve(*args)
-        out["cpu_ms_per_solve"] = (time.perf_counter() - t0) * 1e3
-        out["cpu_cores_used"] = 1
-        out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
-                                                         for a, b in zip(g["poses"], c["poses"])))
     return out
 
 
@@ -177,8 +285,8 @@ def frames_replicas(ctx, dist, world, dev):
     frames, depth0 = load_sequence(20)
     frames = [ctx.pin(f) for f in frames]
     track_sequence_resident(ctx, frames[:4], depth0, pipelined=True)
-    best = None
-    for _ in range(3):
+    times = []
+    for _ in range(7):
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
@@ -186,10 +294,34 @@ def frames_replicas(ctx, dist, world, dev):
         dt = time.perf_counter() - t0
         te = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        dt = float(te.item())
-        best = dt if best is None or dt < best else best
-    return {"replicas": world, "frames_per_s": world * len(frames) / best, "seconds_slowest_rank": best,
+        times.append(float(te.item()))
+    med = statistics.median(times)
+    return {"replicas": world, "frames_per_s": world * len(frames) / med, "seconds_slowest_rank_median": med,
             "note": "one tracker replica per GPU on the same 20 frames (device-resident tracking period, pipelined)"}
+
+
+def timed_steps(step, drain, fence, steps, warmup, torch, dist, use_dist, dev):
+    """The contract's timing: W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize, MAX over ranks."""
+    import gc
+    for _ in range(warmup):
+        step()
+    drain()
+    gc.collect()
+    gc.disable()  # a generation-2 collection of the interpreter (tens of ms with torch loaded) must not land in K steps
+    fence()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(steps):
+        out = step()
+    out = drain() or out
+    fence()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    if use_dist:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    return elapsed, out
 
 
 def main():
@@ -213,37 +345,40 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from visual_slam_amd import Context, _capi
-    from visual_slam_amd.sharded import ShardedMatcher
+    from visual_slam_amd.sharded import ShardedMatcher, shard_bounds
     from visual_slam_amd.workloads import match_workload
     import visual_slam_amd.context as vctx
     ctx = Context(local_rank)
     vctx._DEFAULT = ctx
+    lib = _capi.load()
     if args.target_blocks:
-        _capi.load().vs_match_set_target_blocks(args.target_blocks)
+        lib.vs_match_set_target_blocks(args.target_blocks)
 
     nq, nt = args.nq, args.nt
     q_np, t_np = match_workload(nq, nt)
     if world > 1:  # weak scaling: every rank owns a different 10k-query shard, same train set
         q_np, _ = match_workload(nq, nt, seed=100 + rank)
         _, t_np = match_workload(nq, nt)
-    matcher = ShardedMatcher()
-    stream = matcher.torch_stream()  # the library's stream, shared with torch copies, events and RCCL
+    matcher = ShardedMatcher(force_collective=args.force_collective)
+    stream = matcher.torch_stream()  # the library's stream, shared with torch copies and events
     torch.cuda.set_stream(stream)
     q = torch.from_numpy(q_np).to(dev)
     t = torch.from_numpy(t_np).to(dev)
 
     pending = []
 
-    def step():
+    def make_step(qq, tt, n_total):
         """One pass of the match over this rank's batch.  With a collective, the all-gather of step k is started
         asynchronously and collected after the kernels of step k+1 are enqueued (two rotating buffer sets), so the
         exchange overlaps the next step's compute; drain() collects the last one inside the timed region."""
-        if not use_dist:
-            return matcher.knn2_local_shard(q, t)
-        ticket = matcher.submit(q, t, nq * world)
-        out = matcher.collect(pending.pop()) if pending else None
-        pending.append(ticket)
-        return out
+        def step():
+            if not use_dist:
+                return matcher.knn2_local_shard(qq, tt)
+            ticket = matcher.submit(qq, tt, n_total)
+            out = matcher.collect(pending.pop()) if pending else None
+            pending.append(ticket)
+            return out
+        return step
 
     def drain():
         return matcher.collect(pending.pop()) if pending else None
@@ -254,72 +389,102 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    import gc
-    for _ in range(args.warmup):
-        step()
-    drain()
-    gc.collect()
-    gc.disable()  # a generation-2 collection of the interpreter (tens of ms with torch loaded) must not land in K steps
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    out = drain() or out
-    fence()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
-    if use_dist:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    # ---- BASELINE.json configs[4]: 100 000 x 100 000, query-split over the ranks (strong scaling).  Runs first: its
+    # ~0.2 s of solid matching also brings the GPU to its sustained clocks before the short headline region (20 x 62 us)
+    cfg5 = None
+    if not args.no_cfg5:
+        try:
+            Q5 = T5 = 100000
+            b5, e5, per5 = shard_bounds(Q5, world, rank)
+            q5_np, t5_np = match_workload(Q5, T5)
+            q5 = torch.from_numpy(q5_np[b5:e5]).to(dev)
+            t5 = torch.from_numpy(t5_np).to(dev)
+            del q5_np, t5_np
+            k5, w5 = max(3, min(args.steps, 20)), max(1, min(args.warmup, 3))
+            el5, _ = timed_steps(make_step(q5, t5, Q5), drain, fence, k5, w5, torch, dist, use_dist, dev)
+
+            def local_only():
+                return matcher.knn2_local_shard(q5, t5)
+            el5c, _ = timed_steps(local_only, lambda: None, fence, k5, w5, torch, dist, use_dist, dev)
+            ms5, ms5c = el5 / k5 * 1e3, el5c / k5 * 1e3
+            cfg5 = {"workload": "BASELINE.json configs[4]: 100000 x 100000 x 256-bit, k=2, query-split over %d rank(s): "
+                                "rank r owns ceil(Q/N) queries, train replicated, one RCCL all-gather of 16 B/query" % world,
+                    "scaling": "strong", "n_gpus": world, "steps": k5, "queries_per_rank": per5,
+                    "ms_per_step": ms5, "gmatches_per_s": float(Q5) * T5 / (ms5 * 1e-3) / 1e9,
+                    "ms_per_step_compute_only": ms5c, "collective_overhead_ms": ms5 - ms5c,
+                    "valu_frac_compute_only": OPS_PER_MATCH * float(per5) * T5 / (ms5c * 1e-3) / VALU_PEAK_LANE_OPS,
+                    "note": "collective_overhead_ms = step with the all-gather (overlapped with the next step's kernels) "
+                            "minus the same step without it; max over ranks"}
+            del q5, t5
+        except Exception as e:  # all ranks take the same path: the collectives inside stay matched
+            cfg5 = {"error": repr(e)}
+
+    elapsed, _ = timed_steps(make_step(q, t, nq * world), drain, fence, args.steps, args.warmup, torch, dist, use_dist, dev)
     ms_per_step = elapsed / args.steps * 1e3
     total_matches = float(nq) * nt * world
     value = total_matches / (ms_per_step * 1e-3) / 1e9
 
-    # ---- dominant kernel (hamming_partial_kernel): HIP events recorded by the library on the launch stream around
-    # each kernel of the same K steps, in this process, right after the timed region
+    # ---- dominant kernel (hamming_knn2_kernel): HIP events recorded by the library on the launch stream around each
+    # launch of K more steps, in this process, right after the timed region
     roof = None
     if rank == 0:
         import ctypes as C
-        lib = _capi.load()
         lib.vs_match_profile.argtypes = [C.c_int]
-        lib.vs_match_profile_read.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.vs_match_profile_read.argtypes = [C.POINTER(C.c_float)]
         lib.vs_match_profile(1)
         for _ in range(args.steps):
             matcher.knn2_local_shard(q, t)
         torch.cuda.synchronize()
-        pm, mm = C.c_float(0), C.c_float(0)
-        ncalls = lib.vs_match_profile_read(C.byref(pm), C.byref(mm))
+        km = C.c_float(0)
+        ncalls = lib.vs_match_profile_read(C.byref(km))
         lib.vs_match_profile(0)
-        kernel_ms = float(pm.value)
-        alg_bytes = BYTES_PER_MATCH * float(nq) * nt
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        kernel_ms = float(km.value)
+        pairs = float(nq) * nt
+        lane_ops = OPS_PER_MATCH * pairs
+        achieved = lane_ops / (kernel_ms * 1e-3)
+        alg_bytes = BYTES_PER_MATCH * pairs
         traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes (profiles/), only for the workload they were taken on
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_match.json")))
-            if (nq, nt) == (10000, 10000):
-                traffic = pmc["hamming_partial_kernel_per_launch"]["hbm_bytes_corrected_upper"]
-        except Exception:
-            pass
-        valu_ceiling = VALU_LANE_OPS / OPS_PER_MATCH / 1e9
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "hamming_partial_kernel", "kernel_ms": kernel_ms, "merge_kernel_ms": float(mm.value),
-                "profiled_calls": int(ncalls), "algorithmic_bytes_per_launch": alg_bytes,
-                "algorithmic_model": "32 B per distance evaluation (one streamed train descriptor), SURVEY.md 8d",
-                "traffic_source": "profiles/r01_pmc_match.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                                  "FETCH_SIZE doubled per the gfx950 correction)",
-                "valu_ceiling_gmatches": valu_ceiling,
-                "valu_frac": (float(nq) * nt / (kernel_ms * 1e-3) / 1e9) / valu_ceiling,
-                "valu_frac_of_measured_issue_rate": (float(nq) * nt / (kernel_ms * 1e-3) / 1e9) /
-                                                    (VALU_LANE_OPS_MEASURED / OPS_PER_MATCH / 1e9),
-                "note": "tiles are reused from SGPRs/VGPRs, so real HBM traffic is ~1000x below the streamed-operand "
-                        "model and frac exceeds 1; the binding limit is integer VALU issue (valu_frac)"}
+        pmc_src = None
+        for name in ("r02_pmc_match.json", "r01_pmc_match.json"):
+            try:  # HBM bytes per launch from the committed PMC passes (profiles/), only for the workload they were taken on
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if (nq, nt) == (10000, 10000):
+                    key = "hamming_knn2_kernel_per_launch" if "hamming_knn2_kernel_per_launch" in pmc else "hamming_partial_kernel_per_launch"
+                    traffic = pmc[key]["hbm_bytes_corrected_upper"]
+                    pmc_src = "profiles/" + name
+                break
+            except Exception:
+                continue
+        roof = {"bound": "valu", "achieved": achieved / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "Tlane-op/s",
+                "frac": achieved / VALU_PEAK_LANE_OPS, "traffic": traffic,
+                "kernel": "hamming_knn2_kernel", "kernel_ms": kernel_ms, "profiled_calls": int(ncalls),
+                "lane_ops_per_match": OPS_PER_MATCH,
+                "lane_ops_model": "ISA of the main loop: per 8 distances 64 v_xor_b32 + 64 v_bcnt_u32_b32 + 8 v_lshl_or_b32 + "
+                                  "4 v_med3_u32 + 4 v_min3_u32 + 4 v_min_u32; SQ_INSTS_VALU (profiles/) = this x 1e8 / 64 + 5 %",
+                "peak_model": "integer VALU issues one wave64 op per 4 cycles per SIMD: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz "
+                              "(v_bcnt / v_min3 / v_med3 / v_lshl_or and any op with an SGPR source; VGPR-only v_xor issues faster, "
+                              "which is why its operands are staged into VGPRs -- tools/valu_probe3.hip, profiles/r02_valu_probe*.log)",
+                "valu_ceiling_gmatches": VALU_PEAK_LANE_OPS / OPS_PER_MATCH / 1e9,
+                "frac_whole_step": (lane_ops / (ms_per_step * 1e-3)) / VALU_PEAK_LANE_OPS if world == 1 else None,
+                "hbm_measured": None if traffic is None else {
+                    "bytes_per_launch": traffic, "GBps": traffic / (kernel_ms * 1e-3) / 1e9,
+                    "frac_of_8TBps": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "compulsory_bytes": 32 * (nq + nt) + 16 * nq, "source": pmc_src,
+                    "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 "
+                            "correction (upper bound); the excess over compulsory is the per-chunk partial rows"},
+                "hbm_model_secondary": {
+                    "bound": "hbm", "model": "SURVEY.md 8d streamed-operand: 32 B per distance evaluation",
+                    "algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
+                    "peak_GBps": HBM_PEAK_GBS, "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "note": "> 1 by construction: train rows are reused from SGPRs, queries from VGPRs, so this model cannot "
+                            "bound the kernel; kept because north_star words its target (>= 0.6) in it"},
+                "kernels": {}}
+
     replicas = None
     if use_dist and not args.no_frames:
         try:
             replicas = frames_replicas(ctx, dist, world, dev)
-        except Exception as e:  # all ranks take the same path: the collectives inside stay matched
+        except Exception as e:
             replicas = {"error": repr(e)}
     host_abi = None
     if rank == 0 and world == 1:
@@ -329,17 +494,17 @@ def main():
         try:
             qh, th = q_np.copy(), t_np.copy()
             ctx.hamming_knn2(qh, th)
-            reps = 20
-            torch.cuda.synchronize()
-            t0h = time.perf_counter()
-            for i in range(reps):
-                qh[0, 0] ^= 1 + (i & 1)   # new content at the same address: the descriptor cache must re-upload
-                th[0, 0] ^= 1 + (i & 1)
+            state = {"i": 0}
+
+            def call():
+                state["i"] += 1
+                qh[0, 0] ^= 1 + (state["i"] & 1)   # new content at the same address: both sets are uploaded again
+                th[0, 0] ^= 1 + (state["i"] & 1)
                 ctx.hamming_knn2(qh, th)
-            dth = (time.perf_counter() - t0h) / reps
-            host_abi = {"gmatches_per_s": float(nq) * nt / dth / 1e9, "ms_per_call": dth * 1e3,
-                        "note": "vs_hamming_knn2 on pageable host arrays, fresh contents per call: content fingerprint + "
-                                "H2D 2 x 320 KB + kernels + D2H 160 KB + synchronisation"}
+            dth, _ = median_time(call, 30, warm=3)
+            host_abi = {"gmatches_per_s": float(nq) * nt / dth / 1e9, "ms_per_call": dth * 1e3, "statistic": "median of 30",
+                        "note": "vs_hamming_knn2 on pageable host arrays, fresh contents per call: exact compare against the "
+                                "resident copy + H2D 2 x 320 KB + kernel + D2H 160 KB + synchronisation"}
         except Exception as e:
             host_abi = {"error": repr(e)}
     if rank == 0:
@@ -353,6 +518,8 @@ def main():
                        "queries_per_gpu": nq, "train": nt, "parallelism": "query-shard x%d" % world},
             "roofline": roof,
         }
+        if cfg5 is not None:
+            line["cfg5"] = cfg5
         if host_abi is not None:
             line["host_abi"] = host_abi
         if world == 1 and not args.no_cpu_baseline:
@@ -360,14 +527,29 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(nq, nt)
             except Exception as e:  # never lose the GPU numbers to a host-side problem
                 line["cpu_baseline"] = {"error": repr(e)}
+        cpu = world == 1 and not args.no_cpu_baseline
         if world == 1 and not args.no_frames:
             try:
-                line["local_ba"] = ba_leg(ctx, cpu=not args.no_cpu_baseline)
+                line["cfg2"] = detector_leg(ctx, torch, stream, cpu=cpu)
+                k2 = line["cfg2"]["synthetic_rng2_blur5"]
+                roof["kernels"]["detect_band_kernel+select_describe_kernel"] = {
+                    "bound": "latency", "us_per_frame": k2["kernel_only_us"], "algorithmic_bytes": k2["algorithmic_bytes"],
+                    "hbm_frac_of_8TBps": k2["hbm_frac_of_8TBps"], "launch_floor_us": k2["launch_floor_us"]}
+            except Exception as e:
+                line["cfg2"] = {"error": repr(e)}
+            try:
+                line["local_ba"] = ba_leg(ctx, cpu=cpu)
+                lb = line["local_ba"]
+                roof["kernels"]["local_ba_cfg4 (ba_* kernels of one solve)"] = {
+                    "bound": "latency", "us_per_lm_trial": lb["us_per_trial"],
+                    "algorithmic_bytes_per_trial": lb["algorithmic_bytes_per_trial"],
+                    "hbm_frac_of_8TBps": lb["hbm_frac_of_8TBps"],
+                    "launch_floor_us_per_trial": None}
             except Exception as e:
                 line["local_ba"] = {"error": repr(e)}
         if not args.no_frames:
             try:
-                line["frames"] = frames_leg(ctx, cpu=(world == 1 and not args.no_cpu_baseline))
+                line["frames"] = frames_leg(ctx, cpu=cpu)
                 if replicas is not None:
                     line["frames"]["replicas"] = replicas
                 if world > 1:
@@ -379,6 +561,7 @@ def main():
     if use_dist:
         dist.barrier()  # the other ranks wait here while rank 0 runs the (replica) frames leg and prints
         matcher.close()
+    ctx.close()
     if use_dist:
         dist.destroy_process_group()
 

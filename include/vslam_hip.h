@@ -34,10 +34,11 @@ typedef enum vs_status {
   VS_ENOMEM = -2, /* host or device allocation failed */
   VS_EHIP = -3,   /* a HIP runtime call or kernel launch failed */
   VS_ENOTPD = -4, /* reserved: BA reports indefinite systems in vs_ba_result, it does not fail the call */
-  VS_ECAP = -5    /* an output capacity given by the caller is too small */
+  VS_ECAP = -5,   /* an output capacity given by the caller is too small */
+  VS_ENCCL = -6   /* RCCL is not loaded in the process, or the all-gather failed */
 } vs_status;
 
-#define VS_ABI_VERSION 1
+#define VS_ABI_VERSION 2
 #define VS_DESC_BYTES 32 /* BRIEF-256 */
 
 /* ---- context ---------------------------------------------------------------------------------------------- */
@@ -115,6 +116,20 @@ int vs_hamming_knn2_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, i
  * matcher hands to the RCCL all-gather (north_star: "all-gather of per-shard best matches") */
 int vs_hamming_knn2_packed_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_out,
                                void* stream);
+/* Query-sharded match, one rank's step (north_star: "Shard only the brute-force descriptor match (query-split) across the
+ * 8 GPUs of one node with an RCCL all-gather of per-shard best matches over xGMI"; the call it shards is knnMatch,
+ * src/v2/frame.py:23).  Rank `rank` of `world` owns queries [rank*per, rank*per + nq_shard) of the full set, per =
+ * ceil(Q / world); the train set is replicated, so rows carry GLOBAL train indices and no cross-rank tie-break exists.
+ *   1. the match kernel writes this rank's packed rows straight into its slot of d_gathered (int32[world*per][4],
+ *      16-byte aligned) on `compute_stream` (NULL: the context's stream);
+ *   2. if world > 1 (or nccl_comm != NULL): an event orders `comm_stream` behind the kernel and ONE in-place
+ *      ncclAllGather of per*4 int32 per rank is enqueued there; `done_event` (a hipEvent_t, may be NULL) is recorded
+ *      on comm_stream after it.  nccl_comm is the caller's ncclComm_t; RCCL is resolved at run time from the library
+ *      already loaded in the process (dlopen), libvslam_hip.so does not link it.
+ * Nothing synchronises the host.  With world == 1 and nccl_comm == NULL no collective runs (same code path). */
+int vs_hamming_knn2_sharded_dev(vs_ctx* ctx, const void* d_q_shard, int nq_shard, const void* d_t, int nt,
+                                void* d_gathered, int per, int rank, int world, void* nccl_comm, void* compute_stream,
+                                void* comm_stream, void* done_event);
 /* d_n_out: one int32 in HBM receiving the match count */
 int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, double ratio, void* d_match_q,
                        void* d_match_t, void* d_match_d, void* d_n_out, void* stream);
@@ -226,9 +241,23 @@ typedef struct vs_ba_result {
   int32_t trials;        /* inner trials (linear solves) executed in total */
   int32_t not_pd;        /* trials whose reduced system was not positive definite (the reference's debug.txt case) */
   int32_t terminated;    /* 1 if LM stopped before max_iterations (10 rejected trials or zero gain) */
+  /* optional per-TRIAL record (one row per linear solve, in execution order), or NULL:
+   * row = (lambda the trial was solved with, robust chi2 of the trial state [DBL_MAX when the reduced system was not
+   * positive definite], gain ratio rho, 1.0 if the Cholesky succeeded else 0.0).  At most trial_trace_cap rows are
+   * written; `trials` tells how many exist. */
+  double* trial_trace;   /* [trial_trace_cap][4] */
+  int32_t trial_trace_cap;
+  int32_t reserved;
 } vs_ba_result;
 
 int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* problem, vs_ba_result* result);
+
+/* Test hook: the dense solver of the reduced camera system on its own -- what g2o's LinearSolverCholmod does inside
+ * BlockSolver::solve.  Factorises the symmetric n x n matrix S (row-major, n a multiple of 6, lower triangle
+ * read) with the SAME kernels vs_ba_solve uses for that size (one workgroup in LDS up to 126, blocked panels in HBM
+ * beyond) and solves S x = b.  *ok = 0 if a pivot was not positive (the reference's debug.txt case: g2o dumps the
+ * matrix and rejects the LM trial), x is then untouched. */
+int vs_ba_debug_cholesky(vs_ctx* ctx, const double* S, int n, const double* b, double* x, int* ok);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,7 @@ class BAResult(C.Structure):
         ("poses_out", c_f64p), ("points_out", c_f64p), ("chi2_trace", c_f64p), ("lambda_trace", c_f64p),
         ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
         ("iterations", C.c_int32), ("trials", C.c_int32), ("not_pd", C.c_int32), ("terminated", C.c_int32),
+        ("trial_trace", c_f64p), ("trial_trace_cap", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -253,12 +254,14 @@ def ba_solve(poses, pose_fixed, points, point_fixed, obs_pose, obs_point, obs_uv
     lam = np.full(max(max_iterations, 1), np.nan)
     r.poses_out, r.points_out = _p(poses_out, c_f64p), _p(points_out, c_f64p)
     r.chi2_trace, r.lambda_trace = _p(chi, c_f64p), _p(lam, c_f64p)
+    tt = np.full((max(10 * max_iterations, 1), 4), np.nan)  # per-trial rows: lambda, trial chi2, rho, solve ok
+    r.trial_trace, r.trial_trace_cap = _p(tt, c_f64p), tt.shape[0]
     _chk(lib.vo_ba_solve(C.byref(p), C.byref(r)), "ba_solve")
     del keep
     return dict(poses=poses_out.reshape(-1, 4, 4), points=points_out, chi2_trace=chi[:r.iterations].copy(),
                 lambda_trace=lam[:r.iterations].copy(), chi2_initial=r.chi2_initial, chi2_final=r.chi2_final,
                 lambda_final=r.lambda_final, iterations=r.iterations, trials=r.trials, not_pd=r.not_pd,
-                terminated=r.terminated)
+                terminated=r.terminated, trial_trace=tt[:min(r.trials, tt.shape[0])].copy())
 
 
 def ba_edge(pose, X, K, uv, lib=None):

@@ -807,6 +807,7 @@ VO_EXPORT int vo_ba_solve(const vs_ba_problem* p, vs_ba_result* res) {
     do {
       memcpy(cams_bak, s.cams, sizeof(cam_t) * (size_t)p->n_poses); /* push */
       memcpy(pts_bak, s.pts, sizeof(double) * 3 * (size_t)p->n_points);
+      const double lambda_used = lambda;
       int ok2 = solve_system(&s, lambda, pt_start, obs_by_pt, S, bs, Dinv);
       ++trials;
       if (!ok2) ++not_pd;
@@ -839,8 +840,22 @@ VO_EXPORT int vo_ba_solve(const vs_ba_problem* p, vs_ba_result* res) {
         memcpy(s.pts, pts_bak, sizeof(double) * 3 * (size_t)p->n_points);
         if (!isfinite(lambda)) {
           stop_nonfinite = 1;
+          if (res->trial_trace && trials <= res->trial_trace_cap) {
+            double* row = res->trial_trace + 4 * (size_t)(trials - 1);
+            row[0] = lambda_used;
+            row[1] = tempChi;
+            row[2] = rho;
+            row[3] = ok2 ? 1.0 : 0.0;
+          }
           break;
         }
+      }
+      if (res->trial_trace && trials <= res->trial_trace_cap) { /* test aid: one row per linear solve */
+        double* row = res->trial_trace + 4 * (size_t)(trials - 1);
+        row[0] = lambda_used;
+        row[1] = tempChi;
+        row[2] = rho;
+        row[3] = ok2 ? 1.0 : 0.0;
       }
       ++qmax;
     } while (rho < 0 && qmax < 10);

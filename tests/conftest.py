@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("VS_DATASET_DIR", os.path.join(GOLDEN, "icl_nuim"))  # the harness ships no data of its own
 
 
 def pytest_configure(config):

@@ -25,14 +25,14 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (vs_\w+)", out))
     assert set(names) <= exported, sorted(set(names) - exported)
     assert set(names) == set(_capi.SIGNATURES), sorted(set(names) ^ set(_capi.SIGNATURES))
-    assert lib.vs_abi_version() == 1
+    assert lib.vs_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header():
     import ctypes as C
     from visual_slam_amd import _capi
     assert C.sizeof(_capi.BAProblem) == 4 * 4 + 11 * 8 + 6 * 8 + 2 * 4
-    assert C.sizeof(_capi.BAResult) == 4 * 8 + 3 * 8 + 4 * 4
+    assert C.sizeof(_capi.BAResult) == 4 * 8 + 3 * 8 + 4 * 4 + 8 + 2 * 4
     from oracle import oracle
     assert C.sizeof(oracle.BAProblem) == C.sizeof(_capi.BAProblem) and C.sizeof(oracle.BAResult) == C.sizeof(_capi.BAResult)
 

@@ -109,9 +109,81 @@ def test_sharded_matcher_world1_hip_path(vs, oracle):
     assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
 
 
+def test_sharded_matcher_on_the_callers_stream(vs, oracle):
+    """Round-1 advisor finding: inputs produced on, and results consumed from, torch's CURRENT stream (not the library's)
+    must be ordered by the matcher itself.  The producer here is a long chain of device ops on the default stream that
+    finishes writing q just before the match is submitted; a missing wait would read the buffer half-written."""
+    import torch
+    import visual_slam_amd.context as vctx
+    from visual_slam_amd.sharded import ShardedMatcher
+    vctx._DEFAULT = vs
+    m = ShardedMatcher()
+    for rep in range(5):
+        q, t = match_workload(6000, 3000, seed=40 + rep)
+        junk = torch.zeros((6000, 32), dtype=torch.uint8, device="cuda")
+        dq = torch.empty((6000, 32), dtype=torch.uint8, device="cuda")
+        dt = torch.from_numpy(t).cuda()
+        src = torch.from_numpy(q).cuda()
+        torch.cuda.synchronize()
+        big = torch.ones((4096, 4096), device="cuda")
+        for _ in range(6):                       # keeps the default stream busy for a while ...
+            big = big @ big * 1e-4
+        dq.copy_(junk)
+        dq.copy_(src)                            # ... and only then produces the real queries
+        idx, dist = m.knn2(dq, dt)               # default stream is current: the matcher must wait for the copy
+        got = (idx.clone(), dist.clone())        # consumed on the default stream: must wait for the kernel
+        torch.cuda.synchronize()
+        oidx, odist = oracle.hamming_knn2(q, t, threads=0)
+        assert np.array_equal(got[0].cpu().numpy(), oidx) and np.array_equal(got[1].cpu().numpy(), odist), rep
+        assert float(big.sum()) == float(big.sum())
+
+
+def test_sharded_step_through_the_c_abi_with_a_collective_at_world_1(vs, oracle):
+    """vs_hamming_knn2_sharded_dev with a real RCCL communicator of one rank: kernel into the gather slot + in-place
+    ncclAllGather on RCCL's own stream + done event; rotating buffers through submit / collect as bench.py drives them."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    import visual_slam_amd.context as vctx
+    from visual_slam_amd.sharded import ShardedMatcher
+    if dist.is_initialized():
+        pytest.skip("a process group already exists")
+    vctx._DEFAULT = vs
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", vs.device))
+    try:
+        m = ShardedMatcher(force_collective=True)
+        work = [match_workload(2000 + 37 * k, 1500, seed=60 + k) for k in range(6)]
+        dev = [(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()) for q, t in work]
+        torch.cuda.synchronize()
+        results, pending = [], []
+        for k, (dq, dt) in enumerate(dev):
+            ticket = m.submit(dq, dt, dq.shape[0])
+            if pending:
+                i, d = m.collect(pending.pop())
+                results.append((i.clone(), d.clone()))
+            pending.append(ticket)
+        i, d = m.collect(pending.pop())
+        results.append((i.clone(), d.clone()))
+        torch.cuda.synchronize()
+        assert m._rccl is not None, "the direct RCCL path did not initialise"
+        for (q, t), (i, d) in zip(work, results):
+            oi, od = oracle.hamming_knn2(q, t, threads=0)
+            assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(d.cpu().numpy(), od)
+        m.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_descriptor_cache_never_serves_stale_data(vs, oracle):
-    """The host matcher keeps device copies keyed by (address, n, content fingerprint): in-place edits and buffer
-    re-use must still give the oracle's answer."""
+    """The host matcher keeps device copies keyed by (address, n) and verified byte-for-byte against a host shadow of the
+    uploaded bytes: in-place edits and buffer re-use must still give the oracle's answer (knnMatch never caches,
+    reference src/v2/frame.py:23)."""
     q, t = match_workload(800, 700, seed=21)
     a = vs.hamming_knn2(q, t)
     assert np.array_equal(a[0], oracle.hamming_knn2(q, t)[0])
@@ -127,6 +199,48 @@ def test_descriptor_cache_never_serves_stale_data(vs, oracle):
         mq, mt, md = vs.match_ratio(q, t, 0.8)
         oq, ot, od = oracle.match_ratio(q2, t2, 0.8)
         assert np.array_equal(mq, oq) and np.array_equal(mt, ot) and np.array_equal(md, od)
+
+
+def test_descriptor_cache_two_byte_edits(vs, oracle):
+    """Round-1 regression: the cache key used to be a multiply-xor fingerprint in which the top bit of two words of one
+    lane cancelled, so `t[k,7] ^= 0x80; t[k+1,7] ^= 0x80` (same buffer, edited in place) was served from the stale device
+    copy.  The cache now compares bytes; every in-place edit must be seen."""
+    q, t = match_workload(700, 700, seed=33)
+    # queries sit next to their train partner, so flipping a train bit changes some distance that is reported
+    for k in (5, 6, 100, 698):
+        q[k] = t[k]
+    assert np.array_equal(vs.hamming_knn2(q, t)[1], oracle.hamming_knn2(q, t)[1])
+    for col in (7, 15, 23, 31):       # the four byte positions whose MSB was linear in the old fingerprint
+        t[5, col] ^= 0x80
+        t[6, col] ^= 0x80
+        g, o = vs.hamming_knn2(q, t), oracle.hamming_knn2(q, t)
+        assert np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1]), col
+        assert g[1][5, 0] > 0 and g[1][6, 0] > 0      # the edit is visible in the result (it would be 0 from a stale copy)
+        t[5, col] ^= 0x80
+        t[6, col] ^= 0x80
+    rng = np.random.default_rng(7)
+    for trial in range(300):          # random two-byte edits of either operand, alternating entry points
+        arr = t if trial & 1 else q
+        for _ in range(2):
+            arr[rng.integers(arr.shape[0]), rng.integers(32)] ^= np.uint8(1 << rng.integers(8))
+        if trial % 3 == 0:
+            mq, mt, md = vs.match_ratio(q, t, 0.8)
+            oq, ot, od = oracle.match_ratio(q, t, 0.8)
+            assert np.array_equal(mq, oq) and np.array_equal(mt, ot) and np.array_equal(md, od), trial
+        else:
+            g, o = vs.hamming_knn2(q, t), oracle.hamming_knn2(q, t)
+            assert np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1]), trial
+    # the detector's own output array is adopted without an upload; editing it in place afterwards must be seen too
+    from visual_slam_amd.workloads import synthetic_frame
+    xy, sc, desc = vs.detect_describe_bgr(synthetic_frame(320, 240, 5), 20, 1000)
+    d2 = desc.copy()
+    assert np.array_equal(vs.hamming_knn2(desc, t)[1], oracle.hamming_knn2(d2, t)[1])
+    desc[3, 7] ^= 0x80
+    desc[4, 7] ^= 0x80
+    d2[3, 7] ^= 0x80
+    d2[4, 7] ^= 0x80
+    g, o = vs.hamming_knn2(desc, t), oracle.hamming_knn2(d2, t)
+    assert np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
 
 
 def test_pinned_frames_and_resident_descriptors(vs, oracle):

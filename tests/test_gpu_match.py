@@ -125,3 +125,54 @@ def test_random_shapes_property(vs, oracle):
         ratio = float(rng.choice([0.5, 0.8, 0.9, 1.0]))
         a, b = vs.match_ratio(q, t, ratio), oracle.match_ratio(q, t, ratio)
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_fused_fold_under_back_to_back_launches(vs, oracle):
+    """The match is ONE launch: every (tile, chunk) workgroup publishes an 8-byte partial per query and the workgroup that
+    arrives last at a tile folds them (agent-scope ticket + release/acquire).  Stale partial rows from the previous
+    launch would go unnoticed with repeated identical inputs, so two different workloads alternate through the same
+    scratch buffers, back to back without host synchronisation in between, and every result is checked -- in both
+    train-row staging modes and over several launch geometries (1 chunk = no fold, few, many)."""
+    import torch
+    from visual_slam_amd import _capi
+    lib = _capi.load()
+    stream = torch.cuda.ExternalStream(vs.stream)
+    sets = []
+    for seed, (nq, nt) in enumerate([(3000, 5000), (3000, 5000), (2999, 4100)]):
+        q, t = match_workload(nq, nt, n_dup=16, seed=70 + seed)
+        sets.append((q, t) + oracle.hamming_knn2(q, t, threads=0))
+    try:
+        with torch.cuda.stream(stream):
+            dev = [(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()) for q, t, _, _ in sets]
+            outs = [(torch.empty((3000, 2), dtype=torch.int32, device="cuda"), torch.empty((3000, 2), dtype=torch.int32, device="cuda"))
+                    for _ in range(24)]
+            for tstage in (0, 1):
+                lib.vs_match_set_tstage(tstage)
+                for blocks in (0, 12, 300, 4000):
+                    lib.vs_match_set_target_blocks(blocks)
+                    for k, (oi, od) in enumerate(outs):        # 24 launches enqueued back to back
+                        dq, dt = dev[k % 3]
+                        vs.hamming_knn2_dev(dq.data_ptr(), dq.shape[0], dt.data_ptr(), dt.shape[0], oi.data_ptr(), od.data_ptr())
+                    stream.synchronize()
+                    for k, (oi, od) in enumerate(outs):
+                        _, _, ridx, rdist = sets[k % 3]
+                        n = ridx.shape[0]
+                        assert np.array_equal(oi.cpu().numpy()[:n], ridx) and np.array_equal(od.cpu().numpy()[:n], rdist), (tstage, blocks, k)
+    finally:
+        lib.vs_match_set_target_blocks(0)
+        lib.vs_match_set_tstage(1)
+
+
+@pytest.mark.parametrize("tstage", [0, 1])
+def test_both_train_staging_modes_bit_exact(vs, oracle, tstage):
+    from visual_slam_amd import _capi
+    lib = _capi.load()
+    lib.vs_match_set_tstage(tstage)
+    try:
+        for nq, nt in [(1, 2), (257, 129), (1000, 3000), (5000, 63), (640, 65), (10000, 10000)]:
+            q, t = match_workload(nq, nt, n_dup=min(16, nt // 4), seed=nq + 3 * nt)
+            idx, dist = vs.hamming_knn2(q, t)
+            oidx, odist = oracle.hamming_knn2(q, t, threads=0)
+            assert np.array_equal(idx, oidx) and np.array_equal(dist, odist), (tstage, nq, nt)
+    finally:
+        lib.vs_match_set_tstage(1)

@@ -64,3 +64,60 @@ def test_sharded_knn2_equals_single_process(world, nq, nt):
     for p in procs:
         p.join(timeout=60)
     assert sorted(r for r, _ in results) == list(range(world)) and all(ok for _, ok in results)
+
+
+def _worker_stream(rank, world, port, out):
+    """bench.py's ticket pattern on CPU: submit step k+1, then collect step k (two rotating buffer sets), ragged shards,
+    a different query count every step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle
+    from visual_slam_amd.sharded import ShardedMatcher, shard_bounds
+    from visual_slam_amd.workloads import match_workload
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def local(q, t):
+        idx, d = oracle.hamming_knn2(q.numpy(), t.numpy())
+        return torch.from_numpy(idx), torch.from_numpy(d)
+
+    m = ShardedMatcher(local_knn2=local)
+    sizes = [(101, 64), (64, 80), (101, 64), (7, 33), (250, 40), (101, 64)]   # repeated shapes re-use rotating buffers
+    work = [match_workload(nq, nt, n_dup=4, seed=200 + k) for k, (nq, nt) in enumerate(sizes)]
+    pending, got = [], []
+    for q, t in work:
+        b, e, _ = shard_bounds(q.shape[0], world, rank)
+        ticket = m.submit(torch.from_numpy(q[b:e]), torch.from_numpy(t), q.shape[0])
+        if pending:
+            i, d = m.collect(pending.pop())
+            got.append((i.clone(), d.clone()))
+        pending.append(ticket)
+    i, d = m.collect(pending.pop())
+    got.append((i.clone(), d.clone()))
+    ok = len(got) == len(work)
+    for (q, t), (i, d) in zip(work, got):
+        ri, rd = oracle.hamming_knn2(q, t)
+        ok = ok and np.array_equal(i.numpy(), ri) and np.array_equal(d.numpy(), rd)
+    out.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_submit_collect_with_rotating_buffers(world):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker_stream, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(r for r, _ in results) == list(range(world)) and all(ok for _, ok in results)

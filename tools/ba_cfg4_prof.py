@@ -1,6 +1,6 @@
 """dev tool: timing of the general (Schur) BA path on BASELINE cfg4 (10 cameras x 2000 points)."""
+import _env  # noqa: F401  (sys.path + VS_DATASET_DIR)
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from visual_slam_amd import Context
 from visual_slam_amd.workloads import ba_workload

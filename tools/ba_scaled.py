@@ -2,6 +2,7 @@
 actually moves bytes.  Reports ms per LM trial, residuals/s and the effective HBM rate at 178 B/residual.
   python tools/ba_scaled.py [--cams 100] [--points 200000] [--window 10] [--iters 3] [--check]
 --check also runs the CPU oracle on the same scene and compares chi2 traces and poses."""
+import _env  # noqa: F401  (sys.path + VS_DATASET_DIR)
 import argparse
 import os
 import sys
@@ -9,7 +10,6 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visual_slam_amd.workloads import ICL_NUIM_K  # noqa: E402
 
 

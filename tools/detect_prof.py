@@ -1,6 +1,6 @@
 """dev tool: kernel-only timing of the fused detect+describe path on a resident frame."""
+import _env  # noqa: F401  (sys.path + VS_DATASET_DIR)
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from visual_slam_amd import Context, harness
 ctx = Context(0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Interleaved timing of the Hamming-match kernel variants / grid sizes on one GPU (dev tool, not part of the product).
-Usage: python tools/match_sweep.py [nq nt]"""
-import ctypes as C
+"""Interleaved timing of the Hamming-match kernel over launch geometries on one GPU (dev tool, not part of the product).
+Usage: python tools/match_sweep.py [nq nt]      BLOCKS=0,1280,2560 (0 = the library's automatic plan)"""
+import _env  # noqa: F401  (sys.path + VS_DATASET_DIR)
 import os
 import statistics
 import sys
@@ -9,18 +9,15 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visual_slam_amd import Context, _capi  # noqa: E402
 from visual_slam_amd.workloads import match_workload  # noqa: E402
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 nt = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-variants = [int(v) for v in os.environ.get("VARIANTS", "0,1,2,3").split(",")]
-blocks = [int(v) for v in os.environ.get("BLOCKS", "0,1024,2048,4096").split(",")]
+blocks = [int(v) for v in os.environ.get("BLOCKS", "0,1024,1280,1536,2048,2560").split(",")]
+stages = [int(v) for v in os.environ.get("TSTAGE", "0,1").split(",")]  # 0: train rows from SGPRs, 1: staged via LDS
 ctx = Context(0)
 lib = _capi.load()
-lib.vs_match_set_variant.restype = C.c_int
-lib.vs_match_set_variant.argtypes = [C.c_int]
 stream = torch.cuda.ExternalStream(ctx.stream)
 q_np, t_np = match_workload(nq, nt)
 with torch.cuda.stream(stream):
@@ -31,24 +28,24 @@ with torch.cuda.stream(stream):
     ref = None
     res = {}
     for rnd in range(5):
-        for v in variants:
-            for b in blocks:
-                lib.vs_match_set_variant(v)
-                lib.vs_match_set_target_blocks(b)
-                for _ in range(3):
-                    ctx.hamming_knn2_dev(q.data_ptr(), nq, t.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                n = 20
-                for _ in range(n):
-                    ctx.hamming_knn2_dev(q.data_ptr(), nq, t.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
-                e1.record(stream)
-                stream.synchronize()
-                res.setdefault((v, b), []).append(e0.elapsed_time(e1) / n * 1e3)
-                cur = (idx.cpu().numpy().copy(), dst.cpu().numpy().copy())
-                if ref is None:
-                    ref = cur
-                assert np.array_equal(ref[0], cur[0]) and np.array_equal(ref[1], cur[1]), (v, b)
-for (v, b), ts in sorted(res.items()):
-    med = statistics.median(ts)
-    print("variant %d blocks %5d : %8.1f us/call (min %.1f)  %7.0f Gmatches/s" % (v, b, med, min(ts), nq * nt / med / 1e3))
+      for ts in stages:
+        lib.vs_match_set_tstage(ts)
+        for b in blocks:
+            lib.vs_match_set_target_blocks(b)
+            for _ in range(3):
+                ctx.hamming_knn2_dev(q.data_ptr(), nq, t.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            n = 20
+            for _ in range(n):
+                ctx.hamming_knn2_dev(q.data_ptr(), nq, t.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+            e1.record(stream)
+            stream.synchronize()
+            res.setdefault((ts, b), []).append(e0.elapsed_time(e1) / n * 1e3)
+            cur = (idx.cpu().numpy().copy(), dst.cpu().numpy().copy())
+            if ref is None:
+                ref = cur
+            assert np.array_equal(ref[0], cur[0]) and np.array_equal(ref[1], cur[1]), (ts, b)
+for (ts, b), v in sorted(res.items()):
+    med = statistics.median(v)
+    print("tstage %d blocks %5d : %8.1f us/call (min %.1f)  %7.0f Gmatches/s" % (ts, b, med, min(v), nq * nt / med / 1e3))

@@ -1,8 +1,7 @@
 """dev tool: randomised GPU-vs-oracle sweep of the RANSAC rows (PnP, essential matrix, pose recovery) and small BA scenes.
 Reports how often the two sides disagree on a discrete outcome (inlier sets, masks, LM trial counts)."""
+import _env  # noqa: F401  (sys.path + VS_DATASET_DIR)
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from test_pnp import scene as pnp_scene
 from test_twoview import scene as tv_scene

@@ -1,12 +1,11 @@
 """Timing of Context.pnp_ransac on a tracking-sized problem (420 correspondences, few outliers)."""
+import _env  # noqa: F401  (sys.path + VS_DATASET_DIR)
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from test_pnp import scene  # noqa: E402
 from visual_slam_amd.context import Context  # noqa: E402
 from visual_slam_amd.workloads import ICL_NUIM_K  # noqa: E402

@@ -1,6 +1,6 @@
 """dev tool: the device-resident tracking period alone (for rocprofv3 / timing)."""
+import _env  # noqa: F401  (sys.path + VS_DATASET_DIR)
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from visual_slam_amd import Context, harness
 ctx = Context(0)

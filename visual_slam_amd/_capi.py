@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvslam_hip.so")
 _LIB = None
 
-VS_OK, VS_EINVAL, VS_ENOMEM, VS_EHIP, VS_ENOTPD, VS_ECAP = 0, -1, -2, -3, -4, -5
+VS_OK, VS_EINVAL, VS_ENOMEM, VS_EHIP, VS_ENOTPD, VS_ECAP, VS_ENCCL = 0, -1, -2, -3, -4, -5, -6
 
 c_u8p = C.POINTER(C.c_uint8)
 c_i32p = C.POINTER(C.c_int32)
@@ -41,6 +41,7 @@ class BAResult(C.Structure):
         ("poses_out", c_f64p), ("points_out", c_f64p), ("chi2_trace", c_f64p), ("lambda_trace", c_f64p),
         ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
         ("iterations", C.c_int32), ("trials", C.c_int32), ("not_pd", C.c_int32), ("terminated", C.c_int32),
+        ("trial_trace", c_f64p), ("trial_trace_cap", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -89,6 +90,9 @@ SIGNATURES = {
                                            c_intp, c_f32p, c_u8p, c_intp, c_i32p, c_i32p]),
     "vs_track_end": (C.c_int, [C.c_void_p]),
     "vs_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(BAResult)]),
+    "vs_ba_debug_cholesky": (C.c_int, [C.c_void_p, c_f64p, C.c_int, c_f64p, c_f64p, c_intp]),
+    "vs_hamming_knn2_sharded_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                              C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -114,6 +118,8 @@ def load():
     try:  # optional tuning hook, not part of the ABI
         lib.vs_match_set_target_blocks.restype = C.c_int
         lib.vs_match_set_target_blocks.argtypes = [C.c_int]
+        lib.vs_match_set_tstage.restype = C.c_int
+        lib.vs_match_set_tstage.argtypes = [C.c_int]
     except AttributeError:
         pass
     _LIB = lib

@@ -1,10 +1,29 @@
 """Context: one libvslam_hip context (one GPU, one stream) with NumPy-friendly wrappers around the C ABI."""
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
 from . import _capi
 from ._capi import VsError, c_f32p, c_f64p, c_i32p, c_u8p, ptr
+
+
+# Contexts still open when the interpreter exits are closed by an atexit handler, i.e. BEFORE the C runtime's exit
+# handlers run (HIP's fat-binary unregistration, a profiler's finalisation): streams, events and device memory are
+# released while the HIP runtime is fully alive, never from a destructor that may run after it has shut down.
+_LIVE = weakref.WeakSet()
+
+
+def _close_all():
+    for ctx in list(_LIVE):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_all)
 
 
 class Context:
@@ -20,6 +39,7 @@ class Context:
         self._track = None
         self._pinned = []
         self.device = int(device)
+        _LIVE.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -28,6 +48,7 @@ class Context:
             self._pinned = []
             self._lib.vs_destroy(self._h)
             self._h = None
+            _LIVE.discard(self)
 
     def __del__(self):
         try:
@@ -149,6 +170,16 @@ class Context:
         """d_out: int32[nq][4] = (idx0, idx1, dist0, dist1) per query, 16-byte aligned; enqueues only."""
         self._chk(self._lib.vs_hamming_knn2_packed_dev(self._h, C.c_void_p(d_q), int(nq), C.c_void_p(d_t), int(nt),
                                                        C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
+
+    def hamming_knn2_sharded_dev(self, d_q_shard, nq_shard, d_t, nt, d_gathered, per, rank, world, nccl_comm=None,
+                                 compute_stream=None, comm_stream=None, done_event=None):
+        """One rank's step of the query-sharded match (vs_hamming_knn2_sharded_dev): kernel into this rank's slot of
+        d_gathered int32[world*per][4], then (if nccl_comm) one in-place ncclAllGather on comm_stream; enqueues only."""
+        def vp(x):
+            return C.c_void_p(x) if x else None
+        self._chk(self._lib.vs_hamming_knn2_sharded_dev(self._h, C.c_void_p(d_q_shard), int(nq_shard), C.c_void_p(d_t),
+                                                        int(nt), C.c_void_p(d_gathered), int(per), int(rank), int(world),
+                                                        vp(nccl_comm), vp(compute_stream), vp(comm_stream), vp(done_event)))
 
     def match_ratio_dev(self, d_q, nq, d_t, nt, ratio, d_mq, d_mt, d_md, d_n, stream=None):
         self._chk(self._lib.vs_match_ratio_dev(self._h, C.c_void_p(d_q), int(nq), C.c_void_p(d_t), int(nt),
@@ -303,7 +334,8 @@ class Context:
 
     # ------------------------------------------------------------------ bundle adjustment (A9-A16)
     def ba_solve(self, poses, pose_fixed, points, point_fixed, obs_pose, obs_point, obs_uv, K,
-                 huber_delta=float(np.sqrt(5.991)), max_iterations=10, scale_edges=None, obs_info=None, dcs_phi=1.0):
+                 huber_delta=float(np.sqrt(5.991)), max_iterations=10, scale_edges=None, obs_info=None, dcs_phi=1.0,
+                 trial_trace=False):
         poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 16)
         points = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
         pose_fixed = np.ascontiguousarray(pose_fixed, np.uint8)
@@ -338,12 +370,30 @@ class Context:
         lam = np.full(max(max_iterations, 1), np.nan)
         r.poses_out, r.points_out = ptr(poses_out, c_f64p), ptr(points_out, c_f64p)
         r.chi2_trace, r.lambda_trace = ptr(chi, c_f64p), ptr(lam, c_f64p)
+        tt = None
+        if trial_trace:  # per-trial rows (lambda, trial chi2, rho, solve ok): test / diagnostic aid
+            tt = np.full((max(10 * max_iterations, 1), 4), np.nan)
+            r.trial_trace, r.trial_trace_cap = ptr(tt, c_f64p), tt.shape[0]
         self._chk(self._lib.vs_ba_solve(self._h, C.byref(p), C.byref(r)))
         del keep
-        return dict(poses=poses_out.reshape(-1, 4, 4), points=points_out, chi2_trace=chi[:r.iterations].copy(),
-                    lambda_trace=lam[:r.iterations].copy(), chi2_initial=r.chi2_initial, chi2_final=r.chi2_final,
-                    lambda_final=r.lambda_final, iterations=r.iterations, trials=r.trials, not_pd=r.not_pd,
-                    terminated=r.terminated)
+        out = dict(poses=poses_out.reshape(-1, 4, 4), points=points_out, chi2_trace=chi[:r.iterations].copy(),
+                   lambda_trace=lam[:r.iterations].copy(), chi2_initial=r.chi2_initial, chi2_final=r.chi2_final,
+                   lambda_final=r.lambda_final, iterations=r.iterations, trials=r.trials, not_pd=r.not_pd,
+                   terminated=r.terminated)
+        if tt is not None:
+            out["trial_trace"] = tt[:min(r.trials, tt.shape[0])].copy()
+        return out
+
+    def debug_cholesky(self, S, b):
+        """Test hook (vs_ba_debug_cholesky): the device's dense solver of the reduced camera system on its own.
+        Returns (ok, x)."""
+        S = np.ascontiguousarray(S, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        n = S.shape[0]
+        x = np.zeros(n)
+        ok = C.c_int(0)
+        self._chk(self._lib.vs_ba_debug_cholesky(self._h, ptr(S, c_f64p), n, ptr(b, c_f64p), ptr(x, c_f64p), C.byref(ok)))
+        return bool(ok.value), x
 
 
 _DEFAULT = None

@@ -451,6 +451,8 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur(ba_dev D) {
   double* sY = sDi + (size_t)per * 12;
   double* sB = sY + D.mmax * 18;
   int* sSlot = reinterpret_cast<int*>(sB + D.mmax * 18);
+  int* sRank = sSlot + D.mmax;  // duplicate observations only
+  const int maxr = D.max_rank;
   for (int i = tid; i < slab_elems; i += kSchurThreads) slab[i] = 0.0;
   const double lambda = st.lambda;
   const int l0 = blockIdx.x * per, l1 = min(l0 + per, D.nfl);
@@ -483,30 +485,42 @@ __global__ __launch_bounds__(kSchurThreads) void ba_schur(ba_dev D) {
       sB[i] = B[k];
       sY[i] = B[3 * arow] * sD[bcol] + B[3 * arow + 1] * sD[3 + bcol] + B[3 * arow + 2] * sD[6 + bcol];
     }
-    for (int i = tid; i < m; i += kSchurThreads) sSlot[i] = D.fp_slot[base + i];
+    for (int i = tid; i < m; i += kSchurThreads) {
+      sSlot[i] = D.fp_slot[base + i];
+      sRank[i] = maxr ? D.fp_rank[base + i] : 0;
+    }
     __syncthreads();
-    // rhs: slab_b[ci] += B_i * (Dinv bl)   (one thread per (obs, row); distinct cameras -> distinct elements)
-    for (int i = tid; i < m * 6; i += kSchurThreads) {
-      const int obs = i / 6, arow = i - obs * 6;
-      const double* B = sB + obs * 18 + 3 * arow;
-      const double v = B[0] * sD[9] + B[1] * sD[10] + B[2] * sD[11];
-      double* dst = slab + np * np + 6 * sSlot[obs] + arow;
-      if (D.dups) atomicAdd(dst, v);
-      else *dst += v;
+    // Distinct cameras -> distinct slab elements.  A camera that observes the point more than once (never produced by
+    // the reference's dict-of-frames, but legal at the ABI) would make several (obs, obs) pairs hit one element: those
+    // are processed in rounds by repeat rank -- inside a round every element has one writer, and the rounds run in the
+    // sequential algorithm's order (i ascending, then j), so the sums are deterministic and ordered.  No atomics.
+    // rhs: slab_b[ci] += B_i * (Dinv bl)   (one thread per (obs, row))
+    for (int ri = 0; ri <= maxr; ++ri) {
+      for (int i = tid; i < m * 6; i += kSchurThreads) {
+        const int obs = i / 6, arow = i - obs * 6;
+        if (sRank[obs] != ri) continue;
+        const double* B = sB + obs * 18 + 3 * arow;
+        const double v = B[0] * sD[9] + B[1] * sD[10] + B[2] * sD[11];
+        slab[np * np + 6 * sSlot[obs] + arow] += v;
+      }
+      if (maxr) __syncthreads();
     }
     // matrix: slab[ci][cj] += Y_i * B_j^T
     const int nel = m * m * 36;
-    for (int i = tid; i < nel; i += kSchurThreads) {
-      const int pair = i / 36, k = i - pair * 36;
-      const int oi = pair / m, oj = pair - oi * m;
-      const int arow = k / 6, bcol = k - arow * 6;
-      const double* Y = sY + oi * 18 + 3 * arow;
-      const double* B = sB + oj * 18 + 3 * bcol;
-      const double v = Y[0] * B[0] + Y[1] * B[1] + Y[2] * B[2];
-      double* dst = slab + (size_t)(6 * sSlot[oi] + arow) * np + 6 * sSlot[oj] + bcol;
-      if (D.dups) atomicAdd(dst, v);
-      else *dst += v;
-    }
+    for (int ri = 0; ri <= maxr; ++ri)
+      for (int rj = 0; rj <= maxr; ++rj) {
+        for (int i = tid; i < nel; i += kSchurThreads) {
+          const int pair = i / 36, k = i - pair * 36;
+          const int oi = pair / m, oj = pair - oi * m;
+          if (sRank[oi] != ri || sRank[oj] != rj) continue;
+          const int arow = k / 6, bcol = k - arow * 6;
+          const double* Y = sY + oi * 18 + 3 * arow;
+          const double* B = sB + oj * 18 + 3 * bcol;
+          const double v = Y[0] * B[0] + Y[1] * B[1] + Y[2] * B[2];
+          slab[(size_t)(6 * sSlot[oi] + arow) * np + 6 * sSlot[oj] + bcol] += v;
+        }
+        if (maxr) __syncthreads();
+      }
     __syncthreads();
   }
   if (LDS_SLAB) {
@@ -1334,6 +1348,13 @@ __global__ __launch_bounds__(64) void ba_decide(ba_dev D) {
   scale += 1e-3;
   rho /= scale;
   st->rho = rho;
+  if (D.trial_trace && st->trials >= 1 && st->trials <= D.trial_cap) {
+    double* row = D.trial_trace + 4 * (size_t)(st->trials - 1);
+    row[0] = st->lambda;
+    row[1] = temp;
+    row[2] = rho;
+    row[3] = st->solve_ok ? 1.0 : 0.0;
+  }
   int stop = 0;
   if (rho > 0 && isfinite(temp)) {
     double alpha = 1.0 - pow(2 * rho - 1, 3);
@@ -1501,6 +1522,13 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
         double rho = st.current_chi - temp;
         scale += 1e-3;
         rho /= scale;
+        if (c == 0 && D.trial_trace && st.trials <= D.trial_cap) {
+          double* row = D.trial_trace + 4 * (size_t)(st.trials - 1);
+          row[0] = st.lambda;
+          row[1] = temp;
+          row[2] = rho;
+          row[3] = bad > 0.0 ? 0.0 : 1.0;
+        }
         int stop = 0;
         if (rho > 0 && isfinite(temp)) {
           double alpha = 1.0 - pow(2 * rho - 1, 3);
@@ -1734,7 +1762,108 @@ struct arena {
   }
 };
 
+// dense solver of the reduced camera system: which kernels a system of np unknowns takes, and their launch
+struct solve_plan {
+  bool lds = false;        // np <= kMaxLdsN: ba_solve_block, one workgroup, [S | rhs] in LDS
+  size_t lds_bytes = 0;
+  int nbw = 0;             // otherwise: panel width of the blocked HBM factorisation (0: element-wise last resort)
+  size_t panel_lds = 0;
+};
+
+int plan_solve(vs_ctx* ctx, int np, solve_plan* P) {
+  P->lds = np <= kMaxLdsN;
+  P->lds_bytes = 32 + (P->lds ? sizeof(double) * ((size_t)(np + 1) * ((np + 1) | 1) + 2 * (size_t)np + 4) : 0);
+  P->nbw = 0;
+  P->panel_lds = 0;
+  if (!P->lds) {
+    // widest panel (24 / 12 / 6 columns) whose rows j0..n fit in LDS
+    for (int w : {24, 12, 6}) {
+      const size_t b = sizeof(double) * ((size_t)(np + 1) * (w | 1) + w) + 64;
+      if (b <= 150 * 1024 && sizeof(double) * (size_t)np + 64 <= 150 * 1024) {
+        P->nbw = w;
+        P->panel_lds = b;
+        break;
+      }
+    }
+    if (P->nbw) {
+      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->panel_lds));
+      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (size_t)np + 64)));
+    }
+  }
+  if (P->lds_bytes > 64 * 1024)
+    VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_bytes));
+  return VS_OK;
+}
+
+int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& P) {
+  const int np = D.np;
+  if (P.lds) {
+    hipLaunchKernelGGL(ba_solve_block, dim3(1), dim3(kSolveBlock), P.lds_bytes, s, D);
+  } else if (P.nbw > 0) {
+    for (int j0 = 0; j0 < np; j0 += P.nbw) {
+      const int w = std::min(P.nbw, np - j0);
+      hipLaunchKernelGGL(ba_chol_panel, dim3(1), dim3(kPanelThreads), P.panel_lds, s, D, j0, w);
+      const int rem = np + 1 - (j0 + w);  // trailing rows incl. the rhs row
+      if (rem > 0) {
+        const unsigned T = (unsigned)((rem + kUpdTile - 1) / kUpdTile);
+        hipLaunchKernelGGL(ba_chol_update, dim3(T, T), dim3(256), 0, s, D, j0, w);
+      }
+    }
+    hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * (size_t)np + 64, s, D, P.nbw);
+  } else {
+    hipLaunchKernelGGL(ba_solve<false>, dim3(1), dim3(kSolveThreads), P.lds_bytes, s, D);
+  }
+  VS_LAUNCH_CHECK(ctx, "ba_solve");
+  return VS_OK;
+}
+
 }  // namespace
+
+// Test hook: the dense solver alone (see include/vslam_hip.h).  A minimal ba_dev without cameras or points: the
+// kernels read S, bs, bp and the LM state and write xp and solve_ok.
+VS_API int vs_ba_debug_cholesky(vs_ctx* ctx, const double* S, int n, const double* b, double* x, int* ok) {
+  if (!ctx) return VS_EINVAL;
+  if (!S || !b || !x || !ok || n <= 0 || n % 6 != 0)
+    return vs_fail(ctx, VS_EINVAL, "%s: need S, b, x, ok and n a positive multiple of 6", "vs_ba_debug_cholesky");
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const size_t nn = (size_t)n * n;
+  const size_t bytes = sizeof(double) * (nn + 4 * (size_t)n + 64) + sizeof(lm_state) + 1024;
+  VS_TRY(vs_reserve(ctx, &ctx->d_ba, bytes));
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + 64));
+  VS_HIP(ctx, hipStreamSynchronize(s));
+  ba_dev D;
+  memset(&D, 0, sizeof D);
+  D.np = n;
+  D.nfp = n / 6;
+  double* base = (double*)ctx->d_ba.p;
+  D.S = base;
+  D.bs = D.S + nn;
+  D.bp = D.bs + n;
+  D.xp = D.bp + n;
+  D.rinv = D.xp + n;
+  D.chol_fail = reinterpret_cast<int*>(D.rinv + n);
+  D.st = reinterpret_cast<lm_state*>(D.rinv + n + 8);
+  D.cam[0] = D.cam[1] = base;  // n_poses = 0: never dereferenced
+  lm_state* hst = (lm_state*)ctx->h_pin.p;
+  memset(hst, 0, sizeof(lm_state));
+  VS_HIP(ctx, hipMemcpyAsync(D.st, hst, sizeof(lm_state), hipMemcpyHostToDevice, s));
+  VS_HIP(ctx, hipMemcpyAsync(D.S, S, sizeof(double) * nn, hipMemcpyHostToDevice, s));
+  VS_HIP(ctx, hipMemcpyAsync(D.bs, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  VS_HIP(ctx, hipMemcpyAsync(D.bp, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  VS_HIP(ctx, hipMemsetAsync(D.chol_fail, 0, 16, s));
+  solve_plan P;
+  VS_TRY(plan_solve(ctx, n, &P));
+  VS_TRY(launch_solve(ctx, s, D, P));
+  VS_HIP(ctx, hipMemcpyAsync(hst, D.st, sizeof(lm_state), hipMemcpyDeviceToHost, s));
+  VS_HIP(ctx, hipStreamSynchronize(s));
+  *ok = hst->solve_ok;
+  if (hst->solve_ok) {
+    VS_HIP(ctx, hipMemcpyAsync(x, D.xp, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipStreamSynchronize(s));
+  }
+  return VS_OK;
+}
 
 VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   if (!ctx) return VS_EINVAL;
@@ -1790,10 +1919,11 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   act_pt.reserve(P);
   std::vector<int> seen_by(F, -1);  // seen_by[camera] = last free point with an observation from that free camera
   std::vector<int> cam_start(nfp + 1, 0), cs_sorted(n_obs ? n_obs : 1);  // cs_sorted[i] = camera slot of sorted obs i
-  std::vector<int> o_hpl(n_obs ? n_obs : 1, -1), fp_start(nfl + 1, 0), fp_slot;
+  std::vector<int> o_hpl(n_obs ? n_obs : 1, -1), fp_start(nfl + 1, 0), fp_slot, fp_rank;
+  std::vector<int> seen_cnt(F, 0);  // duplicates: observations of the current point from that camera so far
   std::vector<unsigned long long> fp_mask(nfl, 0ull);
   fp_slot.reserve(n_obs);
-  int mmax = 1, dups = 0;
+  int mmax = 1, dups = 0, max_rank = 0;
   for (int j = 0; j < P; ++j) {
     const int m = cnt[j + 1] - cnt[j], ls = pt_slot[j];
     if (m == 0 && ls < 0) continue;
@@ -1808,10 +1938,17 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       cam_start[cs + 1]++;
       if (ls >= 0) {
         ++mf;
-        if (seen_by[cam] == j) dups = 1;  // same camera twice: LDS atomics
+        if (seen_by[cam] == j) {  // same camera twice: the ordered-rounds path of ba_schur
+          dups = 1;
+          seen_cnt[cam] += 1;
+        } else {
+          seen_cnt[cam] = 0;
+        }
         seen_by[cam] = j;
+        max_rank = std::max(max_rank, seen_cnt[cam]);
         o_hpl[i] = (int)fp_slot.size();
         fp_slot.push_back(cs);
+        fp_rank.push_back(seen_cnt[cam]);
         mask |= 1ull << ((cs / kTileCams) & 63);
       }
     }
@@ -1857,7 +1994,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
                                   2 * (size_t)np * np + 8 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
                                   9 * (size_t)nfl + (tiled ? 4 * (size_t)nfl : 0) + (size_t)(ns ? ns : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
                                   2 * (size_t)q.max_iterations + 64) +
-                256 * 64 + sizeof(int) * (2 * (size_t)n_obs + nfl + 16) + (motion_only ? sizeof(double) * (8 * cam_obs.size() + 50 * (size_t)nfp + 64) : 0);
+                256 * 64 + sizeof(int) * (3 * (size_t)n_obs + nfl + 16) + sizeof(double) * 4 * (size_t)(res->trial_trace ? std::max(res->trial_trace_cap, 0) : 0) + (motion_only ? sizeof(double) * (8 * cam_obs.size() + 50 * (size_t)nfp + 64) : 0);
   VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, need));
   VS_HIP(ctx, hipStreamSynchronize(s));
@@ -1907,6 +2044,12 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.o_hpl = A.take<int>(n_obs, &h_ohpl);
   D.fp_start = A.take<int>(nfl + 1, &h_fps);
   D.fp_slot = A.take<int>(n_hpl, &h_fpl);
+  D.max_rank = max_rank;
+  if (dups) {
+    int* h_fpr;
+    D.fp_rank = A.take<int>(n_hpl, &h_fpr);
+    memcpy(h_fpr, fp_rank.data(), sizeof(int) * (size_t)n_hpl);
+  }
   if (tiled) {
     unsigned long long* h_mask;
     D.fp_mask = A.take<unsigned long long>(nfl, &h_mask);
@@ -1954,6 +2097,11 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.part_maxd = A.take<double>((size_t)nb_pt + nfp);
   D.chi_trace = A.take<double>(q.max_iterations);
   D.lambda_trace = A.take<double>(q.max_iterations);
+  const int trial_cap = res->trial_trace && res->trial_trace_cap > 0 ? res->trial_trace_cap : 0;
+  if (trial_cap) {
+    D.trial_trace = A.take<double>(4 * (size_t)trial_cap);
+    D.trial_cap = trial_cap;
+  }
   if (motion_only) {
     D.mo_part = A.take<double>(8 * (size_t)nfp);
     D.mo_H = A.take<double>(42 * (size_t)nfp);
@@ -2026,9 +2174,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
 
   // ---- kernels
   const int schur_per = ns > 0 ? (nfl + ns - 1) / ns : 0;
-  const size_t schur_lds = sizeof(double) * ((lds_slab ? slab_elems : 0) + 12 * (size_t)schur_per + 36 * (size_t)mmax) + sizeof(int) * ((size_t)mmax + 1) + 16;
-  const bool solve_lds = np <= kMaxLdsN;
-  const size_t solve_lds_bytes = 32 + (solve_lds ? sizeof(double) * ((size_t)(np + 1) * ((np + 1) | 1) + 2 * (size_t)np + 4) : 0);
+  const size_t schur_lds = sizeof(double) * ((lds_slab ? slab_elems : 0) + 12 * (size_t)schur_per + 36 * (size_t)mmax) + sizeof(int) * (2 * (size_t)mmax + 2) + 16;
   const size_t tile_lds = sizeof(double) * (2 * kTileBatch * 12 + 2 * kTileBatch * kTileCams * 18) +
                           sizeof(int) * (3 * kTileBatch * 32 + 3 * kTileChunk + 8) + 64;
   if (tiled) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur_tile, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds));
@@ -2036,25 +2182,8 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     if (lds_slab) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
     else VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_schur<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
   }
-  // blocked HBM factorisation for larger systems: widest panel (24 / 12 / 6 columns) whose rows j0..n fit in LDS
-  int chol_nbw = 0;
-  size_t chol_panel_lds = 0;
-  if (!solve_lds) {
-    for (int w : {24, 12, 6}) {
-      const size_t b = sizeof(double) * ((size_t)(np + 1) * (w | 1) + w) + 64;
-      if (b <= 150 * 1024 && sizeof(double) * (size_t)np + 64 <= 150 * 1024) {
-        chol_nbw = w;
-        chol_panel_lds = b;
-        break;
-      }
-    }
-    if (chol_nbw) {
-      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)chol_panel_lds));
-      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (size_t)np + 64)));
-    }
-  }
-  if (solve_lds_bytes > 64 * 1024)
-    VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_bytes));
+  solve_plan splan;
+  VS_TRY(plan_solve(ctx, np, &splan));
   if (!tiled && schur_lds > 160 * 1024) return vs_fail(ctx, VS_EINVAL, "%s: a point is observed by too many free cameras for the LDS staging", "vs_ba_solve");
 
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + sizeof(mo_state) + 128));
@@ -2079,23 +2208,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 63) / 64)), dim3(256), 0, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_reduce");
     }
-    if (solve_lds) {
-      hipLaunchKernelGGL(ba_solve_block, dim3(1), dim3(kSolveBlock), solve_lds_bytes, s, D);
-    } else if (chol_nbw > 0) {
-      for (int j0 = 0; j0 < np; j0 += chol_nbw) {
-        const int w = std::min(chol_nbw, np - j0);
-        hipLaunchKernelGGL(ba_chol_panel, dim3(1), dim3(kPanelThreads), chol_panel_lds, s, D, j0, w);
-        const int rem = np + 1 - (j0 + w);  // trailing rows incl. the rhs row
-        if (rem > 0) {
-          const unsigned T = (unsigned)((rem + kUpdTile - 1) / kUpdTile);
-          hipLaunchKernelGGL(ba_chol_update, dim3(T, T), dim3(256), 0, s, D, j0, w);
-        }
-      }
-      hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * (size_t)np + 64, s, D, chol_nbw);
-    } else {
-      hipLaunchKernelGGL(ba_solve<false>, dim3(1), dim3(kSolveThreads), solve_lds_bytes, s, D);
-    }
-    VS_LAUNCH_CHECK(ctx, "ba_solve");
+    VS_TRY(launch_solve(ctx, s, D, splan));
     hipLaunchKernelGGL(ba_point_trial, dim3(nb_pt), dim3(kPtThreads), 0, s, D);
     VS_LAUNCH_CHECK(ctx, "ba_point_trial");
     hipLaunchKernelGGL(ba_decide, dim3(1), dim3(64), 0, s, D);
@@ -2171,6 +2284,9 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     VS_HIP(ctx, hipMemcpyAsync(h_tr + q.max_iterations, D.lambda_trace, sizeof(double) * q.max_iterations,
                                hipMemcpyDeviceToHost, s));
   }
+  if (trial_cap)
+    VS_HIP(ctx, hipMemcpyAsync(res->trial_trace, D.trial_trace, sizeof(double) * 4 * (size_t)std::min(trial_cap, hst->trials),
+                               hipMemcpyDeviceToHost, s));
   VS_HIP(ctx, hipStreamSynchronize(s));
   if (timing)
     fprintf(stderr, "vs_ba_solve: structure %.1f us, arena fill %.1f us, upload + kernels %.1f us, read-back %.1f us (upload %zu B)\n",

@@ -40,6 +40,10 @@ struct ba_dev {
   int* chol_fail;  // set by a panel kernel that met a non-positive pivot
   double *part_chi, *part_scale, *part_maxd;  // per point-block partials; part_maxd has nb_pt + nfp entries
   double *chi_trace, *lambda_trace;
+  double* trial_trace;  // [trial_cap][4] per-trial rows (lambda, trial chi2, rho, solve ok) or nullptr (test aid)
+  int trial_cap;
+  int max_rank;         // duplicate observations: highest repeat count of one camera within one point (0: none)
+  const int* fp_rank;   // per Hpl block: how many earlier blocks of the same point belong to the same camera
   lm_state* st;
   // motion-only kernel: camera-major observation copy cut into chunks of 64
   const double *mo_X, *mo_uv, *mo_info;  // [n_obs_free_cam][3|2|3] in camera-major (cam_start) order

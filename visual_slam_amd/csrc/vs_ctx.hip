@@ -41,42 +41,33 @@ static void free_dev(vs_buf* b) {
 
 VS_API int vs_destroy(vs_ctx* ctx) {
   if (!ctx) return VS_OK;
-  (void)hipSetDevice(ctx->device);
+  // A context destroyed after the HIP runtime has begun to shut down (a static destructor, a late finaliser) must not
+  // call into it: the first call tells, and then only the host object is released.
+  if (hipSetDevice(ctx->device) != hipSuccess || hipStreamQuery(ctx->stream) == hipErrorContextIsDestroyed) {
+    (void)hipGetLastError();
+    delete ctx;
+    return VS_OK;
+  }
   (void)hipStreamSynchronize(ctx->stream);
-  vs_buf* dev[] = {&ctx->d_q,   &ctx->d_t,    &ctx->d_idx,     &ctx->d_dist, &ctx->d_partial, &ctx->d_mq,
+  vs_buf* dev[] = {&ctx->d_q,   &ctx->d_t,    &ctx->d_idx,     &ctx->d_dist, &ctx->d_partial, &ctx->d_ticket, &ctx->d_mq,
                    &ctx->d_mt,  &ctx->d_md,   &ctx->d_cnt,     &ctx->d_bgr,  &ctx->d_gray,    &ctx->d_box,
                    &ctx->d_raw, &ctx->d_bandcnt, &ctx->d_hist, &ctx->d_xy,   &ctx->d_score,   &ctx->d_desc,
                    &ctx->d_n,   &ctx->d_xy_in, &ctx->d_keep,   &ctx->d_ba,  &ctx->d_track, &ctx->d_bgr2};
   for (vs_buf* b : dev) free_dev(b);
-  for (vs_desc_entry& e : ctx->desc_cache) free_dev(&e.dev);
+  for (vs_desc_entry& e : ctx->desc_cache) {
+    free_dev(&e.dev);
+    if (e.shadow.p) (void)hipHostFree(e.shadow.p);
+  }
   if (ctx->h_pin.p) (void)hipHostFree(ctx->h_pin.p);
   if (ctx->h_pin_big.p) (void)hipHostFree(ctx->h_pin_big.p);
   if (ctx->h_track.p) (void)hipHostFree(ctx->h_track.p);
   for (hipEvent_t e : ctx->track.ev_front)
     if (e) (void)hipEventDestroy(e);
+  if (ctx->ev_shard) (void)hipEventDestroy(ctx->ev_shard);
   if (ctx->track.front_stream) (void)hipStreamDestroy(ctx->track.front_stream);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return VS_OK;
-}
-
-uint64_t vs_fingerprint(const void* p, size_t bytes) {
-  // four independent multiply-xor lanes over 64-bit words (vectorises; ~10+ GB/s), tail bytes folded at the end
-  const uint64_t* w = (const uint64_t*)p;
-  const size_t nw = bytes / 8;
-  uint64_t h0 = 0x9E3779B97F4A7C15ull, h1 = 0xC2B2AE3D27D4EB4Full, h2 = 0x165667B19E3779F9ull, h3 = 0x27D4EB2F165667C5ull;
-  size_t i = 0;
-  for (; i + 4 <= nw; i += 4) {
-    h0 = (h0 ^ w[i]) * 0x100000001B3ull;
-    h1 = (h1 ^ w[i + 1]) * 0x100000001B3ull;
-    h2 = (h2 ^ w[i + 2]) * 0x100000001B3ull;
-    h3 = (h3 ^ w[i + 3]) * 0x100000001B3ull;
-  }
-  for (; i < nw; ++i) h0 = (h0 ^ w[i]) * 0x100000001B3ull;
-  const uint8_t* b = (const uint8_t*)p + nw * 8;
-  for (size_t k = 0; k < (bytes & 7); ++k) h1 = (h1 ^ b[k]) * 0x100000001B3ull;
-  uint64_t h = h0 ^ (h1 << 1 | h1 >> 63) ^ (h2 << 2 | h2 >> 62) ^ (h3 << 3 | h3 >> 61);
-  return h ^ (uint64_t)bytes;
 }
 
 bool vs_is_pinned(const void* p) {
@@ -88,48 +79,66 @@ bool vs_is_pinned(const void* p) {
   return a.type == hipMemoryTypeHost;
 }
 
-static vs_desc_entry* desc_slot(vs_ctx* ctx, const uint8_t* h, int n, uint64_t fp, bool* hit) {
+// ---- device-resident descriptor sets of the host matcher -----------------------------------------------------------
+// An entry is (host address, row count) -> device copy + a pinned host SHADOW of the bytes that were uploaded.  A later
+// call with the same address and count is a hit only if the caller's bytes are still byte-for-byte equal to the shadow
+// (memcmp); anything else re-uploads.  No hash is involved, so a stale device copy can never be served.  The shadow is
+// also the DMA staging buffer of the upload, i.e. it costs nothing extra on a miss.
+static vs_desc_entry* desc_slot(vs_ctx* ctx, const uint8_t* h, int n, size_t bytes, bool* hit) {
   vs_desc_entry* lru = &ctx->desc_cache[0];
   for (vs_desc_entry& e : ctx->desc_cache) {
-    if (e.host == h && e.n == n && e.fp == fp && e.dev.p) {
+    if (e.host == h && e.n == n && e.dev.p && e.shadow.p) {
       e.stamp = ++ctx->desc_stamp;
-      *hit = true;
-      return &e;
+      *hit = memcmp(h, e.shadow.p, bytes) == 0;
+      return &e;  // same buffer with new contents re-uses its own entry
     }
     if (e.stamp < lru->stamp) lru = &e;
   }
   *hit = false;
-  lru->host = h;
-  lru->n = n;
-  lru->fp = fp;
   lru->stamp = ++ctx->desc_stamp;
   return lru;
 }
 
-int vs_desc_resident(vs_ctx* ctx, const uint8_t* h, int n, const void** dev_out) {
+int vs_desc_resident(vs_ctx* ctx, const uint8_t* h, int n, int role, const void** dev_out) {
   const size_t bytes = (size_t)VS_DESC_BYTES * n;
+  if (bytes > VS_DESC_CACHE_MAX_BYTES) {
+    // large sets (beyond anything a frame produces) are uploaded on every call into the role's own buffer
+    vs_buf* b = role == 0 ? &ctx->d_q : &ctx->d_t;
+    VS_TRY(vs_reserve(ctx, b, bytes));
+    VS_HIP(ctx, hipMemcpyAsync(b->p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev_out = b->p;
+    return VS_OK;
+  }
   bool hit;
-  vs_desc_entry* e = desc_slot(ctx, h, n, vs_fingerprint(h, bytes), &hit);
+  vs_desc_entry* e = desc_slot(ctx, h, n, bytes, &hit);
   if (!hit) {
     e->host = nullptr;  // invalid while the upload is prepared
     VS_TRY(vs_reserve(ctx, &e->dev, bytes));
-    VS_HIP(ctx, hipMemcpyAsync(e->dev.p, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VS_TRY(vs_reserve_pinned(ctx, &e->shadow, bytes));
+    // every host entry point synchronises before it returns, so no earlier copy still reads this shadow
+    memcpy(e->shadow.p, h, bytes);
+    VS_HIP(ctx, hipMemcpyAsync(e->dev.p, e->shadow.p, bytes, hipMemcpyHostToDevice, ctx->stream));
     e->host = h;
+    e->n = n;
   }
   *dev_out = e->dev.p;
   return VS_OK;
 }
 
-int vs_desc_adopt(vs_ctx* ctx, const uint8_t* h, int n, const void* dev_src) {
+int vs_desc_adopt(vs_ctx* ctx, const uint8_t* h, int n, const void* dev_src, const uint8_t* host_src) {
   if (n <= 0) return VS_OK;
   const size_t bytes = (size_t)VS_DESC_BYTES * n;
+  if (bytes > VS_DESC_CACHE_MAX_BYTES) return VS_OK;
   bool hit;
-  vs_desc_entry* e = desc_slot(ctx, h, n, vs_fingerprint(h, bytes), &hit);
+  vs_desc_entry* e = desc_slot(ctx, h, n, bytes, &hit);
   if (!hit) {
     e->host = nullptr;
     VS_TRY(vs_reserve(ctx, &e->dev, bytes));
+    VS_TRY(vs_reserve_pinned(ctx, &e->shadow, bytes));
+    memcpy(e->shadow.p, host_src, bytes);
     VS_HIP(ctx, hipMemcpyAsync(e->dev.p, dev_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     e->host = h;
+    e->n = n;
   }
   return VS_OK;
 }

@@ -595,7 +595,7 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   if (describe) {
     memcpy(desc, hp + L.off_desc, (size_t)n * VS_DESC_BYTES);
     // the matcher will be handed `desc` next: keep the device copy so it is not uploaded again
-    VS_TRY(vs_desc_adopt(ctx, desc, n, res + L.off_desc));
+    VS_TRY(vs_desc_adopt(ctx, desc, n, res + L.off_desc, hp + L.off_desc));
   }
   *n_out = n;
   return VS_OK;

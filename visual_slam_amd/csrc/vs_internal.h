@@ -15,18 +15,20 @@ struct vs_buf {
   size_t cap = 0;
 };
 
-// Device-resident copies of descriptor sets the host API has seen: keyed by host pointer + row count + a 64-bit
-// fingerprint of the contents (so a re-used or modified host buffer can never alias a stale copy).  A frame's
-// descriptors are uploaded once although they are matched many times (as train this frame, as the key frame's query
-// set for every following frame), and the descriptors vs_detect_describe_bgr just produced are never uploaded at all.
+// Device-resident copies of descriptor sets the host API has seen: keyed by host pointer + row count and verified
+// byte-for-byte against a pinned host shadow of what was uploaded (memcmp -- no hash, so a re-used or modified host
+// buffer can never alias a stale copy).  A frame's descriptors are uploaded once although they are matched many times
+// (as train this frame, as the key frame's query set for every following frame), and the descriptors
+// vs_detect_describe_bgr just produced are never uploaded at all.
 struct vs_desc_entry {
   const void* host = nullptr;
   int n = 0;
-  uint64_t fp = 0;
   vs_buf dev;
+  vs_buf shadow;  // pinned host copy of the uploaded bytes (also the staging buffer of the upload)
   uint64_t stamp = 0;
 };
 constexpr int VS_DESC_CACHE = 6;
+constexpr size_t VS_DESC_CACHE_MAX_BYTES = 8u << 20;  // larger sets are uploaded on every call
 
 struct vs_ctx {
   int device = 0;
@@ -34,7 +36,7 @@ struct vs_ctx {
   hipDeviceProp_t prop;
   char err[512];
   // matcher
-  vs_buf d_q, d_t, d_idx, d_dist, d_partial, d_mq, d_mt, d_md, d_cnt;
+  vs_buf d_q, d_t, d_idx, d_dist, d_partial, d_ticket, d_mq, d_mt, d_md, d_cnt;
   // detector
   vs_buf d_bgr, d_gray, d_box, d_raw, d_bandcnt, d_hist, d_xy, d_score, d_desc, d_n, d_xy_in, d_keep;
   // bundle adjustment
@@ -66,14 +68,15 @@ struct vs_ctx {
     } params[2];
   } track;
   vs_buf d_bgr2;  // image buffer of the second set
+  hipEvent_t ev_shard = nullptr;  // orders the all-gather stream behind the match kernel (vs_hamming_knn2_sharded_dev)
 };
 
-uint64_t vs_fingerprint(const void* p, size_t bytes);
-// device copy of the n x 32-byte descriptor set at host pointer `h` (uploads on a miss); the returned pointer stays
-// valid until VS_DESC_CACHE other sets have been used
-int vs_desc_resident(vs_ctx* ctx, const uint8_t* h, int n, const void** dev_out);
-// registers a device-side descriptor set that is known to equal the host array `h` (detector output)
-int vs_desc_adopt(vs_ctx* ctx, const uint8_t* h, int n, const void* dev_src);
+// device copy of the n x 32-byte descriptor set at host pointer `h` (uploads unless the very same bytes are already
+// resident); role 0 = query, 1 = train (buffers of the uncached path); the returned pointer stays valid until
+// VS_DESC_CACHE other sets have been used
+int vs_desc_resident(vs_ctx* ctx, const uint8_t* h, int n, int role, const void** dev_out);
+// registers a device-side descriptor set that equals the host array `h`; host_src = the bytes just copied into `h`
+int vs_desc_adopt(vs_ctx* ctx, const uint8_t* h, int n, const void* dev_src, const uint8_t* host_src);
 // true if `p` is pinned (hipHostMalloc / hipHostRegister) host memory
 bool vs_is_pinned(const void* p);
 

@@ -4,31 +4,50 @@
 // (reference src/v2/frame.py:18,23,25-47).
 //
 // Kernel design (VALU-bound integer work, no MFMA):
-//   * lane = query.  Every lane keeps QPL query descriptors (8 dwords each) in VGPRs for the whole kernel.
+//   * lane = query.  Every lane keeps kQPL query descriptors (8 dwords each) in VGPRs for the whole kernel.
 //   * train descriptors are wave-uniform: they are read with scalar loads (s_load_dwordx8) into SGPRs and fed to
-//     v_xor_b32 as the scalar operand -- no LDS traffic, no VGPRs, one 32-byte scalar load per 64*QPL distances.
-//   * distance = 8 x (v_xor_b32 + v_bcnt_u32_b32 with accumulate), a dependent chain per query, QPL chains in flight.
-//   * top-2 bookkeeping on packed keys  key = dist << 20 | (train index within the chunk):
-//       second = v_med3_u32(best, second, key);  best = v_min_u32(best, key)
-//     so the tie rule "lower train index first" falls out of the packing.  19 VALU ops per distance.
-//   * the grid is (query tiles) x (train chunks) so that ~4 waves sit on every SIMD even at 10k x 10k; each
-//     (chunk, query) pair writes one 8-byte partial; a second tiny kernel merges the chunks per query in chunk order.
+//     v_xor_b32 as the scalar operand -- no LDS traffic, no VGPRs, one 32-byte scalar load per 64*kQPL distances.
+//   * distance = 8 x (v_xor_b32 + v_bcnt_u32_b32 with accumulate), a dependent chain per query, kQPL chains in flight.
+//   * top-2 bookkeeping on packed keys  key = dist << 20 | (train index within the chunk), two train rows per update:
+//       second = v_min_u32(second, v_med3_u32(best, ka, kb));  best = v_min3_u32(best, ka, kb)
+//     (the second smallest of {best, second, ka, kb} with best <= second is min(second, median(best, ka, kb))), so the
+//     tie rule "lower train index first" falls out of the packing.  16 + 1 + 1.5 = 18.5 VALU ops per distance.
+//   * the grid is (query tiles) x (train chunks) so that ~5 waves sit on every SIMD even at 10k x 10k.  Every
+//     (tile, chunk) workgroup publishes one 8-byte partial per query; the workgroup that arrives LAST at a tile (agent-
+//     scope ticket counter, release/acquire fences as MI355X_MICROARCH.md prescribes for inter-workgroup hand-offs)
+//     folds the tile's partials in chunk order and writes the final (idx, dist) rows: ONE launch, no merge kernel.
 //   * the ratio test + ordered compaction is one workgroup using wave ballots and popcounts for the prefix.
 #include "vs_internal.h"
+
+#include <dlfcn.h>
 
 #include <vector>
 
 namespace {
 
 constexpr int kWaves = 4;                  // waves per workgroup
+constexpr int kQPL = 4;                    // queries per lane
+constexpr int kTU = 4;                     // train rows per step (two pair-updates)
+constexpr int kTileQ = 64 * kQPL;          // queries per workgroup (= threads per workgroup: the fold is thread = query)
 constexpr int kIdxBits = 20;
 constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;
 constexpr int kMaxChunk = 1 << kIdxBits;
 constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+static_assert(kTileQ == 64 * kWaves, "the fold maps one thread to one query of the tile");
 
 __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
   uint32_t r;
   asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
   return r;
 }
 
@@ -37,170 +56,199 @@ typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 // one train descriptor = one 32-byte scalar load (s_load_dwordx8); rows are 32-byte aligned
 __device__ __forceinline__ u32x8 load_train(const uint32_t* p) { return *reinterpret_cast<const u32x8*>(p); }
 
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
-  return min(max(a, b), max(min(a, b), c));  // hipcc folds this to v_med3_u32
+__device__ __forceinline__ uint32_t dist_key(const uint32_t (&q)[8], const u32x8& tw, uint32_t j) {
+  uint32_t acc = bcnt_acc(q[0] ^ tw[0], 0u);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) acc = bcnt_acc(q[k] ^ tw[k], acc);
+  return (acc << kIdxBits) | j;
 }
 
-// asm-issued scalar load: invisible to the compiler's waitcnt insertion, so the wait is placed by hand (swait)
-__device__ __forceinline__ u32x8 sload8_async(const uint32_t* p) {
-  u32x8 r;
-  asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(r) : "s"(p));
-  return r;
-}
-template <int N>
-__device__ __forceinline__ void swait(u32x8 (&v)[N]) {
-  static_assert(N == 2 || N == 4, "");
-  if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]), "+s"(v[1]));
-  else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]), "+s"(v[1]), "+s"(v[2]), "+s"(v[3]));
-}
-
-template <int QPL>
-__device__ __forceinline__ void accumulate(const uint32_t (&qv)[QPL][8], const u32x8& tw, uint32_t j,
-                                           uint32_t (&b1)[QPL], uint32_t (&b2)[QPL]) {
+// two train rows (indices j, j + 1 within the chunk) against the lane's kQPL queries
+__device__ __forceinline__ void accumulate2(const uint32_t (&qv)[kQPL][8], const u32x8& ta, const u32x8& tb, uint32_t j,
+                                            uint32_t (&b1)[kQPL], uint32_t (&b2)[kQPL]) {
 #pragma unroll
-  for (int r = 0; r < QPL; ++r) {
-    uint32_t acc = bcnt_acc(qv[r][0] ^ tw[0], 0u);
+  for (int r = 0; r < kQPL; ++r) {
+    const uint32_t ka = dist_key(qv[r], ta, j), kb = dist_key(qv[r], tb, j + 1);
+    b2[r] = min(b2[r], umed3(b1[r], ka, kb));
+    b1[r] = umin3(b1[r], ka, kb);
+  }
+}
+__device__ __forceinline__ void accumulate1(const uint32_t (&qv)[kQPL][8], const u32x8& tw, uint32_t j,
+                                            uint32_t (&b1)[kQPL], uint32_t (&b2)[kQPL]) {
 #pragma unroll
-    for (int k = 1; k < 8; ++k) acc = bcnt_acc(qv[r][k] ^ tw[k], acc);
-    uint32_t key = (acc << kIdxBits) | j;
+  for (int r = 0; r < kQPL; ++r) {
+    const uint32_t key = dist_key(qv[r], tw, j);
     b2[r] = umed3(b1[r], b2[r], key);
     b1[r] = min(b1[r], key);
   }
 }
 
-// partial[chunk][q] = (best key, second key) of query q over the trains of `chunk`.
-// A workgroup = kWaves waves that hold the SAME 64*QPL queries; wave w scans the w-th quarter of the chunk and the
-// four (best, second) pairs are merged through LDS, so only one 8-byte partial per (chunk, query) reaches HBM.
-// QPL: queries per lane; TU: train descriptors per step; PIPE: software-pipelined scalar loads (asm + manual wait)
-template <int QPL, int TU, bool PIPE>
-__global__ __launch_bounds__(64 * kWaves) void hamming_partial_kernel(const uint4* __restrict__ q4, int nq,
-                                                                        const uint32_t* __restrict__ t, int nt,
-                                                                        int chunk_len, int sub_len,
-                                                                        uint2* __restrict__ partial) {
-  __shared__ uint2 lds[kWaves][64 * QPL];
+// (best, second) of two sets whose keys are all distinct
+__device__ __forceinline__ void fold64(unsigned long long& B1, unsigned long long& B2, unsigned long long K) {
+  B2 = min(B2, max(B1, K));
+  B1 = min(B1, K);
+}
+
+// Workgroup (tile, chunk): kWaves waves hold the SAME kTileQ queries; wave w scans the w-th quarter of the chunk and the
+// four (best, second) pairs are merged through LDS, so one 8-byte partial per (chunk, query) is published:
+//   partial[(chunk * qtiles + tile) * kTileQ + local query]      (2 KB rows: no cache line is shared by two workgroups)
+// The last workgroup to arrive at a tile (ticket[tile], reset by that workgroup for the next launch) folds the chunks.
+// PACKED: one 16-byte row (idx0, idx1, dist0, dist1) per query -- the layout the query-sharded matcher all-gathers.
+// TSTAGE (how the wave-uniform train rows reach the VALU):
+//   false: scalar loads (s_load_dwordx16), the row is the SGPR operand of v_xor_b32;
+//   true : every wave stages 64 rows at a time in its own LDS slice (one coalesced 32-B load per lane, prefetched one
+//          batch ahead) and reads each row back as two broadcast ds_read_b128 -- both v_xor_b32 operands are then VGPRs.
+//          tools/valu_probe2.hip: v_xor/v_and/v_or with VGPR sources issue at the 2-cycle wave64 rate on gfx950, with an
+//          SGPR source (and every v_bcnt / v_min3 / v_med3) at the 4-cycle rate.
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ u32x8 row_from(const uint4 a, const uint4 b) {
+  u32x8 r;
+  r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+  r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+  return r;
+}
+
+template <bool PACKED, bool TSTAGE>
+__global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint4* __restrict__ q4, int nq,
+                                                                     const uint32_t* __restrict__ t, int nt,
+                                                                     int chunk_len, int sub_len, uint2* partial,
+                                                                     unsigned* ticket, int2* __restrict__ idx,
+                                                                     int2* __restrict__ dist) {
+  __shared__ uint2 lds[kWaves][kTileQ];
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
-  const int qbase = blockIdx.x * (64 * QPL);
-  const int cbegin = blockIdx.y * chunk_len;
+  const int tile = blockIdx.x, chunk = blockIdx.y, qtiles = gridDim.x, nchunks = gridDim.y;
+  const int qbase = tile * kTileQ;
+  const int cbegin = chunk * chunk_len;
   const int cend = min(cbegin + chunk_len, nt);
   const int begin = min(cbegin + wave * sub_len, cend);
   const int end = min(begin + sub_len, cend);
 
-  uint32_t qv[QPL][8];
+  uint32_t qv[kQPL][8];
 #pragma unroll
-  for (int r = 0; r < QPL; ++r) {
+  for (int r = 0; r < kQPL; ++r) {
     int qi = min(qbase + r * 64 + lane, nq - 1);  // clamp: the tail computes a duplicate, the store is guarded
     uint4 a = q4[2 * (size_t)qi], b = q4[2 * (size_t)qi + 1];
     qv[r][0] = a.x; qv[r][1] = a.y; qv[r][2] = a.z; qv[r][3] = a.w;
     qv[r][4] = b.x; qv[r][5] = b.y; qv[r][6] = b.z; qv[r][7] = b.w;
   }
-  uint32_t b1[QPL], b2[QPL];
+  uint32_t b1[kQPL], b2[kQPL];
 #pragma unroll
-  for (int r = 0; r < QPL; ++r) b1[r] = b2[r] = kEmpty;
+  for (int r = 0; r < kQPL; ++r) b1[r] = b2[r] = kEmpty;
 
   const uint32_t* tp = t + (size_t)begin * 8;  // wave-uniform -> scalar loads
   const uint32_t j0 = (uint32_t)(begin - cbegin); // keys carry the index within the workgroup's chunk
   const int n = end - begin;
-  int j = 0;
-  if constexpr (PIPE) {
-    if (n >= TU) {
-      u32x8 cur[TU];
+  if constexpr (TSTAGE) {
+    __shared__ uint4 stage[kWaves][2][128];  // per wave: two batches of 64 rows x 32 B
+    const uint4* t4 = reinterpret_cast<const uint4*>(t);
+    const int nb = (n + 63) >> 6;
+    uint4 r0 = make_uint4(0, 0, 0, 0), r1 = r0;
+    if (nb > 0) {
+      const int row = min(begin + lane, nt - 1);
+      r0 = t4[2 * (size_t)row];
+      r1 = t4[2 * (size_t)row + 1];
+    }
+    for (int b = 0; b < nb; ++b) {
+      uint4* buf = stage[wave][b & 1];
+      buf[2 * lane] = r0;
+      buf[2 * lane + 1] = r1;
+      if (b + 1 < nb) {  // prefetch the next batch while this one is consumed
+        const int row = min(begin + 64 * (b + 1) + lane, nt - 1);
+        r0 = t4[2 * (size_t)row];
+        r1 = t4[2 * (size_t)row + 1];
+      }
+      wave_lds_order();
+      const int cnt = min(64, n - 64 * b);
+      const uint32_t jb = j0 + (uint32_t)(64 * b);
+      int j = 0;
+      for (; j + 2 <= cnt; j += 2) {
+        const u32x8 ta = row_from(buf[2 * j], buf[2 * j + 1]), tb = row_from(buf[2 * j + 2], buf[2 * j + 3]);
+        accumulate2(qv, ta, tb, jb + (uint32_t)j, b1, b2);
+      }
+      if (j < cnt) accumulate1(qv, row_from(buf[2 * j], buf[2 * j + 1]), jb + (uint32_t)j, b1, b2);
+      wave_lds_order();
+    }
+  } else {
+    int j = 0;
+    for (; j + kTU <= n; j += kTU) {
+      u32x8 tw[kTU];
 #pragma unroll
-      for (int u = 0; u < TU; ++u) cur[u] = sload8_async(tp + (size_t)u * 8);
-      swait(cur);
-      for (; j + TU <= n; j += TU) {
-        const int jn = min(j + TU, n - TU);  // the last step re-reads itself: always in bounds
-        u32x8 nxt[TU];
+      for (int u = 0; u < kTU; ++u) tw[u] = load_train(tp + (size_t)(j + u) * 8);
 #pragma unroll
-        for (int u = 0; u < TU; ++u) nxt[u] = sload8_async(tp + (size_t)(jn + u) * 8);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < kTU; u += 2) accumulate2(qv, tw[u], tw[u + 1], j0 + (uint32_t)(j + u), b1, b2);
+    }
+    for (; j < n; ++j) {
+      u32x8 tw = load_train(tp + (size_t)j * 8);
+      accumulate1(qv, tw, j0 + (uint32_t)j, b1, b2);
+    }
+  }
 #pragma unroll
-        for (int u = 0; u < TU; ++u) accumulate<QPL>(qv, cur[u], j0 + (uint32_t)(j + u), b1, b2);
-        __builtin_amdgcn_sched_barrier(0);
-        swait(nxt);
+  for (int r = 0; r < kQPL; ++r) lds[wave][r * 64 + lane] = make_uint2(b1[r], b2[r]);
+  __syncthreads();
+  // keys of different waves are distinct (disjoint index ranges), so min / max merge them exactly; thread = query
+  const int lq = threadIdx.x, qi = qbase + lq;
+  uint2 m = lds[0][lq];
 #pragma unroll
-        for (int u = 0; u < TU; ++u) cur[u] = nxt[u];
+  for (int w = 1; w < kWaves; ++w) {
+    const uint2 o = lds[w][lq];
+    const uint32_t s2 = min(max(m.x, o.x), min(m.y, o.y));
+    m.x = min(m.x, o.x);
+    m.y = s2;
+  }
+  unsigned long long B1 = ~0ull, B2 = ~0ull;
+  if (nchunks > 1) {
+    // ---- publish this chunk's partial row, then take a ticket (MI355X_MICROARCH.md, inter-workgroup visibility:
+    // plain stores -> every storing wave drains -> barrier -> one lane: agent release, drain, relaxed agent atomic)
+    partial[((size_t)chunk * qtiles + tile) * kTileQ + lq] = m;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned prev = __hip_atomic_fetch_add(&ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == (unsigned)(nchunks - 1);
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 must not serve older lines of `partial`
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ticket[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;  // uniform
+    // ---- fold the tile's chunks in chunk order (loads issued 8 at a time before their use)
+    for (int c0 = 0; c0 < nchunks; c0 += 8) {
+      uint2 p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = min(c0 + u, nchunks - 1);
+        p[u] = partial[((size_t)c * qtiles + tile) * kTileQ + lq];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (c0 + u >= nchunks) break;
+        const unsigned long long base = (unsigned long long)(c0 + u) * (unsigned long long)chunk_len;
+        if (p[u].x != kEmpty) fold64(B1, B2, ((unsigned long long)(p[u].x >> kIdxBits) << 32) | (base + (p[u].x & kIdxMask)));
+        if (p[u].y != kEmpty) fold64(B1, B2, ((unsigned long long)(p[u].y >> kIdxBits) << 32) | (base + (p[u].y & kIdxMask)));
       }
     }
   } else {
-    for (; j + TU <= n; j += TU) {
-      u32x8 tw[TU];
-#pragma unroll
-      for (int u = 0; u < TU; ++u) tw[u] = load_train(tp + (size_t)(j + u) * 8);
-#pragma unroll
-      for (int u = 0; u < TU; ++u) accumulate<QPL>(qv, tw[u], j0 + (uint32_t)(j + u), b1, b2);
-    }
+    if (m.x != kEmpty) fold64(B1, B2, ((unsigned long long)(m.x >> kIdxBits) << 32) | (unsigned long long)(m.x & kIdxMask));
+    if (m.y != kEmpty) fold64(B1, B2, ((unsigned long long)(m.y >> kIdxBits) << 32) | (unsigned long long)(m.y & kIdxMask));
   }
-  for (; j < n; ++j) {
-    u32x8 tw = load_train(tp + (size_t)j * 8);
-    accumulate<QPL>(qv, tw, j0 + (uint32_t)j, b1, b2);
-  }
-#pragma unroll
-  for (int r = 0; r < QPL; ++r) lds[wave][r * 64 + lane] = make_uint2(b1[r], b2[r]);
-  __syncthreads();
-  // keys of different waves are distinct (disjoint index ranges), so min / med3 merge them exactly
-  for (int i = threadIdx.x; i < 64 * QPL; i += 64 * kWaves) {
-    uint2 m = lds[0][i];
-#pragma unroll
-    for (int w = 1; w < kWaves; ++w) {
-      uint2 o = lds[w][i];
-      uint32_t s2 = min(max(m.x, o.x), min(m.y, o.y));
-      m.x = min(m.x, o.x);
-      m.y = s2;
-    }
-    const int qi = qbase + i;
-    if (qi < nq) partial[(size_t)blockIdx.y * nq + qi] = m;
-  }
-}
-
-// kMergeLanes lanes per query: lane g folds chunks g, g + L, ... (all its loads are issued before the first use),
-// then log2(L) xor-shuffles combine the lanes.  Ties cannot occur between chunks (distinct global indices).
-// PACKED: one 16-byte row (idx0, idx1, dist0, dist1) per query -- the layout the query-sharded matcher all-gathers.
-constexpr int kMergeLanes = 8;
-template <bool PACKED>
-__global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2* __restrict__ partial, int nq, int nchunks,
-                                                             int chunk_len, int2* __restrict__ idx,
-                                                             int2* __restrict__ dist) {
-  const int tid = blockIdx.x * 256 + threadIdx.x;
-  const int q = tid / kMergeLanes, g = tid % kMergeLanes;
-  const int qc = min(q, nq - 1);
-  unsigned long long B1 = ~0ull, B2 = ~0ull;
-  for (int c0 = g; c0 < nchunks; c0 += 4 * kMergeLanes) {
-    uint2 p[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = c0 + u * kMergeLanes;
-      p[u] = c < nchunks ? partial[(size_t)c * nq + qc] : make_uint2(kEmpty, kEmpty);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned long long base = (unsigned long long)(c0 + u * kMergeLanes) * (unsigned long long)chunk_len;
-      if (p[u].x != kEmpty) {
-        unsigned long long K = ((unsigned long long)(p[u].x >> kIdxBits) << 32) | (base + (p[u].x & kIdxMask));
-        B2 = min(B2, max(B1, K));
-        B1 = min(B1, K);
-      }
-      if (p[u].y != kEmpty) {
-        unsigned long long K = ((unsigned long long)(p[u].y >> kIdxBits) << 32) | (base + (p[u].y & kIdxMask));
-        B2 = min(B2, max(B1, K));
-        B1 = min(B1, K);
-      }
-    }
-  }
-#pragma unroll
-  for (int off = 1; off < kMergeLanes; off <<= 1) {
-    unsigned long long O1 = __shfl_xor(B1, off), O2 = __shfl_xor(B2, off);
-    unsigned long long S2 = min(max(B1, O1), min(B2, O2));
-    B1 = min(B1, O1);
-    B2 = S2;
-  }
-  if (g == 0 && q < nq) {
+  if (qi < nq) {
     if (PACKED) {
-      reinterpret_cast<int4*>(idx)[q] =
+      reinterpret_cast<int4*>(idx)[qi] =
           make_int4((int)(B1 & 0xFFFFFFFFull), (int)(B2 & 0xFFFFFFFFull), (int)(B1 >> 32), (int)(B2 >> 32));
     } else {
-      idx[q] = make_int2((int)(B1 & 0xFFFFFFFFull), (int)(B2 & 0xFFFFFFFFull));
-      dist[q] = make_int2((int)(B1 >> 32), (int)(B2 >> 32));
+      idx[qi] = make_int2((int)(B1 & 0xFFFFFFFFull), (int)(B2 & 0xFFFFFFFFull));
+      dist[qi] = make_int2((int)(B1 >> 32), (int)(B2 >> 32));
     }
   }
 }
@@ -246,38 +294,24 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int2* __restr
 }
 
 int g_target_blocks = 0;     // 0: automatic plan (plan_chunks); > 0: fixed number of workgroups (tuning hook)
+int g_tstage = 1;            // train rows staged through LDS into VGPRs (1) or fed from SGPRs (0); tuning hook
 
-// optional per-kernel timing (bench.py): hipEvents on the launch stream around the two kernels of each call
+// optional per-kernel timing (bench.py): hipEvents on the launch stream around the kernel of each call
 bool g_profile = false;
 struct prof_rec {
-  hipEvent_t e0, e1, e2;
+  hipEvent_t e0, e1;
 };
 std::vector<prof_rec> g_prof;
-int g_variant = 0;           // see launch_partial
-
-typedef void (*partial_fn)(const uint4*, int, const uint32_t*, int, int, int, uint2*);
-struct variant_t {
-  partial_fn fn;
-  int qpl, tu;
-};
-const variant_t kVariants[] = {
-    {hamming_partial_kernel<4, 4, false>, 4, 4},
-    {hamming_partial_kernel<4, 4, true>, 4, 4},
-    {hamming_partial_kernel<2, 4, true>, 2, 4},
-    {hamming_partial_kernel<4, 2, true>, 4, 2},
-};
-constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 // chunk_len trains per workgroup (split into kWaves sub-ranges of sub_len), nchunks workgroups along y.
 // Automatic plan (g_target_blocks == 0): pick the number of train chunks that minimises
-//     ceil(workgroups / 256 CUs) * chunk_len  +  merge cost per chunk
+//     ceil(workgroups / 256 CUs) * chunk_len  +  fold cost per chunk
 // over plans with 1000..4600 workgroups -- the first term is the busiest CU's share of train rows (workgroups are
-// spread round-robin, 4..16 resident per CU), the second the extra partial rows the merge kernel folds.  At 10k x 10k
-// this gives 32 chunks x 40 query tiles = 1280 workgroups (25 chunks cost 0.2 % more), at 100k x 100k 11 x 391 = 4301 (98.8 % balanced; a fixed
-// 1024-workgroup plan loses 25 % there to 4-vs-3 workgroups per CU).
+// spread round-robin, 4..16 resident per CU), the second the extra partial rows the last workgroup of a tile folds.  At
+// 10k x 10k this gives 32 chunks x 40 query tiles = 1280 workgroups = 5 per CU, at 100k x 100k 11 x 391 = 4301 (98.8 %
+// balanced; a fixed 1024-workgroup plan loses 25 % there to 4-vs-3 workgroups per CU).
 void plan_chunks(int nq, int nt, int* chunk_len, int* sub_len, int* nchunks) {
-  const variant_t& v = kVariants[g_variant];
-  const int qtiles = (nq + 64 * v.qpl - 1) / (64 * v.qpl);
+  const int qtiles = (nq + kTileQ - 1) / kTileQ;
   const int q1 = qtiles > 0 ? qtiles : 1;
   long nch = 1;
   if (g_target_blocks > 0) {
@@ -298,8 +332,8 @@ void plan_chunks(int nq, int nt, int* chunk_len, int* sub_len, int* nchunks) {
   if (nch < 1) nch = 1;
   long len = (nt + nch - 1) / nch;
   long sub = (len + kWaves - 1) / kWaves;
-  sub = (sub + v.tu - 1) / v.tu * v.tu;
-  if (sub < 2 * v.tu) sub = 2 * v.tu;
+  sub = (sub + kTU - 1) / kTU * kTU;
+  if (sub < 2 * kTU) sub = 2 * kTU;
   len = sub * kWaves;
   if (len > kMaxChunk) {
     len = kMaxChunk;
@@ -324,9 +358,9 @@ VS_API int vs_match_set_target_blocks(int blocks) {
   if (blocks >= 0) g_target_blocks = blocks;
   return g_target_blocks;
 }
-VS_API int vs_match_set_variant(int v) {
-  if (v >= 0 && v < kNumVariants) g_variant = v;
-  return g_variant;
+VS_API int vs_match_set_tstage(int v) {
+  if (v == 0 || v == 1) g_tstage = v;
+  return g_tstage;
 }
 
 static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_idx, void* d_dist,
@@ -339,30 +373,29 @@ static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
   plan_chunks(nq, nt, &chunk_len, &sub_len, &nchunks);
   if (((uintptr_t)d_q | (uintptr_t)d_t) & 31)
     return vs_fail(ctx, VS_EINVAL, "%s: descriptor arrays must be 32-byte aligned", "vs_hamming_knn2_dev");
-  VS_TRY(vs_reserve(ctx, &ctx->d_partial, sizeof(uint2) * (size_t)nchunks * nq));
-  const int tile_q = 64 * kVariants[g_variant].qpl;
-  dim3 grid((nq + tile_q - 1) / tile_q, nchunks);
+  const int qtiles = (nq + kTileQ - 1) / kTileQ;
+  VS_TRY(vs_reserve(ctx, &ctx->d_partial, sizeof(uint2) * (size_t)nchunks * qtiles * kTileQ));
+  // per-tile arrival tickets: zero when allocated; every launch leaves them zero again (its last workgroups reset them)
+  if (sizeof(unsigned) * (size_t)qtiles > ctx->d_ticket.cap || !ctx->d_ticket.p) {
+    VS_TRY(vs_reserve(ctx, &ctx->d_ticket, sizeof(unsigned) * (size_t)qtiles));
+    VS_HIP(ctx, hipMemsetAsync(ctx->d_ticket.p, 0, ctx->d_ticket.cap, s));
+  }
+  dim3 grid(qtiles, nchunks);
   prof_rec pr{};
   if (g_profile) {
     VS_HIP(ctx, hipEventCreate(&pr.e0));
     VS_HIP(ctx, hipEventCreate(&pr.e1));
-    VS_HIP(ctx, hipEventCreate(&pr.e2));
     VS_HIP(ctx, hipEventRecord(pr.e0, s));
   }
-  hipLaunchKernelGGL(kVariants[g_variant].fn, grid, dim3(64 * kWaves), 0, s, (const uint4*)d_q, nq,
-                     (const uint32_t*)d_t, nt, chunk_len, sub_len, (uint2*)ctx->d_partial.p);
-  VS_LAUNCH_CHECK(ctx, "hamming_partial_kernel");
-  if (g_profile) VS_HIP(ctx, hipEventRecord(pr.e1, s));
-  const long merge_threads = (long)nq * kMergeLanes;
-  if (packed)
-    hipLaunchKernelGGL(hamming_merge_kernel<true>, dim3((unsigned)((merge_threads + 255) / 256)), dim3(256), 0, s,
-                       (const uint2*)ctx->d_partial.p, nq, nchunks, chunk_len, (int2*)d_idx, (int2*)nullptr);
-  else
-    hipLaunchKernelGGL(hamming_merge_kernel<false>, dim3((unsigned)((merge_threads + 255) / 256)), dim3(256), 0, s,
-                       (const uint2*)ctx->d_partial.p, nq, nchunks, chunk_len, (int2*)d_idx, (int2*)d_dist);
-  VS_LAUNCH_CHECK(ctx, "hamming_merge_kernel");
+  typedef void (*knn2_fn)(const uint4*, int, const uint32_t*, int, int, int, uint2*, unsigned*, int2*, int2*);
+  static const knn2_fn kFn[2][2] = {{hamming_knn2_kernel<false, false>, hamming_knn2_kernel<false, true>},
+                                    {hamming_knn2_kernel<true, false>, hamming_knn2_kernel<true, true>}};
+  hipLaunchKernelGGL(kFn[packed ? 1 : 0][g_tstage ? 1 : 0], grid, dim3(64 * kWaves), 0, s, (const uint4*)d_q, nq,
+                     (const uint32_t*)d_t, nt, chunk_len, sub_len, (uint2*)ctx->d_partial.p, (unsigned*)ctx->d_ticket.p,
+                     (int2*)d_idx, packed ? (int2*)nullptr : (int2*)d_dist);
+  VS_LAUNCH_CHECK(ctx, "hamming_knn2_kernel");
   if (g_profile) {
-    VS_HIP(ctx, hipEventRecord(pr.e2, s));
+    VS_HIP(ctx, hipEventRecord(pr.e1, s));
     g_prof.push_back(pr);
   }
   return VS_OK;
@@ -379,30 +412,82 @@ VS_API int vs_hamming_knn2_packed_dev(vs_ctx* ctx, const void* d_q, int nq, cons
   return knn2_dev_impl(ctx, d_q, nq, d_t, nt, d_out, nullptr, true, stream);
 }
 
-// bench hooks (not part of the stable ABI): HIP-event timing of the two match kernels on their launch stream
+// ---- query-sharded step: local match into this rank's slot of the gather buffer + one in-place ncclAllGather
+namespace {
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+nccl_allgather_fn g_nccl_allgather = nullptr;
+bool g_nccl_tried = false;
+
+nccl_allgather_fn resolve_nccl() {
+  if (g_nccl_tried) return g_nccl_allgather;
+  g_nccl_tried = true;
+  // the RCCL that the process already uses (torch.distributed loads one): never a second copy
+  for (const char* name : {"librccl.so", "librccl.so.1"}) {
+    void* h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    if (!h) continue;
+    if (void* f = dlsym(h, "ncclAllGather")) {
+      g_nccl_allgather = (nccl_allgather_fn)f;
+      return g_nccl_allgather;
+    }
+  }
+  if (void* f = dlsym(RTLD_DEFAULT, "ncclAllGather")) {
+    g_nccl_allgather = (nccl_allgather_fn)f;
+    return g_nccl_allgather;
+  }
+  if (void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL))
+    g_nccl_allgather = (nccl_allgather_fn)dlsym(h, "ncclAllGather");
+  return g_nccl_allgather;
+}
+}  // namespace
+
+VS_API int vs_hamming_knn2_sharded_dev(vs_ctx* ctx, const void* d_q_shard, int nq_shard, const void* d_t, int nt,
+                                       void* d_gathered, int per, int rank, int world, void* nccl_comm,
+                                       void* compute_stream, void* comm_stream, void* done_event) {
+  if (!ctx) return VS_EINVAL;
+  if (world < 1 || rank < 0 || rank >= world || per < 0 || nq_shard < 0 || nq_shard > per || !d_gathered ||
+      ((uintptr_t)d_gathered & 15))
+    return vs_fail(ctx, VS_EINVAL, "%s: bad shard geometry / gather buffer", "vs_hamming_knn2_sharded_dev");
+  if (world > 1 && (!nccl_comm || !comm_stream))
+    return vs_fail(ctx, VS_EINVAL, "%s: world > 1 needs a communicator and a stream for it", "vs_hamming_knn2_sharded_dev");
+  hipStream_t cs = vs_pick_stream(ctx, compute_stream);
+  uint8_t* slot = (uint8_t*)d_gathered + (size_t)rank * per * 16;
+  VS_TRY(knn2_dev_impl(ctx, d_q_shard, nq_shard, d_t, nt, slot, nullptr, true, cs));
+  if (!nccl_comm) return VS_OK;
+  nccl_allgather_fn ag = resolve_nccl();
+  if (!ag) return vs_fail(ctx, VS_ENCCL, "%s: ncclAllGather not found (is RCCL loaded in this process?)", "vs_hamming_knn2_sharded_dev");
+  hipStream_t ms = comm_stream ? (hipStream_t)comm_stream : cs;
+  if (ms != cs) {
+    if (!ctx->ev_shard) VS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_shard, hipEventDisableTiming));
+    VS_HIP(ctx, hipEventRecord(ctx->ev_shard, cs));
+    VS_HIP(ctx, hipStreamWaitEvent(ms, ctx->ev_shard, 0));
+  }
+  // in place: every rank's send buffer is its own slot of the receive buffer (ncclInt32 = 2)
+  const int rc = ag(slot, d_gathered, (size_t)per * 4, 2, nccl_comm, ms);
+  if (rc != 0) return vs_fail(ctx, VS_ENCCL, "%s: ncclAllGather failed", "vs_hamming_knn2_sharded_dev");
+  if (done_event) VS_HIP(ctx, hipEventRecord((hipEvent_t)done_event, ms));
+  return VS_OK;
+}
+
+// bench hooks (not part of the stable ABI): HIP-event timing of the match kernel on its launch stream
 VS_API int vs_match_profile(int enable) {
   g_profile = enable != 0;
   return 0;
 }
-// synchronises, returns the number of profiled calls and their mean kernel durations in milliseconds, then clears
-VS_API int vs_match_profile_read(float* partial_ms, float* merge_ms) {
-  double a = 0, b = 0;
+// synchronises, returns the number of profiled calls and their mean kernel duration in milliseconds, then clears
+VS_API int vs_match_profile_read(float* kernel_ms) {
+  double a = 0;
   int n = 0;
   for (prof_rec& r : g_prof) {
-    float x = 0, y = 0;
-    if (hipEventSynchronize(r.e2) == hipSuccess && hipEventElapsedTime(&x, r.e0, r.e1) == hipSuccess &&
-        hipEventElapsedTime(&y, r.e1, r.e2) == hipSuccess) {
+    float x = 0;
+    if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&x, r.e0, r.e1) == hipSuccess) {
       a += x;
-      b += y;
       ++n;
     }
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
-    (void)hipEventDestroy(r.e2);
   }
   g_prof.clear();
-  if (partial_ms) *partial_ms = n ? (float)(a / n) : 0.f;
-  if (merge_ms) *merge_ms = n ? (float)(b / n) : 0.f;
+  if (kernel_ms) *kernel_ms = n ? (float)(a / n) : 0.f;
   return n;
 }
 
@@ -428,9 +513,9 @@ VS_API int vs_hamming_knn2(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t*
   if (nq == 0) return VS_OK;
   if (!idx || !dist) return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_hamming_knn2");
   VS_HIP(ctx, hipSetDevice(ctx->device));
-  const void *dq, *dt;  // device-resident copies (uploaded only when this content has not been seen at this address)
-  VS_TRY(vs_desc_resident(ctx, q, nq, &dq));
-  VS_TRY(vs_desc_resident(ctx, t, nt, &dt));
+  const void *dq, *dt;  // device-resident copies (uploaded unless these very bytes are already resident: exact compare)
+  VS_TRY(vs_desc_resident(ctx, q, nq, 0, &dq));
+  VS_TRY(vs_desc_resident(ctx, t, nt, 1, &dt));
   // results go to a private pair of buffers (d_mq/d_mt) so they never alias the ratio path's d_idx/d_dist
   VS_TRY(vs_reserve(ctx, &ctx->d_mq, sizeof(int2) * (size_t)nq));
   VS_TRY(vs_reserve(ctx, &ctx->d_mt, sizeof(int2) * (size_t)nq));
@@ -450,8 +535,8 @@ VS_API int vs_match_ratio(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t* 
   if (!match_q || !match_t || !match_d) return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_match_ratio");
   VS_HIP(ctx, hipSetDevice(ctx->device));
   const void *dq, *dt;
-  VS_TRY(vs_desc_resident(ctx, q, nq, &dq));
-  VS_TRY(vs_desc_resident(ctx, t, nt, &dt));
+  VS_TRY(vs_desc_resident(ctx, q, nq, 0, &dq));
+  VS_TRY(vs_desc_resident(ctx, t, nt, 1, &dt));
   // one device block [count (16 B) | match_q | match_t | match_d], copied back in one piece: one synchronisation
   const size_t row = (sizeof(int32_t) * (size_t)nq + 15) & ~(size_t)15;
   const size_t bytes = 16 + 3 * row;

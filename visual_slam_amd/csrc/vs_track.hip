@@ -60,7 +60,8 @@ track_layout track_layout_of(int P, int F, int max_kp, int H) {
     off += (bytes + 255) & ~(size_t)255;
     return o;
   };
-  const int per = P < max_kp ? P : max_kp;
+  // matches per frame: one per surviving QUERY (= map point), so up to P of them whatever max_kp is
+  const int per = P;
   L.cap_obs = F * (per > 0 ? per : 1);
   L.xyz = take(sizeof(double) * 3 * (size_t)P);
   L.mapdesc = take(32 * (size_t)P + 32);
@@ -342,7 +343,8 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   const track_layout L = track_layout_of(n_points, max_frames, max_kp, pnp_iterations > 0 ? pnp_iterations : 1);
   VS_TRY(vs_reserve(ctx, &ctx->d_track, L.total));
   const size_t up = L.f[0].fxy;  // [xyz | mapdesc] are uploaded
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(std::max(up, (size_t)1 << 16), kPinRb + (L.rb_end - L.mst))));
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(std::max(std::max(up, (size_t)1 << 16), kPinRb + (L.rb_end - L.mst)),
+                                                         sizeof(int) * (size_t)max_frames + 2048)));
   VS_HIP(ctx, hipStreamSynchronize(s));
   uint8_t* h = (uint8_t*)ctx->h_track.p;
   uint8_t* d = (uint8_t*)ctx->d_track.p;

@@ -6,8 +6,9 @@ What is NOT reproduced: the two-view essential-matrix initialisation (SURVEY.md 
 map from frame 0's keypoints back-projected with the dataset's depth image (camera 0 = world); no ground-truth pose is
 used.
 
-Data: the first 20 RGB frames of ICL-NUIM living-room trajectory 3 (the trajectory present in the reference's data/;
-BASELINE.json names traj0, which is not there -- SURVEY.md 0) committed under tests/golden/icl_nuim/.
+Data: callers name the sequence directory (data_dir / $VS_DATASET_DIR); tests and bench.py use the first 20 RGB frames of
+ICL-NUIM living-room trajectory 3 (the trajectory present in the reference's data/; BASELINE.json names traj0, which is
+not there -- SURVEY.md 0) that the repository holds as fixtures.
 """
 import os
 import time
@@ -17,17 +18,25 @@ import numpy as np
 from .frame import imread
 from .workloads import ICL_NUIM_K
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ICL_DIR = os.path.join(ROOT, "tests", "golden", "icl_nuim")
 HUBER = float(np.sqrt(5.991))
 
 
-def load_sequence(n_frames=20):
-    frames = [imread(os.path.join(ICL_DIR, "rgb", "%d.png" % i)) for i in range(n_frames)]
+def dataset_dir(data_dir=None):
+    """Directory of an ICL-NUIM / TUM style sequence (rgb/N.png, depth/N.png): the argument, else $VS_DATASET_DIR.  The
+    package ships no data; tests and bench.py point this at the fixture frames they hold."""
+    d = data_dir or os.environ.get("VS_DATASET_DIR")
+    if not d:
+        raise ValueError("no dataset directory: pass data_dir or set VS_DATASET_DIR")
+    return d
+
+
+def load_sequence(n_frames=20, data_dir=None):
+    d = dataset_dir(data_dir)
+    frames = [imread(os.path.join(d, "rgb", "%d.png" % i)) for i in range(n_frames)]
     if any(f is None for f in frames):
-        raise FileNotFoundError("ICL-NUIM fixture frames missing under %s" % ICL_DIR)
+        raise FileNotFoundError("sequence frames missing under %s" % d)
     from PIL import Image
-    depth0 = np.asarray(Image.open(os.path.join(ICL_DIR, "depth", "0.png"))).astype(np.float64) / 5000.0  # metres
+    depth0 = np.asarray(Image.open(os.path.join(d, "depth", "0.png"))).astype(np.float64) / 5000.0  # metres
     return frames, depth0
 
 

@@ -18,11 +18,11 @@ the kernels of the next (two rotating buffer sets).
 
 
 class RcclAllGather:
-    """Direct ncclAllGather on a communicator of our own (created next to torch's, bootstrap through
-    torch.distributed), issued on a dedicated HIP stream.  torch.distributed's Python path costs 30-50 us of host time
-    per collective, more than half a 10k x 10k match step; the raw call costs a few microseconds, and running it on its
-    own stream lets it overlap the next step's kernels.  (RCCL = the NCCL API on ROCm; the library torch itself
-    loaded is used so only one RCCL lives in the process.)"""
+    """A communicator of our own (created next to torch's, bootstrapped through torch.distributed) and a dedicated HIP
+    stream for the all-gather that vs_hamming_knn2_sharded_dev issues through the RCCL C API.  torch.distributed's
+    Python path costs 30-50 us of host time per collective, more than half a 10k x 10k match step; the raw call costs a
+    few microseconds, and running it on its own stream lets it overlap the next step's kernels.  (RCCL = the NCCL API on
+    ROCm; the library torch itself loaded is used so only one RCCL lives in the process.)"""
 
     def __init__(self, group=None):
         import ctypes as C
@@ -44,7 +44,6 @@ class RcclAllGather:
             self.lib = C.CDLL(path if os.path.exists(path) else "librccl.so")
             self.lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
             self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-            self.lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
             self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
             self.lib.ncclGetErrorString.restype = C.c_char_p
         except (OSError, AttributeError):
@@ -59,18 +58,30 @@ class RcclAllGather:
         t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=dev)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        # ncclCommInitRank is itself a collective: if one rank fails before joining, its peers would wait inside it for
+        # ever.  It therefore runs on a helper thread with a time limit (VS_RCCL_INIT_TIMEOUT seconds, default 60); a
+        # rank that times out reports failure to the agreement that follows in ShardedMatcher._init_direct, and every
+        # rank falls back to torch.distributed's collective together.
+        import threading
         self.comm = C.c_void_p()
-        self._chk(self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank))
+        result = {}
+
+        def _init():
+            torch.cuda.set_device(dev)
+            result["rc"] = self.lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank)
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("VS_RCCL_INIT_TIMEOUT", "60")))
+        if th.is_alive():
+            self.comm = None
+            raise RuntimeError("ncclCommInitRank did not return within the time limit (a peer failed to join)")
+        self._chk(result.get("rc", 1))
         self.stream = torch.cuda.Stream(device=dev)
 
     def _chk(self, rc):
         if rc != 0:
             raise RuntimeError("RCCL error %d: %s" % (rc, self.lib.ncclGetErrorString(rc).decode()))
-
-    def all_gather_int32(self, recv, send):
-        """recv [W*n] int32, send [n] int32 device tensors; enqueued on self.stream."""
-        self._chk(self.lib.ncclAllGather(self._C.c_void_p(send.data_ptr()), self._C.c_void_p(recv.data_ptr()),
-                                         send.numel(), 2, self.comm, self._C.c_void_p(self.stream.cuda_stream)))
 
     def close(self):
         if getattr(self, "comm", None):
@@ -91,9 +102,14 @@ class ShardedMatcher:
 
     `local_knn2(q_shard, train) -> (idx, dist)` is the single-GPU kernel.  The default runs the HIP kernel on device
     tensors through the C ABI; tests inject a CPU callable to exercise the partition/gather logic under gloo.
+    force_collective: run the all-gather even at world size 1 (rehearses the N > 1 code path on one GPU).
+
+    Stream contract: inputs may be produced on, and results consumed from, torch's current stream -- submit / collect /
+    knn2 insert the event waits between it and the library's stream (none are needed when the caller already works on
+    `torch_stream()`).
     """
 
-    def __init__(self, group=None, local_knn2=None):
+    def __init__(self, group=None, local_knn2=None, force_collective=False):
         import torch.distributed as dist
         self._dist = dist
         self.group = group
@@ -109,6 +125,8 @@ class ShardedMatcher:
         self._slot = 0
         self._rccl = None
         self._rccl_failed = False
+        self._events = {}
+        self._force_collective = force_collective
 
     # ---- HIP path: torch device tensors in, torch device tensors out, no host copies, no synchronisation
     def torch_stream(self):
@@ -132,6 +150,30 @@ class ShardedMatcher:
             self._bufs[key] = (packed, gathered)
         return self._bufs[key]
 
+    def _order_after_caller(self):
+        """Make the library's stream wait for everything the caller has enqueued on torch's CURRENT stream (the producers
+        of q / t), unless that already is the library's stream."""
+        import torch
+        mine = self.torch_stream()
+        cur = torch.cuda.current_stream(mine.device)
+        if cur.cuda_stream != mine.cuda_stream:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            mine.wait_event(ev)
+
+    def _order_caller_after(self, event=None):
+        """Make torch's CURRENT stream wait for the results (the all-gather's `event`, else the work enqueued so far on
+        the library's stream), so the tensors handed back are safe to use on it."""
+        import torch
+        mine = self.torch_stream()
+        cur = torch.cuda.current_stream(mine.device)
+        if event is None:
+            if cur.cuda_stream == mine.cuda_stream:
+                return
+            event = torch.cuda.Event()
+            event.record(mine)
+        cur.wait_event(event)
+
     def _local_packed(self, q, t, rows, slot):
         """Match this rank's queries; returns the packed [rows, 4] tensor (first len(q) rows valid)."""
         import torch
@@ -145,14 +187,18 @@ class ShardedMatcher:
         self.torch_stream()
         if not (q.is_cuda and t.is_cuda and q.dtype == torch.uint8 and t.dtype == torch.uint8):
             raise TypeError("the HIP matcher needs uint8 device tensors [n, 32]")
+        self._order_after_caller()
         # NULL stream argument = the context's stream (the one torch_stream() wraps)
         self._ctx.hamming_knn2_packed_dev(q.data_ptr(), nq, t.data_ptr(), nt, packed.data_ptr(), None)
         return packed
 
     def knn2_local_shard(self, q_shard, train):
-        """The per-rank compute only (what bench.py times at world size 1): (idx, dist) views of the packed rows."""
+        """The per-rank compute only (what bench.py times at world size 1): (idx, dist) views of the packed rows, ordered
+        for use on torch's current stream."""
         nq = q_shard.shape[0]
         packed = self._local_packed(q_shard, train, nq, 0)
+        if self._local is None:
+            self._order_caller_after()
         return packed[:nq, 0:2], packed[:nq, 2:4]
 
     def submit(self, q_shard, train, n_query):
@@ -161,42 +207,56 @@ class ShardedMatcher:
         assert q_shard.shape[0] == e - b, "q_shard must be this rank's slice of the query set"
         slot = self._slot
         self._slot ^= 1
+        collective = self._dist.is_initialized() and (self.world > 1 or self._force_collective)
+        if collective and self._direct_ready(q_shard):
+            return self._submit_direct(q_shard, train, n_query, per, slot)
         packed = self._local_packed(q_shard, train, per, slot)
         _, gathered = self._buffers(per, q_shard.device, slot)
         work = None
-        if gathered is not None and self._dist.is_initialized():
-            work = self._start_all_gather(gathered, packed)
+        if gathered is not None and collective:
+            work = ("work", self._torch_all_gather(gathered, packed))
             out = gathered
         else:
             out = packed
         return (work, out, n_query)
 
-    def _start_all_gather(self, gathered, packed):
+    # ---- direct path: vs_hamming_knn2_sharded_dev = kernel into this rank's slot of the gather buffer + one in-place
+    # ncclAllGather on RCCL's own stream, ordered by events inside the library (no host synchronisation)
+    def _direct_ready(self, q):
         import os
+        if self._local is not None or not q.is_cuda or self._rccl_failed \
+                or os.environ.get("VS_SHARDED_TORCH_COLLECTIVE", "0") == "1":
+            return False
+        if self._rccl is None:
+            self._init_direct(q.device)
+        return self._rccl is not None
+
+    def _submit_direct(self, q, t, n_query, per, slot):
         import torch
-        if packed.is_cuda and self._local is None and not self._rccl_failed \
-                and os.environ.get("VS_SHARDED_TORCH_COLLECTIVE", "0") != "1":
-            try:
-                if self._rccl is None:
-                    self._init_direct(packed.device)
-                if self._rccl_failed:
-                    raise RuntimeError("direct RCCL path disabled by agreement of the ranks")
-                key = packed.data_ptr()
-                if key not in self._events:               # one (ready, done) event pair per rotating buffer
-                    self._events[key] = (torch.cuda.Event(), torch.cuda.Event())
-                ready, done = self._events[key]
-                ready.record(self.torch_stream())          # after the match kernels of this step
-                self._rccl.stream.wait_event(ready)
-                self._rccl.all_gather_int32(gathered, packed)
-                done.record(self._rccl.stream)
-                return ("event", done)
-            except (OSError, AttributeError, RuntimeError):
-                self._rccl_failed = True                   # fall back to torch.distributed below
-        return ("work", self._dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True))
+        _, gathered = self._buffers(per, q.device, slot)
+        key = gathered.data_ptr()
+        if key not in self._events:               # one `done` event per rotating buffer
+            ev = torch.cuda.Event()
+            ev.record(self._rccl.stream)          # torch creates the hipEvent_t lazily, on the first record
+            self._events[key] = ev
+        done = self._events[key]
+        self._order_after_caller()
+        self._ctx.hamming_knn2_sharded_dev(q.data_ptr(), q.shape[0], t.data_ptr(), t.shape[0], gathered.data_ptr(), per,
+                                           self.rank, self.world, self._rccl.comm.value, None,
+                                           self._rccl.stream.cuda_stream, done.cuda_event)
+        return (("event", done), gathered, n_query)
+
+    def _torch_all_gather(self, gathered, packed):
+        """Fallback: torch.distributed's collective.  It is issued against torch's CURRENT stream, which must first wait
+        for the match kernel on the library's stream."""
+        if packed.is_cuda and self._local is None:
+            self._order_caller_after()
+        return self._dist.all_gather_into_tensor(gathered, packed, group=self.group, async_op=True)
 
     def _init_direct(self, device):
-        """Create the direct communicator on every rank, then agree on the outcome: if any rank failed, all ranks use
-        torch.distributed's collective (a rank alone in ncclAllGather would wait for ever)."""
+        """Create the direct communicator on every rank, then agree on the outcome: if any rank failed (or timed out
+        inside ncclCommInitRank), all ranks use torch.distributed's collective -- a rank alone in ncclAllGather would
+        wait for ever."""
         import torch
         ok = 1
         try:
@@ -213,15 +273,19 @@ class ShardedMatcher:
                 self._rccl = None
 
     def collect(self, ticket):
-        """Wait for a ticket's all-gather; returns (idx [Q,2], dist [Q,2]).  With the ceil partition only trailing ranks
-        are short, so the first Q rows of the gathered buffer are exactly the queries in order."""
+        """Wait for a ticket's all-gather; returns (idx [Q,2], dist [Q,2]) ordered for use on torch's current stream.
+        With the ceil partition only trailing ranks are short, so the first Q rows of the gathered buffer are exactly
+        the queries in order."""
         work, out, n_query = ticket
         if work is not None:
             kind, h = work
             if kind == "event":
-                self.torch_stream().wait_event(h)  # stream-side wait, the host does not block
+                self._order_caller_after(h)        # stream-side wait, the host does not block
+                self.torch_stream().wait_event(h)  # the library's stream too: its next step may reuse the buffer
             else:
                 h.wait()
+        elif self._local is None and out.is_cuda:
+            self._order_caller_after()
         return out[:n_query, 0:2], out[:n_query, 2:4]
 
     def close(self):

@@ -30,6 +30,8 @@ from .frame import FeatureExtractor, FeatureMatcher, Frame
 from .map import Map
 from .point import Point
 
+kMaxPeriod = 256  # frames of one device-resident tracking period (see run_sequence.open_period)
+
 
 class Backends:
     """extractor / matcher objects and factories for BundleAdjustment and triangulate."""
@@ -153,20 +155,28 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             all_poses[k] = np.array(map.GetFrame(1).GetPose(), dtype=np.float64)
         keyframes.append(start - 1)
     # ---- tracking loop (main.py:173-348)
-    def open_period():
-        """resident mode: the local map of the new period (the last key frame's points) goes to the device once"""
+    period = {"cap": 0, "used": 0}
+
+    def open_period(first_frame):
+        """resident mode: the local map of the new period (the last key frame's points) goes to the device once.  The
+        period is sized for the frames that can still follow, at most kMaxPeriod: the device keeps cap x points
+        observation slots and reads back cap + 1 camera records per frame, so it must not be sized by the sequence.  A
+        period that fills up ends with a forced key frame (the reference's local map grows without bound, main.py:210)."""
         _, ft, xyz, ids = map.GetImagePointsWithFrameID(last_keyframe.GetID())
-        resident_ctx.track_begin(xyz, ft, last_keyframe.GetPose(), K4, max_frames=max(len(frames), 1),
+        period["cap"] = max(1, min(len(frames) - first_frame, kMaxPeriod))
+        period["used"] = 0
+        resident_ctx.track_begin(xyz, ft, last_keyframe.GetPose(), K4, max_frames=period["cap"],
                                  pnp_iterations=100 if pnp_guess is not None else 0)
         return ids, len(xyz)
 
     if resident:
-        point_IDs, n_known = open_period()
+        point_IDs, n_known = open_period(start)
     for i in range(start, len(frames)):
         cur_frame = Frame(frames[i], None, id_frame_local)
         if resident:
             # main.py:181-214 as one call on the device-resident period (vs_track_frame)
             r = resident_ctx.track_frame(frames[i], seed=i, want_keypoints=True, want_matches=True)
+            period["used"] += 1
             cur_frame.keypoints, cur_frame.features = r["xy"], r["desc"]
             known_3d_matched_ids = [point_IDs[q] for q in r["match_q"]]
             curMatchedPoints, curMatchedFeatures = r["xy"][r["match_t"]], r["desc"][r["match_t"]]
@@ -203,8 +213,9 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
         all_poses[i] = np.array(W_T_cur)
         tracked.append(len(curMatchedPoints))
         # key-frame rule (main.py:221)
-        if (i - loop_idx > keyframe_gap or len(curMatchedPoints) < min_tracked) and (
-                len(curMatchedPoints) < 0.9 * n_known):
+        period_full = resident and period["used"] >= period["cap"] and i + 1 < len(frames)
+        if period_full or ((i - loop_idx > keyframe_gap or len(curMatchedPoints) < min_tracked) and (
+                len(curMatchedPoints) < 0.9 * n_known)):
             loop_idx = i
             cur_frame.SetAsKeyFrame()
             W_T_prev_key = map.GetFrame(id_frame - 1).GetPose()
@@ -263,7 +274,7 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             id_frame += 1
             id_frame_local = id_frame
             if resident:
-                point_IDs, n_known = open_period()
+                point_IDs, n_known = open_period(i + 1)
             else:
                 local_map.Store3DPoints(map.GetCopyOfPointObjects(last_keyframe.GetID()))
         else:
