@@ -303,11 +303,11 @@ def frames_replicas(ctx, dist, world, dev):
 def timed_steps(step, drain, fence, steps, warmup, torch, dist, use_dist, dev):
     """The contract's timing: W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize, MAX over ranks."""
     import gc
+    gc.collect()  # before the warm-up, not after it: tens of ms with torch loaded, during which the GPU would go idle
+    gc.disable()  # a generation-2 collection of the interpreter must not land in the K steps either
     for _ in range(warmup):
         step()
     drain()
-    gc.collect()
-    gc.disable()  # a generation-2 collection of the interpreter (tens of ms with torch loaded) must not land in K steps
     fence()
     t0 = time.perf_counter()
     out = None
@@ -368,20 +368,25 @@ def main():
     pending = []
 
     def make_step(qq, tt, n_total):
-        """One pass of the match over this rank's batch.  With a collective, the all-gather of step k is started
-        asynchronously and collected after the kernels of step k+1 are enqueued (two rotating buffer sets), so the
-        exchange overlaps the next step's compute; drain() collects the last one inside the timed region."""
+        """One pass of the match over this rank's batch: ONE C call (ShardedMatcher.plan).  With a collective, the
+        all-gather of step k is started asynchronously and collected after the kernels of step k+1 are enqueued (two
+        rotating buffer sets), so the exchange overlaps the next step's compute; drain() collects the last one inside
+        the timed region."""
+        plan = matcher.plan(qq, tt, n_total)
+        plans.append(plan)
+
         def step():
-            if not use_dist:
-                return matcher.knn2_local_shard(qq, tt)
-            ticket = matcher.submit(qq, tt, n_total)
-            out = matcher.collect(pending.pop()) if pending else None
-            pending.append(ticket)
+            slot = plan.submit()
+            out = plan.collect(pending.pop()) if pending else None
+            pending.append(slot)
             return out
+        step.plan = plan
         return step
 
+    plans = []
+
     def drain():
-        return matcher.collect(pending.pop()) if pending else None
+        return plans[-1].collect(pending.pop()) if pending else None
 
     def fence():
         torch.cuda.synchronize()
@@ -419,7 +424,8 @@ def main():
         except Exception as e:  # all ranks take the same path: the collectives inside stay matched
             cfg5 = {"error": repr(e)}
 
-    elapsed, _ = timed_steps(make_step(q, t, nq * world), drain, fence, args.steps, args.warmup, torch, dist, use_dist, dev)
+    head_step = make_step(q, t, nq * world)
+    elapsed, _ = timed_steps(head_step, drain, fence, args.steps, args.warmup, torch, dist, use_dist, dev)
     ms_per_step = elapsed / args.steps * 1e3
     total_matches = float(nq) * nt * world
     value = total_matches / (ms_per_step * 1e-3) / 1e9
@@ -438,7 +444,26 @@ def main():
         km = C.c_float(0)
         ncalls = lib.vs_match_profile_read(C.byref(km))
         lib.vs_match_profile(0)
-        kernel_ms = float(km.value)
+        # the same launches timed as ONE region (a single event pair around K back-to-back launches): the per-launch
+        # pairs above put an event between any two kernels, which keeps them ~7 us apart
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.steps):
+            head_step.plan.submit()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        region_ms = e0.elapsed_time(e1) / args.steps
+        # and once more with the GPU already busy when the region starts (no idle start)
+        for _ in range(5):
+            head_step.plan.submit()
+        e0.record(stream)
+        for _ in range(args.steps):
+            head_step.plan.submit()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        busy_ms = e0.elapsed_time(e1) / args.steps
+        kernel_ms_isolated = float(km.value)
+        kernel_ms = region_ms if not use_dist else kernel_ms_isolated
         pairs = float(nq) * nt
         lane_ops = OPS_PER_MATCH * pairs
         achieved = lane_ops / (kernel_ms * 1e-3)
@@ -458,6 +483,9 @@ def main():
         roof = {"bound": "valu", "achieved": achieved / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "Tlane-op/s",
                 "frac": achieved / VALU_PEAK_LANE_OPS, "traffic": traffic,
                 "kernel": "hamming_knn2_kernel", "kernel_ms": kernel_ms, "profiled_calls": int(ncalls),
+                "kernel_ms_source": "HIP events on the launch stream: one pair around the K back-to-back launches of this "
+                                    "rank's step, divided by K (includes the ~1.5 us kernel boundary)",
+                "kernel_ms_event_pair_per_launch": kernel_ms_isolated, "kernel_ms_busy_start": busy_ms,
                 "lane_ops_per_match": OPS_PER_MATCH,
                 "lane_ops_model": "ISA of the main loop: per 8 distances 64 v_xor_b32 + 64 v_bcnt_u32_b32 + 8 v_lshl_or_b32 + "
                                   "4 v_med3_u32 + 4 v_min3_u32 + 4 v_min_u32; SQ_INSTS_VALU (profiles/) = this x 1e8 / 64 + 5 %",

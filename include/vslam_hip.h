@@ -199,6 +199,14 @@ int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int 
                              double huber_delta, int* has_result, double* poses_out, int* n_poses_out, int* n_matches,
                              int* pnp_found, float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q,
                              int32_t* match_t);
+/* Host-fed variant for callers that match and estimate the start pose themselves, i.e. the reference's class API driven
+ * call by call (FeatureMatcher.match_features, cv2.solvePnPRansac, Map.AddPointToFrameCorrespondences, then
+ * BundleAdjustment.motionOnlyBundleAdjustement, src/v2/main.py:185-214): appends one frame -- observation i = (index of
+ * the map point in the xyz array given to vs_track_begin, image point uv[i]) and the frame's start pose (4x4
+ * camera-to-world) -- to the resident period and runs the motion-only BA over all its poses (LocalBA.py:195-229);
+ * lm_iterations = 0 appends only.  Neither the period's observations nor its points are rebuilt or uploaded again. */
+int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx /*[m]*/, const double* uv /*[m][2]*/, int m,
+                        const double* pose16, int lm_iterations, double huber_delta, double* poses_out, int* n_poses_out);
 int vs_track_end(vs_ctx* ctx);
 
 /* ---- A9-A16: bundle adjustment ------------------------------------------------------------------------------

@@ -351,3 +351,64 @@ def test_tracking_session_on_an_odd_sized_image(vs):
     assert np.array_equal(r["xy"], xy1) and np.array_equal(r["desc"], d1)
     assert np.array_equal(r["match_q"], mq) and np.array_equal(r["match_t"], mt) and len(mq) > 100
     vs.track_end()
+
+
+def test_class_api_keeps_the_tracking_period_resident(vs, oracle):
+    """SURVEY 8f rank 1 behind the class API: the unmodified call sequence of the reference's tracking loop
+    (main.py:181-214 -- Frame.process_frame, Map.GetImagePointsWithFrameID, FeatureMatcher.match_features,
+    solvePnPRansac, Map.AddParentAndPose / AddPointToFrameCorrespondences, BundleAdjustment.motionOnlyBundleAdjustement)
+    must route the per-frame BA to the device-resident period (only the new frame travels) and give the poses of the
+    path that rebuilds and uploads the whole problem every frame, to 1e-9."""
+    from visual_slam_amd import harness
+    from visual_slam_amd.map import Map
+    frames, depth0 = harness.load_sequence(12)
+    Map.use_device_mirror = False
+    try:
+        ref_poses, _ = harness.track_sequence_api(frames, depth0, context=vs)
+    finally:
+        Map.use_device_mirror = True
+    pushed = []
+    orig = vs.track_push_frame
+
+    def spy(*a, **k):
+        pushed.append(len(a[0]))
+        return orig(*a, **k)
+    vs.track_push_frame = spy
+    try:
+        poses, _ = harness.track_sequence_api(frames, depth0, context=vs)
+    finally:
+        del vs.track_push_frame
+    assert len(pushed) == len(frames) - 1 and min(pushed) > 50      # one incremental push per frame, never a rebuild
+    rel = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(poses, ref_poses))
+    assert rel <= 1e-9, rel
+    # edits behind the mirror's back restart the period instead of using stale device state
+    from visual_slam_amd.LocalBA import BundleAdjustment, Camera
+    from visual_slam_amd.frame import FeatureExtractor, FeatureMatcher, Frame
+    from visual_slam_amd.point import Point
+    key = Frame(frames[0], None, 0)
+    key.AddPose(np.eye(4))
+    key.SetAsKeyFrame()
+    kp0, ft0, _ = key.process_frame(FeatureExtractor(context=vs))
+    maps = []
+    for use in (True, False):
+        Map.use_device_mirror = use
+        m = Map()
+        m.AddFrame(0, key)
+        for i, (X, uv, d) in enumerate(zip(harness.backproject(kp0, depth0), kp0, ft0)):
+            pt = Point(location=X, id=i + 1)
+            pt.AddFrame(frame=key, uv=uv, descriptor=d)
+            m.AddPoint3D(point_id=i + 1, point_3d=pt)
+        for k in (1, 2, 3):
+            cur = Frame(frames[k], None, k)
+            kp, ft, _ = cur.process_frame(FeatureExtractor(context=vs))
+            kpp, ftp, xyz, ids = m.GetImagePointsWithFrameID(0)
+            matches, _, _, cp, cf = FeatureMatcher(context=vs).match_features(kpp, ftp, kp, ft)
+            m.AddParentAndPose(parent_id=k - 1, frame_id=k, frame_obj=cur, rel_pose_trans=np.eye(4), pose=np.eye(4))
+            m.AddPointToFrameCorrespondences(ids[matches.query_idx], cp, cf, cur)
+            if k == 2:
+                m.UpdatePoint3D(np.asarray(m.GetPoint(7).Get3dPoint()) + 0.01, 7)   # geometry edit between two solves
+                m.UpdatePose(np.asarray(m.GetFrame(1).GetPose()) @ np.eye(4), 1)    # pose object replaced (same value)
+            BundleAdjustment(Camera(*ICL_NUIM_K), context=vs).motionOnlyBundleAdjustement(m)
+        maps.append(np.stack([m.GetFrame(k).GetPose() for k in range(4)]))
+    Map.use_device_mirror = True
+    assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(*maps)) <= 1e-9

@@ -15,7 +15,8 @@ from visual_slam_amd.workloads import match_workload  # noqa: E402
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 nt = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 blocks = [int(v) for v in os.environ.get("BLOCKS", "0,1024,1280,1536,2048,2560").split(",")]
-stages = [int(v) for v in os.environ.get("TSTAGE", "0,1").split(",")]  # 0: train rows from SGPRs, 1: staged via LDS
+stages = [int(v) for v in os.environ.get("TSTAGE", "0,1").split(",")]
+# 0: train rows from SGPRs, 1: staged via LDS
 ctx = Context(0)
 lib = _capi.load()
 stream = torch.cuda.ExternalStream(ctx.stream)
@@ -25,6 +26,14 @@ with torch.cuda.stream(stream):
     t = torch.from_numpy(t_np).cuda()
     idx = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
     dst = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+    pk = torch.empty((nq, 4), dtype=torch.int32, device="cuda")
+    packed = os.environ.get("PACKED", "0") == "1"
+
+    def launch():
+        if packed:
+            ctx.hamming_knn2_packed_dev(q.data_ptr(), nq, t.data_ptr(), nt, pk.data_ptr())
+        else:
+            ctx.hamming_knn2_dev(q.data_ptr(), nq, t.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
     ref = None
     res = {}
     for rnd in range(5):
@@ -33,16 +42,18 @@ with torch.cuda.stream(stream):
         for b in blocks:
             lib.vs_match_set_target_blocks(b)
             for _ in range(3):
-                ctx.hamming_knn2_dev(q.data_ptr(), nq, t.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+                launch()
+            if os.environ.get("FENCE", "0") == "1":
+                stream.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
             n = 20
             for _ in range(n):
-                ctx.hamming_knn2_dev(q.data_ptr(), nq, t.data_ptr(), nt, idx.data_ptr(), dst.data_ptr())
+                launch()
             e1.record(stream)
             stream.synchronize()
             res.setdefault((ts, b), []).append(e0.elapsed_time(e1) / n * 1e3)
-            cur = (idx.cpu().numpy().copy(), dst.cpu().numpy().copy())
+            cur = (pk.cpu().numpy()[:, :2].copy(), pk.cpu().numpy()[:, 2:].copy()) if packed else (idx.cpu().numpy().copy(), dst.cpu().numpy().copy())
             if ref is None:
                 ref = cur
             assert np.array_equal(ref[0], cur[0]) and np.array_equal(ref[1], cur[1]), (ts, b)

@@ -67,10 +67,9 @@ _DCS_DEFAULT = RobustKernelDCS()
 
 
 class BundleAdjustment:
-    def __init__(self, camera, context=None, solver=None, use_soa=True):
+    def __init__(self, camera, context=None, solver=None):
         """camera: Camera(fx, fy, cx, cy).  `solver` (tests only) replaces the GPU call with a callable of the same
-        signature as Context.ba_solve; use_soa=False forces the reference's per-edge graph construction."""
-        self._use_soa = bool(use_soa)
+        signature as Context.ba_solve."""
         self.focal_length = (camera.fx, camera.fy)
         self.principal_point = (camera.cx, camera.cy)
         self.baseline = 0
@@ -213,10 +212,16 @@ class BundleAdjustment:
     def _graph_from_soa(self, map, frame_fixed, points_fixed, with_scale_edges):
         """Builds the same problem as the reference's P x F double loop (LocalBA.py:164-172 / 207-214) from the map's
         structure-of-arrays mirror: poses in map.frames order, points in map.points_3d order, edges point-major then
-        frame order -- identical arrays, no per-observation Python.  Returns False when the map has no mirror."""
-        if not self._use_soa or not hasattr(map, "soa") or self._poses or len(self._points) or len(self._obs_pose):
-            return False
-        s = map.soa()
+        frame order -- identical arrays, no per-observation Python (tests/ref_graph.py holds the double loop itself and
+        the tests that both give the same arrays)."""
+        if self._poses or len(self._points) or len(self._obs_pose):
+            raise RuntimeError("BundleAdjustment: the graph of this optimizer is already populated (the reference "
+                               "creates one optimizer per solve, main.py:213,322)")
+        if hasattr(map, "soa"):
+            s = map.soa()
+        else:  # any object with .frames / .points_3d dicts of Frame / Point objects: mirror it once
+            from .map import mirror_of_points
+            s = mirror_of_points(map.points_3d)
         frame_ids = list(map.frames.keys())
         for frame_id in frame_ids:
             frame_obj = map.frames[frame_id]
@@ -246,90 +251,66 @@ class BundleAdjustment:
             self._obs_pose, self._obs_point, self._obs_uv = np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 2))
         self._obs_info = []
         self._huber, self._huber_set = float(_HUBER_DEFAULT.delta), True
-        return True
 
     # ------------------------------------------------------------------ the two entry points main.py calls
     def localBundleAdjustement(self, map, last_keyframe_id=None, scale=False, BAwindow=5):
         """LocalBA.py:143-190: all frames (frame 0 fixed) + scaling edge per parent, all points, one edge per
-        (point, observing frame); optimise; optional normalisation by the median point norm; write back."""
+        (point, observing frame); optimise; optional normalisation by the median point norm; write back.
+        last_keyframe_id (LocalBA.py:147-151, never passed by the reference's callers) restricts the points to those
+        visible to every frame of the map."""
         frame_ids = map.frames.keys()
-        point_ids = map.points_3d.keys()
+        self._graph_from_soa(map, lambda fid_, f_: fid_ == 0, points_fixed=False, with_scale_edges=True)
+        keep = None
         if last_keyframe_id is not None:
-            point_ids = map.GetPointsVisibleToFrames(frame_ids)
-        elif self._graph_from_soa(map, lambda fid_, f_: fid_ == 0, points_fixed=False, with_scale_edges=True):
-            self.optimize()
-            median_depth = 1
-            if scale:
-                median_depth = np.median(np.linalg.norm(self.result["points"], axis=1))
-            for frame_id in frame_ids:
-                new_pose = self.get_pose(frame_id).matrix()
-                new_pose[0:3, 3] /= median_depth
-                map.UpdatePose(new_pose=new_pose, frame_id=frame_id)
-            new_points = self.result["points"] / median_depth
-            for point_obj, x in zip(map.points_3d.values(), new_points):
-                point_obj.UpdatePoint(x)  # what map.UpdatePoint3D does, without the per-point dict lookups
-            return
-        for frame_id in frame_ids:
-            frame_obj = map.GetFrame(frame_id)
-            if frame_id == 0:
-                self.add_pose(pose_id=frame_id, pose=frame_obj.GetPose(), fixed=True)
-            else:
-                self.add_pose(pose_id=frame_id, pose=frame_obj.GetPose())
-                for parent_ID in frame_obj.GetParentIDs():
-                    self.AddScalingEdge(parent_id=parent_ID, child_id=frame_id,
-                                        measurement=frame_obj.GetTransitionWithParentID(parent_ID))
-        for point_id in point_ids:
-            point_obj = map.GetPoint(point_id)
-            self.add_point(point_id=point_id, point=point_obj.Get3dPoint())
-            for frame_id in frame_ids:
-                correspondence = point_obj.GetFrame(frame_id)
-                if correspondence is not None:
-                    _, uv, _ = correspondence
-                    self.add_edge(point_id=point_id, pose_id=frame_id, measurement=uv,
-                                  edge_id=point_id * frame_id + 10000000)
+            visible = set(map.GetPointsVisibleToFrames(frame_ids))
+            keep = np.fromiter((pid in visible for pid in map.points_3d.keys()), dtype=bool, count=len(self._points))
+            self._drop_points(~keep)
         self.optimize()
         median_depth = 1
+        pts = self.result["points"] if keep is None else self.result["points"][keep]
         if scale:
-            vector_norms = [np.linalg.norm(self.get_point(point_id)) for point_id in point_ids]
-            median_depth = np.median(np.array(vector_norms))
+            median_depth = np.median(np.linalg.norm(pts, axis=1))
         for frame_id in frame_ids:
             new_pose = self.get_pose(frame_id).matrix()
             new_pose[0:3, 3] /= median_depth
             map.UpdatePose(new_pose=new_pose, frame_id=frame_id)
-        for point_id in point_ids:
-            map.UpdatePoint3D(new_point=self.get_point(point_id) / median_depth, point_id=point_id)
+        new_points = self.result["points"] / median_depth
+        for i, point_obj in enumerate(map.points_3d.values()):
+            if keep is None or keep[i]:
+                point_obj.UpdatePoint(new_points[i])  # what map.UpdatePoint3D does, without the per-point dict lookups
+
+    def _drop_points(self, drop):
+        """Removes the observations of the masked points from the problem and fixes those points (they then take no
+        part in the solve, like vertices that were never added)."""
+        if not drop.any():
+            return
+        sel = ~drop[self._obs_point]
+        self._obs_pose, self._obs_point, self._obs_uv = self._obs_pose[sel], self._obs_point[sel], self._obs_uv[sel]
+        self._point_fixed = np.where(drop, 1, self._point_fixed).astype(np.uint8)
 
     def motionOnlyBundleAdjustement(self, map, scale=False, save=False):
         """LocalBA.py:195-229: key frames and all points fixed, every other pose free; write back poses only."""
         frame_ids = map.frames.keys()
-        point_ids = map.points_3d.keys()
-        if self._graph_from_soa(map, lambda fid_, f_: bool(f_.IsKeyFrame()), points_fixed=True, with_scale_edges=False):
-            self.optimize()
-            median_depth = 1
-            if scale:
-                median_depth = np.median(np.linalg.norm(self.result["points"], axis=1))
-            for frame_id in frame_ids:
-                new_pose = self.get_pose(frame_id).matrix()
-                new_pose[0:3, 3] /= median_depth
-                map.UpdatePose(new_pose=new_pose, frame_id=frame_id)
-            return
-        for frame_id in frame_ids:
-            frame_obj = map.GetFrame(frame_id)
-            self.add_pose(pose_id=frame_id, pose=frame_obj.GetPose(), fixed=bool(frame_obj.IsKeyFrame()))
-        for point_id in point_ids:
-            point_obj = map.GetPoint(point_id)
-            self.add_point(point_id=point_id, point=point_obj.Get3dPoint(), fixed=True)
-            for frame_id in frame_ids:
-                correspondence = point_obj.GetFrame(frame_id)
-                if correspondence is not None:
-                    _, uv, _ = correspondence
-                    self.add_edge(point_id=point_id, pose_id=frame_id, measurement=uv,
-                                  edge_id=point_id * frame_id + 10000000)
+        if self._solver is None and not scale and hasattr(map, "resident_motion_ba"):
+            # a local map of the tracking loop stays resident on the GPU between these calls (map.py, _PeriodMirror):
+            # only the new frame's observations and start pose travel
+            from .context import default_context
+            poses = map.resident_motion_ba(self._ctx or default_context(), (self.fx, self.fy, self.cx, self.cy),
+                                           float(_HUBER_DEFAULT.delta), 10)
+            if poses is not None:
+                self._pose_ids = {fid: i for i, fid in enumerate(frame_ids)}
+                self.result = {"poses": poses, "points": None}
+                dev = map._dev
+                for i, frame_id in enumerate(frame_ids):
+                    new_pose = np.array(poses[i])
+                    map.UpdatePose(new_pose=new_pose, frame_id=frame_id)
+                    dev.wrote(frame_id, new_pose)
+                return
+        self._graph_from_soa(map, lambda fid_, f_: bool(f_.IsKeyFrame()), points_fixed=True, with_scale_edges=False)
         self.optimize()
         median_depth = 1
         if scale:
-            vector_norms = [np.linalg.norm(self.get_point(point_id)) for point_id in point_ids]
-            median_depth = np.median(np.array(vector_norms))
+            median_depth = np.median(np.linalg.norm(self.result["points"], axis=1))
         for frame_id in frame_ids:
             new_pose = self.get_pose(frame_id).matrix()
             new_pose[0:3, 3] /= median_depth

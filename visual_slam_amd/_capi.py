@@ -88,6 +88,7 @@ SIGNATURES = {
     "vs_track_frame_pipelined": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                            C.c_double, C.c_uint64, C.c_int, C.c_double, c_intp, c_f64p, c_intp, c_intp,
                                            c_intp, c_f32p, c_u8p, c_intp, c_i32p, c_i32p]),
+    "vs_track_push_frame": (C.c_int, [C.c_void_p, c_i32p, c_f64p, C.c_int, c_f64p, C.c_int, C.c_double, c_f64p, c_intp]),
     "vs_track_end": (C.c_int, [C.c_void_p]),
     "vs_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(BAResult)]),
     "vs_ba_debug_cholesky": (C.c_int, [C.c_void_p, c_f64p, C.c_int, c_f64p, c_f64p, c_intp]),

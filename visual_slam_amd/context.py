@@ -37,6 +37,7 @@ class Context:
             raise VsError(rc, self._lib.vs_last_error(None).decode())
         self._h = h
         self._track = None
+        self._track_owner = None  # a map's _PeriodMirror when the resident period is driven by the class API
         self._pinned = []
         self.device = int(device)
         _LIVE.add(self)
@@ -238,6 +239,7 @@ class Context:
         fx, fy, cx, cy = (float(v) for v in K)
         self._chk(self._lib.vs_track_begin(self._h, ptr(xyz, c_f64p), ptr(desc, c_u8p), xyz.shape[0], ptr(key_pose, c_f64p),
                                            fx, fy, cx, cy, int(max_frames), int(max_kp), int(pnp_iterations)))
+        self._track_owner = None
         self._track = dict(P=xyz.shape[0], max_frames=int(max_frames), max_kp=int(max_kp),
                            poses=np.zeros((int(max_frames) + 1, 16)), xy=np.zeros((int(max_kp), 2), np.float32),
                            desc=np.zeros((int(max_kp), 32), np.uint8), mq=np.zeros(xyz.shape[0], np.int32),
@@ -296,9 +298,25 @@ class Context:
             out["xy"], out["desc"] = t["xy"][:nk.value].copy(), t["desc"][:nk.value].copy()
         return out
 
+    def track_push_frame(self, point_idx, uv, pose, lm_iterations=10, huber_delta=float(np.sqrt(5.991))):
+        """Host-fed frame of the period (vs_track_push_frame): observations (map point index, uv) + start pose -> poses
+        [n+1,4,4] after the motion-only BA over the whole period."""
+        t = self._track
+        if t is None:
+            raise VsError(-1, "track_push_frame: no tracking period (call track_begin)")
+        point_idx = np.ascontiguousarray(point_idx, np.int32)
+        uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+        pose = np.ascontiguousarray(pose, np.float64).reshape(16)
+        npo = C.c_int(0)
+        self._chk(self._lib.vs_track_push_frame(self._h, ptr(point_idx, c_i32p), ptr(uv, c_f64p), point_idx.shape[0],
+                                                ptr(pose, c_f64p), int(lm_iterations), float(huber_delta),
+                                                ptr(t["poses"], c_f64p), C.byref(npo)))
+        return t["poses"][:npo.value].reshape(-1, 4, 4).copy()
+
     def track_end(self):
         self._chk(self._lib.vs_track_end(self._h))
         self._track = None
+        self._track_owner = None
 
     # ------------------------------------------------------------------ two-view initialisation (SURVEY 8f rank 4)
     def essential_ransac(self, x1, x2, threshold, prob=0.999, max_iters=1000, seed=0):

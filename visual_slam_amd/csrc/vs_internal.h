@@ -30,13 +30,23 @@ struct vs_desc_entry {
 constexpr int VS_DESC_CACHE = 6;
 constexpr size_t VS_DESC_CACHE_MAX_BYTES = 8u << 20;  // larger sets are uploaded on every call
 
+// scratch of the match kernel (per-chunk partial rows + per-tile arrival tickets), one set per stream it is launched on:
+// launches on different streams may overlap on the GPU, launches on one stream never do
+struct vs_match_scratch {
+  hipStream_t stream = nullptr;
+  bool used = false;
+  vs_buf partial, ticket;
+};
+constexpr int VS_MATCH_STREAMS = 4;
+
 struct vs_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipDeviceProp_t prop;
   char err[512];
   // matcher
-  vs_buf d_q, d_t, d_idx, d_dist, d_partial, d_ticket, d_mq, d_mt, d_md, d_cnt;
+  vs_buf d_q, d_t, d_idx, d_dist, d_mq, d_mt, d_md, d_cnt;
+  vs_match_scratch match_scratch[VS_MATCH_STREAMS];
   // detector
   vs_buf d_bgr, d_gray, d_box, d_raw, d_bandcnt, d_hist, d_xy, d_score, d_desc, d_n, d_xy_in, d_keep;
   // bundle adjustment

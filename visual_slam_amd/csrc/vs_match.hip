@@ -203,18 +203,20 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
   }
   unsigned long long B1 = ~0ull, B2 = ~0ull;
   if (nchunks > 1) {
-    // ---- publish this chunk's partial row, then take a ticket (MI355X_MICROARCH.md, inter-workgroup visibility:
-    // plain stores -> every storing wave drains -> barrier -> one lane: agent release, drain, relaxed agent atomic)
-    partial[((size_t)chunk * qtiles + tile) * kTileQ + lq] = m;
+    // ---- publish this chunk's partial row, then take a ticket.  Hand-off form (MI355X_MICROARCH.md, inter-workgroup
+    // visibility): every byte of the row is stored write-through (agent-scope relaxed atomic store = global_store ... sc1),
+    // every storing wave drains (vmcnt(0)), the barrier orders them before the ONE relaxed agent-scope ticket add;
+    // the workgroup whose add returns nchunks-1 is last: agent-scope ACQUIRE (this CU's L1 must not serve older lines
+    // of `partial`), drain, barrier, then plain loads.  No release fence is needed because nothing stays dirty in L2.
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(partial + ((size_t)chunk * qtiles + tile) * kTileQ + lq),
+                       ((unsigned long long)m.y << 32) | m.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned prev = __hip_atomic_fetch_add(&ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int last = prev == (unsigned)(nchunks - 1);
       if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 must not serve older lines of `partial`
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(&ticket[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
       }
@@ -222,16 +224,17 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
     }
     __syncthreads();
     if (!s_last) return;  // uniform
-    // ---- fold the tile's chunks in chunk order (loads issued 8 at a time before their use)
-    for (int c0 = 0; c0 < nchunks; c0 += 8) {
-      uint2 p[8];
+    // ---- fold the tile's chunks in chunk order; the loads of up to 32 chunks are all in flight before the first use
+    constexpr int kFoldBatch = 32;
+    for (int c0 = 0; c0 < nchunks; c0 += kFoldBatch) {
+      uint2 p[kFoldBatch];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kFoldBatch; ++u) {
         const int c = min(c0 + u, nchunks - 1);
         p[u] = partial[((size_t)c * qtiles + tile) * kTileQ + lq];
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < kFoldBatch; ++u) {
         if (c0 + u >= nchunks) break;
         const unsigned long long base = (unsigned long long)(c0 + u) * (unsigned long long)chunk_len;
         if (p[u].x != kEmpty) fold64(B1, B2, ((unsigned long long)(p[u].x >> kIdxBits) << 32) | (base + (p[u].x & kIdxMask)));
@@ -374,11 +377,24 @@ static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
   if (((uintptr_t)d_q | (uintptr_t)d_t) & 31)
     return vs_fail(ctx, VS_EINVAL, "%s: descriptor arrays must be 32-byte aligned", "vs_hamming_knn2_dev");
   const int qtiles = (nq + kTileQ - 1) / kTileQ;
-  VS_TRY(vs_reserve(ctx, &ctx->d_partial, sizeof(uint2) * (size_t)nchunks * qtiles * kTileQ));
+  // scratch of this stream (launches on different streams may run concurrently and must not share it)
+  vs_match_scratch* ms = nullptr;
+  for (vs_match_scratch& m : ctx->match_scratch)
+    if (m.used && m.stream == s) ms = &m;
+  if (!ms)
+    for (vs_match_scratch& m : ctx->match_scratch)
+      if (!m.used) {
+        m.used = true;
+        m.stream = s;
+        ms = &m;
+        break;
+      }
+  if (!ms) return vs_fail(ctx, VS_EINVAL, "%s: the matcher is already in use on 4 other streams", "vs_hamming_knn2_dev");
+  VS_TRY(vs_reserve(ctx, &ms->partial, sizeof(uint2) * (size_t)nchunks * qtiles * kTileQ));
   // per-tile arrival tickets: zero when allocated; every launch leaves them zero again (its last workgroups reset them)
-  if (sizeof(unsigned) * (size_t)qtiles > ctx->d_ticket.cap || !ctx->d_ticket.p) {
-    VS_TRY(vs_reserve(ctx, &ctx->d_ticket, sizeof(unsigned) * (size_t)qtiles));
-    VS_HIP(ctx, hipMemsetAsync(ctx->d_ticket.p, 0, ctx->d_ticket.cap, s));
+  if (sizeof(unsigned) * (size_t)qtiles > ms->ticket.cap || !ms->ticket.p) {
+    VS_TRY(vs_reserve(ctx, &ms->ticket, sizeof(unsigned) * (size_t)qtiles));
+    VS_HIP(ctx, hipMemsetAsync(ms->ticket.p, 0, ms->ticket.cap, s));
   }
   dim3 grid(qtiles, nchunks);
   prof_rec pr{};
@@ -391,7 +407,7 @@ static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
   static const knn2_fn kFn[2][2] = {{hamming_knn2_kernel<false, false>, hamming_knn2_kernel<false, true>},
                                     {hamming_knn2_kernel<true, false>, hamming_knn2_kernel<true, true>}};
   hipLaunchKernelGGL(kFn[packed ? 1 : 0][g_tstage ? 1 : 0], grid, dim3(64 * kWaves), 0, s, (const uint4*)d_q, nq,
-                     (const uint32_t*)d_t, nt, chunk_len, sub_len, (uint2*)ctx->d_partial.p, (unsigned*)ctx->d_ticket.p,
+                     (const uint32_t*)d_t, nt, chunk_len, sub_len, (uint2*)ms->partial.p, (unsigned*)ms->ticket.p,
                      (int2*)d_idx, packed ? (int2*)nullptr : (int2*)d_dist);
   VS_LAUNCH_CHECK(ctx, "hamming_knn2_kernel");
   if (g_profile) {

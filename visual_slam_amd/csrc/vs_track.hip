@@ -32,6 +32,30 @@ __global__ __launch_bounds__(256) void track_append_kernel(const double* xyz, co
   }
 }
 
+// host-fed variant (vs_track_push_frame): obs i = (map point idx[i], image point uv[i]) as the caller matched them
+__global__ __launch_bounds__(256) void track_push_kernel(const double* xyz, const int* idx, const double* uv, int m,
+                                                         int n_points, double* mo_X, double* mo_uv, int* cam_start, int slot,
+                                                         int cap_obs, int* flags) {
+  const int base = cam_start[slot];
+  int M = m;
+  if (base + M > cap_obs) {
+    M = max(0, cap_obs - base);
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[0] = 1;
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < M; i += gridDim.x * 256) {
+    const int q = min(max(idx[i], 0), n_points - 1);  // validated on the host; clamped here so no access can leave the map
+    mo_X[3 * (size_t)(base + i)] = xyz[3 * (size_t)q];
+    mo_X[3 * (size_t)(base + i) + 1] = xyz[3 * (size_t)q + 1];
+    mo_X[3 * (size_t)(base + i) + 2] = xyz[3 * (size_t)q + 2];
+    mo_uv[2 * (size_t)(base + i)] = uv[2 * (size_t)i];
+    mo_uv[2 * (size_t)(base + i) + 1] = uv[2 * (size_t)i + 1];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    cam_start[slot + 1] = base + M;
+    flags[1] = M;
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ tracking session
@@ -48,7 +72,7 @@ struct track_layout {
   size_t xyz, mapdesc;
   track_front f[2];  // two sets of per-frame buffers (the synchronous entry point uses set 0 only)
   size_t flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part, H, mst, pnp_cam, pnp_pose, pnp_good, pnp_res, pnp_inl,
-      rb_end, total;
+      push_idx, push_uv, rb_end, total;
   int cap_obs;
 };
 
@@ -92,6 +116,8 @@ track_layout track_layout_of(int P, int F, int max_kp, int H) {
   L.pnp_pose = take(sizeof(double) * 12 * (size_t)H);
   L.pnp_good = take(sizeof(int) * (size_t)H);
   L.pnp_inl = take(sizeof(int) * (size_t)(per > 0 ? per : 1));
+  L.push_idx = take(sizeof(int) * (size_t)(per > 0 ? per : 1));
+  L.push_uv = take(sizeof(double) * 2 * (size_t)(per > 0 ? per : 1));
   L.total = off;
   return L;
 }
@@ -343,7 +369,9 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   const track_layout L = track_layout_of(n_points, max_frames, max_kp, pnp_iterations > 0 ? pnp_iterations : 1);
   VS_TRY(vs_reserve(ctx, &ctx->d_track, L.total));
   const size_t up = L.f[0].fxy;  // [xyz | mapdesc] are uploaded
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(std::max(std::max(up, (size_t)1 << 16), kPinRb + (L.rb_end - L.mst)),
+  // pinned staging: [control block kPinRb | read-back block | push staging: idx + uv of one frame]
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(std::max(std::max(up, (size_t)1 << 16),
+                                                                  kPinRb + (L.rb_end - L.mst) + 256 + 20 * (size_t)n_points),
                                                          sizeof(int) * (size_t)max_frames + 2048)));
   VS_HIP(ctx, hipStreamSynchronize(s));
   uint8_t* h = (uint8_t*)ctx->h_track.p;
@@ -407,6 +435,65 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   VS_TRY(track_back_enqueue(ctx, 0, &step));
   VS_TRY(track_ba_batch(ctx, 0, &step));
   return track_back_finish(ctx, 0, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out, match_q, match_t);
+}
+
+// Host-fed back half: the caller (the class API: FeatureMatcher.match_features + solvePnPRansac, src/v2/main.py:185-204)
+// matched and estimated the start pose itself.  Appends the frame's observations and start pose to the resident period and
+// runs the motion-only BA over all its poses -- what BundleAdjustment.motionOnlyBundleAdjustement (LocalBA.py:195-229)
+// does on an otherwise unchanged local map, without rebuilding or re-uploading the period.
+VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const double* uv, int m, const double* pose16,
+                               int lm_iterations, double huber_delta, double* poses_out, int* n_poses_out) {
+  if (!ctx) return VS_EINVAL;
+  auto& T = ctx->track;
+  if (!T.active) return vs_fail(ctx, VS_EINVAL, "%s: no tracking period (call vs_track_begin)", "vs_track_push_frame");
+  if (m < 0 || (m > 0 && (!point_idx || !uv)) || !pose16 || lm_iterations < 0 || !poses_out || !n_poses_out)
+    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_push_frame");
+  if (T.pending >= 0) return vs_fail(ctx, VS_EINVAL, "%s: a pipelined frame is pending (flush it first)", "vs_track_push_frame");
+  if (T.n_frames >= T.cap_frames) return vs_fail(ctx, VS_ENOMEM, "%s: the period holds max_frames frames already", "vs_track_push_frame");
+  if (m > T.n_points) return vs_fail(ctx, VS_EINVAL, "%s: more observations than map points", "vs_track_push_frame");
+  for (int i = 0; i < m; ++i)
+    if (point_idx[i] < 0 || point_idx[i] >= T.n_points)
+      return vs_fail(ctx, VS_EINVAL, "%s: map point index out of range", "vs_track_push_frame");
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  const track_layout L = layout_of(ctx);
+  hipStream_t s = ctx->stream;
+  uint8_t* d = (uint8_t*)ctx->d_track.p;
+  uint8_t* hp = (uint8_t*)ctx->h_track.p;
+  uint8_t* stage = hp + kPinRb + ((L.rb_end - L.mst + 255) & ~(size_t)255);
+  T.params[0] = {0.0, 0.0, huber_delta, 0ull, lm_iterations};
+  T.front_nkp[0] = 0;
+  const int slot = T.n_frames, k = T.n_frames + 1;
+  if (m > 0) {
+    memcpy(stage, point_idx, sizeof(int) * (size_t)m);
+    double* suv = (double*)(stage + ((sizeof(int) * (size_t)m + 15) & ~(size_t)15));
+    memcpy(suv, uv, sizeof(double) * 2 * (size_t)m);
+    VS_HIP(ctx, hipMemcpyAsync(d + L.push_idx, stage, sizeof(int) * (size_t)m, hipMemcpyHostToDevice, s));
+    VS_HIP(ctx, hipMemcpyAsync(d + L.push_uv, suv, sizeof(double) * 2 * (size_t)m, hipMemcpyHostToDevice, s));
+  }
+  hipLaunchKernelGGL(track_push_kernel, dim3(8), dim3(256), 0, s, (const double*)(d + L.xyz), (const int*)(d + L.push_idx),
+                     (const double*)(d + L.push_uv), m, T.n_points, (double*)(d + L.moX), (double*)(d + L.moUV),
+                     (int*)(d + L.cam_start), slot, L.cap_obs, (int*)(d + L.flags));
+  VS_LAUNCH_CHECK(ctx, "track_push_kernel");
+  double rec[kCamStride];
+  rec_from_pose(pose16, rec);
+  memcpy(hp + 2048, rec, sizeof rec);
+  double* cam0 = (double*)(d + L.cam0);
+  double* cam1 = (double*)(d + L.cam1);
+  VS_HIP(ctx, hipMemcpyAsync(cam0 + (size_t)k * kCamStride, hp + 2048, sizeof rec, hipMemcpyHostToDevice, s));
+  VS_HIP(ctx, hipMemcpyAsync(cam1 + (size_t)k * kCamStride, hp + 2048, sizeof rec, hipMemcpyHostToDevice, s));
+  if (lm_iterations > 0) {
+    mo_state* h_st = (mo_state*)(hp + 1024);
+    memset(h_st, 0, 2 * sizeof(mo_state));
+    h_st[1].need_lin = 1;
+    h_st[1].ni = 2.0;
+    h_st[1].cur = T.cur;
+    h_st[0].cur = T.cur;
+    VS_HIP(ctx, hipMemcpyAsync(d + L.mst, h_st, 2 * sizeof(mo_state), hipMemcpyHostToDevice, s));
+  }
+  int step = 0, n_matches = 0;
+  VS_TRY(track_ba_batch(ctx, 0, &step));
+  return track_back_finish(ctx, 0, &step, poses_out, n_poses_out, &n_matches, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr);
 }
 
 VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,

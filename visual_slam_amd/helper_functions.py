@@ -63,16 +63,45 @@ def GetListDiff(kp1, kp2):
 
 
 def Rtorvec(R):
-    """helper_functions.py:276-278 (cv2.Rodrigues(R)[0]): rotation matrix -> rotation vector [3,1]."""
-    from scipy.spatial.transform import Rotation
-    return Rotation.from_matrix(np.asarray(R, np.float64)).as_rotvec().reshape(3, 1)
+    """helper_functions.py:276-278 (cv2.Rodrigues(R)[0]): rotation matrix -> rotation vector [3,1].
+    Through the unit quaternion (largest-component branch, as Eigen / scipy do): accurate near 0 and near pi."""
+    m = np.asarray(R, np.float64)
+    m00, m11, m22 = m[0, 0], m[1, 1], m[2, 2]
+    tr = m00 + m11 + m22
+    if tr > 0.0:
+        s = np.sqrt(tr + 1.0) * 2.0
+        w, x, y, z = 0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s
+    elif m00 > m11 and m00 > m22:
+        s = np.sqrt(1.0 + m00 - m11 - m22) * 2.0
+        w, x, y, z = (m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s
+    elif m11 > m22:
+        s = np.sqrt(1.0 + m11 - m00 - m22) * 2.0
+        w, x, y, z = (m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s
+    else:
+        s = np.sqrt(1.0 + m22 - m00 - m11) * 2.0
+        w, x, y, z = (m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s
+    if w < 0.0:
+        w, x, y, z = -w, -x, -y, -z
+    n = np.sqrt(x * x + y * y + z * z)
+    if n < 1e-12:
+        k = 2.0  # angle / sin(angle / 2) -> 2 for small angles
+    else:
+        k = 2.0 * np.arctan2(n, w) / n
+    return np.array([[k * x], [k * y], [k * z]])
 
 
 def transformMatrix(rvec, tvec):
     """helper_functions.py:269-274: 4x4 from a rotation vector (Rodrigues) and a translation."""
-    from scipy.spatial.transform import Rotation
+    r = np.asarray(rvec, np.float64).reshape(3)
+    th = np.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2])
     T = np.eye(4)
-    T[:3, :3] = Rotation.from_rotvec(np.asarray(rvec, np.float64).reshape(3)).as_matrix()
+    if th < 1e-12:
+        a, b = 1.0, 0.5  # sin(th)/th, (1 - cos(th))/th^2
+    else:
+        a, b = np.sin(th) / th, (1.0 - np.cos(th)) / (th * th)
+    x, y, z = r
+    Kx = np.array([[0.0, -z, y], [z, 0.0, -x], [-y, x, 0.0]])
+    T[:3, :3] += a * Kx + b * (Kx @ Kx)
     T[:3, 3] = np.asarray(tvec, np.float64).reshape(3)
     return np.matrix(T)  # the reference returns np.matrix (main.py:202 slices it and squeezes with np.asarray)
 

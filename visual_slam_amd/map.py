@@ -4,9 +4,15 @@ Besides the reference's dict-of-objects (`frames`, `points_3d`, unchanged and au
 structure-of-arrays mirror of its observation graph: every mutation that goes through a Map
 method appends to flat arrays (point slot, frame id, uv, descriptor; xyz per point slot).  `soa()` hands those arrays
 to `BundleAdjustment` and `GetImagePointsWithFrameID`, which then need no per-observation Python loop -- the reference
-walks P x F dict lookups per frame there (LocalBA.py:207-214, map.py:28-44).  The mirror is checked against the object
-graph (observation count, point count, xyz identity) on every use and rebuilt from it when anything was changed behind
-the map's back (e.g. a direct Point.AddFrame), so results never depend on it.
+walks P x F dict lookups per frame there (LocalBA.py:207-214, map.py:28-44).  Every Point reports its mutations to the
+maps that hold it (change counters, point.py), so a mirror that is still in sync is recognised in O(1); after any edit
+behind the map's back (a direct Point.AddFrame / UpdatePoint, a replaced dict) it is re-verified against the object graph
+(observation count, point count, xyz identity) and rebuilt from it if needed -- results never depend on the mirror.
+
+Device residency (`_PeriodMirror`): a local map of the reference's tracking loop -- one fixed key
+frame, fixed points, one more free frame per image (main.py:181-214) -- is kept resident on the GPU between the
+per-frame `BundleAdjustment.motionOnlyBundleAdjustement(local_map)` calls: the call appends only the new frame's
+observations and start pose (vs_track_push_frame) instead of rebuilding and re-uploading the whole period.
 """
 import copy
 
@@ -25,6 +31,8 @@ class _SoA:
         self.n_obs = 0
         self.rev = 0              # sum of Point._rev when the mirror was last known to be in sync
         self.xyz_refs = []        # the location_3d object mirrored in each xyz row (identity check)
+        self.batches = []         # chronological log of add_obs calls: (frame id or None for mixed ids, first row, rows)
+        self.fid_rows = {}        # frame id -> number of observation rows carrying it
 
     def add_point(self, point_id, location):
         slot = self.n_points
@@ -52,7 +60,18 @@ class _SoA:
                     desc = None
             except (ValueError, TypeError):
                 desc = None
-        fids = np.full(k, frame_id, np.int64) if np.ndim(frame_id) == 0 else np.asarray(frame_id, np.int64)
+        if not isinstance(frame_id, np.ndarray) and not np.isscalar(frame_id) and len(frame_id) == k and all(
+                f == frame_id[0] for f in frame_id):
+            frame_id = frame_id[0]  # one id repeated (a point entering the map with its first observation)
+        if np.ndim(frame_id) == 0:
+            fids = np.full(k, frame_id, np.int64)
+            self.batches.append((int(frame_id), self.n_obs, k))
+            self.fid_rows[int(frame_id)] = self.fid_rows.get(int(frame_id), 0) + k
+        else:
+            fids = np.asarray(frame_id, np.int64)
+            self.batches.append((None, self.n_obs, k))
+            for f in fids.tolist():
+                self.fid_rows[f] = self.fid_rows.get(f, 0) + 1
         self._chunks.append((np.asarray(slots, np.int32), fids, uv, desc))
         self._cat = None
         self.n_obs += k
@@ -71,29 +90,155 @@ class _SoA:
         return self._cat
 
 
+def mirror_of_points(points_3d, cell=None):
+    """The flat mirror of a dict of Point objects (point id -> Point with .location_3d and .frames = {frame id: (Frame,
+    uv, descriptor)}), built by one walk over the objects.  `cell`: the change counter of the map that will own the mirror."""
+    s = _SoA()
+    for pid, p in points_3d.items():
+        if cell is not None and hasattr(p, "_adopt"):
+            p._adopt(cell)
+        slot = s.add_point(pid, p.location_3d)
+        s.rev += getattr(p, "_rev", 0)
+        if p.frames:
+            fids = list(p.frames.keys())
+            s.add_obs([slot] * len(fids), fids, [p.frames[f][1] for f in fids], [p.frames[f][2] for f in fids])
+    return s
+
+
+class _PeriodMirror:
+    """One local map's tracking period resident on the GPU (vs_track_begin / vs_track_push_frame), fed incrementally by
+    BundleAdjustment.motionOnlyBundleAdjustement.  It mirrors a map of the shape the reference's tracking loop builds
+    (main.py:153-214): the first frame is the fixed key frame, every other frame is free, all points are fixed; the
+    observations of each free frame arrived as one AddPointToFrameCorrespondences batch.  Anything else -- and any edit
+    to what has already been sent (points, earlier observations, earlier poses) -- makes `sync` start the period afresh
+    or decline, in which case the caller takes the general path."""
+
+    kInitialFrames = 32
+
+    def __init__(self, ctx, K4):
+        self.ctx, self.K4 = ctx, tuple(float(v) for v in K4)
+        self.cap = 0
+        self.pushed = []       # frame ids sent so far, in order
+        self.consumed = 0      # SoA batches consumed so far
+        self.written = {}      # frame id -> pose array object this mirror wrote into the Frame
+        self.state = None      # (points dict id, n_points, geometry counter, observation counter, key id, key pose value)
+
+    def _begin(self, map_, soa, key_id, key_frame, cap):
+        P = soa.n_points
+        self.ctx.track_begin(soa.xyz[:P], np.zeros((P, 32), np.uint8), np.asarray(key_frame.GetPose(), np.float64), self.K4,
+                             max_frames=cap, max_kp=2, pnp_iterations=0)
+        self.ctx._track_owner = self
+        self.cap, self.pushed, self.consumed, self.written = cap, [], 0, {}
+        self.state = (id(map_.points_3d), P, map_._cell[0], map_._cell[1], key_id, np.array(key_frame.GetPose(), np.float64))
+
+    def solve(self, map_, huber_delta, max_iterations):
+        """Appends what is new and runs the motion-only BA; returns poses [n_frames,4,4] in map.frames order, or None if
+        this map is not a tracking period (the caller then builds the general problem)."""
+        ctx = self.ctx
+        frames = list(map_.frames.items())
+        if len(frames) < 2 or not frames[0][1].IsKeyFrame() or any(f.IsKeyFrame() for _, f in frames[1:]):
+            return None
+        soa = map_.soa()
+        P = soa.n_points
+        if P < 1:
+            return None
+        key_id, key_frame = frames[0]
+        ids = [fid for fid, _ in frames[1:]]
+        if len(set(ids)) != len(ids) or key_id in ids:
+            return None
+        # which batches belong to which free frame: exactly one scalar-id batch per frame, none with mixed ids
+        free = set(ids)
+        rows = {}
+        for b, (fid, first, k) in enumerate(soa.batches):
+            if fid is None:
+                _, bf, _, _ = soa.arrays()
+                if free.intersection(np.unique(bf[first:first + k]).tolist()):
+                    return None
+            elif fid in free:
+                if fid in rows:
+                    return None
+                rows[fid] = (b, first, k)
+        state = (id(map_.points_3d), P, map_._cell[0], map_._cell[1], key_id)
+        fresh = (getattr(ctx, "_track_owner", None) is not self or ctx._track is None or self.state is None
+                 or self.state[:5] != state or not np.array_equal(self.state[5], np.asarray(key_frame.GetPose(), np.float64))
+                 or self.pushed != ids[:len(self.pushed)] or len(ids) > self.cap)
+        if not fresh:
+            for fid, f in frames[1:1 + len(self.pushed)]:
+                w = self.written.get(fid)
+                if f.GetPose() is not w and not (w is not None and np.array_equal(np.asarray(f.GetPose()), w)):
+                    fresh = True  # an earlier pose was edited after the last solve
+                    break
+                b = rows.get(fid)
+                if b is not None and b[0] >= self.consumed:
+                    fresh = True  # observations of an already sent frame arrived later
+                    break
+        if fresh:
+            if ctx._track is not None and getattr(ctx, "_track_owner", None) is None:
+                return None  # the context's resident period was opened explicitly (Context.track_begin): not ours to end
+            if ctx._track is not None:
+                ctx.track_end()  # ours, or the previous local map's (a new key frame starts a new local map)
+            cap = self.kInitialFrames
+            while cap < len(ids) + 8:
+                cap *= 2
+            self._begin(map_, soa, key_id, key_frame, cap)
+        slot, _, uv, _ = soa.arrays()
+        poses = None
+        todo = frames[1 + len(self.pushed):]
+        if not todo:  # nothing new: re-run the solve on the last frame's state is not expressible -> general path
+            return None
+        for j, (fid, f) in enumerate(todo):
+            b = rows.get(fid)
+            if b is None:
+                sl, obs = np.zeros(0, np.int32), np.zeros((0, 2))
+            else:
+                sl, obs = slot[b[1]:b[1] + b[2]], np.asarray(uv[b[1]:b[1] + b[2]], np.float64)
+                if sl.size > 1 and not np.all(sl[1:] >= sl[:-1]):  # per-camera order of the general path: point-major
+                    order = np.argsort(sl, kind="stable")
+                    sl, obs = sl[order], obs[order]
+            last = j == len(todo) - 1
+            poses = ctx.track_push_frame(sl, obs, np.asarray(f.GetPose(), np.float64),
+                                         lm_iterations=max_iterations if last else 0, huber_delta=huber_delta)
+            self.pushed.append(fid)
+        self.consumed = len(soa.batches)
+        return poses
+
+    def wrote(self, fid, pose):
+        self.written[fid] = pose
+
+
 class Map:
+    use_device_mirror = True  # False: motionOnlyBundleAdjustement always builds and uploads the whole problem
+
     def __init__(self):
         self.frames = {}
         self.points_3d = {}
+        # shared with the points this map holds (point.py): [geometry edits, observation edits, flush callback or None]
+        self._cell = [0, 0, None]
+        self._pending = []        # observation batches not yet written into the Point objects (see _flush)
+        self._added = []          # points added since the mirror was last used (see _absorb_added)
         self._soa = _SoA()
         self._soa_points_obj = self.points_3d  # the dict object the mirror was built from
+        self._soa_cell = (0, 0)   # counter values at which the mirror was last known to be in sync
+        self._img_cache = {}      # frame id -> (state key, answer of GetImagePointsWithFrameID)
+        self._dev = None          # _PeriodMirror: this local map's tracking period resident on the GPU
 
     # ------------------------------------------------------------------ SoA mirror
     def _soa_rebuild(self):
-        s = _SoA()
-        for pid, p in self.points_3d.items():
-            slot = s.add_point(pid, p.location_3d)
-            s.rev += getattr(p, "_rev", 0)
-            if p.frames:
-                fids = list(p.frames.keys())
-                s.add_obs([slot] * len(fids), fids, [p.frames[f][1] for f in fids], [p.frames[f][2] for f in fids])
-        self._soa = s
+        self._soa = mirror_of_points(self.points_3d, self._cell)
         self._soa_points_obj = self.points_3d
+        self._soa_cell = (self._cell[0], self._cell[1])
 
     def soa(self):
-        """The verified SoA mirror.  Verification is O(#points) of cheap Python (len() and identity per point); a
-        mismatch -- the object graph was edited without going through the Map -- triggers a rebuild from the objects."""
+        """The verified SoA mirror.  In sync and untouched since the last look (the points' change counters, the dict
+        object and its length say so): O(1).  Otherwise one O(#points) walk of cheap Python (len() and identity per
+        point) decides between refreshing the moved xyz rows and a rebuild from the objects."""
+        if self._added:
+            self._absorb_added()
         s = self._soa
+        c = self._cell
+        if (self._soa_points_obj is self.points_3d and s.n_obs >= 0 and s.n_points == len(self.points_3d)
+                and self._soa_cell[0] == c[0] and self._soa_cell[1] == c[1]):
+            return s
         ok = self._soa_points_obj is self.points_3d and s.n_points == len(self.points_3d)
         if ok:
             n = rev = 0
@@ -108,7 +253,18 @@ class Map:
         if not ok:
             self._soa_rebuild()
             s = self._soa
+        self._soa_cell = (c[0], c[1])
         return s
+
+    def resident_motion_ba(self, ctx, K4, huber_delta, max_iterations):
+        """motionOnlyBundleAdjustement on the device-resident period of this map (see _PeriodMirror): poses [n,4,4] in
+        `frames` order, or None when the map does not have the shape of a tracking period."""
+        if not self.use_device_mirror or not hasattr(ctx, "track_push_frame"):
+            return None
+        d = self._dev
+        if d is None or d.ctx is not ctx or d.K4 != tuple(float(v) for v in K4):
+            d = self._dev = _PeriodMirror(ctx, K4)
+        return d.solve(self, huber_delta, max_iterations)
 
     # ------------------------------------------------------------------ reference API
     def AddFrame(self, frame_id, frame):
@@ -128,6 +284,13 @@ class Map:
         (map.py:28-44).  Served from the SoA mirror (one boolean mask) when it holds the descriptors, else by one dict
         lookup per point."""
         s = self.soa()
+        try:
+            key = (id(s), s.n_points, self._cell[0], self._cell[1], s.fid_rows.get(frame_id, 0))
+            hit = self._img_cache.get(frame_id)
+        except TypeError:  # unhashable frame id
+            key = hit = None
+        if hit is not None and hit[0] == key:
+            return hit[1]  # nothing that this answer depends on has changed: the same arrays again
         slot, fid, uv, desc = s.arrays()
         if desc is not None and s.n_obs:
             sel = np.nonzero(fid == frame_id)[0]
@@ -138,7 +301,10 @@ class Map:
                 if np.all(np.diff(sl) > 0):
                     try:
                         ids = np.fromiter(self.points_3d.keys(), dtype=np.int64, count=s.n_points)
-                        return uv[sel], desc[sel], s.xyz[sl].copy(), ids[sl]
+                        out = (uv[sel], desc[sel], s.xyz[sl].copy(), ids[sl])
+                        if key is not None:
+                            self._img_cache = {frame_id: (key, out)}  # one entry: the key frame of the period
+                        return out
                     except (TypeError, ValueError):
                         pass  # non-integer point ids: fall through to the object walk
         image_points, descriptors, locations_3d, point_Ids = [], [], [], []
@@ -178,14 +344,32 @@ class Map:
         if point_id in self.points_3d.keys():
             raise Exception("Duplicate point3d warning")
         self.points_3d[point_id] = point_3d
-        s = self._soa
-        if self._soa_points_obj is self.points_3d and s.n_points == len(self.points_3d) - 1:
-            slot = s.add_point(point_id, point_3d.location_3d)
-            s.rev += getattr(point_3d, "_rev", 0)
-            if point_3d.frames:  # observations attached before the point entered the map (main.py:130-135)
-                fids = list(point_3d.frames.keys())
-                s.add_obs([slot] * len(fids), fids, [point_3d.frames[f][1] for f in fids],
-                          [point_3d.frames[f][2] for f in fids])
+        if hasattr(point_3d, "_adopt"):
+            point_3d._adopt(self._cell)
+        self._cell[0] += 1  # the point set changed: cached answers and the device mirror are stale
+        self._added.append((point_id, point_3d))  # the mirror absorbs new points in bulk on its next use
+
+    def _absorb_added(self):
+        """Takes the points added since the last look into the mirror: one pass, one observation batch (the reference's
+        callers add a few hundred points one by one, main.py:130-135,312-318)."""
+        added, self._added = self._added, []
+        s, c = self._soa, self._cell
+        if not (self._soa_points_obj is self.points_3d and s.n_obs >= 0 and s.n_points + len(added) == len(self.points_3d)
+                and self._soa_cell[0] + len(added) == c[0] and self._soa_cell[1] == c[1]
+                and all(hasattr(p, "_frames") for _, p in added)):
+            return  # something else happened in between: soa() verifies and rebuilds
+        slots, fids, uvs, descs = [], [], [], []
+        for pid, p in added:
+            slot = s.add_point(pid, p.location_3d)
+            s.rev += p._rev
+            for f, (_, uv, d) in p.frames.items():  # observations attached before the point entered the map
+                slots.append(slot)
+                fids.append(f)
+                uvs.append(uv)
+                descs.append(d)
+        if slots:
+            s.add_obs(slots, fids, uvs, descs)
+        self._soa_cell = (c[0], c[1])
 
     def UpdatePose(self, new_pose, frame_id):
         if frame_id in self.frames.keys():
@@ -218,6 +402,8 @@ class Map:
                 viewer.update_pose(pose=iso, colour=colour)
 
     def Store3DPoints(self, points_dict):
+        self._flush()
+        self._added = []
         self.points_3d = {**self.points_3d, **points_dict}  # new dict object: the mirror is rebuilt on next use
 
     def AddParentAndPose(self, parent_id, frame_id, frame_obj, rel_pose_trans, pose):
@@ -226,18 +412,52 @@ class Map:
         frame_obj.AddID(frame_id)
         self.AddFrame(frame_id=frame_id, frame=frame_obj)
 
+    def _flush(self):
+        """Writes the pending AddPointToFrameCorrespondences batches into the Point objects -- what the reference does at
+        once, one Point.AddFrame per match (map.py:120-122).  The mirror took the batch as arrays when it arrived; the
+        per-point dict entries are only needed when somebody looks at a Point's `frames`, which is what triggers this."""
+        self._cell[2] = None
+        pending, self._pending = self._pending, []
+        pts = self.points_3d
+        for point_ids, image_points, descriptors, frame_obj, fid in pending:
+            for point_id, uv, desc in zip(point_ids, image_points, descriptors):
+                p = pts.get(point_id)
+                if p is not None:  # the point may have been discarded since
+                    p._frames[fid] = (frame_obj, uv, desc)
+
     def AddPointToFrameCorrespondences(self, point_ids, image_points, descriptors, frame_obj):
         """map.py:120-122.  The Point objects are updated one by one as in the reference; the SoA mirror takes the whole
         batch as three array appends (a re-observation of the same (point, frame) invalidates it instead)."""
         fid = frame_obj.GetID()
         pts = self.points_3d
+        if self._added:
+            self._absorb_added()
+        s = self._soa
+        # fast path: the mirror is in sync, this frame has no observations yet and no point repeats inside the batch ->
+        # the batch goes to the mirror as arrays now and to the Point objects when one of them is looked at
+        c = self._cell
+        if (self._soa_points_obj is pts and s.n_obs >= 0 and s.n_points == len(pts) and self._soa_cell[0] == c[0]
+                and self._soa_cell[1] == c[1] and hasattr(image_points, "__getitem__") and hasattr(descriptors, "__getitem__")):
+            try:
+                slots = np.fromiter((s.point_slot[pid] for pid in point_ids), dtype=np.int32)
+                n = slots.shape[0]
+                new_frame = s.fid_rows.get(fid, 0) == 0
+            except (KeyError, TypeError):
+                slots, n, new_frame = None, 0, False
+            if slots is not None and new_frame and n and len(image_points) >= n and len(descriptors) >= n and (
+                    n == 1 or bool(np.all(slots[1:] > slots[:-1])) or len(set(slots.tolist())) == n):
+                s.add_obs(slots, fid, image_points[:n], descriptors[:n])
+                self._pending.append((list(point_ids), image_points, descriptors, frame_obj, fid))
+                c[2] = self._flush
+                return
+        self._flush()
         fresh = True
         n = 0
         for point_id, uv, desc in zip(point_ids, image_points, descriptors):
-            p = pts[point_id]
-            if fid in p.frames:
+            fr = pts[point_id].frames
+            if fid in fr:
                 fresh = False
-            p.frames[fid] = (frame_obj, uv, desc)
+            fr[fid] = (frame_obj, uv, desc)  # what Point.AddFrame stores; the mirror takes the batch below instead
             n += 1
         s = self._soa
         if fresh and n and self._soa_points_obj is pts:
@@ -251,4 +471,6 @@ class Map:
             s.n_obs = -1
 
     def DiscardOutlierMapPoints(self, n_visible_frames=3):
+        self._flush()
+        self._added = []
         self.points_3d = {pid: p for pid, p in self.points_3d.items() if p.GetNVisibleFrames() >= n_visible_frames}

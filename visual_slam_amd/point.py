@@ -3,20 +3,67 @@
 The reference keeps, per 3-D point, its id, its position and a dict `frames` that maps a frame id to the triple
 (Frame object, image point uv, descriptor).  The attribute names (`ID`, `frames`, `location_3d`) and the method names are
 part of the drop-in contract -- main.py and LocalBA.py read them directly -- so they are kept; everything else is this
-package's own: observations are counted in `_rev` so that `Map` can tell when the object graph was edited without going
-through it (its structure-of-arrays mirror is then rebuilt, see map.py).
+package's own: every mutation (AddFrame, UpdatePoint, rebinding `frames` / `location_3d`) bumps the change counters of the
+maps that hold the point, so that a `Map` can tell in O(1) whether its structure-of-arrays mirror is still in sync with
+the object graph (map.py).  Only an in-place edit of the `frames` dict itself would go unseen; no caller does that.
 """
 import numpy as np
 
 
 class Point:
-    __slots__ = ("ID", "frames", "location_3d", "_rev")
+    __slots__ = ("ID", "_frames", "_loc", "_rev", "_cells")
 
     def __init__(self, location, id):
-        self.location_3d = location
+        self._cells = ()      # cells of the maps that hold this point: [geometry edits, observation edits, flush or None]
+        self._loc = location
         self.ID = id
-        self.frames = dict()
+        self._frames = dict()
         self._rev = 0  # number of AddFrame calls so far (new or overwriting observations alike)
+
+    # `location_3d` and `frames` are plain attributes in the reference (point.py:8-9); here they are properties over
+    # slots so that rebinding either one is seen by the maps holding the point (their mirrors re-verify on next use).
+    @property
+    def location_3d(self):
+        return self._loc
+
+    @location_3d.setter
+    def location_3d(self, value):
+        self._loc = value
+        for c in self._cells:
+            c[0] += 1
+
+    @property
+    def frames(self):
+        for c in self._cells:
+            if c[2] is not None:  # a holding map has observation batches it has not written into the Point objects yet
+                c[2]()
+        return self._frames
+
+    @frames.setter
+    def frames(self, value):
+        self._frames = value
+        self._rev += 1
+        for c in self._cells:
+            c[1] += 1
+
+    def _adopt(self, cell):
+        """Called by a Map that starts holding this point."""
+        if all(c is not cell for c in self._cells):
+            self._cells = self._cells + (cell,)
+
+    def __copy__(self):
+        q = Point.__new__(Point)
+        q.ID, q._frames, q._loc, q._rev, q._cells = self.ID, self.frames, self._loc, self._rev, ()
+        return q
+
+    def __deepcopy__(self, memo):
+        import copy
+        q = Point.__new__(Point)
+        memo[id(self)] = q
+        q.ID, q._rev, q._cells = copy.deepcopy(self.ID, memo), self._rev, ()
+        q._loc = copy.deepcopy(self._loc, memo)
+        q._frames = copy.deepcopy(self.frames, memo)
+        return q
 
     # ---- identity / geometry -------------------------------------------------------------------- point.py:11-12,52-56
     def GetID(self):
@@ -28,7 +75,7 @@ class Point:
         return self.location_3d
 
     def UpdatePoint(self, new_location):
-        """Rebinds the position (BA write-back); the Map mirror notices the new object by identity."""
+        """Rebinds the position (BA write-back); the maps holding the point are told through their change counters."""
         self.location_3d = new_location
 
     def GetVectorNorm(self):
@@ -41,6 +88,8 @@ class Point:
         key = frame.GetID()
         self.frames[key] = (frame, uv, descriptor)
         self._rev += 1
+        for c in self._cells:
+            c[1] += 1
 
     def GetFrame(self, frame_id):
         """The (Frame, uv, descriptor) triple stored under `frame_id`, or None."""

@@ -288,6 +288,19 @@ class ShardedMatcher:
             self._order_caller_after()
         return out[:n_query, 0:2], out[:n_query, 2:4]
 
+    def plan(self, q_shard, train, n_query):
+        """A pre-bound step for a fixed workload (bench.py, streaming callers): every ctypes argument of the two rotating
+        buffer sets is built once, so `submit()` is one C call (kernel [+ event + in-place ncclAllGather + done event])
+        and `collect(slot)` one stream-side wait.  The caller works on `torch_stream()` (checked here); other callers use
+        submit / collect / knn2, which order against torch's current stream themselves."""
+        import torch
+        mine = self.torch_stream()
+        if torch.cuda.current_stream(mine.device).cuda_stream != mine.cuda_stream:
+            raise RuntimeError("ShardedMatcher.plan: make torch_stream() the current stream first")
+        if self._local is not None:
+            raise RuntimeError("ShardedMatcher.plan needs the HIP path")
+        return _Plan(self, q_shard, train, n_query)
+
     def close(self):
         """Destroy the direct RCCL communicator (if one was created)."""
         if self._rccl is not None:
@@ -303,3 +316,75 @@ class ShardedMatcher:
         nq = query.shape[0]
         b, e, _ = shard_bounds(nq, self.world, self.rank)
         return self.collect(self.submit(query[b:e], train, nq))
+
+
+class _Plan:
+    """Two steps in flight: slot 0 launches on the library's stream, slot 1 on a second stream of its own (own scratch
+    inside the library), so the short tail of one launch -- the fold by the last-arriving workgroups, the kernel
+    boundary -- overlaps the body of the next.  Results of slot 1 are ordered into the library's stream by collect()."""
+
+    def __init__(self, m, q, t, n_query):
+        import ctypes as C
+        import torch
+        from . import _capi
+        b, e, per = shard_bounds(n_query, m.world, m.rank)
+        assert q.shape[0] == e - b, "q_shard must be this rank's slice of the query set"
+        self.m, self.n_query, self.slot = m, n_query, 0
+        lib, h = _capi.load(), m._ctx.handle
+        collective = m._dist.is_initialized() and (m.world > 1 or m._force_collective)
+        self.direct = collective and m._direct_ready(q)
+        self.fallback = collective and not self.direct
+        self.keep = (q, t)
+        self.calls, self.outs, self.done, self.bufs = [], [], [], []
+        self.aux = torch.cuda.Stream(device=q.device)
+        self.aux.wait_stream(m._stream)  # q / t were produced on the library's stream
+        self.streams = (m._stream, self.aux)
+        nq, nt = q.shape[0], t.shape[0]
+        for slot in (0, 1):
+            packed, gathered = m._buffers(per, q.device, 2 + slot)  # buffer sets of their own
+            cs = self.streams[slot]
+            csp = C.c_void_p(cs.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(m._rccl.stream if self.direct else cs)  # creates the hipEvent_t
+            if self.direct:
+                fn = lib.vs_hamming_knn2_sharded_dev
+                args = (h, C.c_void_p(q.data_ptr()), nq, C.c_void_p(t.data_ptr()), nt, C.c_void_p(gathered.data_ptr()), per,
+                        m.rank, m.world, C.c_void_p(m._rccl.comm.value), csp, C.c_void_p(m._rccl.stream.cuda_stream),
+                        C.c_void_p(ev.cuda_event))
+                out = gathered
+            else:
+                fn = lib.vs_hamming_knn2_packed_dev
+                args = (h, C.c_void_p(q.data_ptr()), nq, C.c_void_p(t.data_ptr()), nt, C.c_void_p(packed.data_ptr()), csp)
+                out = gathered if self.fallback else packed
+            self.done.append(ev)
+            self.calls.append((fn, args))
+            self.bufs.append((packed, gathered))
+            self.outs.append((out[:n_query, 0:2], out[:n_query, 2:4]))
+        self.work = [None, None]
+
+    def submit(self):
+        """Enqueue one step; returns the slot to hand to collect()."""
+        slot = self.slot
+        self.slot = slot ^ 1
+        fn, args = self.calls[slot]
+        rc = fn(*args)
+        if rc != 0:
+            self.m._ctx._chk(rc)
+        if self.fallback:
+            import torch
+            packed, gathered = self.bufs[slot]
+            with torch.cuda.stream(self.streams[slot]):
+                self.work[slot] = self.m._dist.all_gather_into_tensor(gathered, packed, group=self.m.group, async_op=True)
+        elif not self.direct and slot == 1:
+            self.done[slot].record(self.aux)
+        return slot
+
+    def collect(self, slot):
+        """(idx [Q,2], dist [Q,2]) of the step submitted into `slot`, ordered on the library's stream."""
+        if self.fallback:
+            if self.work[slot] is not None:
+                self.work[slot].wait()
+                self.work[slot] = None
+        elif self.direct or slot == 1:
+            self.m._stream.wait_event(self.done[slot])
+        return self.outs[slot]
