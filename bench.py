@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frames", action="store_true", help="skip the cfg2 / local BA / frames legs")
     ap.add_argument("--no-cfg5", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="one step at a time on one stream (default: two steps in flight on two streams); the rocprofv3 "
+                         "kernel summaries under profiles/ are taken this way so that kernel durations do not overlap")
     ap.add_argument("--target-blocks", type=int, default=0, help="tuning: workgroups per launch of the match kernel")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the RCCL all-gather even at world size 1 (exercises the N>1 code path)")
@@ -372,7 +375,7 @@ def main():
         all-gather of step k is started asynchronously and collected after the kernels of step k+1 are enqueued (two
         rotating buffer sets), so the exchange overlaps the next step's compute; drain() collects the last one inside
         the timed region."""
-        plan = matcher.plan(qq, tt, n_total)
+        plan = matcher.plan(qq, tt, n_total, single_stream=args.single_stream)
         plans.append(plan)
 
         def step():
@@ -446,19 +449,20 @@ def main():
         lib.vs_match_profile(0)
         # the same launches timed as ONE region (a single event pair around K back-to-back launches): the per-launch
         # pairs above put an event between any two kernels, which keeps them ~7 us apart
+        solo = matcher.plan(q, t, nq * world, single_stream=True)  # one launch at a time: a launch's own duration
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(args.steps):
-            head_step.plan.submit()
+            solo.submit()
         e1.record(stream)
         torch.cuda.synchronize()
         region_ms = e0.elapsed_time(e1) / args.steps
         # and once more with the GPU already busy when the region starts (no idle start)
         for _ in range(5):
-            head_step.plan.submit()
+            solo.submit()
         e0.record(stream)
         for _ in range(args.steps):
-            head_step.plan.submit()
+            solo.submit()
         e1.record(stream)
         torch.cuda.synchronize()
         busy_ms = e0.elapsed_time(e1) / args.steps
@@ -483,8 +487,10 @@ def main():
         roof = {"bound": "valu", "achieved": achieved / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "Tlane-op/s",
                 "frac": achieved / VALU_PEAK_LANE_OPS, "traffic": traffic,
                 "kernel": "hamming_knn2_kernel", "kernel_ms": kernel_ms, "profiled_calls": int(ncalls),
-                "kernel_ms_source": "HIP events on the launch stream: one pair around the K back-to-back launches of this "
-                                    "rank's step, divided by K (includes the ~1.5 us kernel boundary)",
+                "kernel_ms_source": "HIP events on the launch stream: one pair around K launches issued back to back on ONE "
+                                    "stream (no overlap between launches), divided by K; includes the ~1.5 us kernel boundary. "
+                                    "The timed steps themselves keep two launches in flight on two streams (ms_per_step)",
+                "steps_in_flight": 1 if args.single_stream else 2,
                 "kernel_ms_event_pair_per_launch": kernel_ms_isolated, "kernel_ms_busy_start": busy_ms,
                 "lane_ops_per_match": OPS_PER_MATCH,
                 "lane_ops_model": "ISA of the main loop: per 8 distances 64 v_xor_b32 + 64 v_bcnt_u32_b32 + 8 v_lshl_or_b32 + "

@@ -1445,6 +1445,9 @@ __device__ inline void block_reduce28(double (&acc)[28], double (*s_all)[29], do
 
 namespace vsba {
 __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step) {
+  // this launch is a chain of short dependent phases (latency-bound): fused multiply-adds in its own accumulations and
+  // in the 6x6 solve shorten the chain; the edge evaluation (eval_edge) keeps the file's operation-for-operation rounding
+#pragma clang fp contract(fast)
   __shared__ double s_all[kMoRows][29];
   __shared__ double s_grp[kRedGroups][28];
   __shared__ double s_sum[28];
@@ -1655,14 +1658,14 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
       x[k] = s_sum[21 + k];
     }
     int ok = 1;
-    double rinv[6];  // 1 / L[j][j]: one division per pivot; the divisions by the pivot become multiplications
+    double rinv[6];  // 1 / L[j][j] from v_rsq_f64 + Newton (<= 2 ulp from sqrt / divide): no IEEE sequences in the chain
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const double d = A[j][j];
       if (!(d > 0.0)) ok = 0;
-      const double ljj = sqrt(d);
-      A[j][j] = ljj;
-      rinv[j] = 1.0 / ljj;
+      const double ri = vs_fast_rsq(d);
+      A[j][j] = d * ri;
+      rinv[j] = ri;
 #pragma unroll
       for (int i = j + 1; i < 6; ++i) A[i][j] = A[i][j] * rinv[j];
 #pragma unroll
@@ -1693,8 +1696,8 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
     const double xx = aw * bx + ax * bw + ay * bz - az * by;
     const double yy = aw * by + ay * bw + az * bx - ax * bz;
     const double zz = aw * bz + az * bw + ax * by - ay * bx;
-    const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
-    double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
+    const double inrm = vs_fast_rsq(xx * xx + yy * yy + zz * zz + w * w);
+    double q[4] = {xx * inrm, yy * inrm, zz * inrm, w * inrm};
     double rec[kCamStride];
     for (int k = 0; k < 3; ++k) rec[k] = t[k];
     for (int k = 0; k < 4; ++k) rec[3 + k] = q[k];

@@ -58,6 +58,22 @@ struct mo_state {
   int seq;
 };
 
+// Reciprocal / reciprocal square root from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26) + two Newton steps: <= 1-2
+// ulp, a third of the instructions of the IEEE divide / sqrt sequences.  For the serial stretches of latency-bound
+// kernels (6x6 pivots, quaternion normalisation); inputs are positive normal numbers there.
+__device__ __forceinline__ double vs_fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double vs_fast_rsq(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
+  r = r * __builtin_fma(-0.5 * x * r, r, 1.5);
+  return r;
+}
+
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

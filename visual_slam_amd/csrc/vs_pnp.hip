@@ -3,6 +3,12 @@
 
 using namespace vsba;
 
+// The LM of the PnP kernels is a long dependent FP64 chain executed by one wave: fused multiply-adds halve it.  The
+// library is built with -ffp-contract=off for the bundle adjustment (it rounds like the oracle, operation for
+// operation); PnP-RANSAC only has to agree with its oracle to 1e-9 on the pose and exactly on the inlier set (tests/
+// test_pnp.py), which contraction does not touch.
+#pragma clang fp contract(fast)
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ PnP-RANSAC
@@ -32,8 +38,9 @@ __device__ inline void pnp_err(const pnp_args& P, const double* cam, const doubl
   const double* w = cam + 7;
 #pragma unroll
   for (int i = 0; i < 3; ++i) pc[i] = w[4 * i] * X[0] + w[4 * i + 1] * X[1] + w[4 * i + 2] * X[2] + w[4 * i + 3];
-  eu = (P.fx * pc[0] + P.cx * pc[2]) / pc[2] - uv[0];
-  ev = (P.fy * pc[1] + P.cy * pc[2]) / pc[2] - uv[1];
+  const double iz = vs_fast_rcp(pc[2]);
+  eu = (P.fx * pc[0] + P.cx * pc[2]) * iz - uv[0];
+  ev = (P.fy * pc[1] + P.cy * pc[2]) * iz - uv[1];
 }
 
 // one edge into acc[28] = H upper triangle row-major (21), b (6), chi2 (identity information, no robust kernel)
@@ -45,7 +52,7 @@ __device__ inline void pnp_edge(const pnp_args& P, const double* cam, const doub
   if (!JAC) return;
   const double* w = cam + 7;
   const double px = pc[0], py = pc[1], pz = pc[2];
-  const double ipz2 = 1.0 / (pz * pz);
+  const double ipz2 = vs_fast_rcp(pz * pz);
   const double ipz2fx = ipz2 * P.fx, ipz2fy = ipz2 * P.fy;
   const double p0 = X[0] - cam[0], p1 = X[1] - cam[1], p2 = X[2] - cam[2];
   double r[3], J[2][6];
@@ -76,14 +83,14 @@ __device__ inline void pnp_edge(const pnp_args& P, const double* cam, const doub
 __device__ inline void cam_apply(const double* src, const double* x, double* dst) {
   double t[3] = {src[0] + x[0], src[1] + x[1], src[2] + x[2]};
   const double bx = x[3], by = x[4], bz = x[5];
-  const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));
+  const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));  // NaN for an oversized step, as in SBACam::update
   const double ax = src[3], ay = src[4], az = src[5], aw = src[6];
   const double w = aw * bw - ax * bx - ay * by - az * bz;
   const double xx = aw * bx + ax * bw + ay * bz - az * by;
   const double yy = aw * by + ay * bw + az * bx - ax * bz;
   const double zz = aw * bz + az * bw + ax * by - ay * bx;
-  const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
-  double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
+  const double inrm = vs_fast_rsq(xx * xx + yy * yy + zz * zz + w * w);
+  double q[4] = {xx * inrm, yy * inrm, zz * inrm, w * inrm};
   for (int k = 0; k < 3; ++k) dst[k] = t[k];
   for (int k = 0; k < 4; ++k) dst[3 + k] = q[k];
   quat_to_w2n(t, q, dst + 7);
@@ -207,9 +214,9 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
 #pragma unroll
         for (int k = 0; k < j; ++k) sdiag -= A[j][k] * A[j][k];
         if (!(sdiag > 0.0)) ok = 0;
-        const double l = sqrt(sdiag);
-        A[j][j] = l;
-        rinv[j] = 1.0 / l;
+        const double ri = vs_fast_rsq(sdiag);
+        A[j][j] = sdiag * ri;
+        rinv[j] = ri;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
           double v = A[i][j];
@@ -260,7 +267,7 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
 #pragma unroll
       for (int a = 0; a < 6; ++a) scale += x[a] * (lambda * x[a] + b[a]);
       scale += 1e-3;
-      rho /= scale;
+      rho = rho * vs_fast_rcp(scale);  // scale > 0: x^T (lambda x + b) >= 0 for a solved step
       if (rho > 0 && isfinite(temp)) {
         const double g = 2 * rho - 1;
         double alpha = 1.0 - g * g * g;

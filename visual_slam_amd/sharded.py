@@ -288,7 +288,7 @@ class ShardedMatcher:
             self._order_caller_after()
         return out[:n_query, 0:2], out[:n_query, 2:4]
 
-    def plan(self, q_shard, train, n_query):
+    def plan(self, q_shard, train, n_query, single_stream=False):
         """A pre-bound step for a fixed workload (bench.py, streaming callers): every ctypes argument of the two rotating
         buffer sets is built once, so `submit()` is one C call (kernel [+ event + in-place ncclAllGather + done event])
         and `collect(slot)` one stream-side wait.  The caller works on `torch_stream()` (checked here); other callers use
@@ -299,7 +299,7 @@ class ShardedMatcher:
             raise RuntimeError("ShardedMatcher.plan: make torch_stream() the current stream first")
         if self._local is not None:
             raise RuntimeError("ShardedMatcher.plan needs the HIP path")
-        return _Plan(self, q_shard, train, n_query)
+        return _Plan(self, q_shard, train, n_query, single_stream)
 
     def close(self):
         """Destroy the direct RCCL communicator (if one was created)."""
@@ -323,7 +323,7 @@ class _Plan:
     inside the library), so the short tail of one launch -- the fold by the last-arriving workgroups, the kernel
     boundary -- overlaps the body of the next.  Results of slot 1 are ordered into the library's stream by collect()."""
 
-    def __init__(self, m, q, t, n_query):
+    def __init__(self, m, q, t, n_query, single_stream=False):
         import ctypes as C
         import torch
         from . import _capi
@@ -336,9 +336,11 @@ class _Plan:
         self.fallback = collective and not self.direct
         self.keep = (q, t)
         self.calls, self.outs, self.done, self.bufs = [], [], [], []
-        self.aux = torch.cuda.Stream(device=q.device)
-        self.aux.wait_stream(m._stream)  # q / t were produced on the library's stream
+        self.aux = m._stream if single_stream else torch.cuda.Stream(device=q.device)
+        if not single_stream:
+            self.aux.wait_stream(m._stream)  # q / t were produced on the library's stream
         self.streams = (m._stream, self.aux)
+        self.two_streams = not single_stream
         nq, nt = q.shape[0], t.shape[0]
         for slot in (0, 1):
             packed, gathered = m._buffers(per, q.device, 2 + slot)  # buffer sets of their own
@@ -375,7 +377,7 @@ class _Plan:
             packed, gathered = self.bufs[slot]
             with torch.cuda.stream(self.streams[slot]):
                 self.work[slot] = self.m._dist.all_gather_into_tensor(gathered, packed, group=self.m.group, async_op=True)
-        elif not self.direct and slot == 1:
+        elif not self.direct and slot == 1 and self.two_streams:
             self.done[slot].record(self.aux)
         return slot
 
@@ -385,6 +387,6 @@ class _Plan:
             if self.work[slot] is not None:
                 self.work[slot].wait()
                 self.work[slot] = None
-        elif self.direct or slot == 1:
+        elif self.direct or (slot == 1 and self.two_streams):
             self.m._stream.wait_event(self.done[slot])
         return self.outs[slot]
