@@ -264,6 +264,16 @@ def test_device_cholesky_rejects_the_reference_debug_matrix(vs, oracle):
     assert ok and oracle.cholesky_lower(B)[1] == 0
     ref = np.linalg.solve(B, b)
     assert np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref)
+    # the reference's window sizes (n <= 60): leading blocks, definite and with a negative pivot late in the factorisation
+    for n in (6, 30, 54, 60):
+        Bn = B[:n, :n]
+        ok, x = vs.debug_cholesky(Bn, b[:n])
+        refn = np.linalg.solve(Bn, b[:n])
+        assert ok and np.linalg.norm(x - refn) <= 1e-9 * np.linalg.norm(refn), n
+        Cn = Bn.copy()
+        Cn[n - 2, n - 2] = -abs(Cn[n - 2, n - 2])      # a negative pivot late in the factorisation
+        ok, _ = vs.debug_cholesky(Cn, b[:n])
+        assert not ok and oracle.cholesky_lower(Cn)[1] != 0, n
     # blocked path: block-diagonal 180 x 180 with the indefinite block last (the failing pivot sits in the 4th panel)
     C2 = np.zeros((180, 180))
     C2[:90, :90] = B

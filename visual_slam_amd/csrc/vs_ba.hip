@@ -30,8 +30,9 @@
 //                     resort when even a 6-column panel does not fit in LDS
 //   ba_point_trial    8 lanes per point: back-substitution x_l = Dinv (bl - sum Hpl^T x_p) with the sum split over the
 //                     lanes, trial point, robust chi2 of the trial state, fixed-order block reduction
-//   ba_decide         one wave sums the block partials, one thread: gain ratio, accept (flip the state buffer index) or
-//                     reject, lambda update, stop rules
+//   (ba_decide)       inside ba_point_trial, by the workgroup that publishes its partials last: one wave sums the block
+//                     partials, one thread: gain ratio, accept (flip the state buffer index) or reject, lambda
+//                     update, stop rules
 //  motion-only problem (no free points, no scale edges => block diagonal): ba_motion_step, see below.
 // Trial states are written to the OTHER of two state buffers, so a rejected step needs no restore.
 #include "vs_ba_internal.h"
@@ -1269,70 +1270,11 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
   }
 }
 
-// ------------------------------------------------------------------------------------------------ trial + chi2
-__global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
-  __shared__ double s_red[kPtThreads];
-  const lm_state st = *D.st;
-  if (st.done) return;
-  const int tid = threadIdx.x;
-  const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;  // kPtLanes lanes per point, as above
-  double chi = 0.0, sc = 0.0;
-  if (st.solve_ok && a < D.n_act) {
-    const double* cams1 = D.cam[st.cur ^ 1];
-    const double* pts0 = D.pts[st.cur];
-    double* pts1 = D.pts[st.cur ^ 1];
-    const int p = D.act_pt[a];
-    const int ls = D.pt_slot[p];
-    double X[3] = {pts0[3 * (size_t)p], pts0[3 * (size_t)p + 1], pts0[3 * (size_t)p + 2]};
-    const int o0 = D.pt_start[a], o1 = D.pt_start[a + 1];
-    if (ls >= 0) {
-      // back substitution: cl = bl - sum_i Hpl_i^T dx_cam(i); the sum is split over the lanes and shuffle-reduced
-      double part[3] = {0.0, 0.0, 0.0};
-      for (int o = o0 + sub; o < o1; o += kPtLanes) {
-        const int cs = D.pose_slot[D.o_cam[o]];
-        if (cs < 0) continue;
-        const double* B = D.Hpl + 18 * (size_t)D.o_hpl[o];
-        const double* xc = D.xp + 6 * cs;
-#pragma unroll
-        for (int b = 0; b < 3; ++b)
-#pragma unroll
-          for (int k = 0; k < 6; ++k) part[b] += B[3 * k + b] * xc[k];
-      }
-#pragma unroll
-      for (int d = 1; d < kPtLanes; d <<= 1)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) part[b] += __shfl_xor(part[b], d);
-      const double cl[3] = {D.bl[3 * (size_t)ls] - part[0], D.bl[3 * (size_t)ls + 1] - part[1], D.bl[3 * (size_t)ls + 2] - part[2]};
-      const double* Di = D.Dinv + 9 * (size_t)ls;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double xl = Di[3 * k] * cl[0] + Di[3 * k + 1] * cl[1] + Di[3 * k + 2] * cl[2];
-        if (sub == 0) sc += xl * (st.lambda * xl + D.bl[3 * (size_t)ls + k]);
-        X[k] += xl;
-      }
-    }
-    if (sub == 0) {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) pts1[3 * (size_t)p + k] = X[k];
-    }
-    for (int o = o0 + sub; o < o1; o += kPtLanes) {
-      edge_t E;
-      eval_edge<false>(D, cams1 + (size_t)D.o_cam[o] * kCamStride, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
-      chi += E.rho0;
-    }
-  }
-  const double csum = block_reduce_sum<kPtThreads>(chi, s_red);
-  const double ssum = block_reduce_sum<kPtThreads>(sc, s_red);
-  if (tid == 0) {
-    D.part_chi[blockIdx.x] = csum;
-    D.part_scale[blockIdx.x] = ssum;
-  }
-}
-
 // OptimizationAlgorithmLevenberg::solve's accept/reject logic and SparseOptimizer::optimize's loop control
-__global__ __launch_bounds__(64) void ba_decide(ba_dev D) {
+// Runs on ONE wave (threadIdx.x < 64) of the workgroup of ba_point_trial that finished last: no launch of its own.
+__device__ inline void ba_decide(const ba_dev& D) {
   lm_state* st = D.st;
-  if (blockIdx.x != 0 || st->done) return;
+  if (st->done) return;
   const double psum = wave_sum_partials(D.part_chi, D.nb_pt), ssum = wave_sum_partials(D.part_scale, D.nb_pt);
   if (threadIdx.x != 0) return;
   double temp = 0.0, scale = st->scale_pose;
@@ -1387,6 +1329,83 @@ __global__ __launch_bounds__(64) void ba_decide(ba_dev D) {
     st->need_lin = 1;
     st->qmax = 0;
   }
+}
+
+// ------------------------------------------------------------------------------------------------ trial + chi2
+__global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
+  __shared__ double s_red[kPtThreads];
+  const lm_state st = *D.st;
+  if (st.done) return;
+  const int tid = threadIdx.x;
+  const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;  // kPtLanes lanes per point, as above
+  double chi = 0.0, sc = 0.0;
+  if (st.solve_ok && a < D.n_act) {
+    const double* cams1 = D.cam[st.cur ^ 1];
+    const double* pts0 = D.pts[st.cur];
+    double* pts1 = D.pts[st.cur ^ 1];
+    const int p = D.act_pt[a];
+    const int ls = D.pt_slot[p];
+    double X[3] = {pts0[3 * (size_t)p], pts0[3 * (size_t)p + 1], pts0[3 * (size_t)p + 2]};
+    const int o0 = D.pt_start[a], o1 = D.pt_start[a + 1];
+    if (ls >= 0) {
+      // back substitution: cl = bl - sum_i Hpl_i^T dx_cam(i); the sum is split over the lanes and shuffle-reduced
+      double part[3] = {0.0, 0.0, 0.0};
+      for (int o = o0 + sub; o < o1; o += kPtLanes) {
+        const int cs = D.pose_slot[D.o_cam[o]];
+        if (cs < 0) continue;
+        const double* B = D.Hpl + 18 * (size_t)D.o_hpl[o];
+        const double* xc = D.xp + 6 * cs;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int k = 0; k < 6; ++k) part[b] += B[3 * k + b] * xc[k];
+      }
+#pragma unroll
+      for (int d = 1; d < kPtLanes; d <<= 1)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) part[b] += __shfl_xor(part[b], d);
+      const double cl[3] = {D.bl[3 * (size_t)ls] - part[0], D.bl[3 * (size_t)ls + 1] - part[1], D.bl[3 * (size_t)ls + 2] - part[2]};
+      const double* Di = D.Dinv + 9 * (size_t)ls;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double xl = Di[3 * k] * cl[0] + Di[3 * k + 1] * cl[1] + Di[3 * k + 2] * cl[2];
+        if (sub == 0) sc += xl * (st.lambda * xl + D.bl[3 * (size_t)ls + k]);
+        X[k] += xl;
+      }
+    }
+    if (sub == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pts1[3 * (size_t)p + k] = X[k];
+    }
+    for (int o = o0 + sub; o < o1; o += kPtLanes) {
+      edge_t E;
+      eval_edge<false>(D, cams1 + (size_t)D.o_cam[o] * kCamStride, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
+      chi += E.rho0;
+    }
+  }
+  const double csum = block_reduce_sum<kPtThreads>(chi, s_red);
+  const double ssum = block_reduce_sum<kPtThreads>(sc, s_red);
+  // The workgroup that publishes its partials last takes the LM decision (ba_decide) in the same launch.  Hand-off as in
+  // vs_match.hip: write-through stores (agent-scope relaxed atomic stores), drain, one relaxed agent-scope ticket add;
+  // the last arriver acquires (its CU's L1 must not serve older partials) and resets the ticket for the next slot.
+  __shared__ int s_last;
+  if (tid == 0) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(D.part_chi + blockIdx.x), (unsigned long long)__double_as_longlong(csum),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(D.part_scale + blockIdx.x), (unsigned long long)__double_as_longlong(ssum),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned prev = __hip_atomic_fetch_add(D.trial_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = prev == gridDim.x - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(D.trial_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last && tid < 64) ba_decide(D);
 }
 
 // ------------------------------------------------------------------------------------------------ motion-only BA
@@ -2079,6 +2098,9 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.Dinv = A.take<double>(9 * (size_t)nfl);
   lm_state* h_st;
   D.st = A.take<lm_state>(1, &h_st);
+  unsigned* h_ticket;
+  D.trial_ticket = A.take<unsigned>(4, &h_ticket);
+  memset(h_ticket, 0, 4 * sizeof(unsigned));
   const size_t upload_bytes = A.off;
   // not uploaded
   D.cam[1] = A.take<double>((size_t)F * kCamStride);
@@ -2212,10 +2234,8 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       VS_LAUNCH_CHECK(ctx, "ba_reduce");
     }
     VS_TRY(launch_solve(ctx, s, D, splan));
-    hipLaunchKernelGGL(ba_point_trial, dim3(nb_pt), dim3(kPtThreads), 0, s, D);
+    hipLaunchKernelGGL(ba_point_trial, dim3(nb_pt), dim3(kPtThreads), 0, s, D);  // its last workgroup decides
     VS_LAUNCH_CHECK(ctx, "ba_point_trial");
-    hipLaunchKernelGGL(ba_decide, dim3(1), dim3(64), 0, s, D);
-    VS_LAUNCH_CHECK(ctx, "ba_decide");
     return VS_OK;
   };
 

@@ -45,6 +45,7 @@ struct ba_dev {
   int max_rank;         // duplicate observations: highest repeat count of one camera within one point (0: none)
   const int* fp_rank;   // per Hpl block: how many earlier blocks of the same point belong to the same camera
   lm_state* st;
+  unsigned* trial_ticket;  // arrival counter of ba_point_trial's workgroups (the last one takes the LM decision)
   // motion-only kernel: camera-major observation copy cut into chunks of 64
   const double *mo_X, *mo_uv, *mo_info;  // [n_obs_free_cam][3|2|3] in camera-major (cam_start) order
   double *mo_part, *mo_H;                // [2][nfp][4] per-camera partials by step parity; [nfp][42] H upper + b
