@@ -91,9 +91,11 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
                                                                    uint8_t* __restrict__ gray_out,
                                                                    uint16_t* __restrict__ box_out,
                                                                    uint32_t* __restrict__ raw, int band_cap,
-                                                                   int* __restrict__ bandcnt, uint32_t magic_w,
-                                                                   uint32_t magic_w4, uint32_t magic_gpr) {
+                                                                   int* __restrict__ bandcnt, int* __restrict__ bandhist,
+                                                                   uint32_t magic_w, uint32_t magic_w4, uint32_t magic_gpr) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  __shared__ int s_bhist[256];  // scores of this band's survivors (the cap of select_describe_kernel needs their histogram)
+  if (threadIdx.x < 256) s_bhist[threadIdx.x] = 0;
   const int w4 = (w + 3) & ~3;
   const int P = w4;
   const int nseg = (kBand * w + 63) >> 6;
@@ -257,9 +259,14 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
       const int r = fast_div(p, magic_w), x = p - r * w;
       const int pos = s_segoff[seg] + __popcll(bal & ((1ull << lane) - 1ull));
       const uint32_t s = s_score[(r + 1) * w4 + x];
-      if (pos < band_cap) raw[(size_t)blockIdx.x * band_cap + pos] = ((uint32_t)(y0 + r) << 20) | ((uint32_t)x << 8) | s;
+      if (pos < band_cap) {
+        raw[(size_t)blockIdx.x * band_cap + pos] = ((uint32_t)(y0 + r) << 20) | ((uint32_t)x << 8) | s;
+        atomicAdd(&s_bhist[s], 1);  // LDS integer atomic: order-independent
+      }
     }
   }
+  __syncthreads();
+  if (tid < 256) bandhist[(size_t)blockIdx.x * 256 + tid] = s_bhist[tid];
 }
 
 // ------------------------------------------------------------------------------------------------- select + describe
@@ -294,7 +301,8 @@ __device__ __forceinline__ void brief_wave(const uint16_t* __restrict__ box, int
 
 template <bool DO_BRIEF>
 __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const uint32_t* __restrict__ raw, int band_cap,
-                                                                       const int* __restrict__ bandcnt, int nbands,
+                                                                       const int* __restrict__ bandcnt,
+                                                                       const int* __restrict__ bandhist, int nbands,
                                                                        int max_kp, const uint16_t* __restrict__ box,
                                                                        int w, float* __restrict__ xy,
                                                                        uint8_t* __restrict__ score,
@@ -321,17 +329,24 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const uint
   int cut = 0, quota = 0, base = before, eq_before = 0;
   const bool over = total > max_kp;
   if (over) {
-    // histogram of every survivor's score, and of the survivors in earlier bands, in one scan (LDS integer atomics:
-    // order-independent).  Then cut = the score at which the cap is reached, quota = how many of score == cut fit.
-    for (int i = tid; i < 256; i += kSelThreads) s_hist[i] = s_before[i] = 0;
-    __syncthreads();
-    for (int b = 0; b < nbands; ++b) {
-      const int c = min(bandcnt[b], band_cap);
-      for (int i = tid; i < c; i += kSelThreads) {
-        const int s = raw[(size_t)b * band_cap + i] & 255u;
-        atomicAdd(&s_hist[s], 1);
-        if (b < band) atomicAdd(&s_before[s], 1);
+    // histogram of every survivor's score, and of the survivors in earlier bands: sums of the per-band histograms that
+    // detect_band_kernel left behind (thread = score bin; round 1 had every band re-scan every survivor: 80 us on a
+    // frame over the cap).  Then cut = the score at which the cap is reached, quota = how many of score == cut fit.
+    static_assert(kSelThreads == 256, "one thread per score bin");
+    {
+      int all = 0, bef = 0;
+      for (int b0 = 0; b0 < nbands; b0 += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = b0 + u < nbands ? bandhist[(size_t)(b0 + u) * 256 + tid] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          all += v[u];
+          bef += b0 + u < band ? v[u] : 0;
+        }
       }
+      s_hist[tid] = all;
+      s_before[tid] = bef;
     }
     __syncthreads();
     int above = 0;
@@ -515,7 +530,7 @@ int upload_image(vs_ctx* ctx, vs_buf* dst, const uint8_t* src, int row_bytes, in
 
 template <bool FROM_BGR, bool DO_BOX, bool WRITE_GRAY>
 int launch_detect(vs_ctx* ctx, hipStream_t s, const uint8_t* d_img, int pitch, int w, int h, int thr, int border,
-                  uint8_t* d_gray, uint16_t* d_box, uint32_t* d_raw, int band_cap, int* d_bandcnt) {
+                  uint8_t* d_gray, uint16_t* d_box, uint32_t* d_raw, int band_cap, int* d_bandcnt, int* d_bandhist) {
   const int nbands = (h + kBand - 1) / kBand;
   const size_t lds = detect_lds_bytes(w, DO_BOX);
   auto fn = detect_band_kernel<FROM_BGR, DO_BOX, WRITE_GRAY>;
@@ -523,7 +538,7 @@ int launch_detect(vs_ctx* ctx, hipStream_t s, const uint8_t* d_img, int pitch, i
     VS_HIP(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int w4 = (w + 3) & ~3;
   hipLaunchKernelGGL(fn, dim3(nbands), dim3(kDetThreads), lds, s, d_img, pitch, w, h, thr, border, d_gray, d_box, d_raw,
-                     band_cap, d_bandcnt, div_magic(w), div_magic(w4), div_magic(w4 >> 2));
+                     band_cap, d_bandcnt, d_bandhist, div_magic(w), div_magic(w4), div_magic(w4 >> 2));
   VS_LAUNCH_CHECK(ctx, "detect_band_kernel");
   return VS_OK;
 }
@@ -558,6 +573,7 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   VS_TRY(vs_reserve(ctx, &ctx->d_box, sizeof(uint16_t) * (size_t)w * h));
   VS_TRY(vs_reserve(ctx, &ctx->d_raw, sizeof(uint32_t) * (size_t)nbands * band_cap));
   VS_TRY(vs_reserve(ctx, &ctx->d_bandcnt, sizeof(int) * (size_t)nbands));
+  VS_TRY(vs_reserve(ctx, &ctx->d_hist, sizeof(int) * 256 * (size_t)nbands));
   VS_TRY(vs_reserve(ctx, &ctx->d_xy, L.total));
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, L.total));
   uint8_t* res = (uint8_t*)ctx->d_xy.p;
@@ -565,21 +581,21 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   hipStream_t s = ctx->stream;
   if (from_bgr) {
     VS_TRY((launch_detect<true, true, false>(ctx, s, d_img, pitch, w, h, thr, border, nullptr, (uint16_t*)ctx->d_box.p,
-                                             (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p)));
+                                             (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p)));
   } else if (describe) {
     VS_TRY((launch_detect<false, true, false>(ctx, s, d_img, pitch, w, h, thr, border, nullptr, (uint16_t*)ctx->d_box.p,
-                                              (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p)));
+                                              (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p)));
   } else {
     VS_TRY((launch_detect<false, false, false>(ctx, s, d_img, pitch, w, h, thr, border, nullptr, nullptr,
-                                               (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p)));
+                                               (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p)));
   }
   if (describe) {
     hipLaunchKernelGGL(select_describe_kernel<true>, dim3(nbands), dim3(kSelThreads), 0, s, (const uint32_t*)ctx->d_raw.p,
-                       band_cap, (const int*)ctx->d_bandcnt.p, nbands, max_kp, (const uint16_t*)ctx->d_box.p, w,
+                       band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, nbands, max_kp, (const uint16_t*)ctx->d_box.p, w,
                        (float*)(res + L.off_xy), res + L.off_score, res + L.off_desc, (int*)res);
   } else {
     hipLaunchKernelGGL(select_describe_kernel<false>, dim3(nbands), dim3(kSelThreads), 0, s,
-                       (const uint32_t*)ctx->d_raw.p, band_cap, (const int*)ctx->d_bandcnt.p, nbands, max_kp,
+                       (const uint32_t*)ctx->d_raw.p, band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, nbands, max_kp,
                        (const uint16_t*)nullptr, w, (float*)(res + L.off_xy), res + L.off_score, (uint8_t*)nullptr,
                        (int*)res);
   }
@@ -643,11 +659,12 @@ VS_API int vs_detect_describe_bgr_dev(vs_ctx* ctx, const void* d_bgr, int w, int
   VS_TRY(vs_reserve(ctx, &ctx->d_box, sizeof(uint16_t) * (size_t)w * h));
   VS_TRY(vs_reserve(ctx, &ctx->d_raw, sizeof(uint32_t) * (size_t)nbands * band_cap));
   VS_TRY(vs_reserve(ctx, &ctx->d_bandcnt, sizeof(int) * (size_t)nbands));
+  VS_TRY(vs_reserve(ctx, &ctx->d_hist, sizeof(int) * 256 * (size_t)nbands));
   VS_TRY((launch_detect<true, true, false>(ctx, s, (const uint8_t*)d_bgr, pitch, w, h, thr, VS_BRIEF_BORDER, nullptr,
                                            (uint16_t*)ctx->d_box.p, (uint32_t*)ctx->d_raw.p, band_cap,
-                                           (int*)ctx->d_bandcnt.p)));
+                                           (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p)));
   hipLaunchKernelGGL(select_describe_kernel<true>, dim3(nbands), dim3(kSelThreads), 0, s, (const uint32_t*)ctx->d_raw.p,
-                     band_cap, (const int*)ctx->d_bandcnt.p, nbands, max_kp, (const uint16_t*)ctx->d_box.p, w,
+                     band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, nbands, max_kp, (const uint16_t*)ctx->d_box.p, w,
                      (float*)d_xy, (uint8_t*)d_score, (uint8_t*)d_desc, (int*)d_n_out);
   VS_LAUNCH_CHECK(ctx, "select_describe_kernel");
   return VS_OK;

@@ -35,6 +35,7 @@ constexpr size_t VS_DESC_CACHE_MAX_BYTES = 8u << 20;  // larger sets are uploade
 struct vs_match_scratch {
   hipStream_t stream = nullptr;
   bool used = false;
+  uint64_t stamp = 0;  // last use (least recently used set is recycled for a new stream)
   vs_buf partial, ticket;
 };
 constexpr int VS_MATCH_STREAMS = 4;

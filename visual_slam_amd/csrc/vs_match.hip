@@ -381,15 +381,23 @@ static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
   vs_match_scratch* ms = nullptr;
   for (vs_match_scratch& m : ctx->match_scratch)
     if (m.used && m.stream == s) ms = &m;
-  if (!ms)
-    for (vs_match_scratch& m : ctx->match_scratch)
+  if (!ms) {
+    // a stream not seen before takes a free set, else the least recently used one -- after that set's stream has drained
+    // (it may have been destroyed meanwhile: an invalid handle is as good as drained)
+    vs_match_scratch* lru = &ctx->match_scratch[0];
+    for (vs_match_scratch& m : ctx->match_scratch) {
       if (!m.used) {
-        m.used = true;
-        m.stream = s;
-        ms = &m;
+        lru = &m;
         break;
       }
-  if (!ms) return vs_fail(ctx, VS_EINVAL, "%s: the matcher is already in use on 4 other streams", "vs_hamming_knn2_dev");
+      if (m.stamp < lru->stamp) lru = &m;
+    }
+    if (lru->used && hipStreamSynchronize(lru->stream) != hipSuccess) (void)hipGetLastError();
+    lru->used = true;
+    lru->stream = s;
+    ms = lru;
+  }
+  ms->stamp = ++ctx->desc_stamp;
   VS_TRY(vs_reserve(ctx, &ms->partial, sizeof(uint2) * (size_t)nchunks * qtiles * kTileQ));
   // per-tile arrival tickets: zero when allocated; every launch leaves them zero again (its last workgroups reset them)
   if (sizeof(unsigned) * (size_t)qtiles > ms->ticket.cap || !ms->ticket.p) {
