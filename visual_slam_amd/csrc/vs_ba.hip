@@ -564,7 +564,10 @@ __global__ __launch_bounds__(256) void ba_schur_tile(ba_dev D) {
   if (D.st->done) return;
   const double lambda = D.st->lambda;
   const int np = D.np, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int tr = blockIdx.y / D.ntile, tc = blockIdx.y - tr * D.ntile;
+  // blockIdx.y enumerates the tiles of the LOWER triangle (tr >= tc), row by row: the Cholesky reads nothing else
+  int tr = 0;
+  while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.y) ++tr;
+  const int tc = (int)blockIdx.y - tr * (tr + 1) / 2;
   const int per = (D.nfl + D.ns - 1) / D.ns;
   const int l0 = blockIdx.x * per, l1 = min(l0 + per, D.nfl);
   double* sD = s_mem;                                 // [2][batch][12]   Dinv, Dinv bl (double-buffered)
@@ -766,7 +769,14 @@ __global__ __launch_bounds__(256) void ba_reduce(ba_dev D) {
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + e;
   double acc = 0.0;
-  if (i < slab_elems) {
+  // the tiled Schur kernel produces the tiles of the lower triangle only (the Cholesky reads nothing else): elements of
+  // strictly upper tiles have no slab contribution to fetch
+  bool have = i < slab_elems;
+  if (have && D.ntile > 1 && i < np * np) {
+    const int r = i / np, c = i - r * np;
+    have = r / kTileN >= c / kTileN;
+  }
+  if (have) {
     int s = g;
     for (; s + 28 < D.ns; s += 32) {
       double v[8];
@@ -2003,7 +2013,8 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   const int nb_pt = std::max(1, (n_act + kPtPerBlock - 1) / kPtPerBlock);
   int ns = nfl > 0 && nfp > 0 ? std::min(256, (nfl + 7) / 8) : 0;
   const bool lds_slab = np <= kMaxSlabN;
-  if (tiled) ns = std::max(4, std::min(256, (16384 + ntile * ntile - 1) / (ntile * ntile)));  // >= 16k workgroups: most tiles are empty
+  const int ntile_pairs = ntile * (ntile + 1) / 2;  // tiles of the lower triangle
+  if (tiled) ns = std::max(4, std::min(256, (16384 + ntile_pairs - 1) / ntile_pairs));  // >= 16k workgroups: most tiles are empty
   if (!lds_slab && ns > 0) ns = std::min(ns, std::max(1, (int)((512u << 20) / (sizeof(double) * ((size_t)np * np + np)))));
   const size_t slab_elems = (size_t)np * np + np;
 
@@ -2222,7 +2233,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     }
     if (ns > 0 && tiled) {
       if (ntile > 1) hipLaunchKernelGGL(ba_dinv, dim3((unsigned)((nfl + 255) / 256)), dim3(256), 0, s, D);  // single tile: fused
-      hipLaunchKernelGGL(ba_schur_tile, dim3(ns, ntile * ntile), dim3(256), tile_lds, s, D);
+      hipLaunchKernelGGL(ba_schur_tile, dim3(ns, ntile * (ntile + 1) / 2), dim3(256), tile_lds, s, D);  // lower triangle
       VS_LAUNCH_CHECK(ctx, "ba_schur_tile");
     } else if (ns > 0) {
       if (lds_slab) hipLaunchKernelGGL(ba_schur<true>, dim3(ns), dim3(kSchurThreads), schur_lds, s, D);
