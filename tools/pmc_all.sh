@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --no-frames --no-cpu-baseline --no-cfg5 --steps 20 --warmup 5"
+B="python3 $R/bench.py --no-frames --no-cpu-baseline --no-cfg5 --single-stream --steps 20 --warmup 5"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $B > $O/fetch.log 2>&1
 echo fetch done
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $B > $O/write.log 2>&1
