@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frames", action="store_true", help="skip the cfg2 / local BA / frames legs")
     ap.add_argument("--no-cfg5", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight on as many streams (1..4)")
     ap.add_argument("--single-stream", action="store_true",
                     help="one step at a time on one stream (default: two steps in flight on two streams); the rocprofv3 "
                          "kernel summaries under profiles/ are taken this way so that kernel durations do not overlap")
@@ -375,7 +376,7 @@ def main():
         all-gather of step k is started asynchronously and collected after the kernels of step k+1 are enqueued (two
         rotating buffer sets), so the exchange overlaps the next step's compute; drain() collects the last one inside
         the timed region."""
-        plan = matcher.plan(qq, tt, n_total, single_stream=args.single_stream)
+        plan = matcher.plan(qq, tt, n_total, single_stream=args.single_stream, in_flight=args.in_flight)
         plans.append(plan)
 
         def step():
@@ -490,7 +491,7 @@ def main():
                 "kernel_ms_source": "HIP events on the launch stream: one pair around K launches issued back to back on ONE "
                                     "stream (no overlap between launches), divided by K; includes the ~1.5 us kernel boundary. "
                                     "The timed steps themselves keep two launches in flight on two streams (ms_per_step)",
-                "steps_in_flight": 1 if args.single_stream else 2,
+                "steps_in_flight": 1 if args.single_stream else args.in_flight,
                 "kernel_ms_event_pair_per_launch": kernel_ms_isolated, "kernel_ms_busy_start": busy_ms,
                 "lane_ops_per_match": OPS_PER_MATCH,
                 "lane_ops_model": "ISA of the main loop: per 8 distances 64 v_xor_b32 + 64 v_bcnt_u32_b32 + 8 v_lshl_or_b32 + "

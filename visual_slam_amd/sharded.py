@@ -288,7 +288,7 @@ class ShardedMatcher:
             self._order_caller_after()
         return out[:n_query, 0:2], out[:n_query, 2:4]
 
-    def plan(self, q_shard, train, n_query, single_stream=False):
+    def plan(self, q_shard, train, n_query, single_stream=False, in_flight=2):
         """A pre-bound step for a fixed workload (bench.py, streaming callers): every ctypes argument of the two rotating
         buffer sets is built once, so `submit()` is one C call (kernel [+ event + in-place ncclAllGather + done event])
         and `collect(slot)` one stream-side wait.  The caller works on `torch_stream()` (checked here); other callers use
@@ -299,7 +299,7 @@ class ShardedMatcher:
             raise RuntimeError("ShardedMatcher.plan: make torch_stream() the current stream first")
         if self._local is not None:
             raise RuntimeError("ShardedMatcher.plan needs the HIP path")
-        return _Plan(self, q_shard, train, n_query, single_stream)
+        return _Plan(self, q_shard, train, n_query, 1 if single_stream else int(in_flight))
 
     def close(self):
         """Destroy the direct RCCL communicator (if one was created)."""
@@ -319,11 +319,11 @@ class ShardedMatcher:
 
 
 class _Plan:
-    """Two steps in flight: slot 0 launches on the library's stream, slot 1 on a second stream of its own (own scratch
-    inside the library), so the short tail of one launch -- the fold by the last-arriving workgroups, the kernel
-    boundary -- overlaps the body of the next.  Results of slot 1 are ordered into the library's stream by collect()."""
+    """`in_flight` steps in flight (default two): slot 0 launches on the library's stream, every further slot on a stream of
+    its own (own scratch inside the library), so the short tail of one launch -- the fold by the last-arriving workgroups,
+    the kernel boundary -- overlaps the body of the next.  Results are ordered into the library's stream by collect()."""
 
-    def __init__(self, m, q, t, n_query, single_stream=False):
+    def __init__(self, m, q, t, n_query, in_flight=2):
         import ctypes as C
         import torch
         from . import _capi
@@ -336,13 +336,18 @@ class _Plan:
         self.fallback = collective and not self.direct
         self.keep = (q, t)
         self.calls, self.outs, self.done, self.bufs = [], [], [], []
-        self.aux = m._stream if single_stream else torch.cuda.Stream(device=q.device)
-        if not single_stream:
-            self.aux.wait_stream(m._stream)  # q / t were produced on the library's stream
-        self.streams = (m._stream, self.aux)
-        self.two_streams = not single_stream
+        assert 1 <= in_flight <= 4
+        self.nslots = max(2, in_flight)  # two rotating buffer sets even on one stream
+        self.streams = [m._stream]
+        for _ in range(1, self.nslots):
+            if in_flight == 1:
+                self.streams.append(m._stream)
+            else:
+                st = torch.cuda.Stream(device=q.device)
+                st.wait_stream(m._stream)  # q / t were produced on the library's stream
+                self.streams.append(st)
         nq, nt = q.shape[0], t.shape[0]
-        for slot in (0, 1):
+        for slot in range(self.nslots):
             packed, gathered = m._buffers(per, q.device, 2 + slot)  # buffer sets of their own
             cs = self.streams[slot]
             csp = C.c_void_p(cs.cuda_stream)
@@ -362,12 +367,12 @@ class _Plan:
             self.calls.append((fn, args))
             self.bufs.append((packed, gathered))
             self.outs.append((out[:n_query, 0:2], out[:n_query, 2:4]))
-        self.work = [None, None]
+        self.work = [None] * self.nslots
 
     def submit(self):
         """Enqueue one step; returns the slot to hand to collect()."""
         slot = self.slot
-        self.slot = slot ^ 1
+        self.slot = (slot + 1) % self.nslots
         fn, args = self.calls[slot]
         rc = fn(*args)
         if rc != 0:
@@ -377,8 +382,8 @@ class _Plan:
             packed, gathered = self.bufs[slot]
             with torch.cuda.stream(self.streams[slot]):
                 self.work[slot] = self.m._dist.all_gather_into_tensor(gathered, packed, group=self.m.group, async_op=True)
-        elif not self.direct and slot == 1 and self.two_streams:
-            self.done[slot].record(self.aux)
+        elif not self.direct and self.streams[slot] is not self.m._stream:
+            self.done[slot].record(self.streams[slot])
         return slot
 
     def collect(self, slot):
@@ -387,6 +392,6 @@ class _Plan:
             if self.work[slot] is not None:
                 self.work[slot].wait()
                 self.work[slot] = None
-        elif self.direct or (slot == 1 and self.two_streams):
+        elif self.direct or self.streams[slot] is not self.m._stream:
             self.m._stream.wait_event(self.done[slot])
         return self.outs[slot]
