@@ -305,3 +305,36 @@ def test_deterministic(vs):
     b = vs.ba_solve(*_args(w))
     assert np.array_equal(a["poses"], b["poses"]) and np.array_equal(a["points"], b["points"])
     assert np.array_equal(a["chi2_trace"], b["chi2_trace"])
+
+
+def test_single_tile_schur_kernel_equals_the_tile_kernel(vs):
+    """Windows of <= 10 free cameras take ba_schur_small; it keeps ba_schur_tile's accumulator ownership, product
+    expressions and point order, so with the same partition of the points into slabs (2000 points: 250 slabs of 8 vs 256 of
+    8, the extra ones empty) the whole LM run is bit-identical; other partitions and multi-batch workgroups change only the
+    order in which slab sums are added.  The same holds for the linearisation of accepted states, which this path computes
+    inside the trial kernel (points) and next to the Schur workgroups (cameras) instead of in a launch of its own."""
+    from visual_slam_amd import _capi
+    lib = _capi.load()
+
+    def solve(w):
+        r = vs.ba_solve(*_args(w), max_iterations=6)
+        return r["poses"], r["points"], np.array(r["chi2_trace"])
+
+    try:
+        w = ba_workload(n_cams=10, n_points=2000, visibility=1.0)
+        lib.vs_ba_set_schur_variant(1, 0, 0)
+        ref = solve(w)
+        for variant in (2, 0):  # 2: ba_schur_small + a linearisation launch per iteration; 0: linearisation folded into the trial
+            lib.vs_ba_set_schur_variant(variant, 8, 512)
+            got = solve(w)
+            assert all(np.array_equal(a, b) for a, b in zip(ref, got)), variant
+        for (nc, npts, vis, per, cap) in [(6, 333, 0.6, 8, 512), (10, 1500, 0.8, 8, 16), (3, 17, 1.0, 8, 512), (10, 2000, 0.9, 5, 64)]:
+            w = ba_workload(n_cams=nc, n_points=npts, visibility=vis, seed=nc + npts)
+            lib.vs_ba_set_schur_variant(1, 0, 0)
+            ref = solve(w)
+            lib.vs_ba_set_schur_variant(0, per, cap)
+            got = solve(w)
+            for a, b in zip(ref, got):
+                assert np.allclose(a, b, rtol=1e-9, atol=1e-10), (nc, npts, vis, per, cap)
+    finally:
+        lib.vs_ba_set_schur_variant(0, 8, 512)

@@ -121,6 +121,8 @@ def load():
         lib.vs_match_set_target_blocks.argtypes = [C.c_int]
         lib.vs_match_set_tstage.restype = C.c_int
         lib.vs_match_set_tstage.argtypes = [C.c_int]
+        lib.vs_ba_set_schur_variant.restype = C.c_int
+        lib.vs_ba_set_schur_variant.argtypes = [C.c_int, C.c_int, C.c_int]
     except AttributeError:
         pass
     _LIB = lib

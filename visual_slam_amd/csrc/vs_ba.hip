@@ -149,30 +149,31 @@ __device__ inline double scale_err(const double* t1, const double* t2, double me
   return meas - sqrt(dx * dx + dy * dy + dz * dz);
 }
 
-// fixed-order block reduction of one double per thread (power-of-two block)
-template <int T>
-__device__ inline double block_reduce_sum(double v, double* s_red) {
-  __syncthreads();
-  s_red[threadIdx.x] = v;
-  __syncthreads();
+// fixed-order workgroup reduction of two doubles per thread (sum, and sum or max): xor-butterfly inside each wave (every
+// lane ends with the wave's value), the wave values through LDS, then added in wave order -- one barrier instead of a
+// barrier per tree level.  s_red holds 2 * (T / 64) doubles; every thread returns with both results.
+template <int T, bool SECOND_IS_MAX>
+__device__ inline void block_reduce2(double& a, double& b, double* s_red) {
+  constexpr int kW = T / 64;
 #pragma unroll
-  for (int off = T / 2; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
-    __syncthreads();
+  for (int d = 1; d < 64; d <<= 1) {
+    a += __shfl_xor(a, d);
+    const double o = __shfl_xor(b, d);
+    b = SECOND_IS_MAX ? fmax(b, o) : b + o;
   }
-  return s_red[0];
-}
-template <int T>
-__device__ inline double block_reduce_max(double v, double* s_red) {
+  const int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_red[wv] = a;
+    s_red[kW + wv] = b;
+  }
   __syncthreads();
-  s_red[threadIdx.x] = v;
-  __syncthreads();
+  a = s_red[0];
+  b = s_red[kW];
 #pragma unroll
-  for (int off = T / 2; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) s_red[threadIdx.x] = fmax(s_red[threadIdx.x], s_red[threadIdx.x + off]);
-    __syncthreads();
+  for (int w = 1; w < kW; ++w) {
+    a += s_red[w];
+    b = SECOND_IS_MAX ? fmax(b, s_red[kW + w]) : b + s_red[kW + w];
   }
-  return s_red[0];
 }
 
 // sum / max of the per-block partials by one wave: lane l takes entries l, l + 64, ... in order, then an xor-butterfly
@@ -192,94 +193,126 @@ __device__ inline double wave_max_partials(const double* v, int n) {
 }
 
 // ------------------------------------------------------------------------------------------------ linearize
-__global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
-  __shared__ double s_red[kCamThreads];
-  __shared__ double s_all[kCamThreads / 2][27];  // camera role: upper half of the first level lives in registers
-  __shared__ double s_grp[kCamThreads / 64][27];
-  const lm_state st = *D.st;
-  if (st.done || !st.need_lin) return;
-  const double* cams = D.cam[st.cur];
-  const double* pts = D.pts[st.cur];
-  const int tid = threadIdx.x;
-  if ((int)blockIdx.x < D.nb_pt) {
-    // ---- point role: kPtLanes lanes share a point, lane s takes its observations s, s + kPtLanes, ...; the 3x3 block
-    // and the right-hand side are summed over the lanes with xor-shuffles (every lane ends with the same bits)
-    const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;
-    double chi = 0.0, maxd = 0.0;
-    if (tid < kPtThreads && a < D.n_act) {  // the point role uses the first kPtThreads threads of the workgroup
-      const int p = D.act_pt[a];
-      const int ls = D.pt_slot[p];
-      const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
-      double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-      for (int o = D.pt_start[a] + sub; o < D.pt_start[a + 1]; o += kPtLanes) {
-        const int ci = D.o_cam[o];
-        const int cs = D.pose_slot[ci];
-        edge_t E;
-        eval_edge<true>(D, cams + (size_t)ci * kCamStride, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
-        chi += E.rho0;
-        const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
-        const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
-        const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
-        double WJi[2][3];
+// The linearisation (Hpp, bp, Hll, bl, Hpl) of a state.  Single-tile windows keep two of them, indexed like the state
+// buffers: ba_point_trial linearises the TRIAL state's points while it evaluates the trial (speculatively -- the values are
+// simply overwritten if the step is rejected), so an accepted step needs no linearisation launch of its own.
+struct lin_view {
+  double *Hpp, *bp, *Hll, *bl, *Hpl;
+};
+__device__ inline lin_view lin_of(const ba_dev& D, int buf) {
+  lin_view L;
+  const bool second = D.spec && buf;
+  L.Hpp = second ? D.Hpp1 : D.Hpp;
+  L.bp = second ? D.bp1 : D.bp;
+  L.Hll = second ? D.Hll1 : D.Hll;
+  L.bl = second ? D.bl1 : D.bl;
+  L.Hpl = second ? D.Hpl1 : D.Hpl;
+  return L;
+}
+
+// Point role of the linearisation for the kPtLanes lanes that share active point `a` (lane `sub` takes its observations
+// sub, sub + kPtLanes, ...): Hll / bl summed over the lanes with xor-shuffles (every lane ends with the same bits), the
+// Hpl blocks written per observation.  Returns this lane's share of the robust chi2; maxd = largest |diagonal| of Hll.
+__device__ inline double linearize_point(const ba_dev& D, const lin_view& L, const double* cams, const double* X, int a, int ls,
+                                         int sub, double& maxd) {
+  double chi = 0.0;
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+  for (int o = D.pt_start[a] + sub; o < D.pt_start[a + 1]; o += kPtLanes) {
+    const int ci = D.o_cam[o];
+    const int cs = D.pose_slot[ci];
+    edge_t E;
+    eval_edge<true>(D, cams + (size_t)ci * kCamStride, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
+    chi += E.rho0;
+    const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+    const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
+    const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
+    double WJi[2][3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          WJi[0][k] = w0 * E.Ji[0][k] + w1 * E.Ji[1][k];
-          WJi[1][k] = w1 * E.Ji[0][k] + w2 * E.Ji[1][k];
-        }
-        if (ls >= 0) {
+    for (int k = 0; k < 3; ++k) {
+      WJi[0][k] = w0 * E.Ji[0][k] + w1 * E.Ji[1][k];
+      WJi[1][k] = w1 * E.Ji[0][k] + w2 * E.Ji[1][k];
+    }
+    if (ls >= 0) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            b[k] += E.Ji[0][k] * r0 + E.Ji[1][k] * r1;
+      for (int k = 0; k < 3; ++k) {
+        b[k] += E.Ji[0][k] * r0 + E.Ji[1][k] * r1;
 #pragma unroll
-            for (int l = 0; l < 3; ++l) H[3 * k + l] += E.Ji[0][k] * WJi[0][l] + E.Ji[1][k] * WJi[1][l];
-          }
-          if (cs >= 0) {
-            double* B = D.Hpl + 18 * (size_t)D.o_hpl[o];
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-#pragma unroll
-              for (int l = 0; l < 3; ++l) B[3 * k + l] = E.Jj[0][k] * WJi[0][l] + E.Jj[1][k] * WJi[1][l];
-          }
-        }
+        for (int l = 0; l < 3; ++l) H[3 * k + l] += E.Ji[0][k] * WJi[0][l] + E.Ji[1][k] * WJi[1][l];
       }
-      if (ls >= 0) {  // uniform inside the lane group
+      if (cs >= 0) {
+        double* B = L.Hpl + 18 * (size_t)D.o_hpl[o];
 #pragma unroll
-        for (int d = 1; d < kPtLanes; d <<= 1) {
+        for (int k = 0; k < 6; ++k)
 #pragma unroll
-          for (int k = 0; k < 9; ++k) H[k] += __shfl_xor(H[k], d);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) b[k] += __shfl_xor(b[k], d);
-        }
-        if (sub == 0) {
-#pragma unroll
-          for (int k = 0; k < 9; ++k) D.Hll[9 * (size_t)ls + k] = H[k];
-#pragma unroll
-          for (int k = 0; k < 3; ++k) D.bl[3 * (size_t)ls + k] = b[k];
-          maxd = fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8])));
-        }
+          for (int l = 0; l < 3; ++l) B[3 * k + l] = E.Jj[0][k] * WJi[0][l] + E.Jj[1][k] * WJi[1][l];
       }
     }
-    const double csum = block_reduce_sum<kCamThreads>(chi, s_red);
-    const double cmax = block_reduce_max<kCamThreads>(maxd, s_red);
-    if (tid == 0) {
-      D.part_chi[blockIdx.x] = csum;
-      D.part_maxd[blockIdx.x] = cmax;
-    }
-    return;
   }
-  // ---- camera role: free camera slot c
-  const int c = blockIdx.x - D.nb_pt;
+  if (ls >= 0) {  // uniform inside the lane group
+#pragma unroll
+    for (int d = 1; d < kPtLanes; d <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) H[k] += __shfl_xor(H[k], d);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) b[k] += __shfl_xor(b[k], d);
+    }
+    if (sub == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) L.Hll[9 * (size_t)ls + k] = H[k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) L.bl[3 * (size_t)ls + k] = b[k];
+      maxd = fmax(fabs(H[0]), fmax(fabs(H[4]), fabs(H[8])));
+    }
+  }
+  return chi;
+}
+
+// Camera role: block row c of Hpp and bp from free camera slot c's observations.  Evaluating an edge costs some 400 FP64
+// instructions, so one workgroup (= one CU) per camera is compute-bound on that CU: D.cam_split workgroups of kCamThreads
+// threads share a camera (workgroup `part` takes the observations part * kCamThreads + tid + j * cam_split * kCamThreads),
+// publish their 27 sums, and the one that arrives last adds the parts in part order and assembles the block row.
+__device__ inline void linearize_camera(const ba_dev& D, const lin_view& L, const double* cams, const double* pts, int c, int part,
+                                        double (*s_all)[27], double (*s_grp)[27]) {
+  const int tid = threadIdx.x, split = D.cam_split, vthreads = split * kCamThreads;
   const int pose = D.slot_pose[c];
   const double* cam = cams + (size_t)pose * kCamStride;
   double acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-  for (int i = D.cam_start[c] + tid; i < D.cam_start[c + 1]; i += kCamThreads) {
-    const int o = D.cam_obs[i];
-    const int p = D.o_pt[o];
-    const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+  // four observations per thread and pass: the index chain observation -> point -> position is three dependent round
+  // trips, so the loads of all four are issued level by level before the first edge is evaluated
+  constexpr int kCamUnroll = 4;
+  const int i_end = D.cam_start[c + 1];
+  for (int ib = D.cam_start[c] + part * kCamThreads + tid; ib < i_end; ib += kCamUnroll * vthreads) {
+    int ou[kCamUnroll], pu[kCamUnroll];
+    double Xu[kCamUnroll][3], uvu[kCamUnroll][2], infou[kCamUnroll][3];
+#pragma unroll
+    for (int u = 0; u < kCamUnroll; ++u) ou[u] = ib + u * vthreads < i_end ? D.cam_obs[ib + u * vthreads] : -1;
+#pragma unroll
+    for (int u = 0; u < kCamUnroll; ++u) {
+      pu[u] = 0;
+      if (ou[u] >= 0) {
+        pu[u] = D.o_pt[ou[u]];
+        uvu[u][0] = D.o_uv[2 * (size_t)ou[u]];
+        uvu[u][1] = D.o_uv[2 * (size_t)ou[u] + 1];
+        if (D.has_info) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) infou[u][k] = D.o_info[3 * (size_t)ou[u] + k];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kCamUnroll; ++u)
+      if (ou[u] >= 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Xu[u][k] = pts[3 * (size_t)pu[u] + k];
+      }
+#pragma unroll
+    for (int u = 0; u < kCamUnroll; ++u) {
+    if (ou[u] < 0) continue;
+    const double* X = Xu[u];
     edge_t E;
-    eval_edge<true>(D, cam, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
+    eval_edge<true>(D, cam, X, uvu[u], D.has_info ? infou[u] : nullptr, E);
     const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
     const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
     const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
@@ -296,6 +329,7 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
       for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJj[0][l] + E.Jj[1][k] * WJj[1][l];
 #pragma unroll
     for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
+    }
   }
   // fixed-order reduction of the 27 sums: the upper half of the threads hands its values to the lower half through
   // LDS, then the 256 rows are added by (value, group-of-32) threads in row order and the 8 group sums in group order
@@ -327,13 +361,43 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
     s_grp[0][tid] = a2;
   }
   __syncthreads();
+  if (split > 1) {
+    // hand-off as in ba_point_trial: write-through stores, drain, one relaxed agent-scope ticket add; the last arriver
+    // acquires, resets the ticket for the next linearisation and adds the parts in part order
+    __shared__ int s_last;
+    double* mine = D.cam_part + ((size_t)c * split + part) * 27;
+    if (tid < 27)
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(mine + tid), (unsigned long long)__double_as_longlong(s_grp[0][tid]),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned prev = __hip_atomic_fetch_add(D.cam_ticket + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = prev == (unsigned)split - 1;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(D.cam_ticket + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < 27) {
+      const double* parts = D.cam_part + (size_t)c * split * 27;
+      double a2 = parts[tid];
+      for (int k = 1; k < split; ++k) a2 += parts[k * 27 + tid];
+      s_grp[0][tid] = a2;
+    }
+    __syncthreads();
+  }
   const double* s_acc = s_grp[0];
   // block row c of Hpp: zero, diagonal block, then the EdgeSBAScale terms of every scale edge touching this camera
   const int np = D.np;
-  for (int i = tid; i < 6 * np; i += kCamThreads) D.Hpp[(size_t)(6 * c) * np + i] = 0.0;
+  for (int i = tid; i < 6 * np; i += kCamThreads) L.Hpp[(size_t)(6 * c) * np + i] = 0.0;
   __syncthreads();
   if (tid == 0) {
-    double* Hrow = D.Hpp + (size_t)(6 * c) * np;
+    double* Hrow = L.Hpp + (size_t)(6 * c) * np;
     int n = 0;
     for (int k = 0; k < 6; ++k)
       for (int l = k; l < 6; ++l) {
@@ -382,14 +446,47 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
         }
       }
     }
-    for (int k = 0; k < 6; ++k) D.bp[6 * c + k] = b[k];
-  }
-  __syncthreads();
-  if (tid == 0) {
+    for (int k = 0; k < 6; ++k) L.bp[6 * c + k] = b[k];
+    // largest |diagonal| of the block row (lambda_0); with scale edges the diagonal has just been updated in memory
     double mx = 0.0;
-    for (int k = 0; k < 6; ++k) mx = fmax(mx, fabs(D.Hpp[(size_t)(6 * c + k) * np + 6 * c + k]));
+    n = 0;
+    for (int k = 0; k < 6; ++k) {
+      mx = fmax(mx, fabs(D.n_scale ? Hrow[(size_t)k * np + 6 * c + k] : s_acc[n]));
+      n += 6 - k;
+    }
     D.part_maxd[D.nb_pt + c] = mx;
   }
+}
+
+__global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
+  __shared__ double s_red[2 * kCamThreads / 64];
+  __shared__ double s_all[kCamThreads / 2][27];  // camera role: upper half of the first level lives in registers
+  __shared__ double s_grp[kCamThreads / 64][27];
+  const lm_state st = *D.st;
+  if (st.done || !st.need_lin) return;
+  const double* cams = D.cam[st.cur];
+  const double* pts = D.pts[st.cur];
+  const lin_view L = lin_of(D, st.cur);
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < D.nb_pt) {
+    // ---- point role: the first kPtThreads threads of the workgroup, kPtLanes lanes per point
+    const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;
+    double chi = 0.0, maxd = 0.0;
+    if (tid < kPtThreads && a < D.n_act) {
+      const int p = D.act_pt[a];
+      const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+      chi = linearize_point(D, L, cams, X, a, D.pt_slot[p], sub, maxd);
+    }
+    double csum = chi, cmax = maxd;
+    block_reduce2<kCamThreads, true>(csum, cmax, s_red);
+    if (tid == 0) {
+      D.part_chi[blockIdx.x] = csum;
+      D.part_maxd[blockIdx.x] = cmax;
+    }
+    return;
+  }
+  const int cw = blockIdx.x - D.nb_pt;
+  linearize_camera(D, L, cams, pts, cw / D.cam_split, cw % D.cam_split, s_all, s_grp);
 }
 
 // chi2 of the scale edges for state buffer `buf` (few edges: one thread)
@@ -758,46 +855,211 @@ __global__ __launch_bounds__(256) void ba_schur_tile(ba_dev D) {
   }
 }
 
-// S = Hpp + lambda I - sum_s slab_s ; bs = bp - sum_s bslab_s.  Workgroup = 64 elements x 4 slab groups: group g sums the
-// slabs g, g+4, ... (loads batched by 8), the four partial sums are added in group order - fixed order, deterministic.
-__global__ __launch_bounds__(256) void ba_reduce(ba_dev D) {
-  __shared__ double s_part[4][64];
+// Windows of at most kTileCams free cameras (one tile; BASELINE cfg4, the driver's local BA): the tile kernel's camera
+// maps, masks and chunk lists are not needed, and its chain of dependent global loads (mask -> list -> slots -> blocks)
+// is what a workgroup with 8 points spends its time on.  Here the Hpl blocks of a point are read where they lie
+// (contiguous from fp_start[l]), so a batch costs two round trips: [LM state, block ranges, Hll / bl] and then
+// [camera slots, Hpl blocks]; (Hll + lambda I)^-1 is inverted while the second is in flight.  Accumulator ownership, the
+// product expressions and the order in which a workgroup's points arrive are those of ba_schur_tile, so the sums are
+// bit-identical; only the blocks of the lower block triangle are produced (the Cholesky reads nothing else).
+constexpr int kSmallPts = 8, kSmallThreads = kCamThreads, kSmallWaves = kSmallThreads / 64;
+constexpr int kSmallRows = (kTileCams + kSmallWaves - 1) / kSmallWaves;
+
+// Workgroups [0, ns) produce the slabs; with two linearisations (D.spec) workgroups [ns, ns + nfp) run the camera role
+// of the linearisation of a freshly accepted state next to them (its point role ran inside ba_point_trial), so that
+// ba_reduce finds Hpp / bp without a linearisation launch in between.  lin_cameras = 0 in the first slot of a solve,
+// whose state ba_linearize has linearised completely.
+__global__ __launch_bounds__(kSmallThreads) void ba_schur_small(ba_dev D, int lin_cameras) {
+  constexpr int kStage = kSmallPts * kTileCams * 18;
+  constexpr int kSchurDoubles = kSmallPts * 12 + 2 * kStage + kSmallPts * 16 / 2;
+  constexpr int kCamDoubles = (kCamThreads / 2) * 27 + (kCamThreads / 64) * 27;
+  __shared__ double s_raw[kSchurDoubles > kCamDoubles ? kSchurDoubles : kCamDoubles];
+  const lm_state st = *D.st;
+  if (st.done) return;
+  const lin_view L = lin_of(D, st.cur);
+  if ((int)blockIdx.x >= D.ns) {
+    if (lin_cameras && st.need_lin) {
+      const int cw = blockIdx.x - D.ns;
+      linearize_camera(D, L, D.cam[st.cur], D.pts[st.cur], cw / D.cam_split, cw % D.cam_split,
+                       reinterpret_cast<double(*)[27]>(s_raw), reinterpret_cast<double(*)[27]>(s_raw + (kCamThreads / 2) * 27));
+    }
+    return;
+  }
+  double(*sD)[12] = reinterpret_cast<double(*)[12]>(s_raw);
+  double* sY = s_raw + kSmallPts * 12;
+  double* sB = sY + kStage;
+  int(*sMap)[16] = reinterpret_cast<int(*)[16]>(sB + kStage);
+  const double lambda = st.lambda;
+  const int np = D.np, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int per = (D.nfl + D.ns - 1) / D.ns;
+  const int l0 = blockIdx.x * per, l1 = min(l0 + per, D.nfl);
+  const int arow = lane / kTileCams, ccam = lane - arow * kTileCams;  // lanes 60..63 (arow == 6) idle in the products
+  double acc[kSmallRows][6], racc[kSmallRows];
+#pragma unroll
+  for (int r = 0; r < kSmallRows; ++r) {
+    racc[r] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[r][c] = 0.0;
+  }
+  // item = (point of the batch, block of the point, block row): 3 contiguous values of an Hpl block
+  constexpr int kItems = kSmallPts * kTileCams * 6, kRounds = (kItems + kSmallThreads - 1) / kSmallThreads;
+  const int dpb = tid >> 5;  // thread 32 pb + 31 inverts point pb's Hll (one per half wave: the inversions run side by side)
+  for (int b0 = l0; b0 < l1; b0 += kSmallPts) {
+    const int nb = min(kSmallPts, l1 - b0);
+    const bool dinv_thread = (tid & 31) == 31 && dpb < nb;
+    // ---- round trip 1: block ranges, Hll / bl
+    int blk[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r) {
+      const int q = (tid + kSmallThreads * r) / 6, pb = q / kTileCams, j = q - pb * kTileCams;
+      blk[r] = -1;
+      if (pb < nb) {
+        const int f0 = D.fp_start[b0 + pb], f1 = D.fp_start[b0 + pb + 1];
+        if (j < f1 - f0) blk[r] = f0 + j;
+      }
+    }
+    double Dm[9], bl[3];
+    if (dinv_thread) {
+      const size_t l = (size_t)(b0 + dpb);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Dm[k] = L.Hll[9 * l + k];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) bl[k] = L.bl[3 * l + k];
+    }
+    if (tid < kSmallPts * 16) (&sMap[0][0])[tid] = -1;
+    // ---- round trip 2: camera slots and block rows
+    double v[kRounds][3];
+    int slot[kRounds];
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
+      if (blk[r] >= 0) {
+        const int ar = (tid + kSmallThreads * r) % 6;
+        slot[r] = D.fp_slot[blk[r]];
+        const double* B = L.Hpl + 18 * (size_t)blk[r] + 3 * ar;
+        v[r][0] = B[0];
+        v[r][1] = B[1];
+        v[r][2] = B[2];
+      }
+    if (dinv_thread) {
+      double inv[9];
+      Dm[0] += lambda;
+      Dm[4] += lambda;
+      Dm[8] += lambda;
+      inv3(Dm, inv);
+      const size_t l = (size_t)(b0 + dpb);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        sD[dpb][k] = inv[k];
+        D.Dinv[9 * l + k] = inv[k];  // ba_point_trial's back-substitution reads it
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) sD[dpb][9 + k] = inv[3 * k] * bl[0] + inv[3 * k + 1] * bl[1] + inv[3 * k + 2] * bl[2];
+    }
+    __syncthreads();
+    // ---- stage B = Hpl and Y = Hpl (Hll + lambda I)^-1 by camera slot
+#pragma unroll
+    for (int r = 0; r < kRounds; ++r)
+      if (blk[r] >= 0) {
+        const int i = tid + kSmallThreads * r, ar = i % 6, pb = i / (6 * kTileCams);
+        const int o = (pb * kTileCams + slot[r]) * 18 + 3 * ar;
+        const double* sd = sD[pb];
+        sB[o] = v[r][0];
+        sB[o + 1] = v[r][1];
+        sB[o + 2] = v[r][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sY[o + c] = v[r][0] * sd[c] + v[r][1] * sd[3 + c] + v[r][2] * sd[6 + c];
+        if (ar == 0) sMap[pb][slot[r]] = blk[r];
+      }
+    __syncthreads();
+    // ---- products into the register accumulators: wave w owns the row cameras w, w + kSmallWaves
+    for (int pb = 0; pb < nb; ++pb) {
+      const int* map = sMap[pb];
+      const bool have = arow < 6 && map[ccam] >= 0;
+      double Bv[18];
+      if (have) {
+        const double* B = sB + (pb * kTileCams + ccam) * 18;
+#pragma unroll
+        for (int k = 0; k < 18; ++k) Bv[k] = B[k];
+      }
+      const double* sd = sD[pb];
+#pragma unroll
+      for (int r = 0; r < kSmallRows; ++r) {
+        const int ls = wv + kSmallWaves * r;
+        if (ls >= kTileCams || map[ls] < 0) continue;  // wave-uniform
+        if (have && ccam <= ls) {
+          const double* Y = sY + (pb * kTileCams + ls) * 18 + 3 * arow;
+          const double y0 = Y[0], y1 = Y[1], y2 = Y[2];
+#pragma unroll
+          for (int bc = 0; bc < 6; ++bc) acc[r][bc] += y0 * Bv[3 * bc] + y1 * Bv[3 * bc + 1] + y2 * Bv[3 * bc + 2];
+        }
+        if (arow < 6 && ccam == 0) {
+          const double* B = sB + (pb * kTileCams + ls) * 18 + 3 * arow;
+          racc[r] += B[0] * sd[9] + B[1] * sd[10] + B[2] * sd[11];
+        }
+      }
+    }
+    if (b0 + kSmallPts < l1) __syncthreads();  // the next batch overwrites the staging
+  }
+  double* out = D.slab + (size_t)blockIdx.x * ((size_t)np * np + np);
+  if (arow < 6) {
+#pragma unroll
+    for (int r = 0; r < kSmallRows; ++r) {
+      const int ls = wv + kSmallWaves * r;
+      if (ls >= kTileCams) continue;
+      const int row = 6 * ls + arow, col = 6 * ccam;
+      if (row < np && col < np && ccam <= ls) {
+#pragma unroll
+        for (int bc = 0; bc < 6; ++bc) out[(size_t)row * np + col + bc] = acc[r][bc];
+      }
+      if (ccam == 0 && row < np) out[(size_t)np * np + row] = racc[r];
+    }
+  }
+}
+
+// S = Hpp + lambda I - sum_s slab_s ; bs = bp - sum_s bslab_s.  Workgroup = 64 elements x kRedSplit slab groups: group g
+// sums the slabs g, g + kRedSplit, ... with all of its loads in flight at once (up to 16 per pass), the group sums are
+// added in group order - fixed order, deterministic.  The Hpp / bp element is requested before the slabs, not after.
+constexpr int kRedSplit = 16;
+__global__ __launch_bounds__(64 * kRedSplit) void ba_reduce(ba_dev D) {
+  __shared__ double s_part[kRedSplit][64];
   const lm_state st = *D.st;
   if (st.done) return;
   const int np = D.np;
   const int slab_elems = np * np + np;
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + e;
+  const lin_view L = lin_of(D, st.cur);
+  double base = 0.0;
+  if (g == 0 && i < slab_elems) base = i < np * np ? L.Hpp[i] : L.bp[i - np * np];
   double acc = 0.0;
-  // the tiled Schur kernel produces the tiles of the lower triangle only (the Cholesky reads nothing else): elements of
-  // strictly upper tiles have no slab contribution to fetch
+  // the tiled Schur kernels produce the lower triangle only (tiles, or 6x6 blocks for ba_schur_small) - the Cholesky
+  // reads nothing else: elements above it have no slab contribution to fetch
   bool have = i < slab_elems;
-  if (have && D.ntile > 1 && i < np * np) {
+  if (have && D.ntile >= 1 && i < np * np) {
     const int r = i / np, c = i - r * np;
-    have = r / kTileN >= c / kTileN;
+    have = D.small ? r / 6 >= c / 6 : r / kTileN >= c / kTileN;
   }
   if (have) {
-    int s = g;
-    for (; s + 28 < D.ns; s += 32) {
-      double v[8];
+    for (int s = g; s < D.ns; s += 16 * kRedSplit) {
+      double v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = D.slab[(size_t)(s + 4 * u) * slab_elems + i];
+      for (int u = 0; u < 16; ++u) v[u] = D.slab[(size_t)min(s + kRedSplit * u, D.ns - 1) * slab_elems + i];  // unconditional loads
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[u];
+      for (int u = 0; u < 16; ++u) acc += s + kRedSplit * u < D.ns ? v[u] : 0.0;  // a missing slab contributes an exact zero
     }
-    for (; s < D.ns; s += 4) acc += D.slab[(size_t)s * slab_elems + i];
   }
   s_part[g][e] = acc;
   __syncthreads();
   if (g != 0 || i >= slab_elems) return;
-  acc = ((s_part[0][e] + s_part[1][e]) + s_part[2][e]) + s_part[3][e];
+  acc = s_part[0][e];
+#pragma unroll
+  for (int k = 1; k < kRedSplit; ++k) acc += s_part[k][e];
   if (i < np * np) {
     const int r = i / np, c = i - r * np;
-    double v = D.Hpp[i];
-    if (r == c) v += st.lambda;
-    D.S[i] = v - acc;
+    if (r == c) base += st.lambda;
+    D.S[i] = base - acc;
   } else {
-    D.bs[i - np * np] = D.bp[i - np * np] - acc;
+    D.bs[i - np * np] = base - acc;
   }
 }
 
@@ -923,54 +1185,59 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   int* s_flag = reinterpret_cast<int*>(s_bp + n + 1);
   for (int r = ty; r < n; r += kSolveTile)
     for (int c = tx; c < n; c += kSolveTile) A[r * ld + c] = D.S[(size_t)r * n + c];
+  const double* g_bp = lin_of(D, cur).bp;
   for (int c = tid; c < n; c += kSolveBlock) {
     A[n * ld + c] = D.bs[c];
-    s_bp[c] = D.bp[c];
+    s_bp[c] = g_bp[c];
   }
   if (tid == 0) *s_flag = 0;
   if (done) return;  // uniform
   __syncthreads();
-  // ---- blocked right-looking Cholesky on the 6x6 camera blocks (n = 6 * nb); row n carries the right-hand side
+  // ---- blocked right-looking Cholesky on the 6x6 camera blocks (n = 6 * nb); row n carries the right-hand side.
+  // Per block column: (1) thread 0 factorises the diagonal block in registers, (2) every row below solves its 6 entries
+  // against it, (3) the trailing update.  (1) is a long dependent chain on one lane, so it is taken off the critical
+  // path: in step J's trailing update wave 0 updates the NEXT diagonal block first and factorises it while the other
+  // waves update the rest of the trailing matrix -- two barriers per block column, and the chain of (1) overlaps (3).
   int ok = 1;
   const int nb = n / 6;
+  auto factor_diag = [&](int j0) {  // thread 0: L_JJ in registers, reciprocal pivots to rinv
+    double L[6][6], ri[6];
+    int good = 1;
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c <= r; ++c) L[r][c] = A[(j0 + r) * ld + j0 + c];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const double d = L[c][c];
+      if (!(d > 0.0)) good = 0;
+      double r = __builtin_amdgcn_rsq(d);
+      r = r * (1.5 - 0.5 * d * r * r);
+      r = r * (1.5 - 0.5 * d * r * r);
+      double l = d * r;
+      l = l + 0.5 * r * (d - l * l);
+      L[c][c] = l;
+      ri[c] = r;
+#pragma unroll
+      for (int i = c + 1; i < 6; ++i) L[i][c] = L[i][c] * r;
+#pragma unroll
+      for (int i = c + 1; i < 6; ++i)
+#pragma unroll
+        for (int k = c + 1; k <= i; ++k) L[i][k] -= L[i][c] * L[k][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) A[(j0 + r) * ld + j0 + c] = L[r][c];
+      rinv[j0 + r] = ri[r];
+    }
+    if (!good) *s_flag = 1;
+  };
+  if (tid == 0 && nb > 0) factor_diag(0);
+  __syncthreads();
   for (int J = 0; J < nb; ++J) {
     const int j0 = 6 * J;
-    // (1) diagonal block: one thread, registers, reciprocal pivots
-    if (tid == 0) {
-      double L[6][6], ri[6];
-      int good = 1;
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = 0; c <= r; ++c) L[r][c] = A[(j0 + r) * ld + j0 + c];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double d = L[c][c];
-        if (!(d > 0.0)) good = 0;
-        double r = __builtin_amdgcn_rsq(d);
-        r = r * (1.5 - 0.5 * d * r * r);
-        r = r * (1.5 - 0.5 * d * r * r);
-        double l = d * r;
-        l = l + 0.5 * r * (d - l * l);
-        L[c][c] = l;
-        ri[c] = r;
-#pragma unroll
-        for (int i = c + 1; i < 6; ++i) L[i][c] = L[i][c] * r;
-#pragma unroll
-        for (int i = c + 1; i < 6; ++i)
-#pragma unroll
-          for (int k = c + 1; k <= i; ++k) L[i][k] -= L[i][c] * L[k][c];
-      }
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-#pragma unroll
-        for (int c = 0; c <= r; ++c) A[(j0 + r) * ld + j0 + c] = L[r][c];
-        rinv[j0 + r] = ri[r];
-      }
-      if (!good) *s_flag = 1;
-    }
-    __syncthreads();
-    if (*s_flag) {  // uniform
+    if (*s_flag) {  // uniform (written before the last barrier)
       ok = 0;
       break;
     }
@@ -990,21 +1257,46 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
       for (int c = 0; c < 6; ++c) A[r * ld + j0 + c] = a[c];
     }
     __syncthreads();
-    // (3) trailing update: A[r][c] -= sum_k A[r][j0+k] * A[c][j0+k]  for r > j0+5 (incl. rhs row), j0+5 < c <= min(r, n-1)
-    for (int r = j0 + 6 + ty; r <= n; r += kSolveTile) {
-      double ar[6];
+    // (3) trailing update: A[r][c] -= sum_k A[r][j0+k] * A[c][j0+k]  for r > j0+5 (incl. rhs row), j0+5 < c <= min(r, n-1).
+    // Wave 0 owns the next diagonal block (rows/columns j0+6 .. j0+11): 21 lanes update it, then lane 0 factorises it;
+    // the other waves take the rest on a (kSolveTile - 2) x kSolveTile grid of their own.
+    const bool next_diag = J + 1 < nb;
+    if (tid < 64) {
+      if (next_diag) {
+        if (tid < 21) {
+          int r = 0, c = tid;
+          while (c > r) {  // lane -> (r, c) of the lower triangle, row-major
+            c -= r + 1;
+            ++r;
+          }
+          const int rr = j0 + 6 + r, cc = j0 + 6 + c;
+          double acc = A[rr * ld + cc];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) ar[k] = A[r * ld + j0 + k];
-      const int cmax = r < n ? r : n - 1;
-      for (int c = j0 + 6 + tx; c <= cmax; c += kSolveTile) {
-        double acc = A[r * ld + c];
+          for (int k = 0; k < 6; ++k) acc -= A[rr * ld + j0 + k] * A[cc * ld + j0 + k];
+          A[rr * ld + cc] = acc;
+        }
+        wave_lds_sync();
+        if (tid == 0) factor_diag(j0 + 6);
+      }
+    } else {
+      const int t2 = tid - 64, ux = t2 % kSolveTile, uy = t2 / kSolveTile;  // (kSolveBlock - 64) / kSolveTile rows of threads
+      constexpr int kRowsPer = (kSolveBlock - 64) / kSolveTile;
+      for (int r = j0 + (next_diag ? 12 : 6) + uy; r <= n; r += kRowsPer) {  // rows j0+6..j0+11 lie inside wave 0's block
+        double ar[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc -= ar[k] * A[c * ld + j0 + k];
-        A[r * ld + c] = acc;
+        for (int k = 0; k < 6; ++k) ar[k] = A[r * ld + j0 + k];
+        const int cmax = r < n ? r : n - 1;
+        for (int c = j0 + 6 + ux; c <= cmax; c += kSolveTile) {
+          double acc = A[r * ld + c];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc -= ar[k] * A[c * ld + j0 + k];
+          A[r * ld + c] = acc;
+        }
       }
     }
     __syncthreads();
   }
+  if (ok && *s_flag) ok = 0;  // the last look-ahead factorisation failed
   // backward substitution L^T x = y on wave 0, by 6x6 blocks from the bottom: lane 0 solves the block's triangular
   // system in registers (descending k, as the element-wise recurrence does), then the lanes subtract the block's
   // contribution from the rows above -- nb dependent steps instead of n.  x lives in row n.
@@ -1057,21 +1349,27 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
       const double xx = aw * bx + ax * bw + ay * bz - az * by;
       const double yy = aw * by + ay * bw + az * bx - ax * bz;
       const double zz = aw * bz + az * bw + ax * by - ay * bx;
-      const double nrm = sqrt(xx * xx + yy * yy + zz * zz + w * w);
-      double q[4] = {xx / nrm, yy / nrm, zz / nrm, w / nrm};
+      const double inrm = vs_fast_rsq(xx * xx + yy * yy + zz * zz + w * w);  // as ba_motion_step does
+      double q[4] = {xx * inrm, yy * inrm, zz * inrm, w * inrm};
       for (int k = 0; k < 3; ++k) dst[k] = t[k];
       for (int k = 0; k < 4; ++k) dst[3 + k] = q[k];
       quat_to_w2n(t, q, dst + 7);
     }
   }
-  if (tid == 0) {
+  // gain denominator x^T (lambda x + b): the last wave sums it (lane l takes the terms l, l+64; butterfly over the wave)
+  if (tid >= kSolveBlock - 64) {
+    const int lane = tid & 63;
     double sc = 0.0;
     if (ok)
-      for (int j = 0; j < n; ++j) sc += x[j] * (lambda * x[j] + s_bp[j]);
-    st->scale_pose = sc;
-    st->solve_ok = ok;
-    st->trials += 1;
-    if (!ok) st->not_pd += 1;
+      for (int j = lane; j < n; j += 64) sc += x[j] * (lambda * x[j] + s_bp[j]);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) sc += __shfl_xor(sc, d);
+    if (lane == 0) {
+      st->scale_pose = sc;
+      st->solve_ok = ok;
+      st->trials += 1;
+      if (!ok) st->not_pd += 1;
+    }
   }
 }
 
@@ -1343,7 +1641,7 @@ __device__ inline void ba_decide(const ba_dev& D) {
 
 // ------------------------------------------------------------------------------------------------ trial + chi2
 __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
-  __shared__ double s_red[kPtThreads];
+  __shared__ double s_red[2 * kPtThreads / 64];
   const lm_state st = *D.st;
   if (st.done) return;
   const int tid = threadIdx.x;
@@ -1353,6 +1651,7 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
     const double* cams1 = D.cam[st.cur ^ 1];
     const double* pts0 = D.pts[st.cur];
     double* pts1 = D.pts[st.cur ^ 1];
+    const lin_view L = lin_of(D, st.cur);
     const int p = D.act_pt[a];
     const int ls = D.pt_slot[p];
     double X[3] = {pts0[3 * (size_t)p], pts0[3 * (size_t)p + 1], pts0[3 * (size_t)p + 2]};
@@ -1363,7 +1662,7 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
       for (int o = o0 + sub; o < o1; o += kPtLanes) {
         const int cs = D.pose_slot[D.o_cam[o]];
         if (cs < 0) continue;
-        const double* B = D.Hpl + 18 * (size_t)D.o_hpl[o];
+        const double* B = L.Hpl + 18 * (size_t)D.o_hpl[o];
         const double* xc = D.xp + 6 * cs;
 #pragma unroll
         for (int b = 0; b < 3; ++b)
@@ -1374,12 +1673,12 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
       for (int d = 1; d < kPtLanes; d <<= 1)
 #pragma unroll
         for (int b = 0; b < 3; ++b) part[b] += __shfl_xor(part[b], d);
-      const double cl[3] = {D.bl[3 * (size_t)ls] - part[0], D.bl[3 * (size_t)ls + 1] - part[1], D.bl[3 * (size_t)ls + 2] - part[2]};
+      const double cl[3] = {L.bl[3 * (size_t)ls] - part[0], L.bl[3 * (size_t)ls + 1] - part[1], L.bl[3 * (size_t)ls + 2] - part[2]};
       const double* Di = D.Dinv + 9 * (size_t)ls;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const double xl = Di[3 * k] * cl[0] + Di[3 * k + 1] * cl[1] + Di[3 * k + 2] * cl[2];
-        if (sub == 0) sc += xl * (st.lambda * xl + D.bl[3 * (size_t)ls + k]);
+        if (sub == 0) sc += xl * (st.lambda * xl + L.bl[3 * (size_t)ls + k]);
         X[k] += xl;
       }
     }
@@ -1387,14 +1686,21 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) pts1[3 * (size_t)p + k] = X[k];
     }
-    for (int o = o0 + sub; o < o1; o += kPtLanes) {
-      edge_t E;
-      eval_edge<false>(D, cams1 + (size_t)D.o_cam[o] * kCamStride, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
-      chi += E.rho0;
+    if (D.spec) {
+      // the trial state's point role of the linearisation comes with its chi2 (same code, lanes and operands as
+      // ba_linearize would use after an accepted step): written to the other linearisation, dropped if the step is rejected
+      double maxd = 0.0;
+      chi = linearize_point(D, lin_of(D, st.cur ^ 1), cams1, X, a, ls, sub, maxd);
+    } else {
+      for (int o = o0 + sub; o < o1; o += kPtLanes) {
+        edge_t E;
+        eval_edge<false>(D, cams1 + (size_t)D.o_cam[o] * kCamStride, X, D.o_uv + 2 * (size_t)o, D.has_info ? D.o_info + 3 * (size_t)o : nullptr, E);
+        chi += E.rho0;
+      }
     }
   }
-  const double csum = block_reduce_sum<kPtThreads>(chi, s_red);
-  const double ssum = block_reduce_sum<kPtThreads>(sc, s_red);
+  double csum = chi, ssum = sc;
+  block_reduce2<kPtThreads, false>(csum, ssum, s_red);
   // The workgroup that publishes its partials last takes the LM decision (ba_decide) in the same launch.  Hand-off as in
   // vs_match.hip: write-through stores (agent-scope relaxed atomic stores), drain, one relaxed agent-scope ticket add;
   // the last arriver acquires (its CU's L1 must not serve older partials) and resets the ticket for the next slot.
@@ -1853,6 +2159,17 @@ int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& 
 
 // Test hook: the dense solver alone (see include/vslam_hip.h).  A minimal ba_dev without cameras or points: the
 // kernels read S, bs, bp and the LM state and write xp and solve_ok.
+// tuning / test hooks (not part of the stable ABI): Schur kernel of single-tile windows (0 automatic = ba_schur_small with
+// the linearisation of accepted states folded into the trial, 1 = the general tile kernel, 2 = ba_schur_small with a
+// linearisation launch per iteration), points per workgroup and the cap on the number of slabs of ba_schur_small
+static int g_schur_variant = 0, g_small_per = kSmallPts, g_small_ns_cap = 512;
+VS_API int vs_ba_set_schur_variant(int variant, int points_per_workgroup, int max_slabs) {
+  if (variant >= 0 && variant <= 2) g_schur_variant = variant;
+  if (points_per_workgroup > 0) g_small_per = points_per_workgroup;
+  if (max_slabs > 0) g_small_ns_cap = max_slabs;
+  return g_schur_variant;
+}
+
 VS_API int vs_ba_debug_cholesky(vs_ctx* ctx, const double* S, int n, const double* b, double* x, int* ok) {
   if (!ctx) return VS_EINVAL;
   if (!S || !b || !x || !ok || n <= 0 || n % 6 != 0)
@@ -2015,6 +2332,13 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   const bool lds_slab = np <= kMaxSlabN;
   const int ntile_pairs = ntile * (ntile + 1) / 2;  // tiles of the lower triangle
   if (tiled) ns = std::max(4, std::min(256, (16384 + ntile_pairs - 1) / ntile_pairs));  // >= 16k workgroups: most tiles are empty
+  const bool small = tiled && ntile == 1 && g_schur_variant != 1;  // one tile: ba_schur_small, one batch of points per workgroup
+  const bool spec = small && g_schur_variant != 2;  // two linearisations: the trial kernel linearises the trial state
+  // workgroups per camera of the linearisation's camera role: about one observation per thread, at most 8
+  int cam_split = 1;
+  for (int c = 0; c < nfp; ++c) cam_split = std::max(cam_split, (cam_start[c + 1] - cam_start[c] + kCamThreads - 1) / kCamThreads);
+  cam_split = std::min(cam_split, 8);
+  if (small) ns = std::max(1, std::min(g_small_ns_cap, (nfl + g_small_per - 1) / g_small_per));
   if (!lds_slab && ns > 0) ns = std::min(ns, std::max(1, (int)((512u << 20) / (sizeof(double) * ((size_t)np * np + np)))));
   const size_t slab_elems = (size_t)np * np + np;
 
@@ -2027,7 +2351,8 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
                                   2 * (size_t)np * np + 8 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
                                   9 * (size_t)nfl + (tiled ? 4 * (size_t)nfl : 0) + (size_t)(ns ? ns : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
                                   2 * (size_t)q.max_iterations + 64) +
-                256 * 64 + sizeof(int) * (3 * (size_t)n_obs + nfl + 16) + sizeof(double) * 4 * (size_t)(res->trial_trace ? std::max(res->trial_trace_cap, 0) : 0) + (motion_only ? sizeof(double) * (8 * cam_obs.size() + 50 * (size_t)nfp + 64) : 0);
+                256 * 64 + sizeof(int) * (3 * (size_t)n_obs + nfl + 16) + (sizeof(double) * 27 * 8 + 8) * (size_t)nfp + 1024 +
+                (spec ? sizeof(double) * ((size_t)np * np + np + 12 * (size_t)nfl + 18 * (size_t)n_obs) + 5 * 256 : 0) + sizeof(double) * 4 * (size_t)(res->trial_trace ? std::max(res->trial_trace_cap, 0) : 0) + (motion_only ? sizeof(double) * (8 * cam_obs.size() + 50 * (size_t)nfp + 64) : 0);
   VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, need));
   VS_HIP(ctx, hipStreamSynchronize(s));
@@ -2088,6 +2413,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     D.fp_mask = A.take<unsigned long long>(nfl, &h_mask);
     memcpy(h_mask, fp_mask.data(), sizeof(unsigned long long) * (size_t)nfl);
     D.ntile = ntile;
+    D.small = small;
   }
   memcpy(h_ohpl, o_hpl.data(), sizeof(int) * (size_t)n_obs);
   memcpy(h_fps, fp_start.data(), sizeof(int) * ((size_t)nfl + 1));
@@ -2112,6 +2438,10 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   unsigned* h_ticket;
   D.trial_ticket = A.take<unsigned>(4, &h_ticket);
   memset(h_ticket, 0, 4 * sizeof(unsigned));
+  unsigned* h_cticket;
+  D.cam_ticket = A.take<unsigned>(nfp, &h_cticket);
+  memset(h_cticket, 0, sizeof(unsigned) * (size_t)(nfp ? nfp : 1));
+  D.cam_split = cam_split;
   const size_t upload_bytes = A.off;
   // not uploaded
   D.cam[1] = A.take<double>((size_t)F * kCamStride);
@@ -2121,6 +2451,15 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.Hll = A.take<double>(9 * (size_t)nfl);
   D.bl = A.take<double>(3 * (size_t)nfl);
   D.Hpl = A.take<double>(18 * (size_t)n_hpl);
+  D.cam_part = A.take<double>(27 * (size_t)nfp * cam_split);
+  if (spec) {
+    D.spec = 1;
+    D.Hpp1 = A.take<double>((size_t)np * np);
+    D.bp1 = A.take<double>(np);
+    D.Hll1 = A.take<double>(9 * (size_t)nfl);
+    D.bl1 = A.take<double>(3 * (size_t)nfl);
+    D.Hpl1 = A.take<double>(18 * (size_t)n_hpl);
+  }
   D.slab = A.take<double>((size_t)(ns ? ns : 1) * slab_elems);
   D.S = A.take<double>((size_t)np * np);
   D.bs = A.take<double>(np);
@@ -2225,23 +2564,30 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + sizeof(mo_state) + 128));
   lm_state* hst = reinterpret_cast<lm_state*>((uint8_t*)ctx->h_pin.p + 128);
   auto launch_slot = [&](bool first) -> int {
-    hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp), dim3(kCamThreads), 0, s, D);
-    VS_LAUNCH_CHECK(ctx, "ba_linearize");
+    if (first || !spec) {  // spec: later states are linearised inside ba_point_trial (points) and ba_schur_small (cameras)
+      hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp * cam_split), dim3(kCamThreads), 0, s, D);
+      VS_LAUNCH_CHECK(ctx, "ba_linearize");
+    }
     if (first) {
       hipLaunchKernelGGL(ba_lambda_init, dim3(1), dim3(64), 0, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_lambda_init");
     }
     if (ns > 0 && tiled) {
-      if (ntile > 1) hipLaunchKernelGGL(ba_dinv, dim3((unsigned)((nfl + 255) / 256)), dim3(256), 0, s, D);  // single tile: fused
-      hipLaunchKernelGGL(ba_schur_tile, dim3(ns, ntile * (ntile + 1) / 2), dim3(256), tile_lds, s, D);  // lower triangle
-      VS_LAUNCH_CHECK(ctx, "ba_schur_tile");
+      if (small) {
+        hipLaunchKernelGGL(ba_schur_small, dim3(ns + (spec ? nfp * cam_split : 0)), dim3(kSmallThreads), 0, s, D, first ? 0 : 1);
+        VS_LAUNCH_CHECK(ctx, "ba_schur_small");
+      } else {
+        if (ntile > 1) hipLaunchKernelGGL(ba_dinv, dim3((unsigned)((nfl + 255) / 256)), dim3(256), 0, s, D);  // single tile: fused
+        hipLaunchKernelGGL(ba_schur_tile, dim3(ns, ntile * (ntile + 1) / 2), dim3(256), tile_lds, s, D);  // lower triangle
+        VS_LAUNCH_CHECK(ctx, "ba_schur_tile");
+      }
     } else if (ns > 0) {
       if (lds_slab) hipLaunchKernelGGL(ba_schur<true>, dim3(ns), dim3(kSchurThreads), schur_lds, s, D);
       else hipLaunchKernelGGL(ba_schur<false>, dim3(ns), dim3(kSchurThreads), schur_lds, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_schur");
     }
     if (np > 0) {
-      hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 63) / 64)), dim3(256), 0, s, D);
+      hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 63) / 64)), dim3(64 * kRedSplit), 0, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_reduce");
     }
     VS_TRY(launch_solve(ctx, s, D, splan));
@@ -2297,7 +2643,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     }
   } else {
     // chi2 of the start state only
-    hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp), dim3(kCamThreads), 0, s, D);
+    hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp * cam_split), dim3(kCamThreads), 0, s, D);
     VS_LAUNCH_CHECK(ctx, "ba_linearize");
     hipLaunchKernelGGL(ba_lambda_init, dim3(1), dim3(64), 0, s, D);
     VS_LAUNCH_CHECK(ctx, "ba_lambda_init");

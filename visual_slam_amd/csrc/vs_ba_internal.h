@@ -36,6 +36,12 @@ struct ba_dev {
   const unsigned long long* fp_mask;  // per free point: bit t set iff it is observed by a camera of tile row t
   double* Dbl;     // [nfl][3] (Hll + lambda I)^-1 bl (tiled Schur)
   int ntile;       // tiles of kTileCams cameras per side (tiled Schur), 0 otherwise
+  int small;       // 1: ba_schur_small produced the slabs (single tile, lower block triangle only)
+  int cam_split;   // workgroups that share one camera in the linearisation's camera role
+  double* cam_part;       // [nfp][cam_split][27] their partial sums
+  unsigned* cam_ticket;   // [nfp] arrival counters
+  int spec;        // 1: two linearisations, indexed like the state buffers (ba_point_trial linearises the trial state)
+  double *Hpp1, *bp1, *Hll1, *bl1, *Hpl1;  // the second linearisation (spec)
   double* rinv;    // [np] reciprocal Cholesky pivots (large systems)
   int* chol_fail;  // set by a panel kernel that met a non-positive pivot
   double *part_chi, *part_scale, *part_maxd;  // per point-block partials; part_maxd has nb_pt + nfp entries

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const uint
       eq_pre += (k < wave) ? c : 0;
       eq_tot += c;
     }
-    if (is_eq) sel = (eq_running + eq_pre + __popcll(beq & ((1ull << lane) - 1ull))) < quota;
+    if (is_eq) sel = (int)(eq_running + eq_pre + __popcll(beq & ((1ull << lane) - 1ull))) < quota;
     eq_running += eq_tot;
     __syncthreads();
     const unsigned long long bsel = __ballot(sel);

@@ -437,12 +437,12 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
   }
   if (P.rec_out[0] && tid == 0) {
     // the record is re-derived from the 4x4 result, as a caller that passes the pose matrix on would do
-    double m[16], rec[kCamStride];
-    for (int k = 0; k < 12; ++k) m[k] = pose[k];
-    rec[0] = m[3];
-    rec[1] = m[7];
-    rec[2] = m[11];
-    quat_from_pose(m, rec + 3);
+    double mat[16], rec[kCamStride];
+    for (int k = 0; k < 12; ++k) mat[k] = pose[k];
+    rec[0] = mat[3];
+    rec[1] = mat[7];
+    rec[2] = mat[11];
+    quat_from_pose(mat, rec + 3);
     quat_to_w2n(rec, rec + 3, rec + 7);
     for (int k = 0; k < kCamStride; ++k) {
       P.rec_out[0][k] = rec[k];
