@@ -1724,6 +1724,35 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
   if (s_last && tid < 64) ba_decide(D);
 }
 
+// ------------------------------------------------------------------------------------------------ result export
+// Gathers what the host reads after a batch of slots -- LM state, the accepted cameras and points, the traces -- into one
+// contiguous block, so that the poll for `done` and the read-back are ONE device-to-host copy and one synchronisation.
+// Layout in doubles: [state 32 | cameras F x kCamStride | points 3 P | chi2 trace | lambda trace | trial rows 4 x cap].
+__global__ __launch_bounds__(256) void ba_export(ba_dev D, double* out) {
+  const lm_state st = *D.st;
+  const size_t nc = (size_t)D.n_poses * kCamStride, npt = 3 * (size_t)D.n_points, ntr = (size_t)D.max_it, ntt = 4 * (size_t)D.trial_cap;
+  const size_t total = 32 + nc + npt + 2 * ntr + ntt;
+  const double* cam = D.cam[st.cur];
+  const double* pts = D.pts[st.cur];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    double v;
+    if (i < 32) {
+      v = i < sizeof(lm_state) / sizeof(double) ? reinterpret_cast<const double*>(D.st)[i] : 0.0;
+    } else if (i < 32 + nc) {
+      v = cam[i - 32];
+    } else if (i < 32 + nc + npt) {
+      v = pts[i - 32 - nc];
+    } else if (i < 32 + nc + npt + ntr) {
+      v = D.chi_trace[i - 32 - nc - npt];
+    } else if (i < 32 + nc + npt + 2 * ntr) {
+      v = D.lambda_trace[i - 32 - nc - npt - ntr];
+    } else {
+      v = D.trial_trace[i - 32 - nc - npt - 2 * ntr];
+    }
+    out[i] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ motion-only BA
 // motionOnlyBundleAdjustement (reference LocalBA.py:195-229) has no free points and no scale edges: the normal
 // equations are block diagonal, so linearisation, the 6x6 solve, the trial state and the trial chi2 of one camera need
@@ -2222,9 +2251,6 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       (p->n_obs && (!p->obs_pose || !p->obs_point || !p->obs_uv)) ||
       (p->n_scale && (!p->scale_parent || !p->scale_child || !p->scale_meas)))
     return vs_fail(ctx, VS_EINVAL, "%s: inconsistent sizes / null arrays", "vs_ba_solve");
-  for (int o = 0; o < p->n_obs; ++o)
-    if (p->obs_pose[o] < 0 || p->obs_pose[o] >= p->n_poses || p->obs_point[o] < 0 || p->obs_point[o] >= p->n_points)
-      return vs_fail(ctx, VS_EINVAL, "%s: observation index out of range", "vs_ba_solve");
   for (int k = 0; k < p->n_scale; ++k)
     if (p->scale_parent[k] < 0 || p->scale_parent[k] >= p->n_poses || p->scale_child[k] < 0 ||
         p->scale_child[k] >= p->n_poses)
@@ -2239,85 +2265,66 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     return std::chrono::duration<double, std::micro>(b - a).count();
   };
   const auto t_begin = now();
-  // ---- structure (host): slots, active observations grouped by point (stable), per-camera lists
+  // ---- structure (host).  Pass 1 over the observations: index validation, active observations per point and per free
+  // camera, number of Hpl blocks -- every array size is known after it, so pass 2 writes the device arrays straight into
+  // the pinned arena.  Scratch vectors are kept per host thread (no allocation in the steady state).
   const int F = p->n_poses, P = p->n_points;
-  std::vector<int> pose_slot(F), pt_slot(P);
+  static thread_local struct {
+    std::vector<int> pose_slot, pt_slot, cnt, fill, order, cam_start, cfill, seen_by, seen_cnt;
+  } W;
+  W.pose_slot.resize(F ? F : 1);
+  W.pt_slot.resize(P ? P : 1);
+  int* pose_slot = W.pose_slot.data();
+  int* pt_slot = W.pt_slot.data();
   int nfp = 0, nfl = 0;
   for (int i = 0; i < F; ++i) pose_slot[i] = p->pose_fixed[i] ? -1 : nfp++;
   for (int j = 0; j < P; ++j) pt_slot[j] = p->point_fixed[j] ? -1 : nfl++;
   const int np = 6 * nfp;
-  std::vector<int> cnt(P + 1, 0);
-  int n_obs = 0;
-  for (int o = 0; o < p->n_obs; ++o)
-    if (pose_slot[p->obs_pose[o]] >= 0 || pt_slot[p->obs_point[o]] >= 0) {
-      cnt[p->obs_point[o] + 1]++;
-      ++n_obs;
+  W.cnt.assign((size_t)P + 1, 0);
+  W.cam_start.assign((size_t)nfp + 1, 0);
+  int* cnt = W.cnt.data();
+  int* cam_start = W.cam_start.data();
+  int n_obs = 0, n_hpl = 0, prev_pt = -1;
+  bool grouped = true;  // observations arrive grouped by point in ascending order (as the reference adds its edges)
+  for (int o = 0; o < p->n_obs; ++o) {
+    const int ci = p->obs_pose[o], pj = p->obs_point[o];
+    if (ci < 0 || ci >= F || pj < 0 || pj >= P) return vs_fail(ctx, VS_EINVAL, "%s: observation index out of range", "vs_ba_solve");
+    grouped &= pj >= prev_pt;
+    prev_pt = pj;
+    const int cs = pose_slot[ci], ls = pt_slot[pj];
+    if (cs < 0 && ls < 0) continue;  // fixed camera and fixed point: not part of the problem
+    cnt[pj + 1]++;
+    ++n_obs;
+    if (cs >= 0) {
+      cam_start[cs + 1]++;
+      n_hpl += ls >= 0;
     }
-  for (int j = 0; j < P; ++j) cnt[j + 1] += cnt[j];
-  std::vector<int> order(n_obs ? n_obs : 1), fill(cnt.begin(), cnt.end() - 1);
-  for (int o = 0; o < p->n_obs; ++o)
-    if (pose_slot[p->obs_pose[o]] >= 0 || pt_slot[p->obs_point[o]] >= 0) order[fill[p->obs_point[o]]++] = o;
+  }
   // active points = free points (even without observations: they still receive the lambda damping) + fixed points
   // that are observed by a free camera.  Skipped points own no active observation, so the sorted observation ranges
   // of consecutive active points are adjacent: pt_start[a] = cnt[act_pt[a]], pt_start[n_act] = n_obs.
-  // One pass over the sorted observations collects everything that follows from (point, camera slot): the active
-  // points, the per-camera counts, the Hpl blocks (observations whose point AND camera are free, stored contiguously per
-  // free point), duplicate cameras per point, and the camera-tile mask of every free point (tiled Schur).
-  const int ntile = (nfp + kTileCams - 1) / kTileCams;
-  std::vector<int> act_pt;
-  act_pt.reserve(P);
-  std::vector<int> seen_by(F, -1);  // seen_by[camera] = last free point with an observation from that free camera
-  std::vector<int> cam_start(nfp + 1, 0), cs_sorted(n_obs ? n_obs : 1);  // cs_sorted[i] = camera slot of sorted obs i
-  std::vector<int> o_hpl(n_obs ? n_obs : 1, -1), fp_start(nfl + 1, 0), fp_slot, fp_rank;
-  std::vector<int> seen_cnt(F, 0);  // duplicates: observations of the current point from that camera so far
-  std::vector<unsigned long long> fp_mask(nfl, 0ull);
-  fp_slot.reserve(n_obs);
-  int mmax = 1, dups = 0, max_rank = 0;
+  int n_act = 0;
   for (int j = 0; j < P; ++j) {
-    const int m = cnt[j + 1] - cnt[j], ls = pt_slot[j];
-    if (m == 0 && ls < 0) continue;
-    int mf = 0;
-    unsigned long long mask = 0ull;
-    if (ls >= 0) fp_start[ls] = (int)fp_slot.size();
-    for (int i = cnt[j]; i < cnt[j + 1]; ++i) {
-      const int cam = p->obs_pose[order[i]];
-      const int cs = pose_slot[cam];
-      cs_sorted[i] = cs;
-      if (cs < 0) continue;
-      cam_start[cs + 1]++;
-      if (ls >= 0) {
-        ++mf;
-        if (seen_by[cam] == j) {  // same camera twice: the ordered-rounds path of ba_schur
-          dups = 1;
-          seen_cnt[cam] += 1;
-        } else {
-          seen_cnt[cam] = 0;
-        }
-        seen_by[cam] = j;
-        max_rank = std::max(max_rank, seen_cnt[cam]);
-        o_hpl[i] = (int)fp_slot.size();
-        fp_slot.push_back(cs);
-        fp_rank.push_back(seen_cnt[cam]);
-        mask |= 1ull << ((cs / kTileCams) & 63);
-      }
-    }
-    if (ls >= 0) {
-      mmax = std::max(mmax, mf);
-      fp_mask[ls] = mask;
-    }
-    act_pt.push_back(j);
+    n_act += cnt[j + 1] > 0 || pt_slot[j] >= 0;
+    cnt[j + 1] += cnt[j];
   }
-  fp_start[nfl] = (int)fp_slot.size();
-  const int n_hpl = (int)fp_slot.size();
-  const int n_act = (int)act_pt.size();
   for (int c = 0; c < nfp; ++c) cam_start[c + 1] += cam_start[c];
-  std::vector<int> cam_obs(cam_start[nfp] ? cam_start[nfp] : 1), cfill(cam_start.begin(), cam_start.end() - 1);
-  for (int i = 0; i < n_obs; ++i) {
-    const int cs = cs_sorted[i];
-    if (cs >= 0) cam_obs[cfill[cs]++] = i;
+  const int n_cam_obs = cam_start[nfp];
+  // stable order of the active observations by point; the identity when they arrive grouped and all are active
+  const bool identity = grouped && n_obs == p->n_obs;
+  const int* order = nullptr;
+  if (!identity) {
+    W.order.resize(n_obs ? n_obs : 1);
+    W.fill.assign(cnt, cnt + P);
+    int* fill = W.fill.data();
+    for (int o = 0; o < p->n_obs; ++o)
+      if (pose_slot[p->obs_pose[o]] >= 0 || pt_slot[p->obs_point[o]] >= 0) W.order[fill[p->obs_point[o]]++] = o;
+    order = W.order.data();
   }
-  // tiled Schur: measured faster than the LDS-slab kernel at every window size
-  const bool tiled = np > 0 && !dups && ntile <= 64 && nfl > 0;
+  const int ntile = (nfp + kTileCams - 1) / kTileCams;
+  // tiled Schur (measured faster than the LDS-slab kernel at every window size) unless a point is seen twice from one
+  // camera, which pass 2 finds out
+  const bool tiled_possible = np > 0 && ntile <= 64 && nfl > 0;
 
   // ---- motion-only fast path (block-diagonal problem): one launch per LM trial, one workgroup per free camera
   const bool motion_only = nfl == 0 && p->n_scale == 0 && nfp > 0 && p->max_iterations > 0;
@@ -2326,33 +2333,37 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   res->iterations = res->trials = res->not_pd = res->terminated = 0;
   res->chi2_initial = res->chi2_final = res->lambda_final = 0.0;
 
-  // ---- launch geometry
+  // ---- launch geometry (the slab count of the duplicate-observation fallback is the only thing pass 2 can change)
   const int nb_pt = std::max(1, (n_act + kPtPerBlock - 1) / kPtPerBlock);
-  int ns = nfl > 0 && nfp > 0 ? std::min(256, (nfl + 7) / 8) : 0;
   const bool lds_slab = np <= kMaxSlabN;
   const int ntile_pairs = ntile * (ntile + 1) / 2;  // tiles of the lower triangle
-  if (tiled) ns = std::max(4, std::min(256, (16384 + ntile_pairs - 1) / ntile_pairs));  // >= 16k workgroups: most tiles are empty
-  const bool small = tiled && ntile == 1 && g_schur_variant != 1;  // one tile: ba_schur_small, one batch of points per workgroup
-  const bool spec = small && g_schur_variant != 2;  // two linearisations: the trial kernel linearises the trial state
+  const size_t slab_elems = (size_t)np * np + np;
+  auto slabs_for = [&](bool tiled_, bool small_) {
+    int n = nfl > 0 && nfp > 0 ? std::min(256, (nfl + 7) / 8) : 0;
+    if (tiled_) n = std::max(4, std::min(256, (16384 + ntile_pairs - 1) / ntile_pairs));  // >= 16k workgroups: most tiles are empty
+    if (small_) n = std::max(1, std::min(g_small_ns_cap, (nfl + g_small_per - 1) / g_small_per));
+    if (!lds_slab && n > 0) n = std::min(n, std::max(1, (int)((512u << 20) / (sizeof(double) * slab_elems))));
+    return n;
+  };
+  const bool small_possible = tiled_possible && ntile == 1 && g_schur_variant != 1;  // one tile: ba_schur_small
+  const int ns_bound = std::max(slabs_for(false, false), slabs_for(tiled_possible, small_possible));
   // workgroups per camera of the linearisation's camera role: about one observation per thread, at most 8
   int cam_split = 1;
   for (int c = 0; c < nfp; ++c) cam_split = std::max(cam_split, (cam_start[c + 1] - cam_start[c] + kCamThreads - 1) / kCamThreads);
   cam_split = std::min(cam_split, 8);
-  if (small) ns = std::max(1, std::min(g_small_ns_cap, (nfl + g_small_per - 1) / g_small_per));
-  if (!lds_slab && ns > 0) ns = std::min(ns, std::max(1, (int)((512u << 20) / (sizeof(double) * ((size_t)np * np + np)))));
-  const size_t slab_elems = (size_t)np * np + np;
 
   const auto t_struct = now();
   // ---- arena: [uploaded constants | state | system]
   vs_ba_problem const& q = *p;
   size_t need = (1u << 20) + sizeof(int) * ((size_t)F + P + 3 * (size_t)n_act + 4 * (size_t)n_obs + 2 * (size_t)nfp +
-                                            cam_obs.size() + 2 * (size_t)q.n_scale + nfl + 64) +
+                                            (size_t)n_cam_obs + 2 * (size_t)q.n_scale + nfl + 64) +
                 sizeof(double) * (5 * (size_t)n_obs + (size_t)q.n_scale + 2 * (size_t)F * kCamStride + 6 * (size_t)P +
                                   2 * (size_t)np * np + 8 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
-                                  9 * (size_t)nfl + (tiled ? 4 * (size_t)nfl : 0) + (size_t)(ns ? ns : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
+                                  9 * (size_t)nfl + (tiled_possible ? 4 * (size_t)nfl : 0) + (size_t)(ns_bound ? ns_bound : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
                                   2 * (size_t)q.max_iterations + 64) +
                 256 * 64 + sizeof(int) * (3 * (size_t)n_obs + nfl + 16) + (sizeof(double) * 27 * 8 + 8) * (size_t)nfp + 1024 +
-                (spec ? sizeof(double) * ((size_t)np * np + np + 12 * (size_t)nfl + 18 * (size_t)n_obs) + 5 * 256 : 0) + sizeof(double) * 4 * (size_t)(res->trial_trace ? std::max(res->trial_trace_cap, 0) : 0) + (motion_only ? sizeof(double) * (8 * cam_obs.size() + 50 * (size_t)nfp + 64) : 0);
+                sizeof(double) * (64 + (size_t)F * kCamStride + 3 * (size_t)P + 2 * (size_t)q.max_iterations) + 512 +
+                (small_possible ? sizeof(double) * ((size_t)np * np + np + 12 * (size_t)nfl + 18 * (size_t)n_obs) + 5 * 256 : 0) + sizeof(double) * 8 * (size_t)(res->trial_trace ? std::max(res->trial_trace_cap, 0) : 0) + (motion_only ? sizeof(double) * (8 * (size_t)n_cam_obs + 50 * (size_t)nfp + 64) : 0);
   VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, need));
   VS_HIP(ctx, hipStreamSynchronize(s));
@@ -2369,11 +2380,8 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.nfl = nfl;
   D.np = np;
   D.n_act = n_act;
-  D.ns = ns;
   D.nb_pt = nb_pt;
-  D.mmax = mmax;
   D.has_info = q.obs_info != nullptr;
-  D.dups = dups;
   D.max_it = q.max_iterations;
   D.lds_slab = lds_slab;
   D.fx = q.fx;
@@ -2391,7 +2399,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.o_cam = A.take<int>(n_obs, &h_ocam);
   D.o_pt = A.take<int>(n_obs, &h_opt);
   D.cam_start = A.take<int>(nfp + 1, &h_cstart);
-  D.cam_obs = A.take<int>(cam_obs.size(), &h_cobs);
+  D.cam_obs = A.take<int>(n_cam_obs, &h_cobs);
   D.sc_parent = A.take<int>(q.n_scale, &h_scp);
   D.sc_child = A.take<int>(q.n_scale, &h_scc);
   int* h_sp;
@@ -2402,22 +2410,8 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.o_hpl = A.take<int>(n_obs, &h_ohpl);
   D.fp_start = A.take<int>(nfl + 1, &h_fps);
   D.fp_slot = A.take<int>(n_hpl, &h_fpl);
-  D.max_rank = max_rank;
-  if (dups) {
-    int* h_fpr;
-    D.fp_rank = A.take<int>(n_hpl, &h_fpr);
-    memcpy(h_fpr, fp_rank.data(), sizeof(int) * (size_t)n_hpl);
-  }
-  if (tiled) {
-    unsigned long long* h_mask;
-    D.fp_mask = A.take<unsigned long long>(nfl, &h_mask);
-    memcpy(h_mask, fp_mask.data(), sizeof(unsigned long long) * (size_t)nfl);
-    D.ntile = ntile;
-    D.small = small;
-  }
-  memcpy(h_ohpl, o_hpl.data(), sizeof(int) * (size_t)n_obs);
-  memcpy(h_fps, fp_start.data(), sizeof(int) * ((size_t)nfl + 1));
-  if (n_hpl) memcpy(h_fpl, fp_slot.data(), sizeof(int) * (size_t)n_hpl);
+  unsigned long long* h_mask = nullptr;
+  if (tiled_possible) D.fp_mask = A.take<unsigned long long>(nfl, &h_mask);
   D.o_uv = A.take<double>(2 * (size_t)n_obs, &h_uv);
   if (D.has_info) D.o_info = A.take<double>(3 * (size_t)n_obs, &h_info);
   D.sc_meas = A.take<double>(q.n_scale, &h_scm);
@@ -2425,14 +2419,13 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   mo_state* h_mst = nullptr;
   mo_state* d_mst = nullptr;
   if (motion_only) {
-    D.mo_X = A.take<double>(3 * cam_obs.size(), &h_mx);
-    D.mo_uv = A.take<double>(2 * cam_obs.size(), &h_muv);
-    if (D.has_info) D.mo_info = A.take<double>(3 * cam_obs.size(), &h_minfo);
+    D.mo_X = A.take<double>(3 * (size_t)n_cam_obs, &h_mx);
+    D.mo_uv = A.take<double>(2 * (size_t)n_cam_obs, &h_muv);
+    if (D.has_info) D.mo_info = A.take<double>(3 * (size_t)n_cam_obs, &h_minfo);
     d_mst = A.take<mo_state>(2, &h_mst);
   }
   D.cam[0] = A.take<double>((size_t)F * kCamStride, &h_cam0);
   D.pts[0] = A.take<double>(3 * (size_t)P, &h_pts0);
-  D.Dinv = A.take<double>(9 * (size_t)nfl);
   lm_state* h_st;
   D.st = A.take<lm_state>(1, &h_st);
   unsigned* h_ticket;
@@ -2442,8 +2435,104 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.cam_ticket = A.take<unsigned>(nfp, &h_cticket);
   memset(h_cticket, 0, sizeof(unsigned) * (size_t)(nfp ? nfp : 1));
   D.cam_split = cam_split;
+  if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
+
+  // ---- pass 2 over the observations in point order, straight into the pinned arena: the active points, the sorted
+  // observation records, the Hpl blocks (observations whose point AND camera are free, stored contiguously per free
+  // point), the per-camera lists, the camera-tile mask of every free point (tiled Schur) and duplicate cameras per point
+  memcpy(h_pose_slot, pose_slot, sizeof(int) * F);
+  memcpy(h_pt_slot, pt_slot, sizeof(int) * P);
+  memcpy(h_cstart, cam_start, sizeof(int) * ((size_t)nfp + 1));
+  if (identity) {
+    memcpy(h_ocam, q.obs_pose, sizeof(int) * (size_t)n_obs);
+    memcpy(h_opt, q.obs_point, sizeof(int) * (size_t)n_obs);
+    memcpy(h_uv, q.obs_uv, sizeof(double) * 2 * (size_t)n_obs);
+    if (h_info) memcpy(h_info, q.obs_info, sizeof(double) * 3 * (size_t)n_obs);
+  }
+  W.cfill.assign(cam_start, cam_start + nfp + 1);
+  W.seen_by.assign(F ? F : 1, -1);  // seen_by[camera] = last free point with an observation from that free camera
+  int* cfill = W.cfill.data();
+  int* seen_by = W.seen_by.data();
+  int mmax = 1, dups = 0, a_idx = 0, k_hpl = 0;
+  for (int j = 0; j < P; ++j) {
+    const int i0 = cnt[j], i1 = cnt[j + 1], ls = pt_slot[j];
+    if (i0 == i1 && ls < 0) continue;
+    h_act[a_idx] = j;
+    h_ptstart[a_idx] = i0;
+    ++a_idx;
+    int mf = 0;
+    unsigned long long mask = 0ull;
+    if (ls >= 0) h_fps[ls] = k_hpl;
+    for (int i = i0; i < i1; ++i) {
+      const int o = identity ? i : order[i];
+      const int cam = q.obs_pose[o];
+      const int cs = pose_slot[cam];
+      if (!identity) {
+        h_ocam[i] = cam;
+        h_opt[i] = j;
+        h_uv[2 * i] = q.obs_uv[2 * (size_t)o];
+        h_uv[2 * i + 1] = q.obs_uv[2 * (size_t)o + 1];
+        if (h_info) {
+          h_info[3 * i] = q.obs_info[3 * (size_t)o];
+          h_info[3 * i + 1] = q.obs_info[3 * (size_t)o + 1];
+          h_info[3 * i + 2] = q.obs_info[3 * (size_t)o + 2];
+        }
+      }
+      int blk = -1;
+      if (cs >= 0) {
+        h_cobs[cfill[cs]++] = i;
+        if (ls >= 0) {
+          ++mf;
+          dups |= seen_by[cam] == j;  // same camera twice: the ordered-rounds path of ba_schur
+          seen_by[cam] = j;
+          blk = k_hpl;
+          h_fpl[k_hpl++] = cs;
+          mask |= 1ull << ((cs / kTileCams) & 63);
+        }
+      }
+      h_ohpl[i] = blk;
+    }
+    if (ls >= 0) {
+      mmax = std::max(mmax, mf);
+      if (h_mask) h_mask[ls] = mask;
+    }
+  }
+  h_ptstart[n_act] = n_obs;
+  h_fps[nfl] = k_hpl;
+  int max_rank = 0;
+  if (dups) {  // rare: per Hpl block, how many earlier blocks of the same point belong to the same camera
+    int* h_fpr;
+    D.fp_rank = A.take<int>(n_hpl, &h_fpr);
+    if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
+    W.seen_by.assign(F ? F : 1, -1);
+    W.seen_cnt.assign(F ? F : 1, 0);
+    seen_by = W.seen_by.data();
+    int* seen_cnt = W.seen_cnt.data();
+    for (int a = 0; a < n_act; ++a)
+      for (int i = h_ptstart[a]; i < h_ptstart[a + 1]; ++i) {
+        if (h_ohpl[i] < 0) continue;
+        const int cam = h_ocam[i];
+        seen_cnt[cam] = seen_by[cam] == h_act[a] ? seen_cnt[cam] + 1 : 0;
+        seen_by[cam] = h_act[a];
+        h_fpr[h_ohpl[i]] = seen_cnt[cam];
+        max_rank = std::max(max_rank, seen_cnt[cam]);
+      }
+  }
   const size_t upload_bytes = A.off;
+  const bool tiled = tiled_possible && !dups;
+  const bool small = tiled && small_possible;
+  const bool spec = small && g_schur_variant != 2;  // two linearisations: the trial kernel linearises the trial state
+  const int ns = slabs_for(tiled, small);
+  D.ns = ns;
+  D.mmax = mmax;
+  D.dups = dups;
+  D.max_rank = max_rank;
+  if (tiled) {
+    D.ntile = ntile;
+    D.small = small;
+  }
   // not uploaded
+  D.Dinv = A.take<double>(9 * (size_t)nfl);
   D.cam[1] = A.take<double>((size_t)F * kCamStride);
   D.pts[1] = A.take<double>(3 * (size_t)P);
   D.Hpp = A.take<double>((size_t)np * np);
@@ -2481,47 +2570,30 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     D.mo_part = A.take<double>(8 * (size_t)nfp);
     D.mo_H = A.take<double>(42 * (size_t)nfp);
   }
+  const size_t out_elems = 32 + (size_t)F * kCamStride + 3 * (size_t)P + 2 * (size_t)q.max_iterations + 4 * (size_t)trial_cap;
+  double* h_out = nullptr;
+  double* d_out = A.take<double>(out_elems, &h_out);  // ba_export's block and its pinned landing place
   if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
 
-  memcpy(h_pose_slot, pose_slot.data(), sizeof(int) * F);
-  memcpy(h_pt_slot, pt_slot.data(), sizeof(int) * P);
-  memcpy(h_act, act_pt.data(), sizeof(int) * n_act);
-  for (int a = 0; a < n_act; ++a) h_ptstart[a] = cnt[act_pt[a]];
-  h_ptstart[n_act] = n_obs;
-  // ranges of consecutive active points are adjacent because skipped points own no observations
-  for (int i = 0; i < n_obs; ++i) {
-    const int o = order[i];
-    h_ocam[i] = q.obs_pose[o];
-    h_opt[i] = q.obs_point[o];
-    h_uv[2 * i] = q.obs_uv[2 * o];
-    h_uv[2 * i + 1] = q.obs_uv[2 * o + 1];
-    if (h_info) {
-      h_info[3 * i] = q.obs_info[3 * o];
-      h_info[3 * i + 1] = q.obs_info[3 * o + 1];
-      h_info[3 * i + 2] = q.obs_info[3 * o + 2];
-    }
-  }
   if (motion_only) {
     memset(h_mst, 0, 2 * sizeof(mo_state));
     h_mst[1].need_lin = 1;  // step 0 reads the state of parity 1
     h_mst[1].ni = 2.0;
-    for (int i = 0; i < cam_start[nfp]; ++i) {
-      const int o = order[cam_obs[i]];
+    for (int i = 0; i < n_cam_obs; ++i) {
+      const int o = identity ? h_cobs[i] : order[h_cobs[i]];
       const double* X = q.points + 3 * (size_t)q.obs_point[o];
       h_mx[3 * i] = X[0];
       h_mx[3 * i + 1] = X[1];
       h_mx[3 * i + 2] = X[2];
-      h_muv[2 * i] = q.obs_uv[2 * o];
-      h_muv[2 * i + 1] = q.obs_uv[2 * o + 1];
+      h_muv[2 * i] = q.obs_uv[2 * (size_t)o];
+      h_muv[2 * i + 1] = q.obs_uv[2 * (size_t)o + 1];
       if (h_minfo) {
-        h_minfo[3 * i] = q.obs_info[3 * o];
-        h_minfo[3 * i + 1] = q.obs_info[3 * o + 1];
-        h_minfo[3 * i + 2] = q.obs_info[3 * o + 2];
+        h_minfo[3 * i] = q.obs_info[3 * (size_t)o];
+        h_minfo[3 * i + 1] = q.obs_info[3 * (size_t)o + 1];
+        h_minfo[3 * i + 2] = q.obs_info[3 * (size_t)o + 2];
       }
     }
   }
-  memcpy(h_cstart, cam_start.data(), sizeof(int) * (nfp + 1));
-  memcpy(h_cobs, cam_obs.data(), sizeof(int) * cam_obs.size());
   for (int k = 0; k < q.n_scale; ++k) {
     h_scp[k] = q.scale_parent[k];
     h_scc[k] = q.scale_child[k];
@@ -2563,6 +2635,18 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
 
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + sizeof(mo_state) + 128));
   lm_state* hst = reinterpret_cast<lm_state*>((uint8_t*)ctx->h_pin.p + 128);
+  // one copy + one synchronisation bring back the LM state and, if the solve is over, everything else the host wants
+  bool exported = false;
+  auto export_and_fetch = [&]() -> int {
+    const unsigned blocks = (unsigned)std::min<size_t>((out_elems + 255) / 256, 1024);
+    hipLaunchKernelGGL(ba_export, dim3(blocks), dim3(256), 0, s, D, d_out);
+    VS_LAUNCH_CHECK(ctx, "ba_export");
+    VS_HIP(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * out_elems, hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipStreamSynchronize(s));
+    memcpy(hst, h_out, sizeof(lm_state));
+    exported = true;
+    return VS_OK;
+  };
   auto launch_slot = [&](bool first) -> int {
     if (first || !spec) {  // spec: later states are linearised inside ba_point_trial (points) and ba_schur_small (cameras)
       hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp * cam_split), dim3(kCamThreads), 0, s, D);
@@ -2637,8 +2721,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
         first = false;
       }
       launched += batch;
-      VS_HIP(ctx, hipMemcpyAsync(hst, D.st, sizeof(lm_state), hipMemcpyDeviceToHost, s));
-      VS_HIP(ctx, hipStreamSynchronize(s));
+      VS_TRY(export_and_fetch());
       if (hst->done) break;
     }
   } else {
@@ -2647,27 +2730,33 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     VS_LAUNCH_CHECK(ctx, "ba_linearize");
     hipLaunchKernelGGL(ba_lambda_init, dim3(1), dim3(64), 0, s, D);
     VS_LAUNCH_CHECK(ctx, "ba_lambda_init");
-    VS_HIP(ctx, hipMemcpyAsync(hst, D.st, sizeof(lm_state), hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipStreamSynchronize(s));
+    VS_TRY(export_and_fetch());
   }
 
   const auto t_solved = now();
-  // ---- read back the accepted state
+  // ---- the accepted state: already in the export block, except on the motion-only path
   const int cur = hst->cur;
-  double* h_cam = reinterpret_cast<double*>(A.host);  // reuse the pinned mirror
+  double* h_cam = reinterpret_cast<double*>(A.host);  // motion-only: reuse the pinned mirror
   double* h_pts = h_cam + (size_t)F * kCamStride + 8;
   double* h_tr = h_pts + 3 * (size_t)P + 8;
-  VS_HIP(ctx, hipMemcpyAsync(h_cam, D.cam[cur], sizeof(double) * (size_t)F * kCamStride, hipMemcpyDeviceToHost, s));
-  VS_HIP(ctx, hipMemcpyAsync(h_pts, D.pts[cur], sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToHost, s));
-  if (q.max_iterations > 0) {
-    VS_HIP(ctx, hipMemcpyAsync(h_tr, D.chi_trace, sizeof(double) * q.max_iterations, hipMemcpyDeviceToHost, s));
-    VS_HIP(ctx, hipMemcpyAsync(h_tr + q.max_iterations, D.lambda_trace, sizeof(double) * q.max_iterations,
-                               hipMemcpyDeviceToHost, s));
+  if (exported) {
+    h_cam = h_out + 32;
+    h_pts = h_cam + (size_t)F * kCamStride;
+    h_tr = h_pts + 3 * (size_t)P;
+    if (trial_cap) memcpy(res->trial_trace, h_tr + 2 * (size_t)q.max_iterations, sizeof(double) * 4 * (size_t)std::min(trial_cap, hst->trials));
+  } else {
+    VS_HIP(ctx, hipMemcpyAsync(h_cam, D.cam[cur], sizeof(double) * (size_t)F * kCamStride, hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipMemcpyAsync(h_pts, D.pts[cur], sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToHost, s));
+    if (q.max_iterations > 0) {
+      VS_HIP(ctx, hipMemcpyAsync(h_tr, D.chi_trace, sizeof(double) * q.max_iterations, hipMemcpyDeviceToHost, s));
+      VS_HIP(ctx, hipMemcpyAsync(h_tr + q.max_iterations, D.lambda_trace, sizeof(double) * q.max_iterations,
+                                 hipMemcpyDeviceToHost, s));
+    }
+    if (trial_cap)
+      VS_HIP(ctx, hipMemcpyAsync(res->trial_trace, D.trial_trace, sizeof(double) * 4 * (size_t)std::min(trial_cap, hst->trials),
+                                 hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipStreamSynchronize(s));
   }
-  if (trial_cap)
-    VS_HIP(ctx, hipMemcpyAsync(res->trial_trace, D.trial_trace, sizeof(double) * 4 * (size_t)std::min(trial_cap, hst->trials),
-                               hipMemcpyDeviceToHost, s));
-  VS_HIP(ctx, hipStreamSynchronize(s));
   if (timing)
     fprintf(stderr, "vs_ba_solve: structure %.1f us, arena fill %.1f us, upload + kernels %.1f us, read-back %.1f us (upload %zu B)\n",
             us(t_begin, t_struct), us(t_struct, t_filled), us(t_filled, t_solved), us(t_solved, now()), upload_bytes);
