@@ -271,28 +271,28 @@ __device__ inline double linearize_point(const ba_dev& D, const lin_view& L, con
 // instructions, so one workgroup (= one CU) per camera is compute-bound on that CU: D.cam_split workgroups of kCamThreads
 // threads share a camera (workgroup `part` takes the observations part * kCamThreads + tid + j * cam_split * kCamThreads),
 // publish their 27 sums, and the one that arrives last adds the parts in part order and assembles the block row.
-__device__ inline void linearize_camera(const ba_dev& D, const lin_view& L, const double* cams, const double* pts, int c, int part,
-                                        double (*s_all)[27], double (*s_grp)[27]) {
+// publish_only: the workgroup leaves its 27 sums in D.cam_part and is done -- ba_reduce adds the parts itself (windows
+// without scale edges whose Hpp is nothing but these diagonal blocks); otherwise the block row of Hpp / bp is assembled here.
+__device__ inline void linearize_camera(const ba_dev& D, int c, int part, double (*s_all)[27], double (*s_grp)[27],
+                                        bool publish_only = false) {
   const int tid = threadIdx.x, split = D.cam_split, vthreads = split * kCamThreads;
-  const int pose = D.slot_pose[c];
-  const double* cam = cams + (size_t)pose * kCamStride;
-  double acc[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-  // four observations per thread and pass: the index chain observation -> point -> position is three dependent round
-  // trips, so the loads of all four are issued level by level before the first edge is evaluated
+  // four observations per thread and pass.  The chain camera list -> (observation, point) -> position is dependent round
+  // trips, so the loads of all four are issued level by level -- and the first two levels of the first pass before the LM
+  // state is read (their addresses do not depend on it; caches are cold after every kernel boundary)
   constexpr int kCamUnroll = 4;
-  const int i_end = D.cam_start[c + 1];
-  for (int ib = D.cam_start[c] + part * kCamThreads + tid; ib < i_end; ib += kCamUnroll * vthreads) {
-    int ou[kCamUnroll], pu[kCamUnroll];
-    double Xu[kCamUnroll][3], uvu[kCamUnroll][2], infou[kCamUnroll][3];
-#pragma unroll
-    for (int u = 0; u < kCamUnroll; ++u) ou[u] = ib + u * vthreads < i_end ? D.cam_obs[ib + u * vthreads] : -1;
+  const int i_beg = D.cam_start[c] + part * kCamThreads + tid, i_end = D.cam_start[c + 1];
+  int ou[kCamUnroll], pu[kCamUnroll];
+  double Xu[kCamUnroll][3], uvu[kCamUnroll][2], infou[kCamUnroll][3];
+  auto load_indices = [&](int ib) {
 #pragma unroll
     for (int u = 0; u < kCamUnroll; ++u) {
-      pu[u] = 0;
+      const bool have = ib + u * vthreads < i_end;
+      ou[u] = have ? D.cam_obs[ib + u * vthreads] : -1;
+      pu[u] = have ? D.cam_pt[ib + u * vthreads] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kCamUnroll; ++u)
       if (ou[u] >= 0) {
-        pu[u] = D.o_pt[ou[u]];
         uvu[u][0] = D.o_uv[2 * (size_t)ou[u]];
         uvu[u][1] = D.o_uv[2 * (size_t)ou[u] + 1];
         if (D.has_info) {
@@ -300,7 +300,20 @@ __device__ inline void linearize_camera(const ba_dev& D, const lin_view& L, cons
           for (int k = 0; k < 3; ++k) infou[u][k] = D.o_info[3 * (size_t)ou[u] + k];
         }
       }
-    }
+  };
+  load_indices(i_beg);
+  const lm_state st = *D.st;
+  if (st.done || !st.need_lin) return;  // uniform
+  const lin_view L = lin_of(D, st.cur);
+  const double* cams = D.cam[st.cur];
+  const double* pts = D.pts[st.cur];
+  const int pose = D.slot_pose[c];
+  const double* cam = cams + (size_t)pose * kCamStride;
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+  for (int ib = i_beg; ib < i_end; ib += kCamUnroll * vthreads) {
+    if (ib != i_beg) load_indices(ib);
 #pragma unroll
     for (int u = 0; u < kCamUnroll; ++u)
       if (ou[u] >= 0) {
@@ -309,26 +322,26 @@ __device__ inline void linearize_camera(const ba_dev& D, const lin_view& L, cons
       }
 #pragma unroll
     for (int u = 0; u < kCamUnroll; ++u) {
-    if (ou[u] < 0) continue;
-    const double* X = Xu[u];
-    edge_t E;
-    eval_edge<true>(D, cam, X, uvu[u], D.has_info ? infou[u] : nullptr, E);
-    const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
-    const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
-    const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
-    double WJj[2][6];
+      if (ou[u] < 0) continue;
+      const double* X = Xu[u];
+      edge_t E;
+      eval_edge<true>(D, cam, X, uvu[u], D.has_info ? infou[u] : nullptr, E);
+      const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+      const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
+      const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
+      double WJj[2][6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      WJj[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
-      WJj[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
-    }
-    int n = 0;
+      for (int k = 0; k < 6; ++k) {
+        WJj[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
+        WJj[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
+      }
+      int n = 0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k)
+      for (int k = 0; k < 6; ++k)
 #pragma unroll
-      for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJj[0][l] + E.Jj[1][k] * WJj[1][l];
+        for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJj[0][l] + E.Jj[1][k] * WJj[1][l];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
+      for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
     }
   }
   // fixed-order reduction of the 27 sums: the upper half of the threads hands its values to the lower half through
@@ -361,6 +374,10 @@ __device__ inline void linearize_camera(const ba_dev& D, const lin_view& L, cons
     s_grp[0][tid] = a2;
   }
   __syncthreads();
+  if (publish_only) {
+    if (tid < 27) D.cam_part[((size_t)c * split + part) * 27 + tid] = s_grp[0][tid];
+    return;
+  }
   if (split > 1) {
     // hand-off as in ba_point_trial: write-through stores, drain, one relaxed agent-scope ticket add; the last arriver
     // acquires, resets the ticket for the next linearisation and adds the parts in part order
@@ -462,31 +479,32 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
   __shared__ double s_red[2 * kCamThreads / 64];
   __shared__ double s_all[kCamThreads / 2][27];  // camera role: upper half of the first level lives in registers
   __shared__ double s_grp[kCamThreads / 64][27];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= D.nb_pt) {
+    const int cw = blockIdx.x - D.nb_pt;
+    linearize_camera(D, cw / D.cam_split, cw % D.cam_split, s_all, s_grp);
+    return;
+  }
+  // ---- point role: the first kPtThreads threads of the workgroup, kPtLanes lanes per point
+  const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;
+  const bool mine = tid < kPtThreads && a < D.n_act;
+  const int p = mine ? D.act_pt[a] : 0;  // requested before the LM state: the address does not depend on it
   const lm_state st = *D.st;
   if (st.done || !st.need_lin) return;
   const double* cams = D.cam[st.cur];
   const double* pts = D.pts[st.cur];
   const lin_view L = lin_of(D, st.cur);
-  const int tid = threadIdx.x;
-  if ((int)blockIdx.x < D.nb_pt) {
-    // ---- point role: the first kPtThreads threads of the workgroup, kPtLanes lanes per point
-    const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;
-    double chi = 0.0, maxd = 0.0;
-    if (tid < kPtThreads && a < D.n_act) {
-      const int p = D.act_pt[a];
-      const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
-      chi = linearize_point(D, L, cams, X, a, D.pt_slot[p], sub, maxd);
-    }
-    double csum = chi, cmax = maxd;
-    block_reduce2<kCamThreads, true>(csum, cmax, s_red);
-    if (tid == 0) {
-      D.part_chi[blockIdx.x] = csum;
-      D.part_maxd[blockIdx.x] = cmax;
-    }
-    return;
+  double chi = 0.0, maxd = 0.0;
+  if (mine) {
+    const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+    chi = linearize_point(D, L, cams, X, a, D.pt_slot[p], sub, maxd);
   }
-  const int cw = blockIdx.x - D.nb_pt;
-  linearize_camera(D, L, cams, pts, cw / D.cam_split, cw % D.cam_split, s_all, s_grp);
+  double csum = chi, cmax = maxd;
+  block_reduce2<kCamThreads, true>(csum, cmax, s_red);
+  if (tid == 0) {
+    D.part_chi[blockIdx.x] = csum;
+    D.part_maxd[blockIdx.x] = cmax;
+  }
 }
 
 // chi2 of the scale edges for state buffer `buf` (few edges: one thread)
@@ -865,50 +883,37 @@ __global__ __launch_bounds__(256) void ba_schur_tile(ba_dev D) {
 constexpr int kSmallPts = 8, kSmallThreads = kCamThreads, kSmallWaves = kSmallThreads / 64;
 constexpr int kSmallRows = (kTileCams + kSmallWaves - 1) / kSmallWaves;
 
-// Workgroups [0, ns) produce the slabs; with two linearisations (D.spec) workgroups [ns, ns + nfp) run the camera role
-// of the linearisation of a freshly accepted state next to them (its point role ran inside ba_point_trial), so that
+// The last ns workgroups produce the slabs; with two linearisations (D.spec) the first nfp * cam_split workgroups run the
+// camera role of the linearisation of a freshly accepted state next to them (its point role ran inside ba_point_trial), so that
 // ba_reduce finds Hpp / bp without a linearisation launch in between.  lin_cameras = 0 in the first slot of a solve,
 // whose state ba_linearize has linearised completely.
 __global__ __launch_bounds__(kSmallThreads) void ba_schur_small(ba_dev D, int lin_cameras) {
   constexpr int kStage = kSmallPts * kTileCams * 18;
-  constexpr int kSchurDoubles = kSmallPts * 12 + 2 * kStage + kSmallPts * 16 / 2;
+  constexpr int kSchurDoubles = kSmallPts * 12 + 2 * kStage;
   constexpr int kCamDoubles = (kCamThreads / 2) * 27 + (kCamThreads / 64) * 27;
   __shared__ double s_raw[kSchurDoubles > kCamDoubles ? kSchurDoubles : kCamDoubles];
-  const lm_state st = *D.st;
-  if (st.done) return;
-  const lin_view L = lin_of(D, st.cur);
-  if ((int)blockIdx.x >= D.ns) {
-    if (lin_cameras && st.need_lin) {
-      const int cw = blockIdx.x - D.ns;
-      linearize_camera(D, L, D.cam[st.cur], D.pts[st.cur], cw / D.cam_split, cw % D.cam_split,
-                       reinterpret_cast<double(*)[27]>(s_raw), reinterpret_cast<double(*)[27]>(s_raw + (kCamThreads / 2) * 27));
-    }
+  // The camera workgroups come FIRST in the grid.  ns + ncam exceeds the 256 CUs by a few dozen workgroups; the
+  // dispatcher hands them out in order, so the surplus (the last Schur workgroups) shares a CU with a camera workgroup --
+  // short and light on LDS -- instead of with another Schur workgroup, whose LDS-bound product phase would then take
+  // twice as long (measured: 15.0 us per launch with the cameras last, i.e. two Schur workgroups on 30 CUs).
+  const int ncam = (int)gridDim.x - D.ns;
+  if ((int)blockIdx.x < ncam) {
+    if (lin_cameras)
+      linearize_camera(D, blockIdx.x / D.cam_split, blockIdx.x % D.cam_split, reinterpret_cast<double(*)[27]>(s_raw),
+                       reinterpret_cast<double(*)[27]>(s_raw + (kCamThreads / 2) * 27), D.n_scale == 0);
     return;
   }
+  const int sb = (int)blockIdx.x - ncam;  // slab of this workgroup
   double(*sD)[12] = reinterpret_cast<double(*)[12]>(s_raw);
   double* sY = s_raw + kSmallPts * 12;
   double* sB = sY + kStage;
-  int(*sMap)[16] = reinterpret_cast<int(*)[16]>(sB + kStage);
-  const double lambda = st.lambda;
   const int np = D.np, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int per = (D.nfl + D.ns - 1) / D.ns;
-  const int l0 = blockIdx.x * per, l1 = min(l0 + per, D.nfl);
-  const int arow = lane / kTileCams, ccam = lane - arow * kTileCams;  // lanes 60..63 (arow == 6) idle in the products
-  double acc[kSmallRows][6], racc[kSmallRows];
-#pragma unroll
-  for (int r = 0; r < kSmallRows; ++r) {
-    racc[r] = 0.0;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) acc[r][c] = 0.0;
-  }
+  const int l0 = sb * per, l1 = min(l0 + per, D.nfl);
   // item = (point of the batch, block of the point, block row): 3 contiguous values of an Hpl block
   constexpr int kItems = kSmallPts * kTileCams * 6, kRounds = (kItems + kSmallThreads - 1) / kSmallThreads;
-  const int dpb = tid >> 5;  // thread 32 pb + 31 inverts point pb's Hll (one per half wave: the inversions run side by side)
-  for (int b0 = l0; b0 < l1; b0 += kSmallPts) {
-    const int nb = min(kSmallPts, l1 - b0);
-    const bool dinv_thread = (tid & 31) == 31 && dpb < nb;
-    // ---- round trip 1: block ranges, Hll / bl
-    int blk[kRounds];
+  int blk[kRounds];
+  auto block_ranges = [&](int b0, int nb) {  // round trip 1 of a batch: which Hpl block each item reads
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
       const int q = (tid + kSmallThreads * r) / 6, pb = q / kTileCams, j = q - pb * kTileCams;
@@ -918,6 +923,30 @@ __global__ __launch_bounds__(kSmallThreads) void ba_schur_small(ba_dev D, int li
         if (j < f1 - f0) blk[r] = f0 + j;
       }
     }
+  };
+  block_ranges(l0, min(kSmallPts, l1 - l0));  // requested before the LM state: the addresses do not depend on it
+  // A camera that does not see a point contributes zero blocks: the staging is cleared (while the loads above are in
+  // flight) and only the present blocks are written, so the product phase needs no per-camera branches -- its LDS loads
+  // of a point are all issued up front.  Adding the exact zeros does not change a sum.
+  for (int k = tid; k < 2 * kStage; k += kSmallThreads) sY[k] = 0.0;  // sY and sB are adjacent
+  const lm_state st = *D.st;
+  if (st.done) return;
+  const lin_view L = lin_of(D, st.cur);
+  const double lambda = st.lambda;
+  const int arow = lane / kTileCams, ccam = lane - arow * kTileCams;  // lanes 60..63 (arow == 6) idle in the products
+  double acc[kSmallRows][6], racc[kSmallRows];
+#pragma unroll
+  for (int r = 0; r < kSmallRows; ++r) {
+    racc[r] = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[r][c] = 0.0;
+  }
+  const int dpb = tid >> 5;  // thread 32 pb + 31 inverts point pb's Hll (one per half wave: the inversions run side by side)
+  for (int b0 = l0; b0 < l1; b0 += kSmallPts) {
+    const int nb = min(kSmallPts, l1 - b0);
+    const bool dinv_thread = (tid & 31) == 31 && dpb < nb;
+    // ---- round trip 1: block ranges (the first batch's are on their way already), Hll / bl
+    if (b0 != l0) block_ranges(b0, nb);
     double Dm[9], bl[3];
     if (dinv_thread) {
       const size_t l = (size_t)(b0 + dpb);
@@ -926,7 +955,6 @@ __global__ __launch_bounds__(kSmallThreads) void ba_schur_small(ba_dev D, int li
 #pragma unroll
       for (int k = 0; k < 3; ++k) bl[k] = L.bl[3 * l + k];
     }
-    if (tid < kSmallPts * 16) (&sMap[0][0])[tid] = -1;
     // ---- round trip 2: camera slots and block rows
     double v[kRounds][3];
     int slot[kRounds];
@@ -968,39 +996,33 @@ __global__ __launch_bounds__(kSmallThreads) void ba_schur_small(ba_dev D, int li
         sB[o + 2] = v[r][2];
 #pragma unroll
         for (int c = 0; c < 3; ++c) sY[o + c] = v[r][0] * sd[c] + v[r][1] * sd[3 + c] + v[r][2] * sd[6 + c];
-        if (ar == 0) sMap[pb][slot[r]] = blk[r];
       }
     __syncthreads();
-    // ---- products into the register accumulators: wave w owns the row cameras w, w + kSmallWaves
+    // ---- products into the register accumulators: wave w owns the row cameras w, w + kSmallWaves; branch-free
+    const int ar6 = arow < 6 ? arow : 0;  // lanes 60..63 compute on row 0's operands and never store
     for (int pb = 0; pb < nb; ++pb) {
-      const int* map = sMap[pb];
-      const bool have = arow < 6 && map[ccam] >= 0;
       double Bv[18];
-      if (have) {
-        const double* B = sB + (pb * kTileCams + ccam) * 18;
+      const double* B = sB + (pb * kTileCams + ccam) * 18;
 #pragma unroll
-        for (int k = 0; k < 18; ++k) Bv[k] = B[k];
-      }
+      for (int k = 0; k < 18; ++k) Bv[k] = B[k];
       const double* sd = sD[pb];
 #pragma unroll
       for (int r = 0; r < kSmallRows; ++r) {
-        const int ls = wv + kSmallWaves * r;
-        if (ls >= kTileCams || map[ls] < 0) continue;  // wave-uniform
-        if (have && ccam <= ls) {
-          const double* Y = sY + (pb * kTileCams + ls) * 18 + 3 * arow;
-          const double y0 = Y[0], y1 = Y[1], y2 = Y[2];
+        const int ls = min(wv + kSmallWaves * r, kTileCams - 1);  // a row beyond the tile repeats the last one, never stored
+        const double* Y = sY + (pb * kTileCams + ls) * 18 + 3 * ar6;
+        const double y0 = Y[0], y1 = Y[1], y2 = Y[2];
 #pragma unroll
-          for (int bc = 0; bc < 6; ++bc) acc[r][bc] += y0 * Bv[3 * bc] + y1 * Bv[3 * bc + 1] + y2 * Bv[3 * bc + 2];
-        }
-        if (arow < 6 && ccam == 0) {
-          const double* B = sB + (pb * kTileCams + ls) * 18 + 3 * arow;
-          racc[r] += B[0] * sd[9] + B[1] * sd[10] + B[2] * sd[11];
-        }
+        for (int bc = 0; bc < 6; ++bc) acc[r][bc] += y0 * Bv[3 * bc] + y1 * Bv[3 * bc + 1] + y2 * Bv[3 * bc + 2];
+        const double* Br = sB + (pb * kTileCams + ls) * 18 + 3 * ar6;
+        racc[r] += Br[0] * sd[9] + Br[1] * sd[10] + Br[2] * sd[11];
       }
     }
-    if (b0 + kSmallPts < l1) __syncthreads();  // the next batch overwrites the staging
+    if (b0 + kSmallPts < l1) {  // the next batch overwrites the staging: clear it again first
+      __syncthreads();
+      for (int k = tid; k < 2 * kStage; k += kSmallThreads) sY[k] = 0.0;
+    }
   }
-  double* out = D.slab + (size_t)blockIdx.x * ((size_t)np * np + np);
+  double* out = D.slab + (size_t)sb * ((size_t)np * np + np);
   if (arow < 6) {
 #pragma unroll
     for (int r = 0; r < kSmallRows; ++r) {
@@ -1029,8 +1051,35 @@ __global__ __launch_bounds__(64 * kRedSplit) void ba_reduce(ba_dev D) {
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + e;
   const lin_view L = lin_of(D, st.cur);
+  // Two linearisations without scale edges: once a step has been accepted, the camera workgroups next to ba_schur_small
+  // left the 27 sums of every camera in D.cam_part (parts of up to 8 workgroups, added here in part order) instead of
+  // assembling Hpp / bp; bp is written out for the gain denominator of the dense solve.
+  const bool from_parts = D.spec && D.n_scale == 0 && st.accepted > 0;
   double base = 0.0;
-  if (g == 0 && i < slab_elems) base = i < np * np ? L.Hpp[i] : L.bp[i - np * np];
+  if (g == 0 && i < slab_elems) {
+    if (!from_parts) {
+      base = i < np * np ? L.Hpp[i] : L.bp[i - np * np];
+    } else {
+      int cam, n = -1;
+      if (i < np * np) {
+        const int r = i / np, c = i - r * np;
+        cam = r / 6;
+        if (c / 6 == cam) {
+          const int a = r - 6 * cam, b = c - 6 * cam, lo = min(a, b), hi = max(a, b);
+          n = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);  // packed upper triangle, row-major
+        }
+      } else {
+        cam = (i - np * np) / 6;
+        n = 21 + (i - np * np) - 6 * cam;
+      }
+      if (n >= 0) {
+        const double* parts = D.cam_part + (size_t)cam * D.cam_split * 27 + n;
+        base = parts[0];
+        for (int k = 1; k < D.cam_split; ++k) base += parts[k * 27];
+        if (i >= np * np) L.bp[i - np * np] = base;
+      }
+    }
+  }
   double acc = 0.0;
   // the tiled Schur kernels produce the lower triangle only (tiles, or 6x6 blocks for ba_schur_small) - the Cholesky
   // reads nothing else: elements above it have no slab contribution to fetch
@@ -1614,6 +1663,7 @@ __device__ inline void ba_decide(const ba_dev& D) {
     st->ni = 2.0;
     st->current_chi = temp;
     st->cur ^= 1;  // accept: the trial buffer becomes the estimate
+    st->accepted += 1;
   } else {
     st->lambda *= st->ni;
     st->ni *= 2;
@@ -1642,20 +1692,25 @@ __device__ inline void ba_decide(const ba_dev& D) {
 // ------------------------------------------------------------------------------------------------ trial + chi2
 __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
   __shared__ double s_red[2 * kPtThreads / 64];
-  const lm_state st = *D.st;
-  if (st.done) return;
   const int tid = threadIdx.x;
   const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;  // kPtLanes lanes per point, as above
+  // the point's index records are requested before the LM state: their addresses do not depend on it
+  int p = 0, ls = -1, o0 = 0, o1 = 0;
+  if (a < D.n_act) {
+    p = D.act_pt[a];
+    o0 = D.pt_start[a];
+    o1 = D.pt_start[a + 1];
+    ls = D.pt_slot[p];
+  }
+  const lm_state st = *D.st;
+  if (st.done) return;
   double chi = 0.0, sc = 0.0;
   if (st.solve_ok && a < D.n_act) {
     const double* cams1 = D.cam[st.cur ^ 1];
     const double* pts0 = D.pts[st.cur];
     double* pts1 = D.pts[st.cur ^ 1];
     const lin_view L = lin_of(D, st.cur);
-    const int p = D.act_pt[a];
-    const int ls = D.pt_slot[p];
     double X[3] = {pts0[3 * (size_t)p], pts0[3 * (size_t)p + 1], pts0[3 * (size_t)p + 2]};
-    const int o0 = D.pt_start[a], o1 = D.pt_start[a + 1];
     if (ls >= 0) {
       // back substitution: cl = bl - sum_i Hpl_i^T dx_cam(i); the sum is split over the lanes and shuffle-reduced
       double part[3] = {0.0, 0.0, 0.0};
@@ -2356,7 +2411,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   // ---- arena: [uploaded constants | state | system]
   vs_ba_problem const& q = *p;
   size_t need = (1u << 20) + sizeof(int) * ((size_t)F + P + 3 * (size_t)n_act + 4 * (size_t)n_obs + 2 * (size_t)nfp +
-                                            (size_t)n_cam_obs + 2 * (size_t)q.n_scale + nfl + 64) +
+                                            2 * (size_t)n_cam_obs + 2 * (size_t)q.n_scale + nfl + 64) +
                 sizeof(double) * (5 * (size_t)n_obs + (size_t)q.n_scale + 2 * (size_t)F * kCamStride + 6 * (size_t)P +
                                   2 * (size_t)np * np + 8 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
                                   9 * (size_t)nfl + (tiled_possible ? 4 * (size_t)nfl : 0) + (size_t)(ns_bound ? ns_bound : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
@@ -2400,6 +2455,8 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.o_pt = A.take<int>(n_obs, &h_opt);
   D.cam_start = A.take<int>(nfp + 1, &h_cstart);
   D.cam_obs = A.take<int>(n_cam_obs, &h_cobs);
+  int* h_cpt;
+  D.cam_pt = A.take<int>(n_cam_obs, &h_cpt);  // point index of the same entry (saves the camera role one dependent load)
   D.sc_parent = A.take<int>(q.n_scale, &h_scp);
   D.sc_child = A.take<int>(q.n_scale, &h_scc);
   int* h_sp;
@@ -2480,6 +2537,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       }
       int blk = -1;
       if (cs >= 0) {
+        h_cpt[cfill[cs]] = j;
         h_cobs[cfill[cs]++] = i;
         if (ls >= 0) {
           ++mf;
@@ -2522,7 +2580,11 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   const bool tiled = tiled_possible && !dups;
   const bool small = tiled && small_possible;
   const bool spec = small && g_schur_variant != 2;  // two linearisations: the trial kernel linearises the trial state
-  const int ns = slabs_for(tiled, small);
+  int ns = slabs_for(tiled, small);
+  // ba_schur_small with camera workgroups beside it: keep the whole grid within one workgroup per CU.  Two Schur
+  // workgroups on one CU take turns at its LDS in the product phase (measured 14-15 us per launch at 286 workgroups on
+  // 256 CUs against 10 us alone); a workgroup with a few more points costs less than that.
+  if (spec) ns = std::max(1, std::min(ns, std::max(ctx->prop.multiProcessorCount, 64) - nfp * cam_split));
   D.ns = ns;
   D.mmax = mmax;
   D.dups = dups;

@@ -18,7 +18,7 @@ struct lm_state {
   int trials, qmax, not_pd;
   int need_lin;  // 1: the next slot starts with a linearisation
   int done, terminated, solve_ok;
-  int pad;
+  int accepted;  // steps accepted so far in this solve
 };
 
 struct ba_dev {
@@ -26,6 +26,7 @@ struct ba_dev {
   int ns, nb_pt, mmax, has_info, dups, max_it, lds_slab, pad0;
   double fx, fy, cx, cy, huber, dcs;
   const int *pose_slot, *pt_slot, *act_pt, *pt_start, *o_cam, *o_pt, *cam_start, *cam_obs;
+  const int* cam_pt;  // [cam_obs entries] point index of the observation
   const int *o_hpl, *fp_start, *fp_slot, *slot_pose;  // slot_pose[free camera slot] = pose index  // Hpl block index of an observation (-1: none); per free point: its blocks
   const double *o_uv, *o_info;
   const int *sc_parent, *sc_child;
