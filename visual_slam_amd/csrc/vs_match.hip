@@ -142,7 +142,11 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
   for (int r = 0; r < kQPL; ++r) b1[r] = b2[r] = kEmpty;
 
   const uint32_t* tp = t + (size_t)begin * 8;  // wave-uniform -> scalar loads
-  const uint32_t j0 = (uint32_t)(begin - cbegin); // keys carry the index within the workgroup's chunk
+  // keys carry the train index in their low kIdxBits bits: the global row index when all of them fit (nt <= 2^20 -- keys of
+  // different chunks are then comparable as they are and the fold below is 32-bit min3 / med3), else the index within
+  // the workgroup's chunk (the fold rebuilds 64-bit keys from the chunk number)
+  const bool gkey = nt <= kMaxChunk;
+  const uint32_t j0 = (uint32_t)(gkey ? begin : begin - cbegin);
   const int n = end - begin;
   if constexpr (TSTAGE) {
     __shared__ uint4 stage[kWaves][2][128];  // per wave: two batches of 64 rows x 32 B
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
     if (!s_last) return;  // uniform
     // ---- fold the tile's chunks in chunk order; the loads of up to 32 chunks are all in flight before the first use
     constexpr int kFoldBatch = 32;
+    uint32_t g1 = kEmpty, g2 = kEmpty;
     for (int c0 = 0; c0 < nchunks; c0 += kFoldBatch) {
       uint2 p[kFoldBatch];
 #pragma unroll
@@ -233,13 +238,28 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
         const int c = min(c0 + u, nchunks - 1);
         p[u] = partial[((size_t)c * qtiles + tile) * kTileQ + lq];
       }
+      if (gkey) {  // uniform.  The fold sits in the kernel's tail (one workgroup per tile, the rest of the GPU idle): as a
+                   // chain of 64 dependent 64-bit merges it took 6 us of a 61 us launch, as 32 min3 / med3 pairs it does not show
 #pragma unroll
-      for (int u = 0; u < kFoldBatch; ++u) {
-        if (c0 + u >= nchunks) break;
-        const unsigned long long base = (unsigned long long)(c0 + u) * (unsigned long long)chunk_len;
-        if (p[u].x != kEmpty) fold64(B1, B2, ((unsigned long long)(p[u].x >> kIdxBits) << 32) | (base + (p[u].x & kIdxMask)));
-        if (p[u].y != kEmpty) fold64(B1, B2, ((unsigned long long)(p[u].y >> kIdxBits) << 32) | (base + (p[u].y & kIdxMask)));
+        for (int u = 0; u < kFoldBatch; ++u) {
+          const bool in = c0 + u < nchunks;  // beyond the last chunk the (clamped) load repeated a row: neutralise it
+          const uint32_t kx = in ? p[u].x : kEmpty, ky = in ? p[u].y : kEmpty;
+          g2 = min(g2, umed3(g1, kx, ky));
+          g1 = umin3(g1, kx, ky);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < kFoldBatch; ++u) {
+          if (c0 + u >= nchunks) break;
+          const unsigned long long base = (unsigned long long)(c0 + u) * (unsigned long long)chunk_len;
+          if (p[u].x != kEmpty) fold64(B1, B2, ((unsigned long long)(p[u].x >> kIdxBits) << 32) | (base + (p[u].x & kIdxMask)));
+          if (p[u].y != kEmpty) fold64(B1, B2, ((unsigned long long)(p[u].y >> kIdxBits) << 32) | (base + (p[u].y & kIdxMask)));
+        }
       }
+    }
+    if (gkey) {
+      if (g1 != kEmpty) B1 = ((unsigned long long)(g1 >> kIdxBits) << 32) | (unsigned long long)(g1 & kIdxMask);
+      if (g2 != kEmpty) B2 = ((unsigned long long)(g2 >> kIdxBits) << 32) | (unsigned long long)(g2 & kIdxMask);
     }
   } else {
     if (m.x != kEmpty) fold64(B1, B2, ((unsigned long long)(m.x >> kIdxBits) << 32) | (unsigned long long)(m.x & kIdxMask));
