@@ -1902,6 +1902,12 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
   const double pre_gh = tid < 27 ? gH[tid] : 0.0;
   const double pre_cam0 = tid < kCamStride ? D.cam[0][(size_t)pose * kCamStride + tid] : 0.0;
   const double pre_cam1 = tid < kCamStride ? D.cam[1][(size_t)pose * kCamStride + tid] : 0.0;
+  // ... and the previous launch's per-camera partials (thread t: camera t), which the decision below sums
+  double pre_part[4] = {0.0, 0.0, 0.0, 0.0};
+  if (tid < nfp) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pre_part[k] = prev_part[4 * (size_t)tid + k];
+  }
 
   // ---- prologue: every workgroup derives the current LM state from the previous launch's state + partials
   if (tid == 0) s_st = g_state[(step + 1) & 1];
@@ -1909,10 +1915,11 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
   if (s_st.stage != 0 && !s_st.done) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;  // fixed order: thread t sums cameras t, t+256, ... then thread 0 sums threads
     for (int k = tid; k < nfp; k += kMoThreads) {
-      a0 += prev_part[4 * k];
-      if (s_st.stage == 1) a1 = fmax(a1, prev_part[4 * k + 3]);
-      else a1 += prev_part[4 * k + 1];
-      a2 += prev_part[4 * k + 2];  // number of cameras whose 6x6 system was not positive definite
+      const bool pre = k == tid;  // the first pass was requested at the top of the launch
+      a0 += pre ? pre_part[0] : prev_part[4 * k];
+      if (s_st.stage == 1) a1 = fmax(a1, pre ? pre_part[3] : prev_part[4 * k + 3]);
+      else a1 += pre ? pre_part[1] : prev_part[4 * k + 1];
+      a2 += pre ? pre_part[2] : prev_part[4 * k + 2];  // number of cameras whose 6x6 system was not positive definite
     }
     s_part[0][tid] = a0;
     s_part[1][tid] = a1;
