@@ -48,7 +48,7 @@ using namespace vsba;
 namespace {
 
 constexpr int kPtThreads = 256; // threads per point block
-constexpr int kPtLanes = 8;     // lanes that share one point's observations (linearisation and trial)
+constexpr int kPtLanes = 8;  // lanes that share one point's observations (linearisation and trial)
 constexpr int kPtPerBlock = kPtThreads / kPtLanes;
 constexpr int kCamThreads = 512;  // ba_linearize: a camera's observations are spread over this many threads
 constexpr int kSchurThreads = 256;
@@ -1630,63 +1630,66 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
 // OptimizationAlgorithmLevenberg::solve's accept/reject logic and SparseOptimizer::optimize's loop control
 // Runs on ONE wave (threadIdx.x < 64) of the workgroup of ba_point_trial that finished last: no launch of its own.
 __device__ inline void ba_decide(const ba_dev& D) {
-  lm_state* st = D.st;
-  if (st->done) return;
+  // the record is read once, updated in registers and written back once: field-by-field read-modify-writes of global
+  // memory were a chain of dependent round trips at the very end of every trial (2.5 us by in-kernel stamps)
+  lm_state s = *D.st;
+  if (s.done) return;
   const double psum = wave_sum_partials(D.part_chi, D.nb_pt), ssum = wave_sum_partials(D.part_scale, D.nb_pt);
   if (threadIdx.x != 0) return;
-  double temp = 0.0, scale = st->scale_pose;
-  if (st->solve_ok) {
+  double temp = 0.0, scale = s.scale_pose;
+  if (s.solve_ok) {
     temp = psum;
     scale += ssum;
-    temp += scale_edges_chi(D, D.cam[st->cur ^ 1]);
+    if (D.n_scale) temp += scale_edges_chi(D, D.cam[s.cur ^ 1]);
   } else {
     temp = 1.7976931348623157e308;
   }
-  st->temp_chi = temp;
-  double rho = st->current_chi - temp;
+  s.temp_chi = temp;
+  double rho = s.current_chi - temp;
   scale += 1e-3;
   rho /= scale;
-  st->rho = rho;
-  if (D.trial_trace && st->trials >= 1 && st->trials <= D.trial_cap) {
-    double* row = D.trial_trace + 4 * (size_t)(st->trials - 1);
-    row[0] = st->lambda;
+  s.rho = rho;
+  if (D.trial_trace && s.trials >= 1 && s.trials <= D.trial_cap) {
+    double* row = D.trial_trace + 4 * (size_t)(s.trials - 1);
+    row[0] = s.lambda;
     row[1] = temp;
     row[2] = rho;
-    row[3] = st->solve_ok ? 1.0 : 0.0;
+    row[3] = s.solve_ok ? 1.0 : 0.0;
   }
   int stop = 0;
   if (rho > 0 && isfinite(temp)) {
     double alpha = 1.0 - pow(2 * rho - 1, 3);
     alpha = fmin(alpha, 2.0 / 3.0);
     const double f = fmax(1.0 / 3.0, alpha);
-    st->lambda *= f;
-    st->ni = 2.0;
-    st->current_chi = temp;
-    st->cur ^= 1;  // accept: the trial buffer becomes the estimate
-    st->accepted += 1;
+    s.lambda *= f;
+    s.ni = 2.0;
+    s.current_chi = temp;
+    s.cur ^= 1;  // accept: the trial buffer becomes the estimate
+    s.accepted += 1;
   } else {
-    st->lambda *= st->ni;
-    st->ni *= 2;
-    if (!isfinite(st->lambda)) stop = 1;
+    s.lambda *= s.ni;
+    s.ni *= 2;
+    if (!isfinite(s.lambda)) stop = 1;
   }
-  st->qmax += 1;
-  if (!stop && rho < 0 && st->qmax < 10) {
-    st->need_lin = 0;  // retry with the same linearisation
-    return;
-  }
-  // the outer iteration is over
-  if (D.chi_trace) D.chi_trace[st->it] = st->current_chi;
-  if (D.lambda_trace) D.lambda_trace[st->it] = st->lambda;
-  st->it += 1;
-  if (st->qmax == 10 || rho == 0 || stop) {
-    st->done = 1;
-    st->terminated = 1;
-  } else if (st->it >= D.max_it) {
-    st->done = 1;
+  s.qmax += 1;
+  if (!stop && rho < 0 && s.qmax < 10) {
+    s.need_lin = 0;  // retry with the same linearisation
   } else {
-    st->need_lin = 1;
-    st->qmax = 0;
+    // the outer iteration is over
+    if (D.chi_trace) D.chi_trace[s.it] = s.current_chi;
+    if (D.lambda_trace) D.lambda_trace[s.it] = s.lambda;
+    s.it += 1;
+    if (s.qmax == 10 || rho == 0 || stop) {
+      s.done = 1;
+      s.terminated = 1;
+    } else if (s.it >= D.max_it) {
+      s.done = 1;
+    } else {
+      s.need_lin = 1;
+      s.qmax = 0;
+    }
   }
+  *D.st = s;
 }
 
 // ------------------------------------------------------------------------------------------------ trial + chi2
