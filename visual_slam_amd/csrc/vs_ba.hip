@@ -1915,6 +1915,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
   // ---- prologue: every workgroup derives the current LM state from the previous launch's state + partials
   if (tid == 0) s_st = g_state[(step + 1) & 1];
   __syncthreads();
+  const int done_on_entry = s_st.done;
   if (s_st.stage != 0 && !s_st.done) {
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;  // fixed order: thread t sums cameras t, t+256, ... then thread 0 sums threads
     for (int k = tid; k < nfp; k += kMoThreads) {
@@ -1999,7 +2000,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
     __syncthreads();
   }
   mo_state st = s_st;
-  st.seq = step;
+  if (!done_on_entry) st.seq = step;  // ends as the index of the launch whose prologue found the solve finished
   if (st.done) {
     if (c == 0 && tid == 0) g_state[step & 1] = st;
     return;

@@ -156,6 +156,8 @@ struct pnp_args {
   int* inl_out;        // [n]
   const int* n_dev;    // tracking session: the number of correspondences lives on the device (nullptr: use n)
   double* rec_out[2];  // tracking session: camera record of the result (the guess if nothing was found), or nullptr
+  mo_state* lm_init;   // tracking session: the two motion-only LM records to reset for the solve that follows, or nullptr
+  int lm_cur;          // ... their state-buffer index
 };
 
 __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step);

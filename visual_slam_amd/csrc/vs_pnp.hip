@@ -370,6 +370,15 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
   __shared__ int s_best[2], s_cnt[4], s_base;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   P.n = pnp_count(P);
+  if (P.lm_init && tid == 64) {  // the motion-only solve that follows starts from fresh LM records (no upload in between)
+    mo_state z;
+    memset(&z, 0, sizeof z);
+    z.cur = P.lm_cur;
+    P.lm_init[0] = z;
+    z.need_lin = 1;  // step 0 reads the record of parity 1
+    z.ni = 2.0;
+    P.lm_init[1] = z;
+  }
   if (tid == 0) {
     // replay of the sequential RANSAC loop (budget update after every improvement) over the per-hypothesis counts
     int max_good = 0, niters = P.n >= 5 ? P.iterations : 0, best = -1, k = 0;

@@ -217,6 +217,9 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   A.inl_out = (int*)(d + L.pnp_inl);
   A.rec_out[0] = cam0 + (size_t)k * kCamStride;
   A.rec_out[1] = cam1 + (size_t)k * kCamStride;
+  const bool lm_on_device = T.pnp_iters > 0 && Q.lm_iterations > 0;  // pnp_finish_kernel resets the LM records itself
+  A.lm_init = lm_on_device ? reinterpret_cast<mo_state*>(d + L.mst) : nullptr;
+  A.lm_cur = T.cur;
   if (T.pnp_iters > 0) {
     hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(H), dim3(64), 0, s, A);
     VS_LAUNCH_CHECK(ctx, "pnp_hypothesis_kernel");
@@ -228,7 +231,7 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
     VS_HIP(ctx, hipMemcpyAsync(A.rec_out[1], hp + 2048, sizeof T.last_rec, hipMemcpyHostToDevice, s));
   }
   *steps_out = 0;
-  if (Q.lm_iterations > 0) {
+  if (Q.lm_iterations > 0 && !lm_on_device) {
     mo_state* h_st = (mo_state*)(hp + 1024);
     memset(h_st, 0, 2 * sizeof(mo_state));
     h_st[1].need_lin = 1;
@@ -280,7 +283,11 @@ int track_ba_batch(vs_ctx* ctx, int set, int* step) {
   if (lm > 0) {
     const ba_dev D = track_ba_dev(ctx, set);
     const int max_steps = 1 + lm * 10;
-    const int batch = std::min(max_steps + 1 - *step, lm + 2);
+    // Launches after the one that finds the solve finished are predicated no-ops of ~5 us each on the critical path of the
+    // frame, and consecutive frames of a stream need about the same number of LM steps: the first batch is as long as the
+    // previous solve was (+1); a solve that needs more gets further batches (the results do not depend on the split).
+    int batch = std::min(max_steps + 1 - *step, lm + 2);
+    if (*step == 0 && T.lm_steps_hint > 0) batch = std::min(batch, std::max(3, T.lm_steps_hint + 1));
     for (int b = 0; b < batch; ++b, ++*step) {
       hipLaunchKernelGGL(ba_motion_step, dim3(k), dim3(kMoThreads), 0, s, D, *step);
       VS_LAUNCH_CHECK(ctx, "ba_motion_step");
@@ -332,6 +339,7 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   }
   if (copies) VS_HIP(ctx, hipStreamSynchronize(s));
   T.cur = fin.cur;
+  if (lm > 0 && fin.done) T.lm_steps_hint = fin.seq + 1;  // launches this solve needed (fin.seq: the launch that found it done)
   const double* h_cam = (const double*)(rb + ((T.cur ? L.cam1 : L.cam0) - L.mst));
   for (int i = 0; i <= k; ++i) pose_from_rec(h_cam + (size_t)i * kCamStride, poses_out + 16 * (size_t)i);
   memcpy(T.last_rec, h_cam + (size_t)k * kCamStride, sizeof T.last_rec);
@@ -362,7 +370,12 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   hipStream_t s = ctx->stream;
   auto& T = ctx->track;
   if (!T.front_stream) {
-    VS_HIP(ctx, hipStreamCreateWithFlags(&T.front_stream, hipStreamNonBlocking));
+    // lowest priority: in pipelined use the front half (detect, match) of frame k+1 shares the GPU with the back half of
+    // frame k, which is the critical path -- a chain of short launches that should not queue behind the detector's
+    // 240 workgroups (ba_motion_step: 7 us alone, 10-13 us behind them at equal priority)
+    int prio_lo = 0, prio_hi = 0;
+    VS_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    VS_HIP(ctx, hipStreamCreateWithPriority(&T.front_stream, hipStreamNonBlocking, prio_lo));
     for (hipEvent_t& e : T.ev_front) VS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   VS_HIP(ctx, hipStreamSynchronize(T.front_stream));
@@ -400,6 +413,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   T.n_frames = 0;
   T.obs_used = 0;
   T.cur = 0;
+  T.lm_steps_hint = 0;
   T.pending = -1;
   T.next_set = 0;
   T.K[0] = fx;
