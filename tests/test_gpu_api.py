@@ -412,3 +412,20 @@ def test_class_api_keeps_the_tracking_period_resident(vs, oracle):
         maps.append(np.stack([m.GetFrame(k).GetPose() for k in range(4)]))
     Map.use_device_mirror = True
     assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(*maps)) <= 1e-9
+
+
+def test_resident_tracking_one_launch_solve_equals_launch_per_step(vs):
+    """The resident tracking period with the motion-only BA as one launch per frame against one launch per LM step:
+    identical poses, frame by frame and pipelined."""
+    from visual_slam_amd import _capi, harness
+    lib = _capi.load()
+    frames, depth0 = harness.load_sequence(12)
+    try:
+        lib.vs_ba_set_motion_variant(1)
+        ref, _, _ = harness.track_sequence_resident(vs, frames, depth0)
+        lib.vs_ba_set_motion_variant(0)
+        got, _, _ = harness.track_sequence_resident(vs, frames, depth0)
+        piped, _, _ = harness.track_sequence_resident(vs, frames, depth0, pipelined=True)
+    finally:
+        lib.vs_ba_set_motion_variant(0)
+    assert np.array_equal(ref, got) and np.array_equal(ref, piped)

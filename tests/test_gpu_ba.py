@@ -339,3 +339,30 @@ def test_single_tile_schur_kernel_equals_the_tile_kernel(vs):
                 assert np.allclose(a, b, rtol=1e-9, atol=1e-10), (nc, npts, vis, per, cap)
     finally:
         lib.vs_ba_set_schur_variant(0, 8, 512)
+
+
+def test_one_launch_motion_only_solve_equals_the_launch_per_step_form(vs):
+    """Motion-only windows of up to 64 cameras with at most 1024 observations each run the whole LM solve in ONE launch
+    (ba_motion_persistent: observations in registers, a ticket rendezvous after every step); operands, order of operations
+    and the decision are those of the launch-per-step kernel, so the results are bit-identical -- and larger windows keep
+    taking the launch-per-step form."""
+    from visual_slam_amd import _capi
+    lib = _capi.load()
+
+    def solve(w, **kw):
+        fixed = np.ones(len(w["points"]), np.uint8)
+        r = vs.ba_solve(w["poses"], w["pose_fixed"], w["points"], fixed, w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"], **kw)
+        return r["poses"], np.array(r["chi2_trace"]), np.array([r["iterations"], r["trials"]])
+
+    try:
+        for (nc, npts, vis, seed, kw) in [(8, 500, 0.7, 9, {}), (2, 40, 1.0, 3, {}), (19, 420, 1.0, 5, {"max_iterations": 10}),
+                                          (30, 1000, 0.9, 7, {"huber_delta": 0.0}), (6, 1500, 1.0, 11, {})]:
+            w = ba_workload(n_cams=nc, n_points=npts, seed=seed, point_sigma=0, visibility=vis)
+            lib.vs_ba_set_motion_variant(1)
+            ref = solve(w, **kw)
+            lib.vs_ba_set_motion_variant(0)
+            got = solve(w, **kw)
+            assert all(np.array_equal(a, b) for a, b in zip(ref, got)), (nc, npts)
+            assert ref[2][1] >= 1
+    finally:
+        lib.vs_ba_set_motion_variant(0)

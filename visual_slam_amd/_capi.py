@@ -123,6 +123,8 @@ def load():
         lib.vs_match_set_tstage.argtypes = [C.c_int]
         lib.vs_ba_set_schur_variant.restype = C.c_int
         lib.vs_ba_set_schur_variant.argtypes = [C.c_int, C.c_int, C.c_int]
+        lib.vs_ba_set_motion_variant.restype = C.c_int
+        lib.vs_ba_set_motion_variant.argtypes = [C.c_int]
     except AttributeError:
         pass
     _LIB = lib

@@ -1826,6 +1826,68 @@ __global__ __launch_bounds__(256) void ba_export(ba_dev D, double* out) {
 // (mo_X / mo_uv / mo_info) so every load is coalesced and index-free.
 
 
+// The LM bookkeeping of the motion-only path, run on identical inputs by one thread of every camera's workgroup: st is
+// the state after the launch / step that produced the sums (chi2; max diagonal or gain denominator; cameras whose 6x6
+// system was not positive definite).  Camera 0's workgroup records the traces.
+__device__ inline void mo_decide(const ba_dev& D, mo_state& st, double chi, double second, double bad, int c) {
+  if (st.stage == 1) {  // iteration 0 has just been linearised: computeLambdaInit + the first chi2
+    st.lambda = 1e-5 * second;
+    st.ni = 2.0;
+    st.current_chi = chi;
+    st.chi0 = chi;
+    st.need_lin = 0;
+  } else {  // a trial has just been evaluated
+    double temp = chi, scale = second;
+    st.trials += 1;
+    if (bad > 0.0) {
+      temp = 1.7976931348623157e308;
+      st.not_pd += 1;
+    }
+    double rho = st.current_chi - temp;
+    scale += 1e-3;
+    rho /= scale;
+    if (c == 0 && D.trial_trace && st.trials <= D.trial_cap) {
+      double* row = D.trial_trace + 4 * (size_t)(st.trials - 1);
+      row[0] = st.lambda;
+      row[1] = temp;
+      row[2] = rho;
+      row[3] = bad > 0.0 ? 0.0 : 1.0;
+    }
+    int stop = 0;
+    if (rho > 0 && isfinite(temp)) {
+      double alpha = 1.0 - pow(2 * rho - 1, 3);
+      alpha = fmin(alpha, 2.0 / 3.0);
+      st.lambda *= fmax(1.0 / 3.0, alpha);
+      st.ni = 2.0;
+      st.current_chi = temp;
+      st.cur ^= 1;  // accept: the trial buffer becomes the estimate
+    } else {
+      st.lambda *= st.ni;
+      st.ni *= 2;
+      if (!isfinite(st.lambda)) stop = 1;
+    }
+    st.qmax += 1;
+    if (!stop && rho < 0 && st.qmax < 10) {
+      st.need_lin = 0;  // retry with the same linearisation
+    } else {
+      if (c == 0) {
+        if (D.chi_trace) D.chi_trace[st.it] = st.current_chi;
+        if (D.lambda_trace) D.lambda_trace[st.it] = st.lambda;
+      }
+      st.it += 1;
+      if (st.qmax == 10 || rho == 0 || stop) {
+        st.done = 1;
+        st.terminated = 1;
+      } else if (st.it >= D.max_it) {
+        st.done = 1;
+      } else {
+        st.need_lin = 1;
+        st.qmax = 0;
+      }
+    }
+  }
+}
+
 // sums 28 doubles per thread over the workgroup in a fixed order; result in s_out[0..27].  The upper half of the threads
 // hands its values to the lower half through LDS; the kMoRows rows are then transposed-reduced: (value k, group g)
 // threads add the 32 rows of their group in row order and 28 threads add the group sums in group order -- four barriers
@@ -1939,62 +2001,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
         else second += s_part[1][k];
         bad += s_part[2][k];
       }
-      if (st.stage == 1) {  // iteration 0 has just been linearised: computeLambdaInit + the first chi2
-        st.lambda = 1e-5 * second;
-        st.ni = 2.0;
-        st.current_chi = chi;
-        st.chi0 = chi;
-        st.need_lin = 0;
-      } else {  // a trial has just been evaluated
-        double temp = chi, scale = second;
-        st.trials += 1;
-        if (bad > 0.0) {
-          temp = 1.7976931348623157e308;
-          st.not_pd += 1;
-        }
-        double rho = st.current_chi - temp;
-        scale += 1e-3;
-        rho /= scale;
-        if (c == 0 && D.trial_trace && st.trials <= D.trial_cap) {
-          double* row = D.trial_trace + 4 * (size_t)(st.trials - 1);
-          row[0] = st.lambda;
-          row[1] = temp;
-          row[2] = rho;
-          row[3] = bad > 0.0 ? 0.0 : 1.0;
-        }
-        int stop = 0;
-        if (rho > 0 && isfinite(temp)) {
-          double alpha = 1.0 - pow(2 * rho - 1, 3);
-          alpha = fmin(alpha, 2.0 / 3.0);
-          st.lambda *= fmax(1.0 / 3.0, alpha);
-          st.ni = 2.0;
-          st.current_chi = temp;
-          st.cur ^= 1;  // accept: the trial buffer becomes the estimate
-        } else {
-          st.lambda *= st.ni;
-          st.ni *= 2;
-          if (!isfinite(st.lambda)) stop = 1;
-        }
-        st.qmax += 1;
-        if (!stop && rho < 0 && st.qmax < 10) {
-          st.need_lin = 0;  // retry with the same linearisation
-        } else {
-          if (c == 0) {
-            if (D.chi_trace) D.chi_trace[st.it] = st.current_chi;
-            if (D.lambda_trace) D.lambda_trace[st.it] = st.lambda;
-          }
-          st.it += 1;
-          if (st.qmax == 10 || rho == 0 || stop) {
-            st.done = 1;
-            st.terminated = 1;
-          } else if (st.it >= D.max_it) {
-            st.done = 1;
-          } else {
-            st.need_lin = 1;
-            st.qmax = 0;
-          }
-        }
-      }
+      mo_decide(D, st, chi, second, bad, c);
       s_st = st;
     }
     __syncthreads();
@@ -2177,6 +2184,282 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
   }
 }
 
+
+// ---- the same solve as ONE launch.  Between two launches of ba_motion_step lie a kernel boundary (~1.7 us) and a round
+// trip to HBM for everything the next step needs (caches are cold after a boundary: ~2.5 us before the first operand
+// arrives) -- about 4 of the 7.4 us of a step.  For windows of up to kMoMaxPersist cameras (all workgroups co-resident
+// with room to spare) the steps run inside one launch: a thread keeps its observations in registers, the camera record
+// and the normal equations stay in LDS, and the workgroups meet after every step at a ticket (the hand-off of
+// vs_match.hip: write-through stores of the partials, drain, one relaxed agent-scope add; the waiting side polls the
+// ticket, acquires, and reads the partials with agent-scope loads).  Partials are double buffered by step parity, as in
+// the multi-launch form: a workgroup can be at most one step ahead of the slowest.  The arithmetic -- operands, order,
+// reductions, the decision (mo_decide) -- is that of ba_motion_step, the results are bit-identical (tested).
+// Every wait is bounded: a workgroup that does not see the others within ~2^22 polls ends the solve with terminated = 3.
+constexpr int kMoObsRegs = 2;      // observations a thread keeps in registers (kMoThreads * kMoObsRegs per camera)
+static_assert(kMoObsRegs * kMoThreads == kMoPersistObs, "register capacity of ba_motion_persistent");
+
+__global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int max_steps) {
+#pragma clang fp contract(fast)
+  __shared__ double s_all[kMoRows][29];
+  __shared__ double s_grp[kRedGroups][28];
+  __shared__ double s_sum[28];
+  __shared__ double s_part[3][kMoThreads];
+  __shared__ mo_state s_st;
+  __shared__ double s_x[6];
+  __shared__ double s_cam[kCamStride], s_trial[kCamStride];
+  __shared__ int s_ok, s_abort;
+  const int tid = threadIdx.x, c = blockIdx.x, nfp = D.nfp;
+  mo_state* g_state = reinterpret_cast<mo_state*>(D.st);
+  const int pose = D.slot_pose[c];
+  const int o0 = D.cam_start[c], o1 = D.cam_start[c + 1];
+  // this thread's observations, kept for the whole solve
+  double oX[kMoObsRegs][3], oUV[kMoObsRegs][2], oW[kMoObsRegs][3];
+#pragma unroll
+  for (int j = 0; j < kMoObsRegs; ++j) {
+    const int i = o0 + tid + j * kMoThreads;
+    oX[j][0] = oX[j][1] = oX[j][2] = oUV[j][0] = oUV[j][1] = 0.0;
+    oW[j][0] = oW[j][2] = 1.0;
+    oW[j][1] = 0.0;
+    if (i < o1) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) oX[j][k] = D.mo_X[3 * (size_t)i + k];
+      oUV[j][0] = D.mo_uv[2 * (size_t)i];
+      oUV[j][1] = D.mo_uv[2 * (size_t)i + 1];
+      if (D.has_info) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) oW[j][k] = D.mo_info[3 * (size_t)i + k];
+      }
+    }
+  }
+  if (tid == 0) {
+    s_st = g_state[1];  // the initial record (need_lin = 1, ni = 2, cur)
+    s_abort = 0;
+  }
+  __syncthreads();
+  mo_state st = s_st;
+  if (tid < kCamStride) s_cam[tid] = D.cam[st.cur][(size_t)pose * kCamStride + tid];
+  __syncthreads();
+  int step = 0;
+  for (;; ++step) {
+    if (step > 0) {
+      // ---- rendezvous: everybody's partials of step - 1, then the decision (every workgroup, identical inputs)
+      if (tid == 0) {
+        const unsigned target = (unsigned)nfp * (unsigned)step;
+        int polls = 0;
+        while (__hip_atomic_load(D.mo_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++polls > (1 << 22)) {
+            s_abort = 1;
+            break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      if (s_abort) {
+        st.done = 1;
+        st.terminated = 3;
+        break;
+      }
+      const double* prev_part = D.mo_part + (size_t)((step + 1) & 1) * 4 * nfp;
+      auto part_at = [&](int idx) {
+        return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(prev_part + idx),
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      };
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;  // fixed order: thread t sums cameras t, t+512, ... then thread 0 sums threads
+      for (int k = tid; k < nfp; k += kMoThreads) {
+        a0 += part_at(4 * k);
+        if (st.stage == 1) a1 = fmax(a1, part_at(4 * k + 3));
+        else a1 += part_at(4 * k + 1);
+        a2 += part_at(4 * k + 2);
+      }
+      s_part[0][tid] = a0;
+      s_part[1][tid] = a1;
+      s_part[2][tid] = a2;
+      __syncthreads();
+      const int cur_before = st.cur;
+      if (tid == 0) {
+        mo_state nst = st;
+        const int n = min(nfp, kMoThreads);
+        double chi = 0.0, second = 0.0, bad = 0.0;
+        for (int k = 0; k < n; ++k) {
+          chi += s_part[0][k];
+          if (nst.stage == 1) second = fmax(second, s_part[1][k]);
+          else second += s_part[1][k];
+          bad += s_part[2][k];
+        }
+        mo_decide(D, nst, chi, second, bad, c);
+        nst.seq = step;
+        s_st = nst;
+      }
+      __syncthreads();
+      st = s_st;
+      if (st.cur != cur_before) {  // accepted: the trial record is the estimate now
+        if (tid < kCamStride) s_cam[tid] = s_trial[tid];
+        __syncthreads();
+      }
+    }
+    if (st.done || step > max_steps) break;
+    double* my_part = D.mo_part + (size_t)(step & 1) * 4 * nfp;
+    const double* cam = s_cam;
+    const bool lin_only = st.need_lin && st.it == 0 && st.stage == 0;
+    if (st.need_lin) {
+      double acc[28];
+#pragma unroll
+      for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+#pragma unroll
+      for (int j = 0; j < kMoObsRegs; ++j) {
+        if (o0 + tid + j * kMoThreads >= o1) continue;
+        edge_t E;
+        eval_edge<true>(D, cam, oX[j], oUV[j], D.has_info ? oW[j] : nullptr, E);
+        const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+        const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
+        const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
+        double WJ[2][6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          WJ[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
+          WJ[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
+        }
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+          for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJ[0][l] + E.Jj[1][k] * WJ[1][l];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
+        acc[27] += E.rho0;
+      }
+      block_reduce28(acc, s_all, s_grp, s_sum, tid);  // s_sum: upper triangle (21) + b (6) + chi2, kept across retries
+      if (lin_only) {
+        if (tid == 0) {
+          double mx = 0.0;
+          int n = 0;
+          for (int k = 0; k < 6; ++k) {
+            mx = fmax(mx, fabs(s_sum[n]));
+            n += 6 - k;
+          }
+          const double pv[4] = {s_sum[27], 0.0, 0.0, mx};
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(my_part + 4 * c + k), (unsigned long long)__double_as_longlong(pv[k]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_fetch_add(D.mo_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        st.stage = 1;
+        continue;
+      }
+    }
+    // ---- 6x6 solve (H + lambda I) x = b and SBACam::update into the trial buffer: one thread
+    double* trial = D.cam[st.cur ^ 1] + (size_t)pose * kCamStride;
+    if (tid == 0) {
+      double A[6][6], x[6];
+      int n = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int l = k; l < 6; ++l) {
+          A[k][l] = s_sum[n];
+          A[l][k] = s_sum[n];
+          ++n;
+        }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        A[k][k] += st.lambda;
+        x[k] = s_sum[21 + k];
+      }
+      int ok = 1;
+      double rinv[6];
+#pragma unroll
+      for (int jj = 0; jj < 6; ++jj) {
+        const double d = A[jj][jj];
+        if (!(d > 0.0)) ok = 0;
+        const double ri = vs_fast_rsq(d);
+        A[jj][jj] = d * ri;
+        rinv[jj] = ri;
+#pragma unroll
+        for (int i = jj + 1; i < 6; ++i) A[i][jj] = A[i][jj] * rinv[jj];
+#pragma unroll
+        for (int i = jj + 1; i < 6; ++i)
+#pragma unroll
+          for (int k = jj + 1; k <= i; ++k) A[i][k] -= A[i][jj] * A[k][jj];
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        x[k] = x[k] * rinv[k];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) x[i] -= A[i][k] * x[k];
+      }
+#pragma unroll
+      for (int k = 5; k >= 0; --k) {
+        x[k] = x[k] * rinv[k];
+#pragma unroll
+        for (int i = 0; i < k; ++i) x[i] -= A[k][i] * x[k];
+      }
+      double sc = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sc += x[k] * (st.lambda * x[k] + s_sum[21 + k]);
+      double t[3] = {cam[0] + x[0], cam[1] + x[1], cam[2] + x[2]};
+      const double bx = x[3], by = x[4], bz = x[5];
+      const double bw = sqrt(1.0 - (bx * bx + by * by + bz * bz));
+      const double ax = cam[3], ay = cam[4], az = cam[5], aw = cam[6];
+      const double w = aw * bw - ax * bx - ay * by - az * bz;
+      const double xx = aw * bx + ax * bw + ay * bz - az * by;
+      const double yy = aw * by + ay * bw + az * bx - ax * bz;
+      const double zz = aw * bz + az * bw + ax * by - ay * bx;
+      const double inrm = vs_fast_rsq(xx * xx + yy * yy + zz * zz + w * w);
+      double q[4] = {xx * inrm, yy * inrm, zz * inrm, w * inrm};
+      double rec[kCamStride];
+      for (int k = 0; k < 3; ++k) rec[k] = t[k];
+      for (int k = 0; k < 4; ++k) rec[3 + k] = q[k];
+      quat_to_w2n(t, q, rec + 7);
+      for (int k = 0; k < kCamStride; ++k) {
+        trial[k] = rec[k];
+        s_trial[k] = rec[k];  // the workgroup evaluates the trial from LDS
+      }
+      s_x[0] = sc;
+      s_ok = ok;
+    }
+    __syncthreads();
+    // ---- robust chi2 of this camera's trial state
+    double tcam[kCamStride];
+#pragma unroll
+    for (int k = 0; k < kCamStride; ++k) tcam[k] = s_trial[k];
+    const double scl = s_x[0];
+    const int ok = s_ok;
+    double chi = 0.0;
+#pragma unroll
+    for (int j = 0; j < kMoObsRegs; ++j) {
+      if (o0 + tid + j * kMoThreads >= o1) continue;
+      edge_t E;
+      eval_edge<false>(D, tcam, oX[j], oUV[j], D.has_info ? oW[j] : nullptr, E);
+      chi += E.rho0;
+    }
+    // workgroup sum of chi: xor-butterfly inside each wave, then the wave totals in wave order
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) chi += __shfl_xor(chi, d);
+    if ((tid & 63) == 0) s_part[0][tid >> 6] = chi;
+    __syncthreads();
+    if (tid == 0) {
+      double tot = s_part[0][0];
+      for (int wv = 1; wv < kMoThreads / 64; ++wv) tot += s_part[0][wv];
+      const double pv[4] = {tot, scl, ok ? 0.0 : 1.0, 0.0};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(my_part + 4 * c + k), (unsigned long long)__double_as_longlong(pv[k]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(D.mo_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    st.stage = 2;
+  }
+  if (c == 0 && tid == 0) {
+    g_state[0] = st;
+    g_state[1] = st;
+  }
+}
+
 }  // namespace vsba
 
 namespace {
@@ -2258,6 +2541,13 @@ int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& 
 // the linearisation of accepted states folded into the trial, 1 = the general tile kernel, 2 = ba_schur_small with a
 // linearisation launch per iteration), points per workgroup and the cap on the number of slabs of ba_schur_small
 static int g_schur_variant = 0, g_small_per = kSmallPts, g_small_ns_cap = 512;
+namespace vsba {
+int g_motion_variant = 0;  // 0: one launch (ba_motion_persistent) where it applies, 1: one launch per LM step (test hook)
+}
+VS_API int vs_ba_set_motion_variant(int variant) {
+  if (variant == 0 || variant == 1) vsba::g_motion_variant = variant;
+  return vsba::g_motion_variant;
+}
 VS_API int vs_ba_set_schur_variant(int variant, int points_per_workgroup, int max_slabs) {
   if (variant >= 0 && variant <= 2) g_schur_variant = variant;
   if (points_per_workgroup > 0) g_small_per = points_per_workgroup;
@@ -2490,7 +2780,11 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     D.mo_X = A.take<double>(3 * (size_t)n_cam_obs, &h_mx);
     D.mo_uv = A.take<double>(2 * (size_t)n_cam_obs, &h_muv);
     if (D.has_info) D.mo_info = A.take<double>(3 * (size_t)n_cam_obs, &h_minfo);
-    d_mst = A.take<mo_state>(2, &h_mst);
+    unsigned char* h_raw;
+    d_mst = reinterpret_cast<mo_state*>(A.take<unsigned char>(256, &h_raw));  // two records + the rendezvous ticket
+    h_mst = reinterpret_cast<mo_state*>(h_raw);
+    memset(h_raw, 0, 256);
+    D.mo_ticket = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(d_mst) + 192);
   }
   D.cam[0] = A.take<double>((size_t)F * kCamStride, &h_cam0);
   D.pts[0] = A.take<double>(3 * (size_t)P, &h_pts0);
@@ -2761,7 +3055,18 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     mo_state* hms = reinterpret_cast<mo_state*>(ctx->h_pin.p);
     const int max_steps = 1 + q.max_iterations * 10;
     int step = 0;
+    int cam_obs_max = 0;
+    for (int c = 0; c < nfp; ++c) cam_obs_max = std::max(cam_obs_max, cam_start[c + 1] - cam_start[c]);
+    const bool persistent = vsba::g_motion_variant == 0 && nfp <= kMoPersistCameras && cam_obs_max <= kMoPersistObs;
     for (;;) {
+      if (persistent) {  // the whole solve in one launch; the final record lands in both state slots
+        hipLaunchKernelGGL(ba_motion_persistent, dim3(nfp), dim3(kMoThreads), 0, s, Dm, max_steps);
+        VS_LAUNCH_CHECK(ctx, "ba_motion_persistent");
+        VS_HIP(ctx, hipMemcpyAsync(hms, d_mst, sizeof(mo_state), hipMemcpyDeviceToHost, s));
+        VS_HIP(ctx, hipStreamSynchronize(s));
+        if (hms->terminated == 3) return vs_fail(ctx, VS_EHIP, "%s: the camera workgroups did not rendezvous", "vs_ba_solve");
+        break;
+      }
       const int batch = std::min(max_steps + 1 - step, q.max_iterations + 2);  // LIN + trials + the deciding launch
       for (int k = 0; k < batch; ++k, ++step) {
         hipLaunchKernelGGL(ba_motion_step, dim3(nfp), dim3(kMoThreads), 0, s, Dm, step);

@@ -56,6 +56,7 @@ struct ba_dev {
   // motion-only kernel: camera-major observation copy cut into chunks of 64
   const double *mo_X, *mo_uv, *mo_info;  // [n_obs_free_cam][3|2|3] in camera-major (cam_start) order
   double *mo_part, *mo_H;                // [2][nfp][4] per-camera partials by step parity; [nfp][42] H upper + b
+  unsigned* mo_ticket;                   // ba_motion_persistent: arrival counter of the per-step rendezvous (zero at launch)
 };
 
 // motion-only LM state (double-buffered by launch parity, see vs_ba.hip)
@@ -157,10 +158,14 @@ struct pnp_args {
   const int* n_dev;    // tracking session: the number of correspondences lives on the device (nullptr: use n)
   double* rec_out[2];  // tracking session: camera record of the result (the guess if nothing was found), or nullptr
   mo_state* lm_init;   // tracking session: the two motion-only LM records to reset for the solve that follows, or nullptr
+  unsigned* lm_ticket; // ... and the rendezvous ticket of ba_motion_persistent
   int lm_cur;          // ... their state-buffer index
 };
 
 __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step);
+__global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int max_steps);
+extern int g_motion_variant;
+constexpr int kMoPersistCameras = 64, kMoPersistObs = 2 * kMoThreads;  // limits of the one-launch form (cameras, observations per camera)
 __global__ __launch_bounds__(64) void pnp_hypothesis_kernel(pnp_args P);
 __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P);
 

@@ -378,6 +378,7 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
     z.need_lin = 1;  // step 0 reads the record of parity 1
     z.ni = 2.0;
     P.lm_init[1] = z;
+    if (P.lm_ticket) *P.lm_ticket = 0u;
   }
   if (tid == 0) {
     // replay of the sequential RANSAC loop (budget update after every improvement) over the per-hypothesis counts

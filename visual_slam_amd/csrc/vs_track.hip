@@ -219,6 +219,7 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   A.rec_out[1] = cam1 + (size_t)k * kCamStride;
   const bool lm_on_device = T.pnp_iters > 0 && Q.lm_iterations > 0;  // pnp_finish_kernel resets the LM records itself
   A.lm_init = lm_on_device ? reinterpret_cast<mo_state*>(d + L.mst) : nullptr;
+  A.lm_ticket = lm_on_device ? reinterpret_cast<unsigned*>(d + L.mst + 192) : nullptr;
   A.lm_cur = T.cur;
   if (T.pnp_iters > 0) {
     hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(H), dim3(64), 0, s, A);
@@ -233,12 +234,12 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   *steps_out = 0;
   if (Q.lm_iterations > 0 && !lm_on_device) {
     mo_state* h_st = (mo_state*)(hp + 1024);
-    memset(h_st, 0, 2 * sizeof(mo_state));
+    memset(h_st, 0, 256);  // two records + the rendezvous ticket at +192
     h_st[1].need_lin = 1;
     h_st[1].ni = 2.0;
     h_st[1].cur = T.cur;
     h_st[0].cur = T.cur;
-    VS_HIP(ctx, hipMemcpyAsync(d + L.mst, h_st, 2 * sizeof(mo_state), hipMemcpyHostToDevice, s));
+    VS_HIP(ctx, hipMemcpyAsync(d + L.mst, h_st, 256, hipMemcpyHostToDevice, s));
   }
   return VS_OK;
 }
@@ -269,6 +270,7 @@ ba_dev track_ba_dev(vs_ctx* ctx, int set) {
   D.mo_part = (double*)(d + L.part);
   D.mo_H = (double*)(d + L.H);
   D.st = reinterpret_cast<lm_state*>(d + L.mst);
+  D.mo_ticket = reinterpret_cast<unsigned*>(d + L.mst + 192);
   return D;
 }
 
@@ -286,11 +288,18 @@ int track_ba_batch(vs_ctx* ctx, int set, int* step) {
     // Launches after the one that finds the solve finished are predicated no-ops of ~5 us each on the critical path of the
     // frame, and consecutive frames of a stream need about the same number of LM steps: the first batch is as long as the
     // previous solve was (+1); a solve that needs more gets further batches (the results do not depend on the split).
-    int batch = std::min(max_steps + 1 - *step, lm + 2);
-    if (*step == 0 && T.lm_steps_hint > 0) batch = std::min(batch, std::max(3, T.lm_steps_hint + 1));
-    for (int b = 0; b < batch; ++b, ++*step) {
-      hipLaunchKernelGGL(ba_motion_step, dim3(k), dim3(kMoThreads), 0, s, D, *step);
-      VS_LAUNCH_CHECK(ctx, "ba_motion_step");
+    if (*step == 0 && g_motion_variant == 0 && k <= kMoPersistCameras && T.n_points <= kMoPersistObs) {
+      // the whole solve in one launch (a frame has at most n_points matches); the final record lands in both state slots
+      hipLaunchKernelGGL(ba_motion_persistent, dim3(k), dim3(kMoThreads), 0, s, D, max_steps);
+      VS_LAUNCH_CHECK(ctx, "ba_motion_persistent");
+      *step = max_steps + 2;  // nothing left to enqueue
+    } else {
+      int batch = std::min(max_steps + 1 - *step, lm + 2);
+      if (*step == 0 && T.lm_steps_hint > 0) batch = std::min(batch, std::max(3, T.lm_steps_hint + 1));
+      for (int b = 0; b < batch; ++b, ++*step) {
+        hipLaunchKernelGGL(ba_motion_step, dim3(k), dim3(kMoThreads), 0, s, D, *step);
+        VS_LAUNCH_CHECK(ctx, "ba_motion_step");
+      }
     }
   }
   // one copy brings back everything the host wants; if the solve needs another batch it is simply repeated
@@ -316,6 +325,7 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
     VS_HIP(ctx, hipStreamSynchronize(s));
     if (lm == 0) break;
     fin = rb_st[(*step - 1) & 1];
+    if (fin.terminated == 3) return vs_fail(ctx, VS_EHIP, "%s: the camera workgroups of the motion-only solve did not rendezvous", "vs_track_frame");
     if (fin.done || *step > 1 + lm * 10) break;
     VS_TRY(track_ba_batch(ctx, set, step));
   }
@@ -497,12 +507,12 @@ VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const doub
   VS_HIP(ctx, hipMemcpyAsync(cam1 + (size_t)k * kCamStride, hp + 2048, sizeof rec, hipMemcpyHostToDevice, s));
   if (lm_iterations > 0) {
     mo_state* h_st = (mo_state*)(hp + 1024);
-    memset(h_st, 0, 2 * sizeof(mo_state));
+    memset(h_st, 0, 256);  // two records + the rendezvous ticket at +192
     h_st[1].need_lin = 1;
     h_st[1].ni = 2.0;
     h_st[1].cur = T.cur;
     h_st[0].cur = T.cur;
-    VS_HIP(ctx, hipMemcpyAsync(d + L.mst, h_st, 2 * sizeof(mo_state), hipMemcpyHostToDevice, s));
+    VS_HIP(ctx, hipMemcpyAsync(d + L.mst, h_st, 256, hipMemcpyHostToDevice, s));
   }
   int step = 0, n_matches = 0;
   VS_TRY(track_ba_batch(ctx, 0, &step));
