@@ -158,19 +158,45 @@ __device__ inline void pnp_reduce(double* v, double* s_red) {
 // stop once a solved step is numerically zero (|x|^2 < 1e-18; OpenCV's iterative solver stops on a small parameter change
 // too), run redundantly by every thread on identical sums.  Edge e of the thread: e = first, first + stride, ... < m; sel maps to
 // the correspondence (nullptr: identity).
-template <int STEPS, int NWAVES>
+// The thread's edges are fetched once and kept in registers when they fit (NREG per thread: always for the 5-point
+// hypotheses, up to NREG * stride inliers in the final refinement): every LM iteration evaluates them twice, and from
+// memory each evaluation starts with two dependent round trips (index, then point and pixel) on an otherwise idle CU --
+// in-kernel stamps put the refinement at 5.7 us per iteration, mostly waiting for those.
+template <int STEPS, int NWAVES, int NREG>
 __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int first, int stride, double* cam, double* s_red) {
   double trial[kCamStride];
   double lambda = 0.0, ni = 2.0;
+  const bool in_regs = m <= NREG * stride;  // uniform
+  double rX[NREG][3], rUV[NREG][2];
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) {
+      const int e = first + j * stride;
+      rX[j][0] = rX[j][1] = rX[j][2] = rUV[j][0] = rUV[j][1] = 0.0;
+      if (e < m) {
+        const int i = sel ? sel[e] : e;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) rX[j][k] = P.obj[3 * (size_t)i + k];
+        rUV[j][0] = P.img[2 * (size_t)i];
+        rUV[j][1] = P.img[2 * (size_t)i + 1];
+      }
+    }
+  }
   for (int it = 0; it < P.iters_lm; ++it) {
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-    for (int e = first; e < m; e += stride) {
-      const int i = sel ? sel[e] : e;
-      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
-      pnp_edge<true>(P, cam, X, uv, acc);
+    if (in_regs) {
+#pragma unroll
+      for (int j = 0; j < NREG; ++j)
+        if (first + j * stride < m) pnp_edge<true>(P, cam, rX[j], rUV[j], acc);
+    } else {
+      for (int e = first; e < m; e += stride) {
+        const int i = sel ? sel[e] : e;
+        const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
+        const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+        pnp_edge<true>(P, cam, X, uv, acc);
+      }
     }
     pnp_reduce<28, STEPS, NWAVES>(acc, s_red);
     double H[6][6], b[6];
@@ -253,13 +279,20 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
       // the trial chi2 is reduced in any case: the reduction is a workgroup-wide rendezvous
       double tacc[28];
       tacc[27] = 0.0;
-      if (ok)
-        for (int e = first; e < m; e += stride) {
-          const int i = sel ? sel[e] : e;
-          const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-          const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
-          pnp_edge<false>(P, trial, X, uv, tacc);
+      if (ok) {
+        if (in_regs) {
+#pragma unroll
+          for (int j = 0; j < NREG; ++j)
+            if (first + j * stride < m) pnp_edge<false>(P, trial, rX[j], rUV[j], tacc);
+        } else {
+          for (int e = first; e < m; e += stride) {
+            const int i = sel ? sel[e] : e;
+            const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
+            const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+            pnp_edge<false>(P, trial, X, uv, tacc);
+          }
         }
+      }
       pnp_reduce<1, STEPS, NWAVES>(tacc + 27, s_red);
       if (ok) temp = tacc[27];
       rho = cur - temp;
@@ -318,7 +351,7 @@ __global__ __launch_bounds__(64) void pnp_hypothesis_kernel(pnp_args P) {
   __syncthreads();
   double cam[kCamStride];
   for (int k = 0; k < kCamStride; ++k) cam[k] = P.cam0[k];
-  pnp_lm<3, 1>(P, s_idx, 5, lane & 7, 8, cam, nullptr);
+  pnp_lm<3, 1, 1>(P, s_idx, 5, lane & 7, 8, cam, nullptr);
   // the model is handed on as a 4x4 pose (as the sequential algorithm does): re-derive the record from that matrix
   double m[16];
   for (int r = 0; r < 3; ++r) {
@@ -380,11 +413,17 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
     P.lm_init[1] = z;
     if (P.lm_ticket) *P.lm_ticket = 0u;
   }
+  // the per-hypothesis counts go to LDS first (all loads in flight at once): the replay below is a serial loop whose trip
+  // count depends on the data, and from global memory every one of its loads was a dependent L2 round trip
+  constexpr int kGoodLds = 4096;  // more hypotheses than this are read from global memory
+  __shared__ int s_good[kGoodLds];
+  for (int k = tid; k < min(P.iterations, kGoodLds); k += kPnpFinish) s_good[k] = P.good_out[k];
+  __syncthreads();
   if (tid == 0) {
     // replay of the sequential RANSAC loop (budget update after every improvement) over the per-hypothesis counts
     int max_good = 0, niters = P.n >= 5 ? P.iterations : 0, best = -1, k = 0;
     for (; k < niters && k < P.iterations; ++k) {
-      const int g = P.good_out[k];
+      const int g = k < kGoodLds ? s_good[k] : P.good_out[k];
       if (g > (max_good > 4 ? max_good : 4)) {
         max_good = g;
         best = k;
@@ -439,7 +478,7 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
   if (m >= 1 && P.iters_lm > 0) {
     // final refinement on the inliers (solvePnP(inliers, useExtrinsicGuess) in OpenCV)
     __threadfence_block();
-    pnp_lm<6, kPnpFinish / 64>(P, P.inl_out, m, tid, kPnpFinish, cam, s_red);
+    pnp_lm<6, kPnpFinish / 64, 4>(P, P.inl_out, m, tid, kPnpFinish, cam, s_red);
     for (int r = 0; r < 3; ++r) {
       for (int k = 0; k < 3; ++k) pose[4 * r + k] = cam[7 + 4 * k + r];
       pose[4 * r + 3] = cam[r];
