@@ -71,6 +71,7 @@ struct vs_ctx {
     hipStream_t front_stream = nullptr;
     hipEvent_t ev_front[2] = {nullptr, nullptr};
     int pending = -1;   // buffer set of the frame whose front half is done and whose back half is not, or -1
+    int pending_step = -1;  // >= 0: that frame's back half is enqueued already, this many LM launches so far
     int next_set = 0;
     int front_nkp[2] = {0, 0};
     struct {

@@ -425,6 +425,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   T.cur = 0;
   T.lm_steps_hint = 0;
   T.pending = -1;
+  T.pending_step = -1;
   T.next_set = 0;
   T.K[0] = fx;
   T.K[1] = fy;
@@ -440,6 +441,7 @@ VS_API int vs_track_end(vs_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   ctx->track.active = 0;
   ctx->track.pending = -1;
+  ctx->track.pending_step = -1;
   return VS_OK;
 }
 
@@ -533,9 +535,13 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
   if (!T.active) return vs_fail(ctx, VS_EINVAL, "%s: no tracking period (call vs_track_begin)", "vs_track_frame_pipelined");
   if (bgr) VS_TRY(track_check_frame(ctx, bgr, w, h_img, stride, lm_iterations, "vs_track_frame_pipelined"));
   VS_HIP(ctx, hipSetDevice(ctx->device));
+  // The back half of the previous frame is on the GPU already (enqueued at the end of the previous call, the moment its
+  // inputs were known) and runs while this frame's front half is prepared.  When its results are in, the back half of
+  // THIS frame is enqueued before returning: the round trip through the caller (return, next call) is off the GPU's
+  // critical path, which is the chain of back halves.
   const int solve = T.pending;
-  int step = 0;
-  if (solve >= 0) {  // back half of the previous frame: enqueued first, it runs while this frame's front half is prepared
+  int step = T.pending_step >= 0 ? T.pending_step : 0;
+  if (solve >= 0 && T.pending_step < 0) {
     VS_TRY(track_back_enqueue(ctx, solve, &step));
     VS_TRY(track_ba_batch(ctx, solve, &step));
   }
@@ -546,11 +552,19 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
     T.params[submitted] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
     VS_TRY(track_front_half(ctx, submitted, bgr, w, h_img, stride, thr, ratio, T.front_stream));
   }
+  T.pending = -1;
+  T.pending_step = -1;
   if (solve >= 0) {
     VS_TRY(track_back_finish(ctx, solve, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out,
                              match_q, match_t));
     *has_result = 1;
   }
-  T.pending = submitted;
+  if (submitted >= 0) {
+    int next_step = 0;
+    T.pending = submitted;  // from here on the frame counts as pending, whatever happens below
+    VS_TRY(track_back_enqueue(ctx, submitted, &next_step));
+    VS_TRY(track_ba_batch(ctx, submitted, &next_step));
+    T.pending_step = next_step;
+  }
   return VS_OK;
 }
