@@ -2189,10 +2189,10 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
 // trip to HBM for everything the next step needs (caches are cold after a boundary: ~2.5 us before the first operand
 // arrives) -- about 4 of the 7.4 us of a step.  For windows of up to kMoMaxPersist cameras (all workgroups co-resident
 // with room to spare) the steps run inside one launch: a thread keeps its observations in registers, the camera record
-// and the normal equations stay in LDS, and the workgroups meet after every step at a ticket (the hand-off of
-// vs_match.hip: write-through stores of the partials, drain, one relaxed agent-scope add; the waiting side polls the
-// ticket, acquires, and reads the partials with agent-scope loads).  Partials are double buffered by step parity, as in
-// the multi-launch form: a workgroup can be at most one step ahead of the slowest.  The arithmetic -- operands, order,
+// and the normal equations stay in LDS, and the workgroups exchange their per-step partials through tagged mailboxes
+// (post_partials / the rendezvous at the top of the step loop: write-through stores on one side, agent-scope polling
+// loads on the other, no ticket).  Mailboxes are double buffered by step parity, as the partials of the multi-launch form:
+// a workgroup can be at most one step ahead of the slowest.  The arithmetic -- operands, order,
 // reductions, the decision (mo_decide) -- is that of ba_motion_step, the results are bit-identical (tested).
 // Every wait is bounded: a workgroup that does not see the others within ~2^22 polls ends the solve with terminated = 3.
 constexpr int kMoObsRegs = 2;      // observations a thread keeps in registers (kMoThreads * kMoObsRegs per camera)
@@ -2208,6 +2208,8 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
   __shared__ double s_x[6];
   __shared__ double s_cam[kCamStride], s_trial[kCamStride];
   __shared__ int s_ok, s_abort;
+  __shared__ unsigned s_box[kMoPersistCameras][8];  // payload halves of every camera's four partials
+  __shared__ double s_pv[4];
   const int tid = threadIdx.x, c = blockIdx.x, nfp = D.nfp;
   mo_state* g_state = reinterpret_cast<mo_state*>(D.st);
   const int pose = D.slot_pose[c];
@@ -2239,21 +2241,47 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
   mo_state st = s_st;
   if (tid < kCamStride) s_cam[tid] = D.cam[st.cur][(size_t)pose * kCamStride + tid];
   __syncthreads();
+  // This camera's four partials of a step go out as eight 64-bit words, each carrying 32 payload bits and the tag
+  // (solve epoch, step + 1) in its low half: every word validates itself, so the readers need neither a ticket nor an
+  // acknowledged store -- one write-through store instruction of eight lanes, no wait.  Wave 0 only; s_pv from thread 0.
+  auto post_partials = [&](int at_step) {
+    if (tid < 64) {
+      wave_lds_sync();
+      if (tid < 8) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(s_pv[tid >> 1]);
+        const unsigned half = (tid & 1) ? (unsigned)(bits & 0xFFFFFFFFull) : (unsigned)(bits >> 32);
+        const unsigned tag = (D.mo_epoch << 12) | (unsigned)(at_step + 1);
+        __hip_atomic_store(D.mo_box + ((size_t)(at_step & 1) * kMoPersistCameras + c) * 8 + tid, ((unsigned long long)half << 32) | tag,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
   int step = 0;
   for (;; ++step) {
     if (step > 0) {
-      // ---- rendezvous: everybody's partials of step - 1, then the decision (every workgroup, identical inputs)
-      if (tid == 0) {
-        const unsigned target = (unsigned)nfp * (unsigned)step;
+      // ---- rendezvous: everybody's partials of step - 1, then the decision (every workgroup, identical inputs).
+      // Eight lanes per camera poll the eight tagged words of its mailbox (see the end of the step) until every word of
+      // every camera carries this step's tag; the payload halves go through LDS.
+      {
+        const int g = tid >> 3, jw = tid & 7;
+        const unsigned tag = (D.mo_epoch << 12) | (unsigned)step;
+        const unsigned long long* word = D.mo_box + ((size_t)((step + 1) & 1) * kMoPersistCameras + g) * 8 + jw;
         int polls = 0;
-        while (__hip_atomic_load(D.mo_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++polls > (1 << 22)) {
+        for (;;) {
+          unsigned long long w = 0ull;
+          bool ready = true;
+          if (g < nfp) {
+            w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ready = (unsigned)(w & 0xFFFFFFFFull) == tag;
+            s_box[g][jw] = (unsigned)(w >> 32);
+          }
+          if (__syncthreads_and(ready)) break;
+          if (++polls > (1 << 22)) {  // uniform: every thread counts the same rounds
             s_abort = 1;
             break;
           }
+          __builtin_amdgcn_s_sleep(1);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       __syncthreads();
       if (s_abort) {
@@ -2261,17 +2289,15 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
         st.terminated = 3;
         break;
       }
-      const double* prev_part = D.mo_part + (size_t)((step + 1) & 1) * 4 * nfp;
-      auto part_at = [&](int idx) {
-        return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(prev_part + idx),
-                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      auto part_at = [&](int cam_k, int which) {
+        return __longlong_as_double((long long)(((unsigned long long)s_box[cam_k][2 * which] << 32) | (unsigned long long)s_box[cam_k][2 * which + 1]));
       };
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;  // fixed order: thread t sums cameras t, t+512, ... then thread 0 sums threads
-      for (int k = tid; k < nfp; k += kMoThreads) {
-        a0 += part_at(4 * k);
-        if (st.stage == 1) a1 = fmax(a1, part_at(4 * k + 3));
-        else a1 += part_at(4 * k + 1);
-        a2 += part_at(4 * k + 2);
+      for (int kk = tid; kk < nfp; kk += kMoThreads) {
+        a0 += part_at(kk, 0);
+        if (st.stage == 1) a1 = fmax(a1, part_at(kk, 3));
+        else a1 += part_at(kk, 1);
+        a2 += part_at(kk, 2);
       }
       s_part[0][tid] = a0;
       s_part[1][tid] = a1;
@@ -2300,7 +2326,6 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
       }
     }
     if (st.done || step > max_steps) break;
-    double* my_part = D.mo_part + (size_t)(step & 1) * 4 * nfp;
     const double* cam = s_cam;
     const bool lin_only = st.need_lin && st.it == 0 && st.stage == 0;
     if (st.need_lin) {
@@ -2339,14 +2364,12 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
             mx = fmax(mx, fabs(s_sum[n]));
             n += 6 - k;
           }
-          const double pv[4] = {s_sum[27], 0.0, 0.0, mx};
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(my_part + 4 * c + k), (unsigned long long)__double_as_longlong(pv[k]),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_fetch_add(D.mo_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_pv[0] = s_sum[27];
+          s_pv[1] = 0.0;
+          s_pv[2] = 0.0;
+          s_pv[3] = mx;
         }
+        post_partials(step);
         st.stage = 1;
         continue;
       }
@@ -2444,14 +2467,12 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
     if (tid == 0) {
       double tot = s_part[0][0];
       for (int wv = 1; wv < kMoThreads / 64; ++wv) tot += s_part[0][wv];
-      const double pv[4] = {tot, scl, ok ? 0.0 : 1.0, 0.0};
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(my_part + 4 * c + k), (unsigned long long)__double_as_longlong(pv[k]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(D.mo_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_pv[0] = tot;
+      s_pv[1] = scl;
+      s_pv[2] = ok ? 0.0 : 1.0;
+      s_pv[3] = 0.0;
     }
+    post_partials(step);
     st.stage = 2;
   }
   if (c == 0 && tid == 0) {
@@ -2781,10 +2802,13 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     D.mo_uv = A.take<double>(2 * (size_t)n_cam_obs, &h_muv);
     if (D.has_info) D.mo_info = A.take<double>(3 * (size_t)n_cam_obs, &h_minfo);
     unsigned char* h_raw;
-    d_mst = reinterpret_cast<mo_state*>(A.take<unsigned char>(256, &h_raw));  // two records + the rendezvous ticket
+    d_mst = reinterpret_cast<mo_state*>(A.take<unsigned char>(256, &h_raw));  // the two records
     h_mst = reinterpret_cast<mo_state*>(h_raw);
     memset(h_raw, 0, 256);
-    D.mo_ticket = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(d_mst) + 192);
+    unsigned long long* h_box;
+    D.mo_box = A.take<unsigned long long>(2 * (size_t)kMoPersistCameras * 8, &h_box);  // uploaded as zeros: no word carries a tag
+    memset(h_box, 0, sizeof(unsigned long long) * 2 * kMoPersistCameras * 8);
+    D.mo_epoch = 1;
   }
   D.cam[0] = A.take<double>((size_t)F * kCamStride, &h_cam0);
   D.pts[0] = A.take<double>(3 * (size_t)P, &h_pts0);
@@ -3057,7 +3081,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     int step = 0;
     int cam_obs_max = 0;
     for (int c = 0; c < nfp; ++c) cam_obs_max = std::max(cam_obs_max, cam_start[c + 1] - cam_start[c]);
-    const bool persistent = vsba::g_motion_variant == 0 && nfp <= kMoPersistCameras && cam_obs_max <= kMoPersistObs;
+    const bool persistent = vsba::g_motion_variant == 0 && nfp <= kMoPersistCameras && cam_obs_max <= kMoPersistObs && max_steps < 4000;
     for (;;) {
       if (persistent) {  // the whole solve in one launch; the final record lands in both state slots
         hipLaunchKernelGGL(ba_motion_persistent, dim3(nfp), dim3(kMoThreads), 0, s, Dm, max_steps);

@@ -56,7 +56,8 @@ struct ba_dev {
   // motion-only kernel: camera-major observation copy cut into chunks of 64
   const double *mo_X, *mo_uv, *mo_info;  // [n_obs_free_cam][3|2|3] in camera-major (cam_start) order
   double *mo_part, *mo_H;                // [2][nfp][4] per-camera partials by step parity; [nfp][42] H upper + b
-  unsigned* mo_ticket;                   // ba_motion_persistent: arrival counter of the per-step rendezvous (zero at launch)
+  unsigned long long* mo_box;            // ba_motion_persistent: [2][kMoPersistCameras][8] tagged mailbox words
+  unsigned mo_epoch;                     // ... tag of this solve (20 bits), so that words of an earlier solve never match
 };
 
 // motion-only LM state (double-buffered by launch parity, see vs_ba.hip)
@@ -158,7 +159,6 @@ struct pnp_args {
   const int* n_dev;    // tracking session: the number of correspondences lives on the device (nullptr: use n)
   double* rec_out[2];  // tracking session: camera record of the result (the guess if nothing was found), or nullptr
   mo_state* lm_init;   // tracking session: the two motion-only LM records to reset for the solve that follows, or nullptr
-  unsigned* lm_ticket; // ... and the rendezvous ticket of ba_motion_persistent
   int lm_cur;          // ... their state-buffer index
 };
 

@@ -66,6 +66,7 @@ struct vs_ctx {
     double K[4] = {0, 0, 0, 0};
     double last_rec[19];  // camera record of the newest pose (the PnP guess of the next frame)
     int lm_steps_hint = 0;  // motion-only LM launches the previous solve of this period needed (0: unknown)
+    int solve_epoch = 0;    // tag of the newest one-launch motion-only solve (ba_motion_persistent's mailboxes)
     // pipelined use (vs_track_frame_pipelined): the front half (upload, detect, match) of frame k+1 runs on its own
     // stream while the back half (PnP, BA) of frame k runs on the context's stream; two sets of per-frame buffers
     hipStream_t front_stream = nullptr;

@@ -411,7 +411,6 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
     z.need_lin = 1;  // step 0 reads the record of parity 1
     z.ni = 2.0;
     P.lm_init[1] = z;
-    if (P.lm_ticket) *P.lm_ticket = 0u;
   }
   // the per-hypothesis counts go to LDS first (all loads in flight at once): the replay below is a serial loop whose trip
   // count depends on the data, and from global memory every one of its loads was a dependent L2 round trip

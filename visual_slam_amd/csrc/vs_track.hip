@@ -71,7 +71,7 @@ struct track_front {
 struct track_layout {
   size_t xyz, mapdesc;
   track_front f[2];  // two sets of per-frame buffers (the synchronous entry point uses set 0 only)
-  size_t flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part, H, mst, pnp_cam, pnp_pose, pnp_good, pnp_res, pnp_inl,
+  size_t flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part, H, box, mst, pnp_cam, pnp_pose, pnp_good, pnp_res, pnp_inl,
       push_idx, push_uv, rb_end, total;
   int cap_obs;
 };
@@ -112,6 +112,7 @@ track_layout track_layout_of(int P, int F, int max_kp, int H) {
   L.slot_pose = take(sizeof(int) * (size_t)(F + 1));
   L.part = take(sizeof(double) * 8 * (size_t)F);
   L.H = take(sizeof(double) * 42 * (size_t)F);
+  L.box = take(sizeof(unsigned long long) * 2 * kMoPersistCameras * 8);  // mailboxes of ba_motion_persistent
   L.pnp_cam = take(sizeof(double) * kCamStride * (size_t)H);
   L.pnp_pose = take(sizeof(double) * 12 * (size_t)H);
   L.pnp_good = take(sizeof(int) * (size_t)H);
@@ -219,7 +220,6 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   A.rec_out[1] = cam1 + (size_t)k * kCamStride;
   const bool lm_on_device = T.pnp_iters > 0 && Q.lm_iterations > 0;  // pnp_finish_kernel resets the LM records itself
   A.lm_init = lm_on_device ? reinterpret_cast<mo_state*>(d + L.mst) : nullptr;
-  A.lm_ticket = lm_on_device ? reinterpret_cast<unsigned*>(d + L.mst + 192) : nullptr;
   A.lm_cur = T.cur;
   if (T.pnp_iters > 0) {
     hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(H), dim3(64), 0, s, A);
@@ -234,7 +234,7 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   *steps_out = 0;
   if (Q.lm_iterations > 0 && !lm_on_device) {
     mo_state* h_st = (mo_state*)(hp + 1024);
-    memset(h_st, 0, 256);  // two records + the rendezvous ticket at +192
+    memset(h_st, 0, 256);
     h_st[1].need_lin = 1;
     h_st[1].ni = 2.0;
     h_st[1].cur = T.cur;
@@ -270,7 +270,8 @@ ba_dev track_ba_dev(vs_ctx* ctx, int set) {
   D.mo_part = (double*)(d + L.part);
   D.mo_H = (double*)(d + L.H);
   D.st = reinterpret_cast<lm_state*>(d + L.mst);
-  D.mo_ticket = reinterpret_cast<unsigned*>(d + L.mst + 192);
+  D.mo_box = reinterpret_cast<unsigned long long*>(d + L.box);
+  D.mo_epoch = (unsigned)T.solve_epoch & 0xFFFFFu;
   return D;
 }
 
@@ -283,12 +284,13 @@ int track_ba_batch(vs_ctx* ctx, int set, int* step) {
   uint8_t* rb = (uint8_t*)ctx->h_track.p + kPinRb;
   const int lm = T.params[set].lm_iterations, k = T.n_frames + 1;
   if (lm > 0) {
+    if (*step == 0) T.solve_epoch = T.solve_epoch % 0xFFFFF + 1;  // 1 .. 2^20 - 1: never the zero the mailboxes start with
     const ba_dev D = track_ba_dev(ctx, set);
     const int max_steps = 1 + lm * 10;
     // Launches after the one that finds the solve finished are predicated no-ops of ~5 us each on the critical path of the
     // frame, and consecutive frames of a stream need about the same number of LM steps: the first batch is as long as the
     // previous solve was (+1); a solve that needs more gets further batches (the results do not depend on the split).
-    if (*step == 0 && g_motion_variant == 0 && k <= kMoPersistCameras && T.n_points <= kMoPersistObs) {
+    if (*step == 0 && g_motion_variant == 0 && k <= kMoPersistCameras && T.n_points <= kMoPersistObs && max_steps < 4000) {
       // the whole solve in one launch (a frame has at most n_points matches); the final record lands in both state slots
       hipLaunchKernelGGL(ba_motion_persistent, dim3(k), dim3(kMoThreads), 0, s, D, max_steps);
       VS_LAUNCH_CHECK(ctx, "ba_motion_persistent");
@@ -404,6 +406,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   VS_HIP(ctx, hipMemcpyAsync(d, h, up, hipMemcpyHostToDevice, s));
   VS_HIP(ctx, hipMemsetAsync(d + L.cam_start, 0, sizeof(int) * (size_t)(max_frames + 2), s));
   VS_HIP(ctx, hipMemsetAsync(d + L.flags, 0, 4 * sizeof(int), s));
+  VS_HIP(ctx, hipMemsetAsync(d + L.box, 0, sizeof(unsigned long long) * 2 * kMoPersistCameras * 8, s));
   double rec[kCamStride];
   rec_from_pose(key_pose, rec);
   VS_HIP(ctx, hipStreamSynchronize(s));  // the pinned mirror is reused below
@@ -424,6 +427,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   T.obs_used = 0;
   T.cur = 0;
   T.lm_steps_hint = 0;
+  T.solve_epoch = 0;
   T.pending = -1;
   T.pending_step = -1;
   T.next_set = 0;
@@ -509,7 +513,7 @@ VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const doub
   VS_HIP(ctx, hipMemcpyAsync(cam1 + (size_t)k * kCamStride, hp + 2048, sizeof rec, hipMemcpyHostToDevice, s));
   if (lm_iterations > 0) {
     mo_state* h_st = (mo_state*)(hp + 1024);
-    memset(h_st, 0, 256);  // two records + the rendezvous ticket at +192
+    memset(h_st, 0, 256);
     h_st[1].need_lin = 1;
     h_st[1].ni = 2.0;
     h_st[1].cur = T.cur;
