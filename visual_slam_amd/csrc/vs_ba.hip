@@ -1658,7 +1658,8 @@ __device__ inline void ba_decide(const ba_dev& D) {
   }
   int stop = 0;
   if (rho > 0 && isfinite(temp)) {
-    double alpha = 1.0 - pow(2 * rho - 1, 3);
+    const double g = 2 * rho - 1;
+    double alpha = 1.0 - g * g * g;  // as mo_decide
     alpha = fmin(alpha, 2.0 / 3.0);
     const double f = fmax(1.0 / 3.0, alpha);
     s.lambda *= f;
@@ -1855,7 +1856,8 @@ __device__ inline void mo_decide(const ba_dev& D, mo_state& st, double chi, doub
     }
     int stop = 0;
     if (rho > 0 && isfinite(temp)) {
-      double alpha = 1.0 - pow(2 * rho - 1, 3);
+      const double g = 2 * rho - 1;
+      double alpha = 1.0 - g * g * g;  // the cube by two multiplications: the library pow() was 0.85 us of every accepted step
       alpha = fmin(alpha, 2.0 / 3.0);
       st.lambda *= fmax(1.0 / 3.0, alpha);
       st.ni = 2.0;
