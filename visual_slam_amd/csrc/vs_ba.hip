@@ -1232,8 +1232,8 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   double* rinv = s_mem + (size_t)(n + 1) * ld;  // [n]
   double* s_bp = rinv + n + 1;              // [n] right-hand side before the Schur complement (gain denominator)
   int* s_flag = reinterpret_cast<int*>(s_bp + n + 1);
-  for (int r = ty; r < n; r += kSolveTile)
-    for (int c = tx; c < n; c += kSolveTile) A[r * ld + c] = D.S[(size_t)r * n + c];
+  for (int r = ty; r < n; r += kSolveBlock / kSolveTile)  // the lower triangle: nothing else is read
+    for (int c = tx; c <= r; c += kSolveTile) A[r * ld + c] = D.S[(size_t)r * n + c];
   const double* g_bp = lin_of(D, cur).bp;
   for (int c = tid; c < n; c += kSolveBlock) {
     A[n * ld + c] = D.bs[c];
