@@ -11,11 +11,10 @@ _LIB = None
 
 VS_OK, VS_EINVAL, VS_ENOMEM, VS_EHIP, VS_ENOTPD, VS_ECAP, VS_ENCCL = 0, -1, -2, -3, -4, -5, -6
 
-c_u8p = C.POINTER(C.c_uint8)
-c_i32p = C.POINTER(C.c_int32)
-c_f32p = C.POINTER(C.c_float)
-c_f64p = C.POINTER(C.c_double)
-c_intp = C.POINTER(C.c_int)
+# Pointer parameters and struct fields are declared void* under element-type names: ctypes then takes a plain address
+# (ndarray.ctypes.data) instead of a typed pointer object, whose construction (data_as / cast) costs ~3 us apiece -- the
+# tracking loop makes some twenty of them per frame.  The element type each entry point expects is in include/vslam_hip.h.
+c_u8p = c_i32p = c_f32p = c_f64p = c_intp = C.c_void_p
 
 
 class VsError(RuntimeError):
@@ -143,7 +142,8 @@ def device_count():
 
 
 def ptr(a, t):
-    return a.ctypes.data_as(t)
+    """Address of a C-contiguous ndarray for a parameter of (documented) pointer type t; the caller keeps `a` alive."""
+    return a.ctypes.data
 
 
 def as_u8(a, shape_tail=None):
