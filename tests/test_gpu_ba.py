@@ -366,3 +366,33 @@ def test_one_launch_motion_only_solve_equals_the_launch_per_step_form(vs):
             assert ref[2][1] >= 1
     finally:
         lib.vs_ba_set_motion_variant(0)
+
+
+def test_one_launch_motion_only_solve_at_its_limits(vs, oracle):
+    """64 cameras is the largest window the one-launch form takes (65 falls back to a launch per step), 1024 observations
+    per camera the most its threads keep in registers; information matrices ride along in registers too.  All of them
+    against the oracle, and the two forms against each other where both apply."""
+    from visual_slam_amd import _capi
+    lib = _capi.load()
+    rng = np.random.default_rng(3)
+    for (nc, npts, vis, info) in [(65, 300, 0.5, False), (66, 120, 1.0, False), (5, 1024, 1.0, False), (5, 1025, 1.0, False),
+                                  (7, 200, 0.9, True)]:
+        w = ba_workload(n_cams=nc, n_points=npts, seed=nc + npts, point_sigma=0, visibility=vis)
+        fixed = np.ones(len(w["points"]), np.uint8)
+        kw = {}
+        if info:
+            a = rng.uniform(0.5, 2.0, len(w["obs_pose"]))
+            b = rng.uniform(-0.2, 0.2, len(w["obs_pose"]))
+            kw["obs_info"] = np.stack([a, b, a + 0.3], axis=1)
+        args = (w["poses"], w["pose_fixed"], w["points"], fixed, w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
+        try:
+            lib.vs_ba_set_motion_variant(1)
+            ref = vs.ba_solve(*args, **kw)
+            lib.vs_ba_set_motion_variant(0)
+            got = vs.ba_solve(*args, **kw)
+        finally:
+            lib.vs_ba_set_motion_variant(0)
+        assert np.array_equal(ref["poses"], got["poses"]) and ref["trials"] == got["trials"], (nc, npts)
+        o = oracle.ba_solve(*args, **kw)  # at convergence the accept / reject pattern is rounding noise: compare the optimum
+        assert abs(got["chi2_final"] - o["chi2_final"]) <= 1e-9 * max(1.0, o["chi2_final"]), (nc, npts)
+        assert np.allclose(got["poses"], o["poses"], rtol=0, atol=1e-7), (nc, npts)
