@@ -396,3 +396,19 @@ def test_one_launch_motion_only_solve_at_its_limits(vs, oracle):
         o = oracle.ba_solve(*args, **kw)  # at convergence the accept / reject pattern is rounding noise: compare the optimum
         assert abs(got["chi2_final"] - o["chi2_final"]) <= 1e-9 * max(1.0, o["chi2_final"]), (nc, npts)
         assert np.allclose(got["poses"], o["poses"], rtol=0, atol=1e-7), (nc, npts)
+
+
+def test_observation_order_does_not_matter_beyond_rounding(vs, oracle):
+    """vs_ba_solve groups the observations by point on the host (stable); callers that add them point by point (the
+    reference, LocalBA.py:164-172) hit the identity-order fast path, any other order goes through the counting sort.  A
+    shuffled copy of cfg4 must agree with the oracle on the same shuffled input and with the ordered run."""
+    w = ba_workload()
+    rng = np.random.default_rng(17)
+    perm = rng.permutation(len(w["obs_pose"]))
+    ws = dict(w, obs_pose=w["obs_pose"][perm], obs_point=w["obs_point"][perm], obs_uv=w["obs_uv"][perm])
+    g_sorted = vs.ba_solve(*_args(w), max_iterations=5)
+    g_shuf = vs.ba_solve(*_args(ws), max_iterations=5)
+    o_shuf = oracle.ba_solve(*_args(ws), max_iterations=5)
+    _compare(g_shuf, o_shuf)
+    assert np.allclose(g_shuf["poses"], g_sorted["poses"], rtol=0, atol=1e-9)
+    assert np.allclose(g_shuf["points"], g_sorted["points"], rtol=0, atol=1e-9)
