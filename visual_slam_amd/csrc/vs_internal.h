@@ -74,7 +74,6 @@ struct vs_ctx {
     int pending = -1;   // buffer set of the frame whose front half is done and whose back half is not, or -1
     int pending_step = -1;  // >= 0: that frame's back half is enqueued already, this many LM launches so far
     int next_set = 0;
-    int front_nkp[2] = {0, 0};
     struct {
       double reproj_err, confidence, huber;
       unsigned long long seed;
@@ -153,6 +152,9 @@ static inline int vs_reserve_pinned(vs_ctx* ctx, vs_buf* b, size_t bytes) {
   } while (0)
 
 static inline hipStream_t vs_pick_stream(vs_ctx* ctx, void* s) { return s ? (hipStream_t)s : ctx->stream; }
+// vs_match_ratio_dev with the number of train rows read on the device (at most nt of them); vs_match.hip
+int vs_match_ratio_dev_n(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, const int* nt_dev, double ratio,
+                         void* d_match_q, void* d_match_t, void* d_match_d, void* d_n_out, void* stream);
 
 // implemented in vs_match.hip / vs_detect.hip / vs_ba.hip
 void vs_ctx_free_buffers(vs_ctx* ctx);

@@ -117,9 +117,12 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
                                                                      const uint32_t* __restrict__ t, int nt,
                                                                      int chunk_len, int sub_len, uint2* partial,
                                                                      unsigned* ticket, int2* __restrict__ idx,
-                                                                     int2* __restrict__ dist) {
+                                                                     int2* __restrict__ dist, const int* __restrict__ nt_dev) {
   __shared__ uint2 lds[kWaves][kTileQ];
   __shared__ int s_last;
+  // nt_dev: the number of train rows lives on the device (a detector's key-point count the host has not read); the launch
+  // was planned for nt rows at most, chunks beyond the actual count are empty and still take their ticket
+  if (nt_dev) nt = min(nt, *nt_dev);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
   const int tile = blockIdx.x, chunk = blockIdx.y, qtiles = gridDim.x, nchunks = gridDim.y;
@@ -280,8 +283,12 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
 __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int2* __restrict__ idx, const int2* __restrict__ dist,
                                                               int nq, double ratio, int32_t* __restrict__ mq,
                                                               int32_t* __restrict__ mt, int32_t* __restrict__ md,
-                                                              int32_t* __restrict__ n_out) {
+                                                              int32_t* __restrict__ n_out, const int* __restrict__ nt_dev) {
   __shared__ int wave_cnt[16];
+  if (nt_dev && *nt_dev < 2) {  // fewer than two train rows: no second neighbour, no match (frame.py:30 could not unpack (m, n))
+    if (threadIdx.x == 0) *n_out = 0;
+    return;
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int running = 0;
   for (int start = 0; start < nq; start += 1024) {
@@ -387,7 +394,7 @@ VS_API int vs_match_set_tstage(int v) {
 }
 
 static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_idx, void* d_dist,
-                         bool packed, void* stream) {
+                         bool packed, void* stream, const int* nt_dev = nullptr) {
   VS_TRY(check_args(ctx, d_q, nq, d_t, nt, "vs_hamming_knn2_dev"));
   if (nq == 0) return VS_OK;
   if (!d_idx || (!packed && !d_dist)) return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_hamming_knn2_dev");
@@ -431,12 +438,12 @@ static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
     VS_HIP(ctx, hipEventCreate(&pr.e1));
     VS_HIP(ctx, hipEventRecord(pr.e0, s));
   }
-  typedef void (*knn2_fn)(const uint4*, int, const uint32_t*, int, int, int, uint2*, unsigned*, int2*, int2*);
+  typedef void (*knn2_fn)(const uint4*, int, const uint32_t*, int, int, int, uint2*, unsigned*, int2*, int2*, const int*);
   static const knn2_fn kFn[2][2] = {{hamming_knn2_kernel<false, false>, hamming_knn2_kernel<false, true>},
                                     {hamming_knn2_kernel<true, false>, hamming_knn2_kernel<true, true>}};
   hipLaunchKernelGGL(kFn[packed ? 1 : 0][g_tstage ? 1 : 0], grid, dim3(64 * kWaves), 0, s, (const uint4*)d_q, nq,
                      (const uint32_t*)d_t, nt, chunk_len, sub_len, (uint2*)ms->partial.p, (unsigned*)ms->ticket.p,
-                     (int2*)d_idx, packed ? (int2*)nullptr : (int2*)d_dist);
+                     (int2*)d_idx, packed ? (int2*)nullptr : (int2*)d_dist, nt_dev);
   VS_LAUNCH_CHECK(ctx, "hamming_knn2_kernel");
   if (g_profile) {
     VS_HIP(ctx, hipEventRecord(pr.e1, s));
@@ -535,20 +542,28 @@ VS_API int vs_match_profile_read(float* kernel_ms) {
   return n;
 }
 
-VS_API int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, double ratio,
-                              void* d_match_q, void* d_match_t, void* d_match_d, void* d_n_out, void* stream) {
+// nt_dev != nullptr: at most nt train rows, the actual count is read on the device (internal: vs_track.hip matches a frame
+// whose key-point count the host has not seen)
+int vs_match_ratio_dev_n(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, const int* nt_dev, double ratio,
+                         void* d_match_q, void* d_match_t, void* d_match_d, void* d_n_out, void* stream) {
   VS_TRY(check_args(ctx, d_q, nq, d_t, nt, "vs_match_ratio_dev"));
   if (!d_n_out || (nq > 0 && (!d_match_q || !d_match_t || !d_match_d)))
     return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_match_ratio_dev");
   hipStream_t s = vs_pick_stream(ctx, stream);
   VS_TRY(vs_reserve(ctx, &ctx->d_idx, sizeof(int2) * (size_t)(nq > 0 ? nq : 1)));
   VS_TRY(vs_reserve(ctx, &ctx->d_dist, sizeof(int2) * (size_t)(nq > 0 ? nq : 1)));
-  VS_TRY(vs_hamming_knn2_dev(ctx, d_q, nq, d_t, nt, ctx->d_idx.p, ctx->d_dist.p, s));
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_TRY(knn2_dev_impl(ctx, d_q, nq, d_t, nt, ctx->d_idx.p, ctx->d_dist.p, false, s, nt_dev));
   hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, s, (const int2*)ctx->d_idx.p,
                      (const int2*)ctx->d_dist.p, nq, ratio, (int32_t*)d_match_q, (int32_t*)d_match_t,
-                     (int32_t*)d_match_d, (int32_t*)d_n_out);
+                     (int32_t*)d_match_d, (int32_t*)d_n_out, nt_dev);
   VS_LAUNCH_CHECK(ctx, "ratio_compact_kernel");
   return VS_OK;
+}
+
+VS_API int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, double ratio,
+                              void* d_match_q, void* d_match_t, void* d_match_d, void* d_n_out, void* stream) {
+  return vs_match_ratio_dev_n(ctx, d_q, nq, d_t, nt, nullptr, ratio, d_match_q, d_match_t, d_match_d, d_n_out, stream);
 }
 
 VS_API int vs_hamming_knn2(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx,

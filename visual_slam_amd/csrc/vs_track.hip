@@ -11,7 +11,7 @@ namespace {
 // appends the new frame's observations to the period's camera-major arrays: obs i = (map point mq[i], keypoint mt[i])
 __global__ __launch_bounds__(256) void track_append_kernel(const double* xyz, const float* fxy, const int* mq, const int* mt,
                                                            const int* d_M, double* mo_X, double* mo_uv, int* cam_start,
-                                                           int slot, int cap_obs, int* flags) {
+                                                           int slot, int cap_obs, int* flags, const int* d_nkp) {
   const int base = cam_start[slot];
   int M = *d_M;
   if (base + M > cap_obs) {
@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void track_append_kernel(const double* xyz, co
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     cam_start[slot + 1] = base + M;
     flags[1] = M;  // the count PnP and the host see (clamped)
+    flags[2] = *d_nkp;  // the frame's key-point count: the host reads it with the results, not in the middle of the frame
   }
 }
 
@@ -53,6 +54,7 @@ __global__ __launch_bounds__(256) void track_push_kernel(const double* xyz, cons
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     cam_start[slot + 1] = base + M;
     flags[1] = M;
+    flags[2] = 0;  // no key points on this path
   }
 }
 
@@ -161,16 +163,10 @@ int track_front_half(vs_ctx* ctx, int set, const uint8_t* bgr, int w, int h_img,
   if (stride == pitch) VS_HIP(ctx, hipMemcpyAsync(img->p, bgr, (size_t)pitch * h_img, hipMemcpyHostToDevice, s));
   else VS_HIP(ctx, hipMemcpy2DAsync(img->p, pitch, bgr, stride, 3 * (size_t)w, h_img, hipMemcpyHostToDevice, s));
   VS_TRY(vs_detect_describe_bgr_dev(ctx, img->p, w, h_img, pitch, thr, T.max_kp, d + F.fxy, d + F.fscore, d + F.fdesc, d + F.fn, s));
-  int* h_n = (int*)ctx->h_track.p + 4 * set;
-  VS_HIP(ctx, hipMemcpyAsync(h_n, d + F.fn, sizeof(int), hipMemcpyDeviceToHost, s));
-  VS_HIP(ctx, hipStreamSynchronize(s));
-  const int n_kp = h_n[0];
-  T.front_nkp[set] = n_kp;
-  if (n_kp >= 2) {
-    VS_TRY(vs_match_ratio_dev(ctx, d + L.mapdesc, T.n_points, d + F.fdesc, n_kp, ratio, d + F.mq, d + F.mt, d + F.md, d + F.M, s));
-  } else {
-    VS_HIP(ctx, hipMemsetAsync(d + F.M, 0, sizeof(int), s));
-  }
+  // the matcher is launched for max_kp train rows at most and reads the actual key-point count on the device (fewer than
+  // two: no matches): the front half needs no host synchronisation, the count reaches the host with the frame's results
+  VS_TRY(vs_match_ratio_dev_n(ctx, d + L.mapdesc, T.n_points, d + F.fdesc, T.max_kp, (const int*)(d + F.fn), ratio, d + F.mq,
+                              d + F.mt, d + F.md, d + F.M, s));
   VS_HIP(ctx, hipEventRecord(T.ev_front[set], s));
   return VS_OK;
 }
@@ -190,7 +186,7 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   VS_HIP(ctx, hipStreamWaitEvent(s, T.ev_front[set], 0));
   hipLaunchKernelGGL(track_append_kernel, dim3(8), dim3(256), 0, s, (const double*)(d + L.xyz), (const float*)(d + F.fxy),
                      (const int*)(d + F.mq), (const int*)(d + F.mt), (const int*)(d + F.M), (double*)(d + L.moX),
-                     (double*)(d + L.moUV), (int*)(d + L.cam_start), slot, L.cap_obs, (int*)(d + L.flags));
+                     (double*)(d + L.moUV), (int*)(d + L.cam_start), slot, L.cap_obs, (int*)(d + L.flags), (const int*)(d + F.fn));
   VS_LAUNCH_CHECK(ctx, "track_append_kernel");
   double* cam0 = (double*)(d + L.cam0);
   double* cam1 = (double*)(d + L.cam1);
@@ -333,7 +329,7 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   }
   const int* rb_flags = (const int*)(rb + (L.flags - L.mst));
   const double* rb_res = (const double*)(rb + (L.pnp_res - L.mst));
-  const int M = rb_flags[1], n_kp = T.front_nkp[set];
+  const int M = rb_flags[1], n_kp = rb_flags[2];
   if (rb_flags[0]) return vs_fail(ctx, VS_ENOMEM, "%s: observation capacity of the period exceeded", "vs_track_frame");
   bool copies = false;
   if (xy_out && n_kp > 0) {
@@ -491,7 +487,6 @@ VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const doub
   uint8_t* hp = (uint8_t*)ctx->h_track.p;
   uint8_t* stage = hp + kPinRb + ((L.rb_end - L.mst + 255) & ~(size_t)255);
   T.params[0] = {0.0, 0.0, huber_delta, 0ull, lm_iterations};
-  T.front_nkp[0] = 0;
   const int slot = T.n_frames, k = T.n_frames + 1;
   if (m > 0) {
     memcpy(stage, point_idx, sizeof(int) * (size_t)m);
