@@ -11,6 +11,7 @@ i0 = int(len(rows) * frac)
 prev_end = None
 for r in rows[i0:i0 + count]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("(")[0].split("::")[-1][:28]
+    name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("vsba::", "")
+    name = name.split("(")[0].split("<")[0][:28]
     print("%-28s q%-3s dur %6.1f  gap %7.1f" % (name, r.get("Queue_Id", "?"), (e - s) / 1e3, (s - prev_end) / 1e3 if prev_end else 0.0))
     prev_end = max(prev_end or e, e)
