@@ -880,8 +880,10 @@ __global__ __launch_bounds__(256) void ba_schur_tile(ba_dev D) {
 // [camera slots, Hpl blocks]; (Hll + lambda I)^-1 is inverted while the second is in flight.  Accumulator ownership, the
 // product expressions and the order in which a workgroup's points arrive are those of ba_schur_tile, so the sums are
 // bit-identical; only the blocks of the lower block triangle are produced (the Cholesky reads nothing else).
-constexpr int kSmallPts = 8, kSmallThreads = kCamThreads, kSmallWaves = kSmallThreads / 64;
-constexpr int kSmallRows = (kTileCams + kSmallWaves - 1) / kSmallWaves;
+constexpr int kSmallPts = 8, kSmallThreads = kCamThreads;
+// the product phase is bound by LDS reads (every wave re-reads the B blocks): four waves with three row cameras each move
+// 44 % less than eight with two; the other four waves only help with loading and staging
+constexpr int kProdWaves = 4, kSmallRows = (kTileCams + kProdWaves - 1) / kProdWaves;
 
 // The last ns workgroups produce the slabs; with two linearisations (D.spec) the first nfp * cam_split workgroups run the
 // camera role of the linearisation of a freshly accepted state next to them (its point role ran inside ba_point_trial), so that
@@ -998,9 +1000,9 @@ __global__ __launch_bounds__(kSmallThreads) void ba_schur_small(ba_dev D, int li
         for (int c = 0; c < 3; ++c) sY[o + c] = v[r][0] * sd[c] + v[r][1] * sd[3 + c] + v[r][2] * sd[6 + c];
       }
     __syncthreads();
-    // ---- products into the register accumulators: wave w owns the row cameras w, w + kSmallWaves; branch-free
+    // ---- products into the register accumulators: wave w < kProdWaves owns the row cameras w, w + 4, w + 8; branch-free
     const int ar6 = arow < 6 ? arow : 0;  // lanes 60..63 compute on row 0's operands and never store
-    for (int pb = 0; pb < nb; ++pb) {
+    for (int pb = 0; pb < (wv < kProdWaves ? nb : 0); ++pb) {
       double Bv[18];
       const double* B = sB + (pb * kTileCams + ccam) * 18;
 #pragma unroll
@@ -1008,7 +1010,7 @@ __global__ __launch_bounds__(kSmallThreads) void ba_schur_small(ba_dev D, int li
       const double* sd = sD[pb];
 #pragma unroll
       for (int r = 0; r < kSmallRows; ++r) {
-        const int ls = min(wv + kSmallWaves * r, kTileCams - 1);  // a row beyond the tile repeats the last one, never stored
+        const int ls = min(wv + kProdWaves * r, kTileCams - 1);  // a row beyond the tile repeats the last one, never stored
         const double* Y = sY + (pb * kTileCams + ls) * 18 + 3 * ar6;
         const double y0 = Y[0], y1 = Y[1], y2 = Y[2];
 #pragma unroll
@@ -1023,10 +1025,10 @@ __global__ __launch_bounds__(kSmallThreads) void ba_schur_small(ba_dev D, int li
     }
   }
   double* out = D.slab + (size_t)sb * ((size_t)np * np + np);
-  if (arow < 6) {
+  if (arow < 6 && wv < kProdWaves) {
 #pragma unroll
     for (int r = 0; r < kSmallRows; ++r) {
-      const int ls = wv + kSmallWaves * r;
+      const int ls = wv + kProdWaves * r;
       if (ls >= kTileCams) continue;
       const int row = 6 * ls + arow, col = 6 * ccam;
       if (row < np && col < np && ccam <= ls) {
