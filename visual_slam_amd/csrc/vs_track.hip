@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void track_push_kernel(const double* xyz, cons
 // One key-frame period of the reference's tracking loop (src/v2/main.py:173-214) kept resident on the device: the key
 // frame's map points and descriptors are uploaded once (vs_track_begin); every vs_track_frame uploads only the image
 // and runs detect+describe -> match against the map -> PnP-RANSAC from the previous pose -> append the observations
-// -> motion-only BA over all poses of the period, with one host synchronisation for the keypoint count (the matcher's
-// launch geometry needs it) and one at the end.  Same kernels, same arithmetic as the separate entry points.
+// -> motion-only BA over all poses of the period, with ONE host synchronisation, at the end (the matcher is launched for
+// max_kp train rows and reads the key-point count on the device).  Same kernels, same arithmetic as the separate entry points.
 namespace {
 struct track_front {
   size_t fxy, fscore, fdesc, fn, mq, mt, md, M;
@@ -147,10 +147,10 @@ track_layout layout_of(const vs_ctx* ctx) {
   return track_layout_of(T.n_points, T.cap_frames, T.max_kp, T.pnp_iters > 0 ? T.pnp_iters : 1);
 }
 
-constexpr size_t kPinRb = 4096;  // pinned staging: [0,64) keypoint counts, 1024 LM start state, 2048 record, 4096 read-back
+constexpr size_t kPinRb = 4096;  // pinned staging: 1024 LM start state, 2048 record, 4096 read-back
 
-// Front half of a frame on stream `s`: image upload, detect+describe, (host reads the keypoint count), match against the
-// map.  Ends with ev_front[set] recorded on `s`.
+// Front half of a frame on stream `s`: image upload, detect+describe, match against the map -- enqueue only, no host
+// synchronisation.  Ends with ev_front[set] recorded on `s`.
 int track_front_half(vs_ctx* ctx, int set, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
                      hipStream_t s) {
   auto& T = ctx->track;
