@@ -342,10 +342,10 @@ def test_single_tile_schur_kernel_equals_the_tile_kernel(vs):
 
 
 def test_one_launch_motion_only_solve_equals_the_launch_per_step_form(vs):
-    """Motion-only windows of up to 64 cameras with at most 1024 observations each run the whole LM solve in ONE launch
-    (ba_motion_persistent: observations in registers, a ticket rendezvous after every step); operands, order of operations
-    and the decision are those of the launch-per-step kernel, so the results are bit-identical -- and larger windows keep
-    taking the launch-per-step form."""
+    """Motion-only windows of up to 64 cameras run the whole LM solve in ONE launch (ba_motion_persistent: observations in
+    registers -- beyond 1024 per camera re-read from memory -- and a mailbox rendezvous after every step); operands, order
+    of operations and the decision are those of the launch-per-step kernel, so the results are bit-identical -- and
+    windows of more cameras keep taking the launch-per-step form."""
     from visual_slam_amd import _capi
     lib = _capi.load()
 
@@ -370,8 +370,9 @@ def test_one_launch_motion_only_solve_equals_the_launch_per_step_form(vs):
 
 def test_one_launch_motion_only_solve_at_its_limits(vs, oracle):
     """64 cameras is the largest window the one-launch form takes (65 falls back to a launch per step), 1024 observations
-    per camera the most its threads keep in registers; information matrices ride along in registers too.  All of them
-    against the oracle, and the two forms against each other where both apply."""
+    per camera the most its threads keep in registers (1025: the instantiation that re-reads the surplus from memory);
+    information matrices ride along in registers too.  All of them against the oracle, and the two forms against each
+    other."""
     from visual_slam_amd import _capi
     lib = _capi.load()
     rng = np.random.default_rng(3)

@@ -2202,6 +2202,10 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
 constexpr int kMoObsRegs = 2;      // observations a thread keeps in registers (kMoThreads * kMoObsRegs per camera)
 static_assert(kMoObsRegs * kMoThreads == kMoPersistObs, "register capacity of ba_motion_persistent");
 
+// OVF: cameras with more observations than the registers hold re-read the rest from memory in every step (same order of
+// accumulation); a separate instantiation, so that the common one keeps its schedule (folding the extra loops into it
+// cost the ICL-NUIM tracking path 6 %).
+template <bool OVF>
 __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int max_steps) {
 #pragma clang fp contract(fast)
   __shared__ double s_all[kMoRows][29];
@@ -2359,6 +2363,30 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
         for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
         acc[27] += E.rho0;
       }
+      if constexpr (OVF) {
+        for (int i = o0 + tid + kMoObsRegs * kMoThreads; i < o1; i += kMoThreads) {
+          const double X[3] = {D.mo_X[3 * (size_t)i], D.mo_X[3 * (size_t)i + 1], D.mo_X[3 * (size_t)i + 2]};
+          edge_t E;
+          eval_edge<true>(D, cam, X, D.mo_uv + 2 * (size_t)i, D.has_info ? D.mo_info + 3 * (size_t)i : nullptr, E);
+          const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+          const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
+          const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
+          double WJ[2][6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            WJ[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
+            WJ[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
+          }
+          int n = 0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJ[0][l] + E.Jj[1][k] * WJ[1][l];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
+          acc[27] += E.rho0;
+        }
+      }
       block_reduce28(acc, s_all, s_grp, s_sum, tid);  // s_sum: upper triangle (21) + b (6) + chi2, kept across retries
       if (lin_only) {
         if (tid == 0) {
@@ -2463,6 +2491,14 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
       eval_edge<false>(D, tcam, oX[j], oUV[j], D.has_info ? oW[j] : nullptr, E);
       chi += E.rho0;
     }
+    if constexpr (OVF) {
+      for (int i = o0 + tid + kMoObsRegs * kMoThreads; i < o1; i += kMoThreads) {
+        const double X[3] = {D.mo_X[3 * (size_t)i], D.mo_X[3 * (size_t)i + 1], D.mo_X[3 * (size_t)i + 2]};
+        edge_t E;
+        eval_edge<false>(D, tcam, X, D.mo_uv + 2 * (size_t)i, D.has_info ? D.mo_info + 3 * (size_t)i : nullptr, E);
+        chi += E.rho0;
+      }
+    }
     // workgroup sum of chi: xor-butterfly inside each wave, then the wave totals in wave order
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) chi += __shfl_xor(chi, d);
@@ -2484,6 +2520,9 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
     g_state[1] = st;
   }
 }
+
+template __global__ void ba_motion_persistent<false>(ba_dev D, int max_steps);
+template __global__ void ba_motion_persistent<true>(ba_dev D, int max_steps);
 
 }  // namespace vsba
 
@@ -3085,10 +3124,11 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     int step = 0;
     int cam_obs_max = 0;
     for (int c = 0; c < nfp; ++c) cam_obs_max = std::max(cam_obs_max, cam_start[c + 1] - cam_start[c]);
-    const bool persistent = vsba::g_motion_variant == 0 && nfp <= kMoPersistCameras && cam_obs_max <= kMoPersistObs && max_steps < 4000;
+    const bool persistent = vsba::g_motion_variant == 0 && nfp <= kMoPersistCameras && max_steps < 4000;
     for (;;) {
       if (persistent) {  // the whole solve in one launch; the final record lands in both state slots
-        hipLaunchKernelGGL(ba_motion_persistent, dim3(nfp), dim3(kMoThreads), 0, s, Dm, max_steps);
+        if (cam_obs_max <= kMoPersistObs) hipLaunchKernelGGL(ba_motion_persistent<false>, dim3(nfp), dim3(kMoThreads), 0, s, Dm, max_steps);
+        else hipLaunchKernelGGL(ba_motion_persistent<true>, dim3(nfp), dim3(kMoThreads), 0, s, Dm, max_steps);
         VS_LAUNCH_CHECK(ctx, "ba_motion_persistent");
         VS_HIP(ctx, hipMemcpyAsync(hms, d_mst, sizeof(mo_state), hipMemcpyDeviceToHost, s));
         VS_HIP(ctx, hipStreamSynchronize(s));
