@@ -429,3 +429,31 @@ def test_resident_tracking_one_launch_solve_equals_launch_per_step(vs):
     finally:
         lib.vs_ba_set_motion_variant(0)
     assert np.array_equal(ref, got) and np.array_equal(ref, piped)
+
+
+def test_resident_tracking_survives_frames_without_key_points(vs, oracle):
+    """The resident front half never brings the key-point count to the host: the matcher is launched for max_kp train rows
+    and reads the count on the device.  A blank frame (no corner anywhere: zero key points) and a frame with a single
+    corner (one key point: no second neighbour) must give zero matches, leave the pose at the previous one, and the period
+    must go on with the next real frame exactly as a period that never saw them would from the same state."""
+    from visual_slam_amd import harness
+    frames, depth0 = harness.load_sequence(4)
+    xy, _, desc = oracle.detect_describe_bgr(frames[0], 20, 3000)
+    X = harness.backproject(xy, depth0)
+    blank = np.full_like(frames[0], 90)
+    one = blank.copy()
+    one[200:216, 300:316] = 255  # a bright square: at most a handful of corners, all in one place
+    vs.track_begin(X, desc, np.eye(4), ICL_NUIM_K, max_frames=8)
+    try:
+        r1 = vs.track_frame(frames[1], seed=1)
+        rb = vs.track_frame(blank, seed=2, want_keypoints=True)
+        assert rb["n_matches"] == 0 and not rb["pnp_found"] and rb["xy"].shape[0] == 0
+        assert np.allclose(rb["poses"][2], r1["poses"][1], rtol=0, atol=1e-6)  # nothing to go on: the start pose (frame 1's) stays
+        ro = vs.track_frame(one, seed=3, want_keypoints=True)
+        assert ro["n_matches"] <= ro["xy"].shape[0] and not ro["pnp_found"]
+        r2 = vs.track_frame(frames[2], seed=4)
+        assert r2["n_matches"] > 100 and r2["pnp_found"]
+        assert np.all(np.isfinite(r2["poses"]))
+        assert np.allclose(r2["poses"][1], r1["poses"][1], atol=5e-3)  # the first frame's pose only moves within the BA's reach
+    finally:
+        vs.track_end()
