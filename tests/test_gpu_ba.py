@@ -426,3 +426,15 @@ def test_one_launch_motion_only_solve_is_deterministic(vs):
         got = vs.ba_solve(*args)
         assert np.array_equal(ref["poses"], got["poses"]) and np.array_equal(ref["chi2_trace"], got["chi2_trace"])
         assert ref["trials"] == got["trials"]
+
+
+def test_scale_edges_with_the_camera_role_split_over_workgroups(vs, oracle):
+    """More than 512 observations per camera: several workgroups share a camera in the linearisation's camera role; with
+    scale edges the last of them to arrive assembles the block row (the EdgeSBAScale terms live there), without them
+    ba_reduce adds the parts.  Both against the oracle, on a single-tile window (the folded path) and on a two-tile one."""
+    for nc in (5, 14):
+        w = ba_workload(n_cams=nc, n_points=900, seed=40 + nc, noise_px=0.3, outlier_frac=0.02)
+        meas = [np.linalg.norm(w["poses_gt"][i][:3, 3] - w["poses_gt"][i - 1][:3, 3]) * (1.0 + 0.03 * i) for i in range(1, nc)]
+        se = (list(range(0, nc - 1)), list(range(1, nc)), meas)
+        _compare(vs.ba_solve(*_args(w), scale_edges=se), oracle.ba_solve(*_args(w), scale_edges=se))
+        _compare(vs.ba_solve(*_args(w)), oracle.ba_solve(*_args(w)))
