@@ -33,12 +33,19 @@ os.environ.setdefault("VS_DATASET_DIR", os.path.join(ROOT, "tests", "golden", "i
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_MATCH = 32           # SURVEY.md 8d streamed-operand model: one 32-byte train descriptor per evaluation
-# integer VALU: one wave64 op per 4 cycles per SIMD = 16 lanes/clk (tools/valu_probe*.hip: xor/bcnt/min/med3 4.2-4.4 cycles
-# at the clock the chip holds; only f32 FMA-class ops issue at twice that) x 4 SIMD x 256 CU x 2.4 GHz
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # 3.93e13 lane-ops/s
-# main loop of hamming_knn2_kernel (train rows staged through LDS), from its ISA: per 8 distances 64 v_xor + 64 v_bcnt +
-# 8 v_lshl_or + 4 v_med3 + 4 v_min3 + 4 v_min = 148 VALU instructions
-OPS_PER_MATCH = 148.0 / 8.0
+# integer VALU issue on gfx950 (tools/valu_probe*.hip, profiles/r02_valu_probe*.log): v_xor/v_and/v_or/v_add_u32 with
+# VGPR-only sources issue one wave64 op per 2 cycles per SIMD, everything else in the loop (v_bcnt, v_min3, v_med3, v_min,
+# v_lshl_or) one per 4 cycles.  Main loop of hamming_knn2_kernel (train rows staged through LDS), from its ISA: per 8
+# distances 64 v_xor + 64 v_bcnt + 8 v_lshl_or + 4 v_med3 + 4 v_min3 + 4 v_min = 148 VALU instructions.
+OPS_2CYCLE, OPS_4CYCLE = 64.0, 84.0
+OPS_PER_MATCH = (OPS_2CYCLE + OPS_4CYCLE) / 8.0
+CLOCK_HZ, N_SIMD = 2.4e9, 256 * 4
+# uniform 4-cycle model (round 2's yard-stick): 16 lanes/clk/SIMD
+VALU_PEAK_UNIFORM_4CYCLE = N_SIMD * 16 * CLOCK_HZ                                   # 3.93e13 lane-ops/s
+# mix-specific ceiling (the roofline `peak`): the 148 instructions of 8 distances need 64*2 + 84*4 = 464 issue cycles
+VALU_PEAK_LANE_OPS = N_SIMD * 64 * (OPS_2CYCLE + OPS_4CYCLE) / (2 * OPS_2CYCLE + 4 * OPS_4CYCLE) * CLOCK_HZ   # 5.02e13
+# what a dependent xor -> bcnt stream was MEASURED to issue at with 5 waves per SIMD (chain_grp_vv: 1.597 ns per instruction)
+VALU_PROBE_MIX_LANE_OPS = N_SIMD * 64 / 1.597e-9                                     # 4.10e13
 LAUNCH_BOUNDARY_US = 1.45      # dependent kernel boundary on MI355X (MI355X_MICROARCH.md price list, row "boundary")
 PCIE_GBS = 63.0
 
@@ -94,6 +101,77 @@ def all_threads_rate(fn, threads, seconds=6.0):
     for th in ths:
         th.join()
     return sum(counts) / (time.perf_counter() - t0)
+
+
+def cpu_trackers_all_cores(cores, seconds=8.0):
+    """frames/s of the CPU oracle with EVERY host core busy: one sequential tracker per core on the 20 fixture frames.
+    The tracker's glue is Python, so the trackers are spread over worker PROCESSES (a few threads each; one interpreter
+    lock would cap the figure); the workers never touch the GPU (no torch, no Context).  Each worker counts the frames it
+    completes inside one common wall-clock window."""
+    import subprocess
+    procs_n = max(1, min(32, cores // 4))
+    per = max(1, cores // procs_n)
+    start = time.time() + 6.0 + 0.02 * procs_n   # imports + PNG decode + warm-up happen before the window opens
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-tracker-worker", str(per), repr(start), repr(seconds)]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(procs_n)]
+    frames = 0.0
+    late = 0
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        last = [ln for ln in out.splitlines() if ln.startswith("frames ")]
+        if last:
+            frames += float(last[-1].split()[1])
+            late += int(last[-1].split()[2])
+    return {"threads": procs_n * per, "processes": procs_n, "threads_per_process": per, "frames_per_s": frames / seconds,
+            "workers_late_for_the_window": late, "window_s": seconds,
+            "note": "one sequential CPU-oracle tracker per host core on the same 20 frames (streams side by side), "
+                    "%d processes x %d threads" % (procs_n, per)}
+
+
+def cpu_tracker_worker(threads, start, seconds):
+    """Worker of cpu_trackers_all_cores (runs in its own process, CPU only): `threads` trackers, frames completed inside
+    [start, start + seconds) of the wall clock."""
+    import threading
+    from oracle import oracle
+    from visual_slam_amd.harness import HUBER, load_sequence, track_sequence
+    oracle.load()
+
+    def detect(bgr):
+        xy, _, desc = oracle.detect_describe_bgr(bgr, 20, 3000)
+        return xy, desc
+
+    def match(q, t):
+        mq, mt, _ = oracle.match_ratio(q, t, 0.8)
+        return mq, mt
+
+    def ba(*problem):
+        return oracle.ba_solve(*problem, huber_delta=HUBER, max_iterations=10)
+
+    def pnp(obj, img, K4, pose0, seed=0):
+        return oracle.pnp_ransac(obj, img, K4, pose0, seed=seed)
+
+    frames, depth0 = load_sequence(20)
+    track_sequence(detect, match, ba, frames[:3], depth0, pnp=pnp)
+    late = int(time.time() > start)
+    counts = [0.0] * threads
+
+    def work(i):
+        while time.time() < start:
+            time.sleep(0.001)
+        while True:
+            t0 = time.time()
+            if t0 >= start + seconds:
+                break
+            track_sequence(detect, match, ba, frames, depth0, pnp=pnp)
+            t1 = time.time()
+            counts[i] += len(frames) * (min(t1, start + seconds) - t0) / (t1 - t0)  # the run that crosses the end counts pro rata
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    print("frames %.3f %d" % (sum(counts), late))
 
 
 def cpu_baseline(nq, nt):
@@ -196,6 +274,8 @@ def ba_leg(ctx, cpu=True):
     out = {"workload": "BASELINE.json configs[3]: 10 cameras x 2000 points, 20000 residuals, Huber, 10 LM iterations",
            "ms_per_solve": med * 1e3, "ms_per_solve_min": min(ts) * 1e3, "repetitions": len(ts), "statistic": "median",
            "lm_trials": trials, "us_per_trial": med * 1e6 / max(trials, 1),
+           # a trial of a single-tile window is four dependent launches (schur+cameras, reduce, solve, point_trial)
+           "launches_per_trial": 4, "launch_floor_us_per_trial": 4 * LAUNCH_BOUNDARY_US,
            "chi2": [float(g["chi2_initial"]), float(g["chi2_final"])],
            # ~178 B and ~150 flop per residual per linearisation
            "algorithmic_bytes_per_trial": 178 * n_res,
@@ -209,10 +289,11 @@ def ba_leg(ctx, cpu=True):
         cmed, _ = median_time(lambda: oracle.ba_solve(*args), 5, warm=1)
         out["cpu_ms_per_solve_1_thread"] = cmed * 1e3
         cores = os.cpu_count() or 1
-        thr = min(cores, 64)
-        rate = all_threads_rate(lambda: oracle.ba_solve(*args), thr, seconds=5.0)
-        out["cpu_all_threads"] = {"threads": thr, "solves_per_s": rate, "ms_per_solve_equivalent": 1e3 / rate,
-                                  "note": "the LM solve is sequential; all-threads = independent solves side by side"}
+        rate = all_threads_rate(lambda: oracle.ba_solve(*args), cores, seconds=6.0)
+        out["cpu_all_threads"] = {"threads": cores, "of_host_cores": cores, "solves_per_s": rate,
+                                  "ms_per_solve_equivalent": 1e3 / rate,
+                                  "note": "the LM solve is sequential; all-threads = independent solves side by side, one per "
+                                          "host core (the C solve releases the interpreter lock)"}
         out["gpu_solves_per_s"] = 1.0 / med
         out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
                                                          for a, b in zip(g["poses"], c["poses"])))
@@ -221,7 +302,8 @@ def ba_leg(ctx, cpu=True):
 
 def frames_leg(ctx, cpu=True):
     """frames/s of the 640x480 ICL-NUIM stream (detect+describe -> match -> PnP-RANSAC -> motion-only BA), GPU path and -- as the
-    checker/baseline only -- the CPU oracle through the same harness.  Medians over >= 20 repetitions."""
+    checker/baseline only -- the CPU oracle through the same harness.  GPU legs: medians of 20 repetitions (minima
+    beside them); CPU: median of 5 on one core, and one tracker per host core."""
     from visual_slam_amd.harness import HUBER, bench_frames, dataset_dir, load_sequence, track_sequence
     out, poses = bench_frames(ctx, repeats=20)
     if cpu:
@@ -243,17 +325,23 @@ def frames_leg(ctx, cpu=True):
             return oracle.pnp_ransac(obj, img, K4, pose0, seed=seed)
 
         frames, depth0 = load_sequence(20)
-        t0 = time.perf_counter()
-        cposes, cstages, _ = track_sequence(detect, match, ba, frames, depth0, pnp=pnp)
-        cdt = time.perf_counter() - t0
+        cts, cposes, cstages = [], None, None
+        track_sequence(detect, match, ba, frames[:3], depth0, pnp=pnp)
+        for _ in range(5):
+            t0 = time.perf_counter()
+            cposes, cstages, _ = track_sequence(detect, match, ba, frames, depth0, pnp=pnp)
+            cts.append(time.perf_counter() - t0)
+        cdt = statistics.median(cts)
         out["cpu_frames_per_s"] = len(frames) / cdt
+        out["cpu_frames_per_s_max"] = len(frames) / min(cts)
+        out["cpu_statistic"] = "median of %d runs" % len(cts)
         out["cpu_stage_ms_per_frame"] = {k: v / len(frames) * 1e3 for k, v in cstages.items()}
         out["cpu_cores_used"] = 1
         cores = os.cpu_count() or 1
-        thr = min(cores, 32)
-        rate = all_threads_rate(lambda: track_sequence(detect, match, ba, frames, depth0, pnp=pnp), thr, seconds=8.0)
-        out["cpu_all_threads"] = {"threads": thr, "frames_per_s": rate * len(frames),
-                                  "note": "one sequential tracker per host thread on the same 20 frames (streams side by side)"}
+        try:
+            out["cpu_all_threads"] = cpu_trackers_all_cores(cores)
+        except Exception as e:
+            out["cpu_all_threads"] = {"error": repr(e)}
         out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
                                                          for a, b in zip(poses, cposes)))
     # the full headless driver (main.py's tracking loop + key-frame insertion: triangulation + local BA), class API
@@ -333,6 +421,9 @@ def timed_steps(step, drain, fence, steps, warmup, torch, dist, use_dist, dev, c
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-tracker-worker":  # CPU-only helper process of the frames leg
+        cpu_tracker_worker(int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4]))
+        return
     args = parse()
     import torch
     import torch.distributed as dist
@@ -360,7 +451,7 @@ def main():
     vctx._DEFAULT = ctx
     lib = _capi.load()
     if args.target_blocks:
-        lib.vs_match_set_target_blocks(args.target_blocks)
+        ctx.tune_match(target_blocks=args.target_blocks)
 
     nq, nt = args.nq, args.nt
     q_np, t_np = match_workload(nq, nt)
@@ -375,12 +466,12 @@ def main():
 
     pending = []
 
-    def make_step(qq, tt, n_total):
+    def make_step(qq, tt, n_total, single=False):
         """One pass of the match over this rank's batch: ONE C call (ShardedMatcher.plan).  With a collective, the
         all-gather of step k is started asynchronously and collected after the kernels of step k+1 are enqueued (two
         rotating buffer sets), so the exchange overlaps the next step's compute; drain() collects the last one inside
         the timed region."""
-        plan = matcher.plan(qq, tt, n_total, single_stream=args.single_stream, in_flight=args.in_flight)
+        plan = matcher.plan(qq, tt, n_total, single_stream=args.single_stream or single, in_flight=args.in_flight)
         plans.append(plan)
 
         def step():
@@ -408,6 +499,7 @@ def main():
     # steps of the headline follow the last cfg5 step without an idle gap.
     import gc
     head_step = make_step(q, t, nq * world)
+    solo_step = make_step(q, t, nq * world, single=True)  # the same step, one launch at a time on the library's stream
     gc.collect()
     gc.disable()
     cfg5 = None
@@ -432,6 +524,7 @@ def main():
                     "ms_per_step": ms5, "gmatches_per_s": float(Q5) * T5 / (ms5 * 1e-3) / 1e9,
                     "ms_per_step_compute_only": ms5c, "collective_overhead_ms": ms5 - ms5c,
                     "valu_frac_compute_only": OPS_PER_MATCH * float(per5) * T5 / (ms5c * 1e-3) / VALU_PEAK_LANE_OPS,
+                    "valu_frac_compute_only_uniform_4cycle": OPS_PER_MATCH * float(per5) * T5 / (ms5c * 1e-3) / VALU_PEAK_UNIFORM_4CYCLE,
                     "note": "collective_overhead_ms = step with the all-gather (overlapped with the next step's kernels) "
                             "minus the same step without it; max over ranks"}
         except Exception as e:  # all ranks take the same path: the collectives inside stay matched
@@ -439,26 +532,29 @@ def main():
 
     plans.append(head_step.plan)  # drain() collects from the newest plan
     elapsed, _ = timed_steps(head_step, drain, fence, args.steps, args.warmup, torch, dist, use_dist, dev, collect=False)
+    # the same K steps under the same contract with ONE step in flight (one stream): the mode roofline.frac is measured in
+    plans.append(solo_step.plan)
+    elapsed1, _ = timed_steps(solo_step, drain, fence, args.steps, args.warmup, torch, dist, use_dist, dev, collect=False)
     gc.enable()
     q5 = t5 = None
     ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step_1 = elapsed1 / args.steps * 1e3
     total_matches = float(nq) * nt * world
     value = total_matches / (ms_per_step * 1e-3) / 1e9
+    value_1 = total_matches / (ms_per_step_1 * 1e-3) / 1e9
 
     # ---- dominant kernel (hamming_knn2_kernel): HIP events recorded by the library on the launch stream around each
     # launch of K more steps, in this process, right after the timed region
     roof = None
     if rank == 0:
         import ctypes as C
-        lib.vs_match_profile.argtypes = [C.c_int]
-        lib.vs_match_profile_read.argtypes = [C.POINTER(C.c_float)]
-        lib.vs_match_profile(1)
+        lib.vs_match_profile(ctx.handle, 1)
         for _ in range(args.steps):
             matcher.knn2_local_shard(q, t)
         torch.cuda.synchronize()
         km = C.c_float(0)
-        ncalls = lib.vs_match_profile_read(C.byref(km))
-        lib.vs_match_profile(0)
+        ncalls = lib.vs_match_profile_read(ctx.handle, C.byref(km))
+        lib.vs_match_profile(ctx.handle, 0)
         # the same launches timed as ONE region (a single event pair around K back-to-back launches): the per-launch
         # pairs above put an event between any two kernels, which keeps them ~7 us apart
         solo = matcher.plan(q, t, nq * world, single_stream=True)  # one launch at a time: a launch's own duration
@@ -486,7 +582,7 @@ def main():
         alg_bytes = BYTES_PER_MATCH * pairs
         traffic = None
         pmc_src = None
-        for name in ("r02_pmc_match.json", "r01_pmc_match.json"):
+        for name in ("r03_pmc_match.json", "r02_pmc_match.json", "r01_pmc_match.json"):
             try:  # HBM bytes per launch from the committed PMC passes (profiles/), only for the workload they were taken on
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if (nq, nt) == (10000, 10000):
@@ -496,22 +592,35 @@ def main():
                 break
             except Exception:
                 continue
+        frac_of = lambda ms, peak: (lane_ops / (ms * 1e-3)) / peak  # noqa: E731
         roof = {"bound": "valu", "achieved": achieved / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "Tlane-op/s",
                 "frac": achieved / VALU_PEAK_LANE_OPS, "traffic": traffic,
                 "kernel": "hamming_knn2_kernel", "kernel_ms": kernel_ms, "profiled_calls": int(ncalls),
+                "measured_in": "single_stream: one launch at a time on one stream -- the mode of value_single_stream / "
+                               "ms_per_step_single_stream, NOT of the headline value (two steps in flight on two streams)",
                 "kernel_ms_source": "HIP events on the launch stream: one pair around K launches issued back to back on ONE "
-                                    "stream (no overlap between launches), divided by K; includes the ~1.5 us kernel boundary. "
-                                    "The timed steps themselves keep two launches in flight on two streams (ms_per_step)",
-                "steps_in_flight": 1 if args.single_stream else args.in_flight,
+                                    "stream (no overlap between launches), divided by K; includes the ~1.5 us kernel boundary",
+                "steps_in_flight_of_value": 1 if args.single_stream else args.in_flight,
                 "kernel_ms_event_pair_per_launch": kernel_ms_isolated, "kernel_ms_busy_start": busy_ms,
                 "lane_ops_per_match": OPS_PER_MATCH,
                 "lane_ops_model": "ISA of the main loop: per 8 distances 64 v_xor_b32 + 64 v_bcnt_u32_b32 + 8 v_lshl_or_b32 + "
                                   "4 v_med3_u32 + 4 v_min3_u32 + 4 v_min_u32; SQ_INSTS_VALU (profiles/) = this x 1e8 / 64 + 5 %",
-                "peak_model": "integer VALU issues one wave64 op per 4 cycles per SIMD: 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz "
-                              "(v_bcnt / v_min3 / v_med3 / v_lshl_or and any op with an SGPR source; VGPR-only v_xor issues faster, "
-                              "which is why its operands are staged into VGPRs -- tools/valu_probe3.hip, profiles/r02_valu_probe*.log)",
+                "peak_model": "mix-specific integer-VALU ceiling: the 64 VGPR-only v_xor of 8 distances issue at one wave64 op per "
+                              "2 cycles per SIMD, the other 84 instructions (v_bcnt / v_lshl_or / v_med3 / v_min3 / v_min) at one "
+                              "per 4 cycles: 148 x 64 lanes / 464 cycles x 1024 SIMDs x 2.4 GHz (tools/valu_probe2/3.hip, "
+                              "profiles/r02_valu_probe*.log)",
                 "valu_ceiling_gmatches": VALU_PEAK_LANE_OPS / OPS_PER_MATCH / 1e9,
-                "frac_whole_step": (lane_ops / (ms_per_step * 1e-3)) / VALU_PEAK_LANE_OPS if world == 1 else None,
+                "frac_two_in_flight": frac_of(ms_per_step, VALU_PEAK_LANE_OPS) if world == 1 else None,
+                "frac_whole_step_single_stream": frac_of(ms_per_step_1, VALU_PEAK_LANE_OPS) if world == 1 else None,
+                "against_uniform_4cycle_peak": {
+                    "peak": VALU_PEAK_UNIFORM_4CYCLE / 1e12, "frac": achieved / VALU_PEAK_UNIFORM_4CYCLE,
+                    "frac_two_in_flight": frac_of(ms_per_step, VALU_PEAK_UNIFORM_4CYCLE) if world == 1 else None,
+                    "note": "round 2's yard-stick: every op priced at one wave64 op per 4 cycles per SIMD (understates the "
+                            "roof by 1.28x for this mix: the xor operands are staged into VGPRs precisely to issue faster)"},
+                "against_measured_mix_rate": {
+                    "peak": VALU_PROBE_MIX_LANE_OPS / 1e12, "frac": achieved / VALU_PROBE_MIX_LANE_OPS,
+                    "note": "what a dependent xor -> bcnt stream was measured to issue at on this chip with 5 waves per SIMD "
+                            "(tools/valu_probe3.hip chain_grp_vv: 1.597 ns per wave64 instruction per SIMD)"},
                 "hbm_measured": None if traffic is None else {
                     "bytes_per_launch": traffic, "GBps": traffic / (kernel_ms * 1e-3) / 1e9,
                     "frac_of_8TBps": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -522,7 +631,7 @@ def main():
                     "bound": "hbm", "model": "SURVEY.md 8d streamed-operand: 32 B per distance evaluation",
                     "algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,
                     "peak_GBps": HBM_PEAK_GBS, "frac": alg_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "note": "> 1 by construction: train rows are reused from SGPRs, queries from VGPRs, so this model cannot "
+                    "note": "> 1 by construction: train rows are reused from LDS, queries from VGPRs, so this model cannot "
                             "bound the kernel; kept because north_star words its target (>= 0.6) in it"},
                 "kernels": {}}
 
@@ -558,6 +667,9 @@ def main():
             "metric": "10k x 10k 256-bit Hamming 2-NN brute-force match throughput", "value": value,
             "unit": "Gmatches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value_mode": "%d steps in flight on as many streams (throughput, not the latency of one launch)"
+                          % (1 if args.single_stream else args.in_flight),
+            "value_single_stream": value_1, "ms_per_step_single_stream": ms_per_step_1,
             "dtype": "u32 (xor + popcount on 256-bit descriptors)", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: %d x %d x 256-bit descriptors, k=2, per GPU%s"
                                    % (nq, nt, "" if world == 1 else "; %d query shards + RCCL all-gather (16 B/query, overlapped with the next step)" % world),
@@ -590,7 +702,7 @@ def main():
                     "bound": "latency", "us_per_lm_trial": lb["us_per_trial"],
                     "algorithmic_bytes_per_trial": lb["algorithmic_bytes_per_trial"],
                     "hbm_frac_of_8TBps": lb["hbm_frac_of_8TBps"],
-                    "launch_floor_us_per_trial": None}
+                    "launch_floor_us_per_trial": lb["launch_floor_us_per_trial"]}
             except Exception as e:
                 line["local_ba"] = {"error": repr(e)}
         if not args.no_frames:

@@ -38,7 +38,7 @@ typedef enum vs_status {
   VS_ENCCL = -6   /* RCCL is not loaded in the process, or the all-gather failed */
 } vs_status;
 
-#define VS_ABI_VERSION 2
+#define VS_ABI_VERSION 3
 #define VS_DESC_BYTES 32 /* BRIEF-256 */
 
 /* ---- context ---------------------------------------------------------------------------------------------- */
@@ -120,16 +120,24 @@ int vs_hamming_knn2_packed_dev(vs_ctx* ctx, const void* d_q, int nq, const void*
  * 8 GPUs of one node with an RCCL all-gather of per-shard best matches over xGMI"; the call it shards is knnMatch,
  * src/v2/frame.py:23).  Rank `rank` of `world` owns queries [rank*per, rank*per + nq_shard) of the full set, per =
  * ceil(Q / world); the train set is replicated, so rows carry GLOBAL train indices and no cross-rank tie-break exists.
+ *   0. ordering of the compute stream, so that a caller may keep several steps in flight on several streams:
+ *      - if `done_event` != NULL the compute stream first waits for it AS RECORDED BY THE PREVIOUS STEP ON THIS GATHER
+ *        BUFFER (that step's all-gather sends from, and receives into, the rows the kernel overwrites); keep one event
+ *        per gather buffer.  An event that was never recorded counts as complete;
+ *      - if `after_stream` != NULL (and is not the compute stream) the compute stream is ordered behind everything
+ *        enqueued on after_stream so far: the producers of q / t and the consumers of d_gathered's previous results.
+ *      The inputs of a step must stay untouched until that step's done_event has completed.
  *   1. the match kernel writes this rank's packed rows straight into its slot of d_gathered (int32[world*per][4],
  *      16-byte aligned) on `compute_stream` (NULL: the context's stream);
- *   2. if world > 1 (or nccl_comm != NULL): an event orders `comm_stream` behind the kernel and ONE in-place
+ *   2. if nccl_comm != NULL (required when world > 1): an event orders `comm_stream` behind the kernel and ONE in-place
  *      ncclAllGather of per*4 int32 per rank is enqueued there; `done_event` (a hipEvent_t, may be NULL) is recorded
  *      on comm_stream after it.  nccl_comm is the caller's ncclComm_t; RCCL is resolved at run time from the library
- *      already loaded in the process (dlopen), libvslam_hip.so does not link it.
- * Nothing synchronises the host.  With world == 1 and nccl_comm == NULL no collective runs (same code path). */
+ *      already loaded in the process (dlopen), libvslam_hip.so does not link it.  With nccl_comm == NULL no collective
+ *      runs (same code path) and done_event is recorded on the compute stream after the kernel.
+ * Nothing synchronises the host. */
 int vs_hamming_knn2_sharded_dev(vs_ctx* ctx, const void* d_q_shard, int nq_shard, const void* d_t, int nt,
                                 void* d_gathered, int per, int rank, int world, void* nccl_comm, void* compute_stream,
-                                void* comm_stream, void* done_event);
+                                void* comm_stream, void* done_event, void* after_stream);
 /* d_n_out: one int32 in HBM receiving the match count */
 int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, double ratio, void* d_match_q,
                        void* d_match_t, void* d_match_d, void* d_n_out, void* stream);

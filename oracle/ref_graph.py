@@ -1,7 +1,7 @@
-"""Test infrastructure: the reference's own graph construction for the two BA entry points -- the P x F double loop over
+"""TEST INFRASTRUCTURE ONLY (like the rest of oracle/: only tests/ may import it).  The reference's own graph construction for the two BA entry points -- the P x F double loop over
 Point / Frame objects through add_pose / add_point / add_edge / AddScalingEdge (reference src/v2/LocalBA.py:143-190 and
 195-229) -- as a subclass of the product's BundleAdjustment.  The product builds the same problem from the map's
-structure-of-arrays mirror; tests/test_host_api.py checks that both produce identical arrays and identical results."""
+structure-of-arrays mirror; tests/test_host_api.py and tests/test_period_mirror.py check that both produce identical arrays and identical results."""
 import numpy as np
 
 from visual_slam_amd.LocalBA import BundleAdjustment

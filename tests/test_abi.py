@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (vs_\w+)", out))
     assert set(names) <= exported, sorted(set(names) - exported)
     assert set(names) == set(_capi.SIGNATURES), sorted(set(names) ^ set(_capi.SIGNATURES))
-    assert lib.vs_abi_version() == 2
+    assert lib.vs_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header():
@@ -53,3 +53,51 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "vs_oracle" not in txt.replace(
                     "oracle/vs_oracle.c", ""), os.path.join(dirpath, f)
+
+
+def _header_prototypes():
+    txt = open(os.path.join(ROOT, "include", "vslam_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = {}
+    for ret, name, params in re.findall(r"\b(int|void\s*\*|const char\s*\*)\s*(vs_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):
+        protos[name] = [p.strip() for p in params.split(",") if p.strip() and p.strip() != "void"]
+    return protos
+
+
+def test_binding_pointee_types_match_the_header():
+    """The ctypes binding passes plain addresses (void*) for speed; the element type of every pointer parameter is carried
+    by a tag (visual_slam_amd/_capi.py) that _capi.ptr() enforces on the array it is given.  Here every tag -- and every
+    scalar type and the parameter count -- is compared with the prototype in include/vslam_hip.h, so a drift between
+    header and binding is caught without a GPU."""
+    import ctypes as C
+    from visual_slam_amd import _capi
+    scalars = {"int": C.c_int, "double": C.c_double, "size_t": C.c_size_t, "uint64_t": C.c_uint64, "unsigned long long": C.c_uint64}
+    protos = _header_prototypes()
+    assert set(protos) == set(_capi.SIGNATURES)
+    checked = 0
+    for name, (_, argtypes) in _capi.SIGNATURES.items():
+        params = protos[name]
+        assert len(params) == len(argtypes), (name, params, argtypes)
+        for p, a in zip(params, argtypes):
+            if "*" in p:
+                pointee = re.sub(r"\bconst\b", "", p.split("*")[0]).strip()
+                if p.count("*") == 2 or pointee in ("vs_ba_problem", "vs_ba_result"):
+                    assert not hasattr(a, "ctype"), (name, p)  # vs_ctx** / void** / struct pointers: ctypes POINTER types
+                    continue
+                assert getattr(a, "ctype", None) == pointee, (name, p, getattr(a, "ctype", a))
+                checked += 1
+            else:
+                ctype = re.sub(r"\s+\w+$", "", p).strip()
+                assert scalars[ctype] is a, (name, p, a)
+    assert checked > 100
+
+
+def test_ptr_refuses_a_wrong_element_type():
+    import numpy as np
+    from visual_slam_amd import _capi
+    a = np.zeros((4, 2), np.float32)
+    assert _capi.ptr(a, _capi.c_f32p) == a.ctypes.data
+    with pytest.raises(TypeError):
+        _capi.ptr(a, _capi.c_f64p)
+    with pytest.raises(TypeError):
+        _capi.ptr(np.zeros((4, 4), np.uint8)[:, ::2], _capi.c_u8p)

@@ -312,8 +312,6 @@ def test_single_tile_schur_kernel_equals_the_tile_kernel(vs):
     expressions and point order, so with the same partition of the points into slabs the whole LM run is bit-identical; other partitions and multi-batch workgroups change only the
     order in which slab sums are added.  The same holds for the linearisation of accepted states, which this path computes
     inside the trial kernel (points) and next to the Schur workgroups (cameras) instead of in a launch of its own."""
-    from visual_slam_amd import _capi
-    lib = _capi.load()
 
     def solve(w):
         r = vs.ba_solve(*_args(w), max_iterations=6)
@@ -323,22 +321,22 @@ def test_single_tile_schur_kernel_equals_the_tile_kernel(vs):
         # 1540 points: the tile kernel cuts them into 256 slabs of 7 (36 of them empty), ba_schur_small at 7 points per
         # workgroup into 220 -- the same partition, also under the one-workgroup-per-CU cap of the folded path
         w = ba_workload(n_cams=10, n_points=1540, visibility=1.0)
-        lib.vs_ba_set_schur_variant(1, 0, 0)
+        vs.tune_ba(1, 0, 0)
         ref = solve(w)
         for variant in (2, 0):  # 2: ba_schur_small + a linearisation launch per iteration; 0: linearisation folded into the trial
-            lib.vs_ba_set_schur_variant(variant, 7, 512)
+            vs.tune_ba(variant, 7, 512)
             got = solve(w)
             assert all(np.array_equal(a, b) for a, b in zip(ref, got)), variant
         for (nc, npts, vis, per, cap) in [(6, 333, 0.6, 8, 512), (10, 1500, 0.8, 8, 16), (3, 17, 1.0, 8, 512), (10, 2000, 0.9, 5, 64), (10, 2000, 1.0, 8, 512)]:
             w = ba_workload(n_cams=nc, n_points=npts, visibility=vis, seed=nc + npts)
-            lib.vs_ba_set_schur_variant(1, 0, 0)
+            vs.tune_ba(1, 0, 0)
             ref = solve(w)
-            lib.vs_ba_set_schur_variant(0, per, cap)
+            vs.tune_ba(0, per, cap)
             got = solve(w)
             for a, b in zip(ref, got):
                 assert np.allclose(a, b, rtol=1e-9, atol=1e-10), (nc, npts, vis, per, cap)
     finally:
-        lib.vs_ba_set_schur_variant(0, 8, 512)
+        vs.tune_ba(0, 8, 512)
 
 
 def test_one_launch_motion_only_solve_equals_the_launch_per_step_form(vs):
@@ -346,8 +344,6 @@ def test_one_launch_motion_only_solve_equals_the_launch_per_step_form(vs):
     registers -- beyond 1024 per camera re-read from memory -- and a mailbox rendezvous after every step); operands, order
     of operations and the decision are those of the launch-per-step kernel, so the results are bit-identical -- and
     windows of more cameras keep taking the launch-per-step form."""
-    from visual_slam_amd import _capi
-    lib = _capi.load()
 
     def solve(w, **kw):
         fixed = np.ones(len(w["points"]), np.uint8)
@@ -358,14 +354,14 @@ def test_one_launch_motion_only_solve_equals_the_launch_per_step_form(vs):
         for (nc, npts, vis, seed, kw) in [(8, 500, 0.7, 9, {}), (2, 40, 1.0, 3, {}), (19, 420, 1.0, 5, {"max_iterations": 10}),
                                           (30, 1000, 0.9, 7, {"huber_delta": 0.0}), (6, 1500, 1.0, 11, {})]:
             w = ba_workload(n_cams=nc, n_points=npts, seed=seed, point_sigma=0, visibility=vis)
-            lib.vs_ba_set_motion_variant(1)
+            vs.tune_ba(motion_variant=1)
             ref = solve(w, **kw)
-            lib.vs_ba_set_motion_variant(0)
+            vs.tune_ba(motion_variant=0)
             got = solve(w, **kw)
             assert all(np.array_equal(a, b) for a, b in zip(ref, got)), (nc, npts)
             assert ref[2][1] >= 1
     finally:
-        lib.vs_ba_set_motion_variant(0)
+        vs.tune_ba(motion_variant=0)
 
 
 def test_one_launch_motion_only_solve_at_its_limits(vs, oracle):
@@ -373,8 +369,6 @@ def test_one_launch_motion_only_solve_at_its_limits(vs, oracle):
     per camera the most its threads keep in registers (1025: the instantiation that re-reads the surplus from memory);
     information matrices ride along in registers too.  All of them against the oracle, and the two forms against each
     other."""
-    from visual_slam_amd import _capi
-    lib = _capi.load()
     rng = np.random.default_rng(3)
     for (nc, npts, vis, info) in [(65, 300, 0.5, False), (66, 120, 1.0, False), (5, 1024, 1.0, False), (5, 1025, 1.0, False),
                                   (7, 200, 0.9, True)]:
@@ -387,12 +381,12 @@ def test_one_launch_motion_only_solve_at_its_limits(vs, oracle):
             kw["obs_info"] = np.stack([a, b, a + 0.3], axis=1)
         args = (w["poses"], w["pose_fixed"], w["points"], fixed, w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
         try:
-            lib.vs_ba_set_motion_variant(1)
+            vs.tune_ba(motion_variant=1)
             ref = vs.ba_solve(*args, **kw)
-            lib.vs_ba_set_motion_variant(0)
+            vs.tune_ba(motion_variant=0)
             got = vs.ba_solve(*args, **kw)
         finally:
-            lib.vs_ba_set_motion_variant(0)
+            vs.tune_ba(motion_variant=0)
         assert np.array_equal(ref["poses"], got["poses"]) and ref["trials"] == got["trials"], (nc, npts)
         o = oracle.ba_solve(*args, **kw)  # at convergence the accept / reject pattern is rounding noise: compare the optimum
         assert abs(got["chi2_final"] - o["chi2_final"]) <= 1e-9 * max(1.0, o["chi2_final"]), (nc, npts)

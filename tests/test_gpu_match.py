@@ -134,8 +134,6 @@ def test_fused_fold_under_back_to_back_launches(vs, oracle):
     scratch buffers, back to back without host synchronisation in between, and every result is checked -- in both
     train-row staging modes and over several launch geometries (1 chunk = no fold, few, many)."""
     import torch
-    from visual_slam_amd import _capi
-    lib = _capi.load()
     stream = torch.cuda.ExternalStream(vs.stream)
     sets = []
     for seed, (nq, nt) in enumerate([(3000, 5000), (3000, 5000), (2999, 4100)]):
@@ -147,9 +145,9 @@ def test_fused_fold_under_back_to_back_launches(vs, oracle):
             outs = [(torch.empty((3000, 2), dtype=torch.int32, device="cuda"), torch.empty((3000, 2), dtype=torch.int32, device="cuda"))
                     for _ in range(24)]
             for tstage in (0, 1):
-                lib.vs_match_set_tstage(tstage)
+                vs.tune_match(tstage=tstage)
                 for blocks in (0, 12, 300, 4000):
-                    lib.vs_match_set_target_blocks(blocks)
+                    vs.tune_match(target_blocks=blocks)
                     for k, (oi, od) in enumerate(outs):        # 24 launches enqueued back to back
                         dq, dt = dev[k % 3]
                         vs.hamming_knn2_dev(dq.data_ptr(), dq.shape[0], dt.data_ptr(), dt.shape[0], oi.data_ptr(), od.data_ptr())
@@ -159,15 +157,13 @@ def test_fused_fold_under_back_to_back_launches(vs, oracle):
                         n = ridx.shape[0]
                         assert np.array_equal(oi.cpu().numpy()[:n], ridx) and np.array_equal(od.cpu().numpy()[:n], rdist), (tstage, blocks, k)
     finally:
-        lib.vs_match_set_target_blocks(0)
-        lib.vs_match_set_tstage(1)
+        vs.tune_match(target_blocks=0)
+        vs.tune_match(tstage=1)
 
 
 @pytest.mark.parametrize("tstage", [0, 1])
 def test_both_train_staging_modes_bit_exact(vs, oracle, tstage):
-    from visual_slam_amd import _capi
-    lib = _capi.load()
-    lib.vs_match_set_tstage(tstage)
+    vs.tune_match(tstage=tstage)
     try:
         for nq, nt in [(1, 2), (257, 129), (1000, 3000), (5000, 63), (640, 65), (10000, 10000)]:
             q, t = match_workload(nq, nt, n_dup=min(16, nt // 4), seed=nq + 3 * nt)
@@ -175,4 +171,4 @@ def test_both_train_staging_modes_bit_exact(vs, oracle, tstage):
             oidx, odist = oracle.hamming_knn2(q, t, threads=0)
             assert np.array_equal(idx, oidx) and np.array_equal(dist, odist), (tstage, nq, nt)
     finally:
-        lib.vs_match_set_tstage(1)
+        vs.tune_match(tstage=1)

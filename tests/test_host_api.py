@@ -8,7 +8,7 @@ from visual_slam_amd.frame import DMatch, Frame, MatchList
 from visual_slam_amd.map import Map
 from visual_slam_amd.point import Point
 from visual_slam_amd.workloads import ICL_NUIM_K, ba_workload
-from ref_graph import RefLoopBundleAdjustment
+from oracle.ref_graph import RefLoopBundleAdjustment
 
 
 def _frame(i, pose=None, key=False):
@@ -247,3 +247,33 @@ def test_soa_notices_an_overwritten_observation(oracle):
     BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve).motionOnlyBundleAdjustement(a)
     RefLoopBundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve).motionOnlyBundleAdjustement(b)
     assert np.array_equal(_poses(a), _poses(b))
+
+
+def test_correspondences_from_a_generator_and_the_read_only_cached_answer():
+    """Round-2 advisor: AddPointToFrameCorrespondences walks point_ids more than once (mirror, then the Point objects),
+    so a generator -- which the reference's zip() accepts -- must be materialised first; and the cached answer of
+    GetImagePointsWithFrameID is handed to every caller as the same arrays, so they are read-only."""
+    m = Map()
+    f0, f1 = _frame(0, np.eye(4), key=True), _frame(1, np.eye(4))
+    m.AddFrame(0, f0)
+    m.AddParentAndPose(parent_id=0, frame_id=1, frame_obj=f1, rel_pose_trans=np.eye(4), pose=np.eye(4))
+    for pid in range(1, 7):
+        p = Point(np.array([pid, 0.0, 5.0]), pid)
+        p.AddFrame(f0, np.array([10.0 * pid, 20.0]), np.full(32, pid, np.uint8))
+        m.AddPoint3D(pid, p)
+    m.GetImagePointsWithFrameID(0)  # the mirror is in sync: the batch below takes the array fast path
+    uv1 = np.arange(8.0).reshape(4, 2)
+    m.AddPointToFrameCorrespondences((pid for pid in (1, 2, 4, 6)), uv1, np.zeros((4, 32), np.uint8), f1)
+    assert [pid for pid in range(1, 7) if m.GetPoint(pid).IsVisibleTo(1)] == [1, 2, 4, 6]       # the Point objects ...
+    assert [m.GetPoint(pid).GetNVisibleFrames() for pid in (1, 3)] == [2, 1]
+    uv, desc, xyz, ids = m.GetImagePointsWithFrameID(1)                                          # ... and the mirror
+    assert ids.tolist() == [1, 2, 4, 6] and np.array_equal(uv, uv1)
+    m.DiscardOutlierMapPoints(n_visible_frames=2)
+    assert sorted(m.points_3d) == [1, 2, 4, 6]
+    a = m.GetImagePointsWithFrameID(1)
+    b = m.GetImagePointsWithFrameID(1)
+    if a[0] is b[0]:  # served from the cache: the very same objects, hence read-only
+        for arr in a:
+            with pytest.raises(ValueError):
+                arr[...] = 0
+    assert np.array_equal(b[0], uv1) and b[3].tolist() == [1, 2, 4, 6]

@@ -10,7 +10,7 @@ from visual_slam_amd.frame import Frame
 from visual_slam_amd.map import Map
 from visual_slam_amd.point import Point
 from visual_slam_amd.workloads import ICL_NUIM_K, ba_workload
-from ref_graph import RefLoopBundleAdjustment
+from oracle.ref_graph import RefLoopBundleAdjustment
 
 
 class FakePeriodContext:

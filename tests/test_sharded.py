@@ -68,7 +68,8 @@ def test_sharded_knn2_equals_single_process(world, nq, nt):
 
 def _worker_stream(rank, world, port, out):
     """bench.py's ticket pattern on CPU: submit step k+1, then collect step k (two rotating buffer sets), ragged shards,
-    a different query count every step."""
+    14 steps with different data every step -- first different shapes, then eight steps of one shape, so that each of the
+    two buffer sets is overwritten four times while the previous step's ticket is still out."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -84,7 +85,8 @@ def _worker_stream(rank, world, port, out):
         return torch.from_numpy(idx), torch.from_numpy(d)
 
     m = ShardedMatcher(local_knn2=local)
-    sizes = [(101, 64), (64, 80), (101, 64), (7, 33), (250, 40), (101, 64)]   # repeated shapes re-use rotating buffers
+    # repeated shapes re-use the two rotating buffer sets; every step carries different data (seed 200 + k)
+    sizes = [(101, 64), (64, 80), (101, 64), (7, 33), (250, 40), (101, 64)] + [(101, 64)] * 8
     work = [match_workload(nq, nt, n_dup=4, seed=200 + k) for k, (nq, nt) in enumerate(sizes)]
     pending, got = [], []
     for q, t in work:

@@ -10,8 +10,7 @@ from visual_slam_amd.workloads import ba_workload
 
 ctx = Context(0)
 if os.environ.get("SCHUR"):  # "variant,points per workgroup,max slabs" -> the library's tuning hook
-    from visual_slam_amd import _capi
-    _capi.load().vs_ba_set_schur_variant(*[int(v) for v in os.environ["SCHUR"].split(",")])
+    ctx.tune_ba(*[int(v) for v in os.environ["SCHUR"].split(",")])
 for (nc, npts, vis) in [(10, 2000, 1.0), (15, 5000, 0.7)]:
     w = ba_workload(n_cams=nc, n_points=npts, visibility=vis)
     args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])

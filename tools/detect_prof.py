@@ -14,7 +14,7 @@ with torch.cuda.stream(st):
     import ctypes as C
     lib = ctx._lib
     def run():
-        rc = lib.vs_detect_describe_bgr_dev(ctx._h, C.c_void_p(img.data_ptr()), 640, 480, 1920, 20, 3000, C.c_void_p(xy.data_ptr()), C.c_void_p(sc.data_ptr()), C.c_void_p(desc.data_ptr()), C.c_void_p(n.data_ptr()), None)
+        rc = lib.vs_detect_describe_bgr_dev(ctx._h, img.data_ptr(), 640, 480, 1920, 20, 3000, xy.data_ptr(), sc.data_ptr(), desc.data_ptr(), n.data_ptr(), None)
         assert rc == 0
     for _ in range(5): run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

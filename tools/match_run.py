@@ -5,14 +5,12 @@ import os
 
 import torch
 
-from visual_slam_amd import Context, _capi
+from visual_slam_amd import Context
 from visual_slam_amd.workloads import match_workload
 
 nq = nt = 10000
 ctx = Context(0)
-lib = _capi.load()
-lib.vs_match_set_tstage(int(os.environ.get("TSTAGE", "1")))
-lib.vs_match_set_target_blocks(int(os.environ.get("BLOCKS", "0")))
+ctx.tune_match(target_blocks=int(os.environ.get("BLOCKS", "0")), tstage=int(os.environ.get("TSTAGE", "1")))
 stream = torch.cuda.ExternalStream(ctx.stream)
 q_np, t_np = match_workload(nq, nt)
 with torch.cuda.stream(stream):

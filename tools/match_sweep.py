@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import torch
 
-from visual_slam_amd import Context, _capi  # noqa: E402
+from visual_slam_amd import Context  # noqa: E402
 from visual_slam_amd.workloads import match_workload  # noqa: E402
 
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
@@ -18,7 +18,6 @@ blocks = [int(v) for v in os.environ.get("BLOCKS", "0,1024,1280,1536,2048,2560")
 stages = [int(v) for v in os.environ.get("TSTAGE", "0,1").split(",")]
 # 0: train rows from SGPRs, 1: staged via LDS
 ctx = Context(0)
-lib = _capi.load()
 stream = torch.cuda.ExternalStream(ctx.stream)
 q_np, t_np = match_workload(nq, nt)
 with torch.cuda.stream(stream):
@@ -38,9 +37,9 @@ with torch.cuda.stream(stream):
     res = {}
     for rnd in range(5):
       for ts in stages:
-        lib.vs_match_set_tstage(ts)
+        ctx.tune_match(tstage=ts)
         for b in blocks:
-            lib.vs_match_set_target_blocks(b)
+            ctx.tune_match(target_blocks=b)
             for _ in range(3):
                 launch()
             if os.environ.get("FENCE", "0") == "1":

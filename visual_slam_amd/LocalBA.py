@@ -212,7 +212,7 @@ class BundleAdjustment:
     def _graph_from_soa(self, map, frame_fixed, points_fixed, with_scale_edges):
         """Builds the same problem as the reference's P x F double loop (LocalBA.py:164-172 / 207-214) from the map's
         structure-of-arrays mirror: poses in map.frames order, points in map.points_3d order, edges point-major then
-        frame order -- identical arrays, no per-observation Python (tests/ref_graph.py holds the double loop itself and
+        frame order -- identical arrays, no per-observation Python (oracle/ref_graph.py holds the double loop itself and
         the tests that both give the same arrays)."""
         if self._poses or len(self._points) or len(self._obs_pose):
             raise RuntimeError("BundleAdjustment: the graph of this optimizer is already populated (the reference "

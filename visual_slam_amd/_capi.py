@@ -11,10 +11,22 @@ _LIB = None
 
 VS_OK, VS_EINVAL, VS_ENOMEM, VS_EHIP, VS_ENOTPD, VS_ECAP, VS_ENCCL = 0, -1, -2, -3, -4, -5, -6
 
-# Pointer parameters and struct fields are declared void* under element-type names: ctypes then takes a plain address
-# (ndarray.ctypes.data) instead of a typed pointer object, whose construction (data_as / cast) costs ~3 us apiece -- the
-# tracking loop makes some twenty of them per frame.  The element type each entry point expects is in include/vslam_hip.h.
-c_u8p = c_i32p = c_f32p = c_f64p = c_intp = C.c_void_p
+# Typed pointer tags.  A pointer parameter is declared as a subclass of c_void_p that names its pointee type: ctypes then
+# still takes a plain address (ndarray.ctypes.data -- a typed pointer object built with data_as / cast costs ~3 us apiece
+# and the tracking loop makes some twenty per frame), while (a) ptr() below refuses an array whose dtype is not the
+# declared pointee, and (b) tests/test_abi.py compares every tag with the pointee type in include/vslam_hip.h, so a
+# signature drift is caught without a GPU.
+def _tag(name, dtype, ctype):
+    return type(name, (C.c_void_p,), {"dtype": np.dtype(dtype) if dtype is not None else None, "ctype": ctype})
+
+
+c_u8p = _tag("c_u8p", np.uint8, "uint8_t")
+c_i32p = _tag("c_i32p", np.int32, "int32_t")
+c_f32p = _tag("c_f32p", np.float32, "float")
+c_f64p = _tag("c_f64p", np.float64, "double")
+c_intp = _tag("c_intp", np.intc, "int")           # int* out-parameters (passed with ctypes.byref)
+c_ctxp = _tag("c_ctxp", None, "vs_ctx")           # vs_ctx*
+c_voidp = _tag("c_voidp", None, "void")           # device pointers, streams, events, communicators
 
 
 class VsError(RuntimeError):
@@ -48,51 +60,57 @@ class BAResult(C.Structure):
 SIGNATURES = {
     "vs_abi_version": (C.c_int, []),
     "vs_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
-    "vs_destroy": (C.c_int, [C.c_void_p]),
-    "vs_last_error": (C.c_char_p, [C.c_void_p]),
-    "vs_stream": (C.c_void_p, [C.c_void_p]),
-    "vs_synchronize": (C.c_int, [C.c_void_p]),
-    "vs_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
-    "vs_host_free": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "vs_gray_mean3_u8": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, c_u8p]),
-    "vs_fast9_detect": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
+    "vs_destroy": (C.c_int, [c_ctxp]),
+    "vs_last_error": (C.c_char_p, [c_ctxp]),
+    "vs_stream": (C.c_void_p, [c_ctxp]),
+    "vs_synchronize": (C.c_int, [c_ctxp]),
+    "vs_host_alloc": (C.c_int, [c_ctxp, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vs_host_free": (C.c_int, [c_ctxp, c_voidp]),
+    "vs_gray_mean3_u8": (C.c_int, [c_ctxp, c_u8p, C.c_int, C.c_int, C.c_int, c_u8p]),
+    "vs_fast9_detect": (C.c_int, [c_ctxp, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
                                   c_u8p, c_intp]),
-    "vs_brief256": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_u8p, c_i32p, c_intp]),
-    "vs_detect_describe_bgr": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
+    "vs_brief256": (C.c_int, [c_ctxp, c_u8p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, c_u8p, c_i32p, c_intp]),
+    "vs_detect_describe_bgr": (C.c_int, [c_ctxp, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p,
                                          c_u8p, c_u8p, c_intp]),
-    "vs_detect_describe_bgr_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "vs_hamming_knn2": (C.c_int, [C.c_void_p, c_u8p, C.c_int, c_u8p, C.c_int, c_i32p, c_i32p]),
-    "vs_match_ratio": (C.c_int, [C.c_void_p, c_u8p, C.c_int, c_u8p, C.c_int, C.c_double, c_i32p, c_i32p, c_i32p,
+    "vs_detect_describe_bgr_dev": (C.c_int, [c_ctxp, c_voidp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             c_voidp, c_voidp, c_voidp, c_voidp, c_voidp]),
+    "vs_hamming_knn2": (C.c_int, [c_ctxp, c_u8p, C.c_int, c_u8p, C.c_int, c_i32p, c_i32p]),
+    "vs_match_ratio": (C.c_int, [c_ctxp, c_u8p, C.c_int, c_u8p, C.c_int, C.c_double, c_i32p, c_i32p, c_i32p,
                                  c_intp]),
-    "vs_hamming_knn2_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                      C.c_void_p]),
-    "vs_hamming_knn2_packed_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
-                                             C.c_void_p]),
-    "vs_match_ratio_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
-                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "vs_triangulate_dlt": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p, c_f64p, C.c_int, C.c_int, c_f64p, c_f64p, c_f64p,
+    "vs_hamming_knn2_dev": (C.c_int, [c_ctxp, c_voidp, C.c_int, c_voidp, C.c_int, c_voidp, c_voidp, c_voidp]),
+    "vs_hamming_knn2_packed_dev": (C.c_int, [c_ctxp, c_voidp, C.c_int, c_voidp, C.c_int, c_voidp, c_voidp]),
+    "vs_match_ratio_dev": (C.c_int, [c_ctxp, c_voidp, C.c_int, c_voidp, C.c_int, C.c_double, c_voidp, c_voidp, c_voidp,
+                                     c_voidp, c_voidp]),
+    "vs_triangulate_dlt": (C.c_int, [c_ctxp, c_f64p, c_f64p, c_f64p, c_f64p, C.c_int, C.c_int, c_f64p, c_f64p, c_f64p,
                                      c_f64p]),
-    "vs_pnp_ransac": (C.c_int, [C.c_void_p, c_f64p, c_f64p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, c_f64p,
+    "vs_pnp_ransac": (C.c_int, [c_ctxp, c_f64p, c_f64p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, c_f64p,
                                 C.c_int, C.c_double, C.c_double, C.c_uint64, C.c_int, c_f64p, c_i32p, c_intp, c_intp]),
-    "vs_essential_ransac": (C.c_int, [C.c_void_p, c_f64p, c_f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64,
+    "vs_essential_ransac": (C.c_int, [c_ctxp, c_f64p, c_f64p, C.c_int, C.c_double, C.c_double, C.c_int, C.c_uint64,
                                       c_f64p, c_u8p, c_intp, c_intp]),
-    "vs_recover_pose": (C.c_int, [C.c_void_p, c_f64p, c_f64p, c_f64p, C.c_int, C.c_double, c_f64p, c_f64p, c_u8p, c_f64p,
+    "vs_recover_pose": (C.c_int, [c_ctxp, c_f64p, c_f64p, c_f64p, C.c_int, C.c_double, c_f64p, c_f64p, c_u8p, c_f64p,
                                   c_intp]),
-    "vs_track_begin": (C.c_int, [C.c_void_p, c_f64p, c_u8p, C.c_int, c_f64p, C.c_double, C.c_double, C.c_double, C.c_double,
+    "vs_track_begin": (C.c_int, [c_ctxp, c_f64p, c_u8p, C.c_int, c_f64p, C.c_double, C.c_double, C.c_double, C.c_double,
                                  C.c_int, C.c_int, C.c_int]),
-    "vs_track_frame": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+    "vs_track_frame": (C.c_int, [c_ctxp, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                  C.c_uint64, C.c_int, C.c_double, c_f64p, c_intp, c_intp, c_intp, c_f32p, c_u8p, c_intp,
                                  c_i32p, c_i32p]),
-    "vs_track_frame_pipelined": (C.c_int, [C.c_void_p, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+    "vs_track_frame_pipelined": (C.c_int, [c_ctxp, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                            C.c_double, C.c_uint64, C.c_int, C.c_double, c_intp, c_f64p, c_intp, c_intp,
                                            c_intp, c_f32p, c_u8p, c_intp, c_i32p, c_i32p]),
-    "vs_track_push_frame": (C.c_int, [C.c_void_p, c_i32p, c_f64p, C.c_int, c_f64p, C.c_int, C.c_double, c_f64p, c_intp]),
-    "vs_track_end": (C.c_int, [C.c_void_p]),
-    "vs_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(BAProblem), C.POINTER(BAResult)]),
-    "vs_ba_debug_cholesky": (C.c_int, [C.c_void_p, c_f64p, C.c_int, c_f64p, c_f64p, c_intp]),
-    "vs_hamming_knn2_sharded_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
-                                              C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vs_track_push_frame": (C.c_int, [c_ctxp, c_i32p, c_f64p, C.c_int, c_f64p, C.c_int, C.c_double, c_f64p, c_intp]),
+    "vs_track_end": (C.c_int, [c_ctxp]),
+    "vs_ba_solve": (C.c_int, [c_ctxp, C.POINTER(BAProblem), C.POINTER(BAResult)]),
+    "vs_ba_debug_cholesky": (C.c_int, [c_ctxp, c_f64p, C.c_int, c_f64p, c_f64p, c_intp]),
+    "vs_hamming_knn2_sharded_dev": (C.c_int, [c_ctxp, c_voidp, C.c_int, c_voidp, C.c_int, c_voidp, C.c_int,
+                                              C.c_int, C.c_int, c_voidp, c_voidp, c_voidp, c_voidp, c_voidp]),
+}
+
+# test / sweep hooks (per context, not part of the stable ABI and not declared in the header)
+HOOKS = {
+    "vs_tune_match": (C.c_int, [c_ctxp, C.c_int, C.c_int]),                 # target workgroups, train staging (-1: keep)
+    "vs_tune_ba": (C.c_int, [c_ctxp, C.c_int, C.c_int, C.c_int, C.c_int]),  # schur variant, points / workgroup, slab cap, motion variant
+    "vs_match_profile": (C.c_int, [c_ctxp, C.c_int]),
+    "vs_match_profile_read": (C.c_int, [c_ctxp, C.POINTER(C.c_float)]),
 }
 
 
@@ -115,17 +133,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     lib._vs_missing = missing
-    try:  # optional tuning hook, not part of the ABI
-        lib.vs_match_set_target_blocks.restype = C.c_int
-        lib.vs_match_set_target_blocks.argtypes = [C.c_int]
-        lib.vs_match_set_tstage.restype = C.c_int
-        lib.vs_match_set_tstage.argtypes = [C.c_int]
-        lib.vs_ba_set_schur_variant.restype = C.c_int
-        lib.vs_ba_set_schur_variant.argtypes = [C.c_int, C.c_int, C.c_int]
-        lib.vs_ba_set_motion_variant.restype = C.c_int
-        lib.vs_ba_set_motion_variant.argtypes = [C.c_int]
-    except AttributeError:
-        pass
+    for name, (res, args) in HOOKS.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _LIB = lib
     return lib
 
@@ -142,7 +154,12 @@ def device_count():
 
 
 def ptr(a, t):
-    """Address of a C-contiguous ndarray for a parameter of (documented) pointer type t; the caller keeps `a` alive."""
+    """Address of a C-contiguous ndarray for a parameter whose pointee type is the tag `t`; the caller keeps `a` alive.
+    A wrong element type or a strided array would be silent memory corruption behind a void*: refused here."""
+    if a.dtype is not t.dtype and a.dtype != t.dtype:
+        raise TypeError("libvslam_hip: %s* parameter got an array of %s" % (t.ctype, a.dtype))
+    if not a.flags.c_contiguous:
+        raise TypeError("libvslam_hip: %s* parameter needs a C-contiguous array" % t.ctype)
     return a.ctypes.data
 
 

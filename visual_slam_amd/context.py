@@ -35,7 +35,7 @@ class Context:
         rc = self._lib.vs_create(C.byref(h), int(device))
         if rc != 0:
             raise VsError(rc, self._lib.vs_last_error(None).decode())
-        self._h = h
+        self._h = h.value  # a plain address: the typed void* tags of _capi take ints
         self._track = None
         self._track_owner = None  # a map's _PeriodMirror when the resident period is driven by the class API
         self._pinned = []
@@ -71,6 +71,19 @@ class Context:
 
     def synchronize(self):
         self._chk(self._lib.vs_synchronize(self._h))
+
+    # ------------------------------------------------------------------ test / sweep hooks (state of THIS context)
+    def tune_match(self, target_blocks=-1, tstage=-1):
+        """Matcher knobs (vs_tune_match; negative = leave as it is): fixed number of workgroups per launch (0 = the
+        automatic plan), train rows staged through LDS (1, default) or fed from SGPRs (0)."""
+        self._chk(self._lib.vs_tune_match(self._h, int(target_blocks), int(tstage)))
+
+    def tune_ba(self, schur_variant=-1, points_per_workgroup=0, max_slabs=0, motion_variant=-1):
+        """BA knobs (vs_tune_ba; negative / zero = leave as it is): Schur kernel of single-tile windows (0 automatic,
+        1 tile kernel, 2 ba_schur_small + linearise launch), its points per workgroup and slab cap; motion-only form
+        (0 one launch where it applies, 1 one launch per LM step)."""
+        self._chk(self._lib.vs_tune_ba(self._h, int(schur_variant), int(points_per_workgroup), int(max_slabs),
+                                       int(motion_variant)))
 
     # ------------------------------------------------------------------ detection / description (A2-A4)
     def gray_mean3(self, bgr):
@@ -123,7 +136,7 @@ class Context:
         nbytes = int(np.prod(shape)) * dtype.itemsize
         p = C.c_void_p()
         self._chk(self._lib.vs_host_alloc(self._h, nbytes, C.byref(p)))
-        self._pinned.append(p)
+        self._pinned.append(p.value)
         buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
@@ -163,29 +176,31 @@ class Context:
 
     def hamming_knn2_dev(self, d_q, nq, d_t, nt, d_idx, d_dist, stream=None):
         """Device pointers (ints, e.g. torch.Tensor.data_ptr()); enqueues, does not synchronise."""
-        self._chk(self._lib.vs_hamming_knn2_dev(self._h, C.c_void_p(d_q), int(nq), C.c_void_p(d_t), int(nt),
-                                                C.c_void_p(d_idx), C.c_void_p(d_dist),
-                                                C.c_void_p(stream) if stream else None))
+        self._chk(self._lib.vs_hamming_knn2_dev(self._h, int(d_q), int(nq), int(d_t), int(nt),
+                                                int(d_idx), int(d_dist),
+                                                int(stream) if stream else None))
 
     def hamming_knn2_packed_dev(self, d_q, nq, d_t, nt, d_out, stream=None):
         """d_out: int32[nq][4] = (idx0, idx1, dist0, dist1) per query, 16-byte aligned; enqueues only."""
-        self._chk(self._lib.vs_hamming_knn2_packed_dev(self._h, C.c_void_p(d_q), int(nq), C.c_void_p(d_t), int(nt),
-                                                       C.c_void_p(d_out), C.c_void_p(stream) if stream else None))
+        self._chk(self._lib.vs_hamming_knn2_packed_dev(self._h, int(d_q), int(nq), int(d_t), int(nt),
+                                                       int(d_out), int(stream) if stream else None))
 
     def hamming_knn2_sharded_dev(self, d_q_shard, nq_shard, d_t, nt, d_gathered, per, rank, world, nccl_comm=None,
-                                 compute_stream=None, comm_stream=None, done_event=None):
-        """One rank's step of the query-sharded match (vs_hamming_knn2_sharded_dev): kernel into this rank's slot of
-        d_gathered int32[world*per][4], then (if nccl_comm) one in-place ncclAllGather on comm_stream; enqueues only."""
+                                 compute_stream=None, comm_stream=None, done_event=None, after_stream=None):
+        """One rank's step of the query-sharded match (vs_hamming_knn2_sharded_dev): the compute stream waits for
+        done_event's previous recording and for after_stream, kernel into this rank's slot of d_gathered
+        int32[world*per][4], then (if nccl_comm) one in-place ncclAllGather on comm_stream; enqueues only."""
         def vp(x):
-            return C.c_void_p(x) if x else None
-        self._chk(self._lib.vs_hamming_knn2_sharded_dev(self._h, C.c_void_p(d_q_shard), int(nq_shard), C.c_void_p(d_t),
-                                                        int(nt), C.c_void_p(d_gathered), int(per), int(rank), int(world),
-                                                        vp(nccl_comm), vp(compute_stream), vp(comm_stream), vp(done_event)))
+            return int(x) if x else None
+        self._chk(self._lib.vs_hamming_knn2_sharded_dev(self._h, int(d_q_shard), int(nq_shard), int(d_t),
+                                                        int(nt), int(d_gathered), int(per), int(rank), int(world),
+                                                        vp(nccl_comm), vp(compute_stream), vp(comm_stream), vp(done_event),
+                                                        vp(after_stream)))
 
     def match_ratio_dev(self, d_q, nq, d_t, nt, ratio, d_mq, d_mt, d_md, d_n, stream=None):
-        self._chk(self._lib.vs_match_ratio_dev(self._h, C.c_void_p(d_q), int(nq), C.c_void_p(d_t), int(nt),
-                                               float(ratio), C.c_void_p(d_mq), C.c_void_p(d_mt), C.c_void_p(d_md),
-                                               C.c_void_p(d_n), C.c_void_p(stream) if stream else None))
+        self._chk(self._lib.vs_match_ratio_dev(self._h, int(d_q), int(nq), int(d_t), int(nt),
+                                               float(ratio), int(d_mq), int(d_mt), int(d_md),
+                                               int(d_n), int(stream) if stream else None))
 
     # ------------------------------------------------------------------ triangulation (SURVEY 8f rank 3)
     def triangulate_dlt(self, P1, P2, pts1, pts2, T1=None, T2=None):

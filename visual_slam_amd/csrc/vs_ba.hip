@@ -2271,6 +2271,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
       // Eight lanes per camera poll the eight tagged words of its mailbox (see the end of the step) until every word of
       // every camera carries this step's tag; the payload halves go through LDS.
       {
+        static_assert(kMoThreads / 8 == kMoPersistCameras, "eight polling lanes per camera mailbox: thread tid >> 3 polls camera tid >> 3");
         const int g = tid >> 3, jw = tid & 7;
         const unsigned tag = (D.mo_epoch << 12) | (unsigned)step;
         const unsigned long long* word = D.mo_box + ((size_t)((step + 1) & 1) * kMoPersistCameras + g) * 8 + jw;
@@ -2601,23 +2602,39 @@ int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& 
 
 // Test hook: the dense solver alone (see include/vslam_hip.h).  A minimal ba_dev without cameras or points: the
 // kernels read S, bs, bp and the LM state and write xp and solve_ok.
-// tuning / test hooks (not part of the stable ABI): Schur kernel of single-tile windows (0 automatic = ba_schur_small with
-// the linearisation of accepted states folded into the trial, 1 = the general tile kernel, 2 = ba_schur_small with a
-// linearisation launch per iteration), points per workgroup and the cap on the number of slabs of ba_schur_small
-static int g_schur_variant = 0, g_small_per = kSmallPts, g_small_ns_cap = 512;
+// tuning / test hooks (not part of the stable ABI; per context, vs_tuning in vs_internal.h): Schur kernel of single-tile
+// windows (0 automatic = ba_schur_small with the linearisation of accepted states folded into the trial, 1 = the general
+// tile kernel, 2 = ba_schur_small with a linearisation launch per iteration), points per workgroup and the cap on the
+// number of slabs of ba_schur_small; motion-only form (0 = one launch where it applies, 1 = one launch per LM step)
+VS_API int vs_tune_ba(vs_ctx* ctx, int schur_variant, int points_per_workgroup, int max_slabs, int motion_variant) {
+  if (!ctx) return VS_EINVAL;
+  if (schur_variant >= 0 && schur_variant <= 2) ctx->tune.schur_variant = schur_variant;
+  if (points_per_workgroup > 0) ctx->tune.small_per = points_per_workgroup;
+  if (max_slabs > 0) ctx->tune.small_ns_cap = max_slabs;
+  if (motion_variant == 0 || motion_variant == 1) ctx->tune.motion_variant = motion_variant;
+  return VS_OK;
+}
+
 namespace vsba {
-int g_motion_variant = 0;  // 0: one launch (ba_motion_persistent) where it applies, 1: one launch per LM step (test hook)
+// The one-launch motion-only solve needs all its camera workgroups resident at the same time (they rendezvous through
+// mailboxes).  The bound is what THIS device can hold -- compute units x workgroups of this kernel per unit, as the runtime
+// reports it -- not a constant: a partitioned or smaller device takes the launch-per-step form instead of spinning.
+bool mo_persistent_ok(vs_ctx* ctx, int cameras, int max_steps) {
+  if (ctx->tune.motion_variant != 0 || cameras > kMoPersistCameras || max_steps >= 4000) return false;
+  if (ctx->mo_persist_cap < 0) {
+    int per_cu = 0, cap = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ba_motion_persistent<true>, kMoThreads, 0) == hipSuccess && per_cu > 0) {
+      int per_cu2 = per_cu;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, (const void*)ba_motion_persistent<false>, kMoThreads, 0) != hipSuccess || per_cu2 <= 0) per_cu2 = per_cu;
+      cap = std::min(per_cu, per_cu2) * ctx->prop.multiProcessorCount;
+    } else {
+      (void)hipGetLastError();
+    }
+    ctx->mo_persist_cap = cap;
+  }
+  return cameras <= ctx->mo_persist_cap;
 }
-VS_API int vs_ba_set_motion_variant(int variant) {
-  if (variant == 0 || variant == 1) vsba::g_motion_variant = variant;
-  return vsba::g_motion_variant;
-}
-VS_API int vs_ba_set_schur_variant(int variant, int points_per_workgroup, int max_slabs) {
-  if (variant >= 0 && variant <= 2) g_schur_variant = variant;
-  if (points_per_workgroup > 0) g_small_per = points_per_workgroup;
-  if (max_slabs > 0) g_small_ns_cap = max_slabs;
-  return g_schur_variant;
-}
+}  // namespace vsba
 
 VS_API int vs_ba_debug_cholesky(vs_ctx* ctx, const double* S, int n, const double* b, double* x, int* ok) {
   if (!ctx) return VS_EINVAL;
@@ -2758,14 +2775,15 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   const bool lds_slab = np <= kMaxSlabN;
   const int ntile_pairs = ntile * (ntile + 1) / 2;  // tiles of the lower triangle
   const size_t slab_elems = (size_t)np * np + np;
+  const int small_per = ctx->tune.small_per > 0 ? ctx->tune.small_per : kSmallPts;
   auto slabs_for = [&](bool tiled_, bool small_) {
     int n = nfl > 0 && nfp > 0 ? std::min(256, (nfl + 7) / 8) : 0;
     if (tiled_) n = std::max(4, std::min(256, (16384 + ntile_pairs - 1) / ntile_pairs));  // >= 16k workgroups: most tiles are empty
-    if (small_) n = std::max(1, std::min(g_small_ns_cap, (nfl + g_small_per - 1) / g_small_per));
+    if (small_) n = std::max(1, std::min(ctx->tune.small_ns_cap, (nfl + small_per - 1) / small_per));
     if (!lds_slab && n > 0) n = std::min(n, std::max(1, (int)((512u << 20) / (sizeof(double) * slab_elems))));
     return n;
   };
-  const bool small_possible = tiled_possible && ntile == 1 && g_schur_variant != 1;  // one tile: ba_schur_small
+  const bool small_possible = tiled_possible && ntile == 1 && ctx->tune.schur_variant != 1;  // one tile: ba_schur_small
   const int ns_bound = std::max(slabs_for(false, false), slabs_for(tiled_possible, small_possible));
   // workgroups per camera of the linearisation's camera role: about one observation per thread, at most 8
   int cam_split = 1;
@@ -2951,7 +2969,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   const size_t upload_bytes = A.off;
   const bool tiled = tiled_possible && !dups;
   const bool small = tiled && small_possible;
-  const bool spec = small && g_schur_variant != 2;  // two linearisations: the trial kernel linearises the trial state
+  const bool spec = small && ctx->tune.schur_variant != 2;  // two linearisations: the trial kernel linearises the trial state
   int ns = slabs_for(tiled, small);
   // ba_schur_small with camera workgroups beside it: keep the whole grid within one workgroup per CU.  Two Schur
   // workgroups on one CU take turns at its LDS in the product phase (measured 14-15 us per launch at 286 workgroups on
@@ -3124,7 +3142,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     int step = 0;
     int cam_obs_max = 0;
     for (int c = 0; c < nfp; ++c) cam_obs_max = std::max(cam_obs_max, cam_start[c + 1] - cam_start[c]);
-    const bool persistent = vsba::g_motion_variant == 0 && nfp <= kMoPersistCameras && max_steps < 4000;
+    bool persistent = vsba::mo_persistent_ok(ctx, nfp, max_steps);
     for (;;) {
       if (persistent) {  // the whole solve in one launch; the final record lands in both state slots
         if (cam_obs_max <= kMoPersistObs) hipLaunchKernelGGL(ba_motion_persistent<false>, dim3(nfp), dim3(kMoThreads), 0, s, Dm, max_steps);
@@ -3132,8 +3150,14 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
         VS_LAUNCH_CHECK(ctx, "ba_motion_persistent");
         VS_HIP(ctx, hipMemcpyAsync(hms, d_mst, sizeof(mo_state), hipMemcpyDeviceToHost, s));
         VS_HIP(ctx, hipStreamSynchronize(s));
-        if (hms->terminated == 3) return vs_fail(ctx, VS_EHIP, "%s: the camera workgroups did not rendezvous", "vs_ba_solve");
-        break;
+        if (hms->terminated != 3) break;
+        // the camera workgroups did not meet (the device was shared with long-running foreign work, or is smaller than it
+        // reports): restore the start state from the pinned arena mirror and run the launch-per-step form once instead
+        VS_HIP(ctx, hipMemcpyAsync(A.base, A.host, upload_bytes, hipMemcpyHostToDevice, s));
+        VS_HIP(ctx, hipMemcpyAsync(D.cam[1], D.cam[0], sizeof(double) * (size_t)F * kCamStride, hipMemcpyDeviceToDevice, s));
+        VS_HIP(ctx, hipMemcpyAsync(D.pts[1], D.pts[0], sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToDevice, s));
+        persistent = false;
+        ctx->mo_persist_cap = 0;  // and do not try the one-launch form again on this context
       }
       const int batch = std::min(max_steps + 1 - step, q.max_iterations + 2);  // LIN + trials + the deciding launch
       for (int k = 0; k < batch; ++k, ++step) {

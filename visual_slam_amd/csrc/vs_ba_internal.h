@@ -165,7 +165,7 @@ struct pnp_args {
 __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step);
 template <bool OVF>
 __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int max_steps);
-extern int g_motion_variant;
+bool mo_persistent_ok(vs_ctx* ctx, int cameras, int max_steps);  // vs_ba.hip: may the one-launch form run on this device?
 constexpr int kMoPersistCameras = 64;          // limit of the one-launch form: workgroups that have to be resident together
 constexpr int kMoPersistObs = 2 * kMoThreads;  // observations per camera its threads keep in registers (more: the <true> instantiation)
 __global__ __launch_bounds__(64) void pnp_hypothesis_kernel(pnp_args P);

@@ -48,8 +48,8 @@ VS_API int vs_destroy(vs_ctx* ctx) {
     delete ctx;
     return VS_OK;
   }
-  (void)hipStreamSynchronize(ctx->stream);
-  vs_buf* dev[] = {&ctx->d_q,   &ctx->d_t,    &ctx->d_idx,     &ctx->d_dist, &ctx->d_mq,
+  (void)hipDeviceSynchronize();  // every stream the context has launched on (front half, a plan's match streams)
+  vs_buf* dev[] = {&ctx->d_q,   &ctx->d_t,    &ctx->d_mq,
                    &ctx->d_mt,  &ctx->d_md,   &ctx->d_cnt,     &ctx->d_bgr,  &ctx->d_gray,    &ctx->d_box,
                    &ctx->d_raw, &ctx->d_bandcnt, &ctx->d_hist, &ctx->d_xy,   &ctx->d_score,   &ctx->d_desc,
                    &ctx->d_n,   &ctx->d_xy_in, &ctx->d_keep,   &ctx->d_ba,  &ctx->d_track, &ctx->d_bgr2};
@@ -57,6 +57,12 @@ VS_API int vs_destroy(vs_ctx* ctx) {
   for (vs_match_scratch& m : ctx->match_scratch) {
     free_dev(&m.partial);
     free_dev(&m.ticket);
+    free_dev(&m.idx);
+    free_dev(&m.dist);
+  }
+  for (vs_prof_rec& r : ctx->match_prof) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
   }
   for (vs_desc_entry& e : ctx->desc_cache) {
     free_dev(&e.dev);
@@ -68,6 +74,7 @@ VS_API int vs_destroy(vs_ctx* ctx) {
   for (hipEvent_t e : ctx->track.ev_front)
     if (e) (void)hipEventDestroy(e);
   if (ctx->ev_shard) (void)hipEventDestroy(ctx->ev_shard);
+  if (ctx->ev_after) (void)hipEventDestroy(ctx->ev_after);
   if (ctx->track.front_stream) (void)hipStreamDestroy(ctx->track.front_stream);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;

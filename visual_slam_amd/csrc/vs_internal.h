@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/vslam_hip.h"
 
 #define VS_API extern "C" __attribute__((visibility("default")))
@@ -37,8 +39,24 @@ struct vs_match_scratch {
   bool used = false;
   uint64_t stamp = 0;  // last use (least recently used set is recycled for a new stream)
   vs_buf partial, ticket;
+  vs_buf idx, dist;    // 2-NN rows between the match kernel and the ratio kernel (vs_match_ratio_dev)
 };
 constexpr int VS_MATCH_STREAMS = 4;
+
+// Test / sweep hooks.  They live in the context (one per process and GPU), not in process-wide globals: two contexts, or a
+// test that flips a knob, never change what another context computes.  Set through vs_tune_* (not part of the stable ABI).
+struct vs_tuning {
+  int match_target_blocks = 0;  // 0: automatic plan (plan_chunks); > 0: fixed number of workgroups
+  int match_tstage = 1;         // train rows staged through LDS into VGPRs (1) or fed from SGPRs (0)
+  bool match_profile = false;   // HIP events around every match launch (bench.py)
+  int schur_variant = 0;        // single-tile windows: 0 ba_schur_small + speculative linearisation, 1 tile kernel, 2 ba_schur_small + linearise launch
+  int small_per = 0;            // points per ba_schur_small workgroup (0: kSmallPts)
+  int small_ns_cap = 512;       // cap on its slab count
+  int motion_variant = 0;       // 0: one-launch motion-only solve where it applies, 1: one launch per LM step
+};
+struct vs_prof_rec {
+  hipEvent_t e0, e1;
+};
 
 struct vs_ctx {
   int device = 0;
@@ -46,7 +64,7 @@ struct vs_ctx {
   hipDeviceProp_t prop;
   char err[512];
   // matcher
-  vs_buf d_q, d_t, d_idx, d_dist, d_mq, d_mt, d_md, d_cnt;
+  vs_buf d_q, d_t, d_mq, d_mt, d_md, d_cnt;
   vs_match_scratch match_scratch[VS_MATCH_STREAMS];
   // detector
   vs_buf d_bgr, d_gray, d_box, d_raw, d_bandcnt, d_hist, d_xy, d_score, d_desc, d_n, d_xy_in, d_keep;
@@ -82,6 +100,10 @@ struct vs_ctx {
   } track;
   vs_buf d_bgr2;  // image buffer of the second set
   hipEvent_t ev_shard = nullptr;  // orders the all-gather stream behind the match kernel (vs_hamming_knn2_sharded_dev)
+  hipEvent_t ev_after = nullptr;  // orders a compute stream behind the caller's stream (same entry point, after_stream)
+  vs_tuning tune;
+  std::vector<vs_prof_rec> match_prof;
+  int mo_persist_cap = -1;  // camera workgroups of ba_motion_persistent the device keeps resident together (-1: not asked yet)
 };
 
 // device copy of the n x 32-byte descriptor set at host pointer `h` (uploads unless the very same bytes are already
@@ -119,7 +141,7 @@ static inline int vs_reserve(vs_ctx* ctx, vs_buf* b, size_t bytes) {
   if (bytes < 256) bytes = 256;
   size_t want = bytes + bytes / 4;  // headroom so a growing map does not reallocate every frame
   if (b->p) {
-    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VS_HIP(ctx, hipDeviceSynchronize());  // the buffer may be in use on any stream (front half, match streams of a plan)
     VS_HIP(ctx, hipFree(b->p));
     b->p = nullptr;
     b->cap = 0;
@@ -134,7 +156,7 @@ static inline int vs_reserve_pinned(vs_ctx* ctx, vs_buf* b, size_t bytes) {
   if (bytes <= b->cap && b->p) return VS_OK;
   if (bytes < 4096) bytes = 4096;
   if (b->p) {
-    VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VS_HIP(ctx, hipDeviceSynchronize());
     VS_HIP(ctx, hipHostFree(b->p));
     b->p = nullptr;
     b->cap = 0;

@@ -5,17 +5,20 @@
 //
 // Kernel design (VALU-bound integer work, no MFMA):
 //   * lane = query.  Every lane keeps kQPL query descriptors (8 dwords each) in VGPRs for the whole kernel.
-//   * train descriptors are wave-uniform: they are read with scalar loads (s_load_dwordx8) into SGPRs and fed to
-//     v_xor_b32 as the scalar operand -- no LDS traffic, no VGPRs, one 32-byte scalar load per 64*kQPL distances.
+//   * train descriptors are wave-uniform.  Default (TSTAGE): every wave stages 64 train rows at a time in its own 2 KB LDS
+//     slice (one coalesced 32-byte load per lane, prefetched one batch ahead, wave-synchronous: no barrier) and reads each
+//     row back as two broadcast ds_read_b128, so both v_xor_b32 operands are VGPRs (on gfx950 a VGPR-only v_xor issues at
+//     the 2-cycle wave64 rate, with an SGPR source at the 4-cycle rate: tools/valu_probe2.hip).  The older form -- scalar
+//     loads (s_load_dwordx8), the row as the SGPR operand of v_xor_b32 -- remains as the !TSTAGE instantiation (sweeps).
 //   * distance = 8 x (v_xor_b32 + v_bcnt_u32_b32 with accumulate), a dependent chain per query, kQPL chains in flight.
-//   * top-2 bookkeeping on packed keys  key = dist << 20 | (train index within the chunk), two train rows per update:
+//   * top-2 bookkeeping on packed keys  key = dist << 20 | train index, two train rows per update:
 //       second = v_min_u32(second, v_med3_u32(best, ka, kb));  best = v_min3_u32(best, ka, kb)
 //     (the second smallest of {best, second, ka, kb} with best <= second is min(second, median(best, ka, kb))), so the
 //     tie rule "lower train index first" falls out of the packing.  16 + 1 + 1.5 = 18.5 VALU ops per distance.
 //   * the grid is (query tiles) x (train chunks) so that ~5 waves sit on every SIMD even at 10k x 10k.  Every
 //     (tile, chunk) workgroup publishes one 8-byte partial per query; the workgroup that arrives LAST at a tile (agent-
-//     scope ticket counter, release/acquire fences as MI355X_MICROARCH.md prescribes for inter-workgroup hand-offs)
-//     folds the tile's partials in chunk order and writes the final (idx, dist) rows: ONE launch, no merge kernel.
+//     scope ticket counter; write-through stores + acquire as MI355X_MICROARCH.md prescribes for inter-workgroup
+//     hand-offs) folds the tile's partials in chunk order and writes the final (idx, dist) rows: ONE launch, no merge kernel.
 //   * the ratio test + ordered compaction is one workgroup using wave ballots and popcounts for the prefix.
 #include "vs_internal.h"
 
@@ -323,29 +326,19 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int2* __restr
   if (threadIdx.x == 0) *n_out = running;
 }
 
-int g_target_blocks = 0;     // 0: automatic plan (plan_chunks); > 0: fixed number of workgroups (tuning hook)
-int g_tstage = 1;            // train rows staged through LDS into VGPRs (1) or fed from SGPRs (0); tuning hook
-
-// optional per-kernel timing (bench.py): hipEvents on the launch stream around the kernel of each call
-bool g_profile = false;
-struct prof_rec {
-  hipEvent_t e0, e1;
-};
-std::vector<prof_rec> g_prof;
-
 // chunk_len trains per workgroup (split into kWaves sub-ranges of sub_len), nchunks workgroups along y.
-// Automatic plan (g_target_blocks == 0): pick the number of train chunks that minimises
+// Automatic plan (target_blocks == 0; > 0 is the sweep hook vs_tune_match): pick the number of train chunks that minimises
 //     ceil(workgroups / 256 CUs) * chunk_len  +  fold cost per chunk
 // over plans with 1000..4600 workgroups -- the first term is the busiest CU's share of train rows (workgroups are
 // spread round-robin, 4..16 resident per CU), the second the extra partial rows the last workgroup of a tile folds.  At
 // 10k x 10k this gives 32 chunks x 40 query tiles = 1280 workgroups = 5 per CU, at 100k x 100k 11 x 391 = 4301 (98.8 %
 // balanced; a fixed 1024-workgroup plan loses 25 % there to 4-vs-3 workgroups per CU).
-void plan_chunks(int nq, int nt, int* chunk_len, int* sub_len, int* nchunks) {
+void plan_chunks(int target_blocks, int nq, int nt, int* chunk_len, int* sub_len, int* nchunks) {
   const int qtiles = (nq + kTileQ - 1) / kTileQ;
   const int q1 = qtiles > 0 ? qtiles : 1;
   long nch = 1;
-  if (g_target_blocks > 0) {
-    nch = g_target_blocks / q1;
+  if (target_blocks > 0) {
+    nch = target_blocks / q1;
   } else {
     const long lo = (1000 + q1 - 1) / q1, hi = 4600 / q1 > lo ? 4600 / q1 : lo;
     double best = 1e300;
@@ -383,14 +376,38 @@ int check_args(vs_ctx* ctx, const void* q, int nq, const void* t, int nt, const 
 
 }  // namespace
 
-// tuning hook for bench sweeps (not part of the stable ABI)
-VS_API int vs_match_set_target_blocks(int blocks) {
-  if (blocks >= 0) g_target_blocks = blocks;
-  return g_target_blocks;
+// tuning hooks for bench sweeps and tests (not part of the stable ABI; per context): a negative value leaves a knob as it is
+VS_API int vs_tune_match(vs_ctx* ctx, int target_blocks, int tstage) {
+  if (!ctx) return VS_EINVAL;
+  if (target_blocks >= 0) ctx->tune.match_target_blocks = target_blocks;
+  if (tstage == 0 || tstage == 1) ctx->tune.match_tstage = tstage;
+  return VS_OK;
 }
-VS_API int vs_match_set_tstage(int v) {
-  if (v == 0 || v == 1) g_tstage = v;
-  return g_tstage;
+
+// scratch of the stream `s` (launches on different streams may run concurrently and must not share it)
+static int match_scratch_for(vs_ctx* ctx, hipStream_t s, vs_match_scratch** out) {
+  vs_match_scratch* ms = nullptr;
+  for (vs_match_scratch& m : ctx->match_scratch)
+    if (m.used && m.stream == s) ms = &m;
+  if (!ms) {
+    // a stream not seen before takes a free set, else the least recently used one -- once the device has drained: the set's
+    // old stream may have been destroyed by its owner meanwhile, so its handle is never touched again
+    vs_match_scratch* lru = &ctx->match_scratch[0];
+    for (vs_match_scratch& m : ctx->match_scratch) {
+      if (!m.used) {
+        lru = &m;
+        break;
+      }
+      if (m.stamp < lru->stamp) lru = &m;
+    }
+    if (lru->used) VS_HIP(ctx, hipDeviceSynchronize());
+    lru->used = true;
+    lru->stream = s;
+    ms = lru;
+  }
+  ms->stamp = ++ctx->desc_stamp;
+  *out = ms;
+  return VS_OK;
 }
 
 static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_idx, void* d_dist,
@@ -400,31 +417,12 @@ static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
   if (!d_idx || (!packed && !d_dist)) return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_hamming_knn2_dev");
   hipStream_t s = vs_pick_stream(ctx, stream);
   int chunk_len, sub_len, nchunks;
-  plan_chunks(nq, nt, &chunk_len, &sub_len, &nchunks);
+  plan_chunks(ctx->tune.match_target_blocks, nq, nt, &chunk_len, &sub_len, &nchunks);
   if (((uintptr_t)d_q | (uintptr_t)d_t) & 31)
     return vs_fail(ctx, VS_EINVAL, "%s: descriptor arrays must be 32-byte aligned", "vs_hamming_knn2_dev");
   const int qtiles = (nq + kTileQ - 1) / kTileQ;
-  // scratch of this stream (launches on different streams may run concurrently and must not share it)
   vs_match_scratch* ms = nullptr;
-  for (vs_match_scratch& m : ctx->match_scratch)
-    if (m.used && m.stream == s) ms = &m;
-  if (!ms) {
-    // a stream not seen before takes a free set, else the least recently used one -- after that set's stream has drained
-    // (it may have been destroyed meanwhile: an invalid handle is as good as drained)
-    vs_match_scratch* lru = &ctx->match_scratch[0];
-    for (vs_match_scratch& m : ctx->match_scratch) {
-      if (!m.used) {
-        lru = &m;
-        break;
-      }
-      if (m.stamp < lru->stamp) lru = &m;
-    }
-    if (lru->used && hipStreamSynchronize(lru->stream) != hipSuccess) (void)hipGetLastError();
-    lru->used = true;
-    lru->stream = s;
-    ms = lru;
-  }
-  ms->stamp = ++ctx->desc_stamp;
+  VS_TRY(match_scratch_for(ctx, s, &ms));
   VS_TRY(vs_reserve(ctx, &ms->partial, sizeof(uint2) * (size_t)nchunks * qtiles * kTileQ));
   // per-tile arrival tickets: zero when allocated; every launch leaves them zero again (its last workgroups reset them)
   if (sizeof(unsigned) * (size_t)qtiles > ms->ticket.cap || !ms->ticket.p) {
@@ -432,8 +430,8 @@ static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
     VS_HIP(ctx, hipMemsetAsync(ms->ticket.p, 0, ms->ticket.cap, s));
   }
   dim3 grid(qtiles, nchunks);
-  prof_rec pr{};
-  if (g_profile) {
+  vs_prof_rec pr{};
+  if (ctx->tune.match_profile) {
     VS_HIP(ctx, hipEventCreate(&pr.e0));
     VS_HIP(ctx, hipEventCreate(&pr.e1));
     VS_HIP(ctx, hipEventRecord(pr.e0, s));
@@ -441,13 +439,13 @@ static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
   typedef void (*knn2_fn)(const uint4*, int, const uint32_t*, int, int, int, uint2*, unsigned*, int2*, int2*, const int*);
   static const knn2_fn kFn[2][2] = {{hamming_knn2_kernel<false, false>, hamming_knn2_kernel<false, true>},
                                     {hamming_knn2_kernel<true, false>, hamming_knn2_kernel<true, true>}};
-  hipLaunchKernelGGL(kFn[packed ? 1 : 0][g_tstage ? 1 : 0], grid, dim3(64 * kWaves), 0, s, (const uint4*)d_q, nq,
+  hipLaunchKernelGGL(kFn[packed ? 1 : 0][ctx->tune.match_tstage ? 1 : 0], grid, dim3(64 * kWaves), 0, s, (const uint4*)d_q, nq,
                      (const uint32_t*)d_t, nt, chunk_len, sub_len, (uint2*)ms->partial.p, (unsigned*)ms->ticket.p,
                      (int2*)d_idx, packed ? (int2*)nullptr : (int2*)d_dist, nt_dev);
   VS_LAUNCH_CHECK(ctx, "hamming_knn2_kernel");
-  if (g_profile) {
+  if (ctx->tune.match_profile) {
     VS_HIP(ctx, hipEventRecord(pr.e1, s));
-    g_prof.push_back(pr);
+    ctx->match_prof.push_back(pr);
   }
   return VS_OK;
 }
@@ -493,7 +491,7 @@ nccl_allgather_fn resolve_nccl() {
 
 VS_API int vs_hamming_knn2_sharded_dev(vs_ctx* ctx, const void* d_q_shard, int nq_shard, const void* d_t, int nt,
                                        void* d_gathered, int per, int rank, int world, void* nccl_comm,
-                                       void* compute_stream, void* comm_stream, void* done_event) {
+                                       void* compute_stream, void* comm_stream, void* done_event, void* after_stream) {
   if (!ctx) return VS_EINVAL;
   if (world < 1 || rank < 0 || rank >= world || per < 0 || nq_shard < 0 || nq_shard > per || !d_gathered ||
       ((uintptr_t)d_gathered & 15))
@@ -501,9 +499,22 @@ VS_API int vs_hamming_knn2_sharded_dev(vs_ctx* ctx, const void* d_q_shard, int n
   if (world > 1 && (!nccl_comm || !comm_stream))
     return vs_fail(ctx, VS_EINVAL, "%s: world > 1 needs a communicator and a stream for it", "vs_hamming_knn2_sharded_dev");
   hipStream_t cs = vs_pick_stream(ctx, compute_stream);
+  // ---- everything that may still touch d_gathered, or that produces this step's inputs, comes first on the compute stream:
+  //  (1) done_event as recorded by the PREVIOUS step on this gather buffer -- its all-gather sends from, and receives into,
+  //      the rows the kernel is about to overwrite (an event that was never recorded counts as complete);
+  //  (2) the caller's stream up to now: the consumers of the previous results of d_gathered and the producers of q / t.
+  if (done_event) VS_HIP(ctx, hipStreamWaitEvent(cs, (hipEvent_t)done_event, 0));
+  if (after_stream && (hipStream_t)after_stream != cs) {
+    if (!ctx->ev_after) VS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_after, hipEventDisableTiming));
+    VS_HIP(ctx, hipEventRecord(ctx->ev_after, (hipStream_t)after_stream));
+    VS_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_after, 0));
+  }
   uint8_t* slot = (uint8_t*)d_gathered + (size_t)rank * per * 16;
   VS_TRY(knn2_dev_impl(ctx, d_q_shard, nq_shard, d_t, nt, slot, nullptr, true, cs));
-  if (!nccl_comm) return VS_OK;
+  if (!nccl_comm) {  // no collective: the step is complete when the kernel is
+    if (done_event) VS_HIP(ctx, hipEventRecord((hipEvent_t)done_event, cs));
+    return VS_OK;
+  }
   nccl_allgather_fn ag = resolve_nccl();
   if (!ag) return vs_fail(ctx, VS_ENCCL, "%s: ncclAllGather not found (is RCCL loaded in this process?)", "vs_hamming_knn2_sharded_dev");
   hipStream_t ms = comm_stream ? (hipStream_t)comm_stream : cs;
@@ -520,15 +531,17 @@ VS_API int vs_hamming_knn2_sharded_dev(vs_ctx* ctx, const void* d_q_shard, int n
 }
 
 // bench hooks (not part of the stable ABI): HIP-event timing of the match kernel on its launch stream
-VS_API int vs_match_profile(int enable) {
-  g_profile = enable != 0;
-  return 0;
+VS_API int vs_match_profile(vs_ctx* ctx, int enable) {
+  if (!ctx) return VS_EINVAL;
+  ctx->tune.match_profile = enable != 0;
+  return VS_OK;
 }
 // synchronises, returns the number of profiled calls and their mean kernel duration in milliseconds, then clears
-VS_API int vs_match_profile_read(float* kernel_ms) {
+VS_API int vs_match_profile_read(vs_ctx* ctx, float* kernel_ms) {
+  if (!ctx) return VS_EINVAL;
   double a = 0;
   int n = 0;
-  for (prof_rec& r : g_prof) {
+  for (vs_prof_rec& r : ctx->match_prof) {
     float x = 0;
     if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&x, r.e0, r.e1) == hipSuccess) {
       a += x;
@@ -537,7 +550,7 @@ VS_API int vs_match_profile_read(float* kernel_ms) {
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
   }
-  g_prof.clear();
+  ctx->match_prof.clear();
   if (kernel_ms) *kernel_ms = n ? (float)(a / n) : 0.f;
   return n;
 }
@@ -550,12 +563,16 @@ int vs_match_ratio_dev_n(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
   if (!d_n_out || (nq > 0 && (!d_match_q || !d_match_t || !d_match_d)))
     return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_match_ratio_dev");
   hipStream_t s = vs_pick_stream(ctx, stream);
-  VS_TRY(vs_reserve(ctx, &ctx->d_idx, sizeof(int2) * (size_t)(nq > 0 ? nq : 1)));
-  VS_TRY(vs_reserve(ctx, &ctx->d_dist, sizeof(int2) * (size_t)(nq > 0 ? nq : 1)));
+  // the 2-NN rows between the two kernels belong to the launch stream's scratch set: calls on different streams (a host
+  // match while a pipelined front half is in flight, two streams of a caller) never share them
+  vs_match_scratch* ms = nullptr;
+  VS_TRY(match_scratch_for(ctx, s, &ms));
+  VS_TRY(vs_reserve(ctx, &ms->idx, sizeof(int2) * (size_t)(nq > 0 ? nq : 1)));
+  VS_TRY(vs_reserve(ctx, &ms->dist, sizeof(int2) * (size_t)(nq > 0 ? nq : 1)));
   VS_HIP(ctx, hipSetDevice(ctx->device));
-  VS_TRY(knn2_dev_impl(ctx, d_q, nq, d_t, nt, ctx->d_idx.p, ctx->d_dist.p, false, s, nt_dev));
-  hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, s, (const int2*)ctx->d_idx.p,
-                     (const int2*)ctx->d_dist.p, nq, ratio, (int32_t*)d_match_q, (int32_t*)d_match_t,
+  VS_TRY(knn2_dev_impl(ctx, d_q, nq, d_t, nt, ms->idx.p, ms->dist.p, false, s, nt_dev));
+  hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, s, (const int2*)ms->idx.p,
+                     (const int2*)ms->dist.p, nq, ratio, (int32_t*)d_match_q, (int32_t*)d_match_t,
                      (int32_t*)d_match_d, (int32_t*)d_n_out, nt_dev);
   VS_LAUNCH_CHECK(ctx, "ratio_compact_kernel");
   return VS_OK;

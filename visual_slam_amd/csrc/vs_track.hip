@@ -286,7 +286,7 @@ int track_ba_batch(vs_ctx* ctx, int set, int* step) {
     // Launches after the one that finds the solve finished are predicated no-ops of ~5 us each on the critical path of the
     // frame, and consecutive frames of a stream need about the same number of LM steps: the first batch is as long as the
     // previous solve was (+1); a solve that needs more gets further batches (the results do not depend on the split).
-    if (*step == 0 && g_motion_variant == 0 && k <= kMoPersistCameras && max_steps < 4000) {
+    if (*step == 0 && mo_persistent_ok(ctx, k, max_steps)) {
       // the whole solve in one launch (a frame has at most n_points matches); the final record lands in both state slots
       if (T.n_points <= kMoPersistObs) hipLaunchKernelGGL(ba_motion_persistent<false>, dim3(k), dim3(kMoThreads), 0, s, D, max_steps);
       else hipLaunchKernelGGL(ba_motion_persistent<true>, dim3(k), dim3(kMoThreads), 0, s, D, max_steps);

@@ -202,49 +202,44 @@ def gpu_pnp(ctx):
 
 
 def bench_frames(ctx, repeats=5):
-    """frames/s of the 20-frame ICL-NUIM stream through the host C ABI (PNG decode excluded, H2D copies included).
-    Returns (report dict, poses) -- bench.py times the CPU oracle through track_sequence() for the comparison."""
+    """frames/s of the 20-frame ICL-NUIM stream through the host C ABI (PNG decode excluded, H2D copies included), the
+    class API and the device-resident period.  Every figure is the MEDIAN of `repeats` runs of the whole period (the
+    fastest run is reported beside it as *_max).  Returns (report dict, poses) -- bench.py times the CPU oracle through
+    track_sequence() for the comparison."""
+    import statistics
     frames, depth0 = load_sequence(20)
     frames = [ctx.pin(f) for f in frames]  # decoded frames live in pinned memory: H2D is a plain DMA
     det, mat, ba = gpu_callables(ctx)
     pnp = gpu_pnp(ctx)
+    n = len(frames)
+
+    def timed(fn, reps):
+        ts, last = [], None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            last = fn()
+            ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), min(ts), last
+
     track_sequence(det, mat, ba, frames[:4], depth0, pnp=pnp)  # warm-up (allocations, code objects)
-    best = None
-    for _ in range(repeats):
-        t0 = time.perf_counter()
-        poses, stages, nm = track_sequence(det, mat, ba, frames, depth0, pnp=pnp)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, stages, poses, nm)
-    dt, stages, poses, nm = best
+    dt, dt_min, (poses, stages, nm) = timed(lambda: track_sequence(det, mat, ba, frames, depth0, pnp=pnp), repeats)
     # the same period through the reference's class API (Frame / Map / FeatureMatcher / BundleAdjustment objects)
     track_sequence_api(frames[:3], depth0, context=ctx)
-    api_dt, api_poses = None, None
-    for _ in range(max(2, repeats // 2)):
-        ap, adt = track_sequence_api(frames, depth0, context=ctx)
-        if api_dt is None or adt < api_dt:
-            api_dt, api_poses = adt, ap
+    api_dt, api_min, (api_poses, _) = timed(lambda: track_sequence_api(frames, depth0, context=ctx), repeats)
     # the same period with the map resident on the device (one image upload per frame)
     track_sequence_resident(ctx, frames[:4], depth0)
-    res_dt, res_poses = None, None
-    for _ in range(repeats):
-        rp, rdt, _ = track_sequence_resident(ctx, frames, depth0)
-        if res_dt is None or rdt < res_dt:
-            res_dt, res_poses = rdt, rp
+    res_dt, res_min, (res_poses, _, _) = timed(lambda: track_sequence_resident(ctx, frames, depth0), repeats)
     track_sequence_resident(ctx, frames[:4], depth0, pipelined=True)
-    pipe_dt, pipe_poses = None, None
-    for _ in range(repeats):
-        pp, pdt, _ = track_sequence_resident(ctx, frames, depth0, pipelined=True)
-        if pipe_dt is None or pdt < pipe_dt:
-            pipe_dt, pipe_poses = pdt, pp
-    out = {"frames_per_s": len(frames) / dt, "n_frames": len(frames), "seconds": dt,
-           "resident_frames_per_s": len(frames) / res_dt,
-           "resident_pipelined_frames_per_s": len(frames) / pipe_dt,
+    pipe_dt, pipe_min, (pipe_poses, _, _) = timed(lambda: track_sequence_resident(ctx, frames, depth0, pipelined=True), repeats)
+    out = {"statistic": "median of %d runs of the 20-frame period (fastest run as *_max)" % repeats,
+           "frames_per_s": n / dt, "frames_per_s_max": n / dt_min, "n_frames": n, "seconds": dt,
+           "resident_frames_per_s": n / res_dt, "resident_frames_per_s_max": n / res_min,
+           "resident_pipelined_frames_per_s": n / pipe_dt, "resident_pipelined_frames_per_s_max": n / pipe_min,
            "resident_pipelined_equals_resident": bool(np.array_equal(pipe_poses, res_poses)),
            "resident_vs_array_path": float(max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(res_poses, poses))),
-           "class_api_frames_per_s": len(frames) / api_dt,
+           "class_api_frames_per_s": n / api_dt, "class_api_frames_per_s_max": n / api_min,
            "class_api_vs_array_path": float(max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(api_poses, poses))),
-           "stage_ms_per_frame": {k: v / len(frames) * 1e3 for k, v in stages.items()},
+           "stage_ms_per_frame": {k: v / n * 1e3 for k, v in stages.items()},
            "mean_matches": float(np.mean(nm)), "resolution": "640x480",
            "data": "ICL-NUIM living-room traj3 frames 0-19 (fixtures)",
            "note": "host C-ABI path incl. H2D/D2H copies; detect+describe -> match -> PnP-RANSAC -> motion-only BA per "

@@ -19,10 +19,15 @@ import copy
 import numpy as np
 
 
+_SOA_GENERATION = [0]  # every mirror ever built gets the next number: a cache key that, unlike id(), is never recycled
+
+
 class _SoA:
     """Flat mirror of the observation graph.  Observation rows are kept in chunks and concatenated lazily."""
 
     def __init__(self):
+        _SOA_GENERATION[0] += 1
+        self.gen = _SOA_GENERATION[0]
         self.point_slot = {}      # point id -> slot (row of xyz); slots follow points_3d insertion order
         self.xyz = np.zeros((0, 3))
         self.n_points = 0
@@ -285,12 +290,12 @@ class Map:
         lookup per point."""
         s = self.soa()
         try:
-            key = (id(s), s.n_points, self._cell[0], self._cell[1], s.fid_rows.get(frame_id, 0))
+            key = (s.gen, s.n_points, self._cell[0], self._cell[1], s.fid_rows.get(frame_id, 0))
             hit = self._img_cache.get(frame_id)
         except TypeError:  # unhashable frame id
             key = hit = None
         if hit is not None and hit[0] == key:
-            return hit[1]  # nothing that this answer depends on has changed: the same arrays again
+            return hit[1]  # nothing that this answer depends on has changed: the same (read-only) arrays again
         slot, fid, uv, desc = s.arrays()
         if desc is not None and s.n_obs:
             sel = np.nonzero(fid == frame_id)[0]
@@ -303,6 +308,11 @@ class Map:
                         ids = np.fromiter(self.points_3d.keys(), dtype=np.int64, count=s.n_points)
                         out = (uv[sel], desc[sel], s.xyz[sl].copy(), ids[sl])
                         if key is not None:
+                            # the cached answer is handed to every later caller as the same array objects (the descriptor
+                            # array's address is also what keeps its device copy resident): read-only, so that an in-place
+                            # edit by one caller raises instead of silently changing what the next caller is given
+                            for a in out:
+                                a.setflags(write=False)
                             self._img_cache = {frame_id: (key, out)}  # one entry: the key frame of the period
                         return out
                     except (TypeError, ValueError):
@@ -430,6 +440,8 @@ class Map:
         batch as three array appends (a re-observation of the same (point, frame) invalidates it instead)."""
         fid = frame_obj.GetID()
         pts = self.points_3d
+        if not isinstance(point_ids, (list, tuple, np.ndarray)):
+            point_ids = list(point_ids)  # the reference's zip() takes any iterable; it is walked more than once here
         if self._added:
             self._absorb_added()
         s = self._soa

@@ -14,6 +14,12 @@ without a collective.
 Streaming use (bench.py --gpus N): `submit()` enqueues the local match and starts the all-gather asynchronously on
 RCCL's stream; `collect()` of step k is called after `submit()` of step k+1, so the collective of one step overlaps
 the kernels of the next (two rotating buffer sets).
+
+Ordering of a step (enforced inside vs_hamming_knn2_sharded_dev, include/vslam_hip.h): before the kernel overwrites a
+gather buffer its compute stream waits (1) for the `done` event of the previous step on that buffer -- the in-place
+all-gather sends from and receives into those very rows -- and (2) for the caller's stream as of submit(): the consumers
+of the buffer's previous results and the producers of the new inputs.  The inputs of a step must stay untouched until
+that step has been collected.
 """
 
 
@@ -241,6 +247,7 @@ class ShardedMatcher:
             self._events[key] = ev
         done = self._events[key]
         self._order_after_caller()
+        # the library's stream first waits for `done` as the previous step on this buffer recorded it (inside the C call)
         self._ctx.hamming_knn2_sharded_dev(q.data_ptr(), q.shape[0], t.data_ptr(), t.shape[0], gathered.data_ptr(), per,
                                            self.rank, self.world, self._rccl.comm.value, None,
                                            self._rccl.stream.cuda_stream, done.cuda_event)
@@ -289,10 +296,10 @@ class ShardedMatcher:
         return out[:n_query, 0:2], out[:n_query, 2:4]
 
     def plan(self, q_shard, train, n_query, single_stream=False, in_flight=2):
-        """A pre-bound step for a fixed workload (bench.py, streaming callers): every ctypes argument of the two rotating
-        buffer sets is built once, so `submit()` is one C call (kernel [+ event + in-place ncclAllGather + done event])
-        and `collect(slot)` one stream-side wait.  The caller works on `torch_stream()` (checked here); other callers use
-        submit / collect / knn2, which order against torch's current stream themselves."""
+        """A pre-bound step for a fixed shape (bench.py, streaming callers): every ctypes argument of the rotating buffer
+        sets is built once, so `submit()` is one C call (stream waits + kernel [+ event + in-place ncclAllGather] + done
+        event) and `collect(slot)` one stream-side wait.  The caller works on `torch_stream()` (checked here); other
+        callers use submit / collect / knn2, which order against torch's current stream themselves."""
         import torch
         mine = self.torch_stream()
         if torch.cuda.current_stream(mine.device).cuda_stream != mine.cuda_stream:
@@ -319,62 +326,78 @@ class ShardedMatcher:
 
 
 class _Plan:
-    """`in_flight` steps in flight (default two): slot 0 launches on the library's stream, every further slot on a stream of
-    its own (own scratch inside the library), so the short tail of one launch -- the fold by the last-arriving workgroups,
-    the kernel boundary -- overlaps the body of the next.  Results are ordered into the library's stream by collect()."""
+    """`in_flight` steps in flight (default two), each slot with a compute stream, a buffer set and a `done` event of its
+    own, so the short tail of one launch -- the fold by the last-arriving workgroups, the kernel boundary -- overlaps the
+    body of the next.  The library's stream (torch_stream(), the caller's) carries only the caller's own work: producers
+    of the inputs before submit(), consumers of the results after collect().
+
+    What orders a step (one C call, vs_hamming_knn2_sharded_dev):
+        compute stream of the slot  <-  done[slot] as the slot's PREVIOUS step recorded it (its in-place all-gather reads
+                                        and writes the buffer the kernel is about to overwrite)
+                                    <-  the library's stream as of submit() (the producers of this step's q / t, the
+                                        consumers of the slot's previous results)
+        kernel -> [event -> RCCL stream: in-place ncclAllGather] -> done[slot]
+        collect(slot): the library's stream waits for done[slot].
+    Contract: the inputs of a step stay untouched until that step has been collected -- a streaming caller rotates at
+    least `in_flight` input buffers and names them per step, submit(q=..., t=...).  in_flight == 1: everything on the
+    library's stream."""
 
     def __init__(self, m, q, t, n_query, in_flight=2):
-        import ctypes as C
         import torch
         from . import _capi
         b, e, per = shard_bounds(n_query, m.world, m.rank)
         assert q.shape[0] == e - b, "q_shard must be this rank's slice of the query set"
         self.m, self.n_query, self.slot = m, n_query, 0
-        lib, h = _capi.load(), m._ctx.handle
+        self.lib, self.h = _capi.load(), m._ctx.handle
         collective = m._dist.is_initialized() and (m.world > 1 or m._force_collective)
         self.direct = collective and m._direct_ready(q)
         self.fallback = collective and not self.direct
-        self.keep = (q, t)
-        self.calls, self.outs, self.done, self.bufs = [], [], [], []
         assert 1 <= in_flight <= 4
         self.nslots = max(2, in_flight)  # two rotating buffer sets even on one stream
-        self.streams = [m._stream]
-        for _ in range(1, self.nslots):
-            if in_flight == 1:
-                self.streams.append(m._stream)
-            else:
-                st = torch.cuda.Stream(device=q.device)
-                st.wait_stream(m._stream)  # q / t were produced on the library's stream
-                self.streams.append(st)
+        self.shape = (tuple(q.shape), tuple(t.shape))
+        main = m._stream
+        self.streams = [main if in_flight == 1 else torch.cuda.Stream(device=q.device) for _ in range(self.nslots)]
+        self.args, self.outs, self.done, self.bufs, self.keep = [], [], [], [], []
         nq, nt = q.shape[0], t.shape[0]
         for slot in range(self.nslots):
             packed, gathered = m._buffers(per, q.device, 2 + slot)  # buffer sets of their own
             cs = self.streams[slot]
-            csp = C.c_void_p(cs.cuda_stream)
             ev = torch.cuda.Event()
-            ev.record(m._rccl.stream if self.direct else cs)  # creates the hipEvent_t
-            if self.direct:
-                fn = lib.vs_hamming_knn2_sharded_dev
-                args = (h, C.c_void_p(q.data_ptr()), nq, C.c_void_p(t.data_ptr()), nt, C.c_void_p(gathered.data_ptr()), per,
-                        m.rank, m.world, C.c_void_p(m._rccl.comm.value), csp, C.c_void_p(m._rccl.stream.cuda_stream),
-                        C.c_void_p(ev.cuda_event))
+            ev.record(cs)  # creates the hipEvent_t; complete by the time anything waits for it
+            after = main.cuda_stream if cs is not main else None
+            if self.direct:   # this rank's rows go straight into its slot of the gather buffer, then the in-place all-gather
+                args = [self.h, q.data_ptr(), nq, t.data_ptr(), nt, gathered.data_ptr(), per, m.rank, m.world,
+                        m._rccl.comm.value, cs.cuda_stream, m._rccl.stream.cuda_stream, ev.cuda_event, after]
                 out = gathered
-            else:
-                fn = lib.vs_hamming_knn2_packed_dev
-                args = (h, C.c_void_p(q.data_ptr()), nq, C.c_void_p(t.data_ptr()), nt, C.c_void_p(packed.data_ptr()), csp)
+            else:             # no collective inside the call (world 1, or torch's collective afterwards): packed rows only
+                args = [self.h, q.data_ptr(), nq, t.data_ptr(), nt, packed.data_ptr(), per, 0, 1,
+                        None, cs.cuda_stream, None, ev.cuda_event, after]
                 out = gathered if self.fallback else packed
             self.done.append(ev)
-            self.calls.append((fn, args))
+            self.args.append(args)
             self.bufs.append((packed, gathered))
+            self.keep.append((q, t))
             self.outs.append((out[:n_query, 0:2], out[:n_query, 2:4]))
         self.work = [None] * self.nslots
 
-    def submit(self):
-        """Enqueue one step; returns the slot to hand to collect()."""
+    def submit(self, q=None, t=None):
+        """Enqueue one step; returns the slot to hand to collect().  q / t: this step's inputs (device tensors of the plan's
+        shapes, produced on the library's stream); default: the tensors the plan was made with."""
         slot = self.slot
         self.slot = (slot + 1) % self.nslots
-        fn, args = self.calls[slot]
-        rc = fn(*args)
+        args = self.args[slot]
+        if q is not None or t is not None:
+            kq, kt = self.keep[slot]
+            q = kq if q is None else q
+            t = kt if t is None else t
+            if (tuple(q.shape), tuple(t.shape)) != self.shape or not (q.is_cuda and t.is_cuda):
+                raise ValueError("ShardedMatcher.plan: a step's inputs must be device tensors of the planned shapes")
+            args[1], args[3] = q.data_ptr(), t.data_ptr()
+            self.keep[slot] = (q, t)  # alive until the slot's next step
+        if self.work[slot] is not None:  # torch's collective of the slot's previous step was never collected
+            self.work[slot].wait()
+            self.work[slot] = None
+        rc = self.lib.vs_hamming_knn2_sharded_dev(*args)
         if rc != 0:
             self.m._ctx._chk(rc)
         if self.fallback:
@@ -382,16 +405,14 @@ class _Plan:
             packed, gathered = self.bufs[slot]
             with torch.cuda.stream(self.streams[slot]):
                 self.work[slot] = self.m._dist.all_gather_into_tensor(gathered, packed, group=self.m.group, async_op=True)
-        elif not self.direct and self.streams[slot] is not self.m._stream:
-            self.done[slot].record(self.streams[slot])
         return slot
 
     def collect(self, slot):
         """(idx [Q,2], dist [Q,2]) of the step submitted into `slot`, ordered on the library's stream."""
         if self.fallback:
             if self.work[slot] is not None:
-                self.work[slot].wait()
+                self.work[slot].wait()   # torch's current stream = the library's (plan() checked it)
                 self.work[slot] = None
-        elif self.direct or self.streams[slot] is not self.m._stream:
+        elif self.streams[slot] is not self.m._stream or self.direct:
             self.m._stream.wait_event(self.done[slot])
         return self.outs[slot]
