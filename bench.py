@@ -103,29 +103,48 @@ def all_threads_rate(fn, threads, seconds=6.0):
     return sum(counts) / (time.perf_counter() - t0)
 
 
-def cpu_trackers_all_cores(cores, seconds=8.0):
-    """frames/s of the CPU oracle with EVERY host core busy: one sequential tracker per core on the 20 fixture frames.
+def host_cpu_share():
+    """(logical CPUs the OS reports, CPU quota of this container in cores or None): the GPU boxes give one job a share of a
+    larger host, so 'all cores' figures say what they ran on."""
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    return os.cpu_count() or 1, quota
+
+
+def cpu_trackers_all_cores(cores, seconds=4.0):
+    """frames/s of the CPU oracle with the host's cores busy: one sequential tracker per thread on the 20 fixture frames.
     The tracker's glue is Python, so the trackers are spread over worker PROCESSES (a few threads each; one interpreter
     lock would cap the figure); the workers never touch the GPU (no torch, no Context).  Each worker counts the frames it
-    completes inside one common wall-clock window."""
+    completes inside one common wall-clock window.  More threads is not always more frames/s on a shared host: three
+    thread counts are run, all are reported, the best one is the figure."""
     import subprocess
-    procs_n = max(1, min(32, cores // 4))
-    per = max(1, cores // procs_n)
-    start = time.time() + 6.0 + 0.02 * procs_n   # imports + PNG decode + warm-up happen before the window opens
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-tracker-worker", str(per), repr(start), repr(seconds)]
-    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(procs_n)]
-    frames = 0.0
-    late = 0
-    for p in procs:
-        out, _ = p.communicate(timeout=120)
-        last = [ln for ln in out.splitlines() if ln.startswith("frames ")]
-        if last:
-            frames += float(last[-1].split()[1])
-            late += int(last[-1].split()[2])
-    return {"threads": procs_n * per, "processes": procs_n, "threads_per_process": per, "frames_per_s": frames / seconds,
-            "workers_late_for_the_window": late, "window_s": seconds,
-            "note": "one sequential CPU-oracle tracker per host core on the same 20 frames (streams side by side), "
-                    "%d processes x %d threads" % (procs_n, per)}
+
+    def run(total):
+        procs_n = max(1, min(32, total // 4))
+        per = max(1, total // procs_n)
+        start = time.time() + 5.0 + 0.02 * procs_n   # imports + PNG decode + warm-up happen before the window opens
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-tracker-worker", str(per), repr(start), repr(seconds)]
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(procs_n)]
+        frames, late = 0.0, 0
+        for p in procs:
+            out, _ = p.communicate(timeout=120)
+            last = [ln for ln in out.splitlines() if ln.startswith("frames ")]
+            if last:
+                frames += float(last[-1].split()[1])
+                late += int(last[-1].split()[2])
+        return {"threads": procs_n * per, "processes": procs_n, "threads_per_process": per, "frames_per_s": frames / seconds,
+                "workers_late_for_the_window": late}
+
+    runs = [run(t) for t in sorted({min(cores, 32), min(cores, 96), cores})]
+    best = max(runs, key=lambda r: r["frames_per_s"])
+    return dict(best, window_s=seconds, host_logical_cpus=cores, cpu_quota_cores=host_cpu_share()[1], sweep=runs,
+                note="one sequential CPU-oracle tracker per thread on the same 20 frames (streams side by side), worker "
+                     "processes x threads; best of the thread counts in `sweep`")
 
 
 def cpu_tracker_worker(threads, start, seconds):
@@ -289,11 +308,14 @@ def ba_leg(ctx, cpu=True):
         cmed, _ = median_time(lambda: oracle.ba_solve(*args), 5, warm=1)
         out["cpu_ms_per_solve_1_thread"] = cmed * 1e3
         cores = os.cpu_count() or 1
-        rate = all_threads_rate(lambda: oracle.ba_solve(*args), cores, seconds=6.0)
-        out["cpu_all_threads"] = {"threads": cores, "of_host_cores": cores, "solves_per_s": rate,
-                                  "ms_per_solve_equivalent": 1e3 / rate,
-                                  "note": "the LM solve is sequential; all-threads = independent solves side by side, one per "
-                                          "host core (the C solve releases the interpreter lock)"}
+        sweep = [{"threads": t, "solves_per_s": all_threads_rate(lambda: oracle.ba_solve(*args), t, seconds=3.0)}
+                 for t in sorted({min(cores, 32), min(cores, 96), cores})]
+        bestr = max(sweep, key=lambda r: r["solves_per_s"])
+        out["cpu_all_threads"] = {"threads": bestr["threads"], "host_logical_cpus": cores, "cpu_quota_cores": host_cpu_share()[1],
+                                  "solves_per_s": bestr["solves_per_s"], "ms_per_solve_equivalent": 1e3 / bestr["solves_per_s"],
+                                  "sweep": sweep,
+                                  "note": "the LM solve is sequential; all-threads = independent solves side by side (the C "
+                                          "solve releases the interpreter lock); best of the thread counts in `sweep`"}
         out["gpu_solves_per_s"] = 1.0 / med
         out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
                                                          for a, b in zip(g["poses"], c["poses"])))

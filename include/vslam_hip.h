@@ -49,6 +49,10 @@ int vs_destroy(vs_ctx* ctx);
 const char* vs_last_error(const vs_ctx* ctx);
 /* the context's hipStream_t as void* (so torch / RCCL work can be ordered against it) */
 void* vs_stream(vs_ctx* ctx);
+/* auxiliary compute streams of the context (index 0 .. 1; NULL beyond): created together with the main stream so that
+ * each sits on a hardware queue of its own -- for callers that keep several steps in flight (the query-sharded matcher,
+ * vs_hamming_knn2_sharded_dev with compute_stream = one of these).  Owned by the context. */
+void* vs_aux_stream(vs_ctx* ctx, int index);
 int vs_synchronize(vs_ctx* ctx);
 
 /* Pinned host memory (optional).  Host entry points accept any host pointer; when a frame lives in memory obtained

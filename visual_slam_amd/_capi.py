@@ -63,6 +63,7 @@ SIGNATURES = {
     "vs_destroy": (C.c_int, [c_ctxp]),
     "vs_last_error": (C.c_char_p, [c_ctxp]),
     "vs_stream": (C.c_void_p, [c_ctxp]),
+    "vs_aux_stream": (C.c_void_p, [c_ctxp, C.c_int]),
     "vs_synchronize": (C.c_int, [c_ctxp]),
     "vs_host_alloc": (C.c_int, [c_ctxp, C.c_size_t, C.POINTER(C.c_void_p)]),
     "vs_host_free": (C.c_int, [c_ctxp, c_voidp]),

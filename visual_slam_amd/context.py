@@ -69,6 +69,11 @@ class Context:
     def stream(self):
         return self._lib.vs_stream(self._h)
 
+    def aux_stream(self, index):
+        """One of the context's auxiliary compute streams (a hipStream_t address; None beyond the last): created with the
+        context, so each has a hardware queue of its own."""
+        return self._lib.vs_aux_stream(self._h, int(index))
+
     def synchronize(self):
         self._chk(self._lib.vs_synchronize(self._h))
 

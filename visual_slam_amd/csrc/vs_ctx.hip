@@ -23,6 +23,21 @@ VS_API int vs_create(vs_ctx** out, int device) {
     delete ctx;
     return VS_EHIP;
   }
+  // all streams of the context at once, so that they land on hardware queues of their own (see vs_internal.h).  The
+  // front-half stream has the lowest priority: in pipelined tracking the front half (detect, match) of frame k+1 shares
+  // the GPU with the back half of frame k, which is the critical path -- a chain of short launches that should not queue
+  // behind the detector's 240 workgroups (ba_motion_step: 7 us alone, 10-13 us behind them at equal priority)
+  int prio_lo = 0, prio_hi = 0;
+  e = hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->track.front_stream, hipStreamNonBlocking, prio_lo);
+  for (int i = 0; i < VS_AUX_STREAMS && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking);
+  for (hipEvent_t& ev : ctx->track.ev_front)
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    vs_fail(nullptr, VS_EHIP, "vs_create: %s", hipGetErrorString(e));
+    vs_destroy(ctx);
+    return VS_EHIP;
+  }
   if (strncmp(ctx->prop.gcnArchName, "gfx950", 6) != 0) {
     vs_fail(nullptr, VS_EHIP, "vs_create: this library is built for gfx950 only, device is %s", ctx->prop.gcnArchName);
     (void)hipStreamDestroy(ctx->stream);
@@ -76,6 +91,8 @@ VS_API int vs_destroy(vs_ctx* ctx) {
   if (ctx->ev_shard) (void)hipEventDestroy(ctx->ev_shard);
   if (ctx->ev_after) (void)hipEventDestroy(ctx->ev_after);
   if (ctx->track.front_stream) (void)hipStreamDestroy(ctx->track.front_stream);
+  for (hipStream_t a : ctx->aux_stream)
+    if (a) (void)hipStreamDestroy(a);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return VS_OK;
@@ -172,6 +189,10 @@ VS_API int vs_host_free(vs_ctx* ctx, void* p) {
 VS_API const char* vs_last_error(const vs_ctx* ctx) { return ctx ? ctx->err : g_vs_create_error; }
 
 VS_API void* vs_stream(vs_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+VS_API void* vs_aux_stream(vs_ctx* ctx, int index) {
+  return ctx && index >= 0 && index < VS_AUX_STREAMS ? (void*)ctx->aux_stream[index] : nullptr;
+}
 
 VS_API int vs_synchronize(vs_ctx* ctx) {
   if (!ctx) return VS_EINVAL;

@@ -58,9 +58,16 @@ struct vs_prof_rec {
   hipEvent_t e0, e1;
 };
 
+constexpr int VS_AUX_STREAMS = 2;
+
 struct vs_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // Further streams of the context, created TOGETHER with `stream` in vs_create: the runtime spreads streams over a few
+  // hardware queues as they are created, and two streams that end up on one queue never overlap.  Measured (round 3,
+  // tools/stream_pressure.py): with the front-half stream created lazily, after the process had made other streams (one
+  // torch.cuda.Stream() creates torch's whole pool), the pipelined tracking period ran at 210 us per frame instead of 139.
+  hipStream_t aux_stream[VS_AUX_STREAMS] = {nullptr, nullptr};  // compute streams for callers that keep steps in flight (vs_aux_stream)
   hipDeviceProp_t prop;
   char err[512];
   // matcher

@@ -378,15 +378,6 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   VS_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   auto& T = ctx->track;
-  if (!T.front_stream) {
-    // lowest priority: in pipelined use the front half (detect, match) of frame k+1 shares the GPU with the back half of
-    // frame k, which is the critical path -- a chain of short launches that should not queue behind the detector's
-    // 240 workgroups (ba_motion_step: 7 us alone, 10-13 us behind them at equal priority)
-    int prio_lo = 0, prio_hi = 0;
-    VS_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    VS_HIP(ctx, hipStreamCreateWithPriority(&T.front_stream, hipStreamNonBlocking, prio_lo));
-    for (hipEvent_t& e : T.ev_front) VS_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  }
   VS_HIP(ctx, hipStreamSynchronize(T.front_stream));
   const track_layout L = track_layout_of(n_points, max_frames, max_kp, pnp_iterations > 0 ? pnp_iterations : 1);
   VS_TRY(vs_reserve(ctx, &ctx->d_track, L.total));

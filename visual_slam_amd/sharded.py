@@ -356,7 +356,14 @@ class _Plan:
         self.nslots = max(2, in_flight)  # two rotating buffer sets even on one stream
         self.shape = (tuple(q.shape), tuple(t.shape))
         main = m._stream
-        self.streams = [main if in_flight == 1 else torch.cuda.Stream(device=q.device) for _ in range(self.nslots)]
+        # compute streams of the slots: the context's own auxiliary streams first (created with the context, each on a
+        # hardware queue of its own -- streams made later may share a queue with the library's and then never overlap it),
+        # torch streams only beyond those
+        self.streams = []
+        for slot in range(self.nslots):
+            aux = m._ctx.aux_stream(slot) if in_flight > 1 else None
+            self.streams.append(main if in_flight == 1 else torch.cuda.ExternalStream(aux, device=q.device) if aux
+                                else torch.cuda.Stream(device=q.device))
         self.args, self.outs, self.done, self.bufs, self.keep = [], [], [], [], []
         nq, nt = q.shape[0], t.shape[0]
         for slot in range(self.nslots):
@@ -370,8 +377,10 @@ class _Plan:
                         m._rccl.comm.value, cs.cuda_stream, m._rccl.stream.cuda_stream, ev.cuda_event, after]
                 out = gathered
             else:             # no collective inside the call (world 1, or torch's collective afterwards): packed rows only
+                # everything on the library's own stream is ordered by the stream itself: no event between two launches
+                # (an event record / wait pair keeps back-to-back kernels a few microseconds apart)
                 args = [self.h, q.data_ptr(), nq, t.data_ptr(), nt, packed.data_ptr(), per, 0, 1,
-                        None, cs.cuda_stream, None, ev.cuda_event, after]
+                        None, cs.cuda_stream, None, ev.cuda_event if cs is not main else None, after]
                 out = gathered if self.fallback else packed
             self.done.append(ev)
             self.args.append(args)
