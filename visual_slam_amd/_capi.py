@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvslam_hip.so")
+LIB_PATH = os.environ.get("VS_LIB_PATH") or os.path.join(_HERE, "libvslam_hip.so")  # VS_LIB_PATH: dev builds (A/B variants)
 _LIB = None
 
 VS_OK, VS_EINVAL, VS_ENOMEM, VS_EHIP, VS_ENOTPD, VS_ECAP, VS_ENCCL = 0, -1, -2, -3, -4, -5, -6
@@ -112,6 +112,8 @@ HOOKS = {
     "vs_tune_ba": (C.c_int, [c_ctxp, C.c_int, C.c_int, C.c_int, C.c_int]),  # schur variant, points / workgroup, slab cap, motion variant
     "vs_match_profile": (C.c_int, [c_ctxp, C.c_int]),
     "vs_match_profile_read": (C.c_int, [c_ctxp, C.POINTER(C.c_float)]),
+    "vs_pnp_profile": (C.c_int, [c_ctxp, C.c_int]),
+    "vs_pnp_profile_read": (C.c_int, [c_ctxp, c_f64p, C.c_int]),
 }
 
 

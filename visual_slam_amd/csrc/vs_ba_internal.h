@@ -10,6 +10,9 @@ namespace vsba {
 constexpr int kCamStride = 19;  // t[3] q[4] w2n[12]
 constexpr int kMoThreads = 512;  // threads per camera workgroup of the motion-only step (one observation per thread at ~500 matches)
 constexpr int kPnpFinish = 256;
+constexpr int kPnpModel = 32;        // doubles per hypothesis model row
+constexpr int kPnpHypIters = 5;      // LM iterations of a RANSAC hypothesis at most (specification, oracle alike: vo_pnp_ransac)
+constexpr double kPnpStep2 = 1e-14;  // the PnP LM stops on a step with |x|^2 below this (specification, oracle alike)
 
 struct lm_state {
   double lambda, ni, current_chi, temp_chi, rho, scale_pose, chi0;
@@ -151,9 +154,10 @@ struct pnp_args {
   double fx, fy, cx, cy, thr2, confidence;
   unsigned long long seed;
   double cam0[kCamStride];
-  double* cam_out;     // [H][19] record re-derived from the 4x4 model
-  double* pose_out;    // [H][12] the model itself: rows of [R|t], camera-to-world
-  int* good_out;       // [H]
+  double* model_out;   // [H][kPnpModel]: rows of [R|t] (camera-to-world, 12), the record re-derived from it (19), pad; 256-byte rows
+  unsigned long long* tag;  // [H] (call epoch << 32) | inlier count of hypothesis h, published when its model is complete
+  unsigned epoch;      // this call's epoch (never 0; words of earlier calls never carry it)
+  unsigned long long* stamps;  // diagnostic (vs_pnp_profile): wall-clock stamps [H + 1][8] of the roles' phases, or nullptr
   double* result;      // [20]: pose 4x4, found, inliers, best hypothesis, hypotheses used
   int* inl_out;        // [n]
   const int* n_dev;    // tracking session: the number of correspondences lives on the device (nullptr: use n)
@@ -168,7 +172,9 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
 bool mo_persistent_ok(vs_ctx* ctx, int cameras, int max_steps);  // vs_ba.hip: may the one-launch form run on this device?
 constexpr int kMoPersistCameras = 64;          // limit of the one-launch form: workgroups that have to be resident together
 constexpr int kMoPersistObs = 2 * kMoThreads;  // observations per camera its threads keep in registers (more: the <true> instantiation)
-__global__ __launch_bounds__(64) void pnp_hypothesis_kernel(pnp_args P);
-__global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P);
+__global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(pnp_args P);
+int pnp_grid(int iterations);  // workgroups of pnp_ransac_kernel: four hypotheses each + the finishing one
+int pnp_tags(vs_ctx* ctx, int iterations, hipStream_t s, unsigned long long** tag, unsigned* epoch);  // vs_pnp.hip
+int pnp_stamps(vs_ctx* ctx, int iterations, hipStream_t s, unsigned long long** stamps);
 
 }  // namespace vsba

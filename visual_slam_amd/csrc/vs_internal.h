@@ -110,6 +110,11 @@ struct vs_ctx {
   hipEvent_t ev_after = nullptr;  // orders a compute stream behind the caller's stream (same entry point, after_stream)
   vs_tuning tune;
   std::vector<vs_prof_rec> match_prof;
+  vs_buf d_pnp_tag;         // tagged per-hypothesis words of pnp_ransac_kernel (zero when allocated)
+  unsigned pnp_epoch = 0;   // epoch of the newest PnP call
+  vs_buf d_pnp_stamps;      // diagnostic phase stamps of the newest PnP launch (vs_pnp_profile)
+  bool pnp_profile = false;
+  int pnp_profile_h = 0;
   int mo_persist_cap = -1;  // camera workgroups of ba_motion_persistent the device keeps resident together (-1: not asked yet)
 };
 

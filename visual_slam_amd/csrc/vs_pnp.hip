@@ -15,13 +15,13 @@ namespace {
 // cv2.solvePnPRansac as the reference calls it (src/v2/main.py:196-197; useExtrinsicGuess, ITERATIVE, 100 iterations,
 // 8 px, 0.99): hypothesis h refines the extrinsic guess on 5 sampled correspondences, inliers are counted over all
 // points, RANSACUpdateNumIters shrinks the budget, the best model is refined on its inliers.
-//   pnp_hypothesis_kernel: one wave per hypothesis.  The 5 sampled edges sit on lanes 0..4 of every group of 8 lanes;
-//     the 28 sums of a linearisation (21 H, 6 b, chi2) are butterfly-reduced inside the group, so every lane holds the
-//     same normal equations and runs the same LM step redundantly in registers - no LDS, no broadcast.  Then the 64
+//   pnp_ransac_kernel, hypothesis waves: one wave per hypothesis.  The 5 sampled edges sit on lanes 0..4 of every group of 8
+//     lanes; the 28 sums of a linearisation (21 H, 6 b, chi2) are butterfly-reduced inside the group, so every lane holds
+//     the same normal equations and runs the same LM step redundantly in registers - no LDS, no broadcast.  Then the 64
 //     lanes score the n points and a ballot counts the inliers.
-//   pnp_finish_kernel: one workgroup replays the sequential budget rule over the per-hypothesis counts (which yields
-//     exactly the sequential algorithm's winner), lists the winner's inliers in order and refines the pose on them
-//     with the same cooperative LM (edges strided over 256 threads), all inside the one launch.
+//   pnp_ransac_kernel, finishing workgroup: replays the sequential budget rule over the per-hypothesis counts as they arrive
+//     (which yields exactly the sequential algorithm's winner), lists the winner's inliers in order and refines the pose on
+//     them with the same cooperative LM (edges strided over 256 threads).  One launch for all of it.
 
 
 __device__ inline int pnp_count(const pnp_args& P) { return P.n_dev ? *P.n_dev : P.n; }
@@ -155,15 +155,18 @@ __device__ inline void pnp_reduce(double* v, double* s_red) {
 }
 
 // Levenberg-Marquardt as OptimizationAlgorithmLevenberg drives it (one camera, fixed points, no robust kernel) plus a
-// stop once a solved step is numerically zero (|x|^2 < 1e-18; OpenCV's iterative solver stops on a small parameter change
-// too), run redundantly by every thread on identical sums.  Edge e of the thread: e = first, first + stride, ... < m; sel maps to
+// stop once a solved step is small (|x|^2 < kPnpStep2 = 1e-14, i.e. |x| < 1e-7: OpenCV's iterative solver stops when the
+// parameter change falls below FLT_EPSILON = 1.2e-7 relative), run redundantly by every thread on identical sums; at most
+// max_it iterations (the final refinement: the caller's refine_iters; a hypothesis: kPnpHypIters of them -- a hypothesis
+// only has to be good enough to count inliers at a threshold of pixels, and the slowest of the first few hypotheses is what
+// the finishing workgroup waits for).  Edge e of the thread: e = first, first + stride, ... < m; sel maps to
 // the correspondence (nullptr: identity).
 // The thread's edges are fetched once and kept in registers when they fit (NREG per thread: always for the 5-point
 // hypotheses, up to NREG * stride inliers in the final refinement): every LM iteration evaluates them twice, and from
 // memory each evaluation starts with two dependent round trips (index, then point and pixel) on an otherwise idle CU --
 // in-kernel stamps put the refinement at 5.7 us per iteration, mostly waiting for those.
 template <int STEPS, int NWAVES, int NREG>
-__device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int first, int stride, double* cam, double* s_red) {
+__device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int first, int stride, double* cam, double* s_red, int max_it) {
   double trial[kCamStride];
   double lambda = 0.0, ni = 2.0;
   const bool in_regs = m <= NREG * stride;  // uniform
@@ -182,7 +185,7 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
       }
     }
   }
-  for (int it = 0; it < P.iters_lm; ++it) {
+  for (int it = 0; it < max_it; ++it) {
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; ++k) acc[k] = 0.0;
@@ -271,7 +274,7 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
         double step2 = 0.0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) step2 += x[a] * x[a];
-        conv = step2 < 1e-18;  // below the numerical resolution of chi2: this trial is the last one
+        conv = step2 < kPnpStep2;  // a step this small: this trial is the last one
       } else {
 #pragma unroll
         for (int a = 0; a < 6; ++a) x[a] = 0.0;
@@ -325,75 +328,6 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
 
 }  // namespace
 
-namespace vsba {
-__global__ __launch_bounds__(64) void pnp_hypothesis_kernel(pnp_args P) {
-  __shared__ int s_idx[8];
-  const int h = blockIdx.x, lane = threadIdx.x;
-  P.n = pnp_count(P);
-  if (P.n < 5) {
-    if (lane == 0) P.good_out[h] = 0;
-    return;
-  }
-  if (P.n == 5) {
-    if (lane < 5) s_idx[lane] = lane;
-  } else {
-    // the first five distinct values of the stream c_k = splitmix64(base ^ ((h << 20) + k)) % n, k = 0, 1, ...: eight
-    // lanes draw eight candidates at a time (a 64-bit modulo is ~200 instructions: 2.4 us when one lane drew them one by
-    // one), lane 0 picks in order
-    __shared__ int s_cand[8];
-    const unsigned long long base = splitmix64(P.seed);  // unrelated streams for neighbouring seeds
-    int got = 0;
-    for (unsigned long long k0 = 0; got < 5; k0 += 8) {
-      if (lane < 8)
-        s_cand[lane] = (int)(splitmix64(base ^ (((unsigned long long)h << 20) + k0 + (unsigned long long)lane)) % (unsigned long long)P.n);
-      __syncthreads();
-      if (lane == 0) {
-        for (int k = 0; k < 8 && got < 5; ++k) {
-          const int c = s_cand[k];
-          bool dup = false;
-          for (int j = 0; j < got; ++j) dup |= s_idx[j] == c;
-          if (!dup) s_idx[got++] = c;
-        }
-        s_idx[7] = got;
-      }
-      __syncthreads();
-      got = s_idx[7];
-    }
-  }
-  __syncthreads();
-  double cam[kCamStride];
-  for (int k = 0; k < kCamStride; ++k) cam[k] = P.cam0[k];
-  pnp_lm<3, 1, 1>(P, s_idx, 5, lane & 7, 8, cam, nullptr);
-  // the model is handed on as a 4x4 pose (as the sequential algorithm does): re-derive the record from that matrix
-  double m[16];
-  for (int r = 0; r < 3; ++r) {
-    for (int k = 0; k < 3; ++k) m[4 * r + k] = cam[7 + 4 * k + r];
-    m[4 * r + 3] = cam[r];
-  }
-  quat_from_pose(m, cam + 3);
-  quat_to_w2n(cam, cam + 3, cam + 7);
-  if (lane == 0) {
-    for (int k = 0; k < 12; ++k) P.pose_out[(size_t)h * 12 + k] = m[k];
-    for (int k = 0; k < kCamStride; ++k) P.cam_out[(size_t)h * kCamStride + k] = cam[k];
-  }
-  int good = 0;
-  for (int i0 = 0; i0 < P.n; i0 += 64) {
-    const int i = i0 + lane;
-    bool in = false;
-    if (i < P.n) {
-      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
-      double eu, ev, pc[3];
-      pnp_err(P, cam, X, uv, eu, ev, pc);
-      in = eu * eu + ev * ev <= P.thr2;
-    }
-    good += __popcll(__ballot(in));
-  }
-  if (lane == 0) P.good_out[h] = good;
-}
-
-}  // namespace vsba
-
 namespace {
 __device__ inline int ransac_update_iters_dev(double p, double ep, int model_points, int max_iters) {
   p = fmin(fmax(p, 0.0), 1.0);
@@ -410,11 +344,118 @@ __device__ inline int ransac_update_iters_dev(double p, double ep, int model_poi
 }  // namespace
 
 namespace vsba {
-__global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
+// ONE launch: workgroups 0 .. nhw-1 hold four hypotheses each (one per wave; hypothesis h = wave * nhw + workgroup, so the
+// first hypotheses -- the ones the budget replay reads -- sit on different compute units), workgroup nhw finishes.
+//   hypothesis wave: sample, refine the guess on the five correspondences (pnp_lm on lanes 0..4 of every group of 8),
+//     write the model (write-through), count the inliers over all points, then publish ONE tagged word
+//     (call epoch << 32 | count): the word validates itself, stale words of earlier calls never carry this call's epoch.
+//   finishing workgroup: wave 0 polls the tagged words 64 at a time and replays the sequential budget rule over the
+//     leading run that has arrived -- it needs hypothesis k only when the budget still reaches k, which is typically a
+//     handful -- then acquires, lists the winner's inliers in order and refines on them.  It therefore starts as soon as the
+//     hypotheses the sequential algorithm would have looked at are in, not when the slowest of all of them is; hypotheses
+//     beyond the budget finish on their own compute units meanwhile, nothing waits for them but the end of the launch.
+// Two launches and a kernel boundary before (pnp_hypothesis_kernel 35 us + pnp_finish_kernel 30 us per tracked frame).
+constexpr int kPnpWaves = kPnpFinish / 64;
+
+__device__ inline void st_wt(double* p, double v) {  // write-through (sc1) store: the reader is on another compute unit
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline void pnp_stamp(const pnp_args& P, int row, int col) {  // diagnostic only
+  if (P.stamps) P.stamps[(size_t)row * 8 + col] = wall_clock64();
+}
+
+__device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
+  __shared__ int s_idx[kPnpWaves][8];
+  __shared__ int s_cand[kPnpWaves][8];
+  __shared__ double s_rec[kPnpWaves][kPnpModel];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int h = wv * nhw + blockIdx.x;
+  if (h >= P.iterations) return;  // whole wave
+  if (lane == 0) pnp_stamp(P, h, 0);
+  const unsigned long long tag_hi = (unsigned long long)P.epoch << 32;
+  if (P.n < 5) {
+    if (lane == 0) __hip_atomic_store(&P.tag[h], tag_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  int* idx = s_idx[wv];
+  if (P.n == 5) {
+    if (lane < 5) idx[lane] = lane;
+  } else {
+    // the first five distinct values of the stream c_k = splitmix64(base ^ ((h << 20) + k)) % n, k = 0, 1, ...: eight
+    // lanes draw eight candidates at a time (a 64-bit modulo is ~200 instructions), lane 0 picks in order
+    int* cand = s_cand[wv];
+    const unsigned long long base = splitmix64(P.seed);  // unrelated streams for neighbouring seeds
+    int got = 0;
+    for (unsigned long long k0 = 0; got < 5; k0 += 8) {
+      if (lane < 8)
+        cand[lane] = (int)(splitmix64(base ^ (((unsigned long long)h << 20) + k0 + (unsigned long long)lane)) % (unsigned long long)P.n);
+      wave_lds_sync();
+      if (lane == 0) {
+        for (int k = 0; k < 8 && got < 5; ++k) {
+          const int c = cand[k];
+          bool dup = false;
+          for (int j = 0; j < got; ++j) dup |= idx[j] == c;
+          if (!dup) idx[got++] = c;
+        }
+        idx[7] = got;
+      }
+      wave_lds_sync();
+      got = idx[7];
+    }
+  }
+  wave_lds_sync();
+  if (lane == 0) pnp_stamp(P, h, 1);
+  double cam[kCamStride];
+  for (int k = 0; k < kCamStride; ++k) cam[k] = P.cam0[k];
+  pnp_lm<3, 1, 1>(P, idx, 5, lane & 7, 8, cam, nullptr, min(P.iters_lm, kPnpHypIters));
+  if (lane == 0) pnp_stamp(P, h, 2);
+  // the model is handed on as a 4x4 pose (as the sequential algorithm does): re-derive the record from that matrix
+  double m[16];
+  for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) m[4 * r + k] = cam[7 + 4 * k + r];
+    m[4 * r + 3] = cam[r];
+  }
+  quat_from_pose(m, cam + 3);
+  quat_to_w2n(cam, cam + 3, cam + 7);
+  // the model leaves as ONE wave-wide write-through store: [pose rows 12 | record 19 | pad] = 32 doubles, lane l stores
+  // word l (through LDS: every lane holds the whole model, a store needs lane-indexed words).  One store instruction = one
+  // round trip to wait for before the tag; 31 scalar write-through stores by one lane cost ~12 us here.
+  double* rec = s_rec[wv];
+  if (lane == 0) {
+    for (int k = 0; k < 12; ++k) rec[k] = m[k];
+    for (int k = 0; k < kCamStride; ++k) rec[12 + k] = cam[k];
+    rec[31] = 0.0;
+  }
+  wave_lds_sync();
+  if (lane < kPnpModel) st_wt(P.model_out + (size_t)h * kPnpModel + lane, rec[lane]);
+  int good = 0;
+  for (int i0 = 0; i0 < P.n; i0 += 64) {
+    const int i = i0 + lane;
+    bool in = false;
+    if (i < P.n) {
+      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
+      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+      double eu, ev, pc[3];
+      pnp_err(P, cam, X, uv, eu, ev, pc);
+      in = eu * eu + ev * ev <= P.thr2;
+    }
+    good += __popcll(__ballot(in));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the model has left this compute unit before the word that announces it
+  if (lane == 0) {
+    __hip_atomic_store(&P.tag[h], tag_hi | (unsigned long long)(unsigned)good, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pnp_stamp(P, h, 3);
+  }
+}
+
+__device__ inline void pnp_finish_role(pnp_args& P) {
   __shared__ double s_red[kPnpRedDoubles];
-  __shared__ int s_best[2], s_cnt[4], s_base;
+  __shared__ int s_best[3], s_cnt[4], s_base, s_g[64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  P.n = pnp_count(P);
+  const int srow = P.iterations;  // diagnostic row of the finishing workgroup
+  if (tid == 0) pnp_stamp(P, srow, 0);
   if (P.lm_init && tid == 64) {  // the motion-only solve that follows starts from fresh LM records (no upload in between)
     mo_state z;
     memset(&z, 0, sizeof z);
@@ -424,32 +465,54 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
     z.ni = 2.0;
     P.lm_init[1] = z;
   }
-  // the per-hypothesis counts go to LDS first (all loads in flight at once): the replay below is a serial loop whose trip
-  // count depends on the data, and from global memory every one of its loads was a dependent L2 round trip
-  constexpr int kGoodLds = 4096;  // more hypotheses than this are read from global memory
-  __shared__ int s_good[kGoodLds];
-  for (int k = tid; k < min(P.iterations, kGoodLds); k += kPnpFinish) s_good[k] = P.good_out[k];
-  __syncthreads();
-  if (tid == 0) {
-    // replay of the sequential RANSAC loop (budget update after every improvement) over the per-hypothesis counts
-    int max_good = 0, niters = P.n >= 5 ? P.iterations : 0, best = -1, k = 0;
-    for (; k < niters && k < P.iterations; ++k) {
-      const int g = k < kGoodLds ? s_good[k] : P.good_out[k];
-      if (g > (max_good > 4 ? max_good : 4)) {
-        max_good = g;
-        best = k;
-        niters = ransac_update_iters_dev(P.confidence, (double)(P.n - g) / P.n, 5, niters);
+  if (wv == 0) {
+    // replay of the sequential RANSAC loop (budget update after every improvement) over the per-hypothesis counts, as they
+    // arrive: 64 tagged words per poll, the leading run that carries this call's epoch is consumed in order.  Every lane
+    // of the wave runs the same replay on the same values.
+    int max_good = 0, niters = P.n >= 5 ? P.iterations : 0, best = -1, k = 0, timed_out = 0;
+    int rounds = 0;
+    while (k < niters && k < P.iterations) {
+      const int kk = min(k + lane, P.iterations - 1);
+      const unsigned long long w = __hip_atomic_load(&P.tag[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool ready = (unsigned)(w >> 32) == P.epoch && k + lane < P.iterations;
+      const unsigned long long bal = __ballot(ready);
+      const int run = bal == ~0ull ? 64 : __ffsll((long long)~bal) - 1;  // lanes 0 .. run-1 have arrived
+      if (run == 0) {
+        if (++rounds > (1 << 21)) {  // bounded wait: hypothesis workgroups that never ran (a device without room for them)
+          timed_out = 1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        continue;
       }
+      s_g[lane] = (int)(unsigned)(w & 0xFFFFFFFFull);
+      wave_lds_sync();
+      for (int j = 0; j < run && k < niters; ++j, ++k) {
+        const int g = s_g[j];
+        if (g > (max_good > 4 ? max_good : 4)) {
+          max_good = g;
+          best = k;
+          niters = ransac_update_iters_dev(P.confidence, (double)(P.n - g) / P.n, 5, niters);
+        }
+      }
+      wave_lds_sync();
     }
-    s_best[0] = best;
-    s_best[1] = k;
-    s_base = 0;
+    if (lane == 0) {
+      pnp_stamp(P, srow, 1);
+      s_best[0] = best;
+      s_best[1] = k;
+      s_best[2] = timed_out;
+      s_base = 0;
+      // the winner's model was stored write-through by another compute unit: agent-scope acquire before anybody loads it
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __syncthreads();
-  const int best = s_best[0];
+  const int best = s_best[2] ? -1 : s_best[0];
   if (best < 0) {
     if (tid == 0) {
-      P.result[16] = 0.0;
+      P.result[16] = s_best[2] ? -1.0 : 0.0;  // -1: the hypotheses never arrived (reported as an error by the host)
       P.result[17] = 0.0;
       P.result[18] = -1.0;
       P.result[19] = (double)s_best[1];
@@ -461,7 +524,7 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
     return;
   }
   double cam[kCamStride];
-  for (int k = 0; k < kCamStride; ++k) cam[k] = P.cam_out[(size_t)best * kCamStride + k];
+  for (int k = 0; k < kCamStride; ++k) cam[k] = P.model_out[(size_t)best * kPnpModel + 12 + k];
   // ordered inlier list of the best model
   for (int i0 = 0; i0 < P.n; i0 += kPnpFinish) {
     const int i = i0 + tid;
@@ -484,12 +547,14 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
     __syncthreads();
   }
   const int m = s_base;
+  if (tid == 0) pnp_stamp(P, srow, 2);
   double pose[12];
-  for (int k = 0; k < 12; ++k) pose[k] = P.pose_out[(size_t)best * 12 + k];
+  for (int k = 0; k < 12; ++k) pose[k] = P.model_out[(size_t)best * kPnpModel + k];
   if (m >= 1 && P.iters_lm > 0) {
     // final refinement on the inliers (solvePnP(inliers, useExtrinsicGuess) in OpenCV)
     __threadfence_block();
-    pnp_lm<6, kPnpFinish / 64, 4>(P, P.inl_out, m, tid, kPnpFinish, cam, s_red);
+    pnp_lm<6, kPnpFinish / 64, 4>(P, P.inl_out, m, tid, kPnpFinish, cam, s_red, P.iters_lm);
+    if (tid == 0) pnp_stamp(P, srow, 4);
     for (int r = 0; r < 3; ++r) {
       for (int k = 0; k < 3; ++k) pose[4 * r + k] = cam[7 + 4 * k + r];
       pose[4 * r + 3] = cam[r];
@@ -517,9 +582,70 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_finish_kernel(pnp_args P) {
     P.result[17] = (double)m;
     P.result[18] = (double)best;
     P.result[19] = (double)s_best[1];
+    pnp_stamp(P, srow, 3);
   }
 }
+
+__global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(pnp_args P) {
+  const int nhw = (int)gridDim.x - 1;
+  P.n = pnp_count(P);
+  if ((int)blockIdx.x < nhw) pnp_hypothesis_role(P, nhw);
+  else pnp_finish_role(P);
+}
+
+// grid of pnp_ransac_kernel for `iterations` hypotheses
+int pnp_grid(int iterations) { return (iterations + kPnpWaves - 1) / kPnpWaves + 1; }
+
+// the tagged words of the hypotheses: a buffer of its own, zero when (re)allocated, and a call epoch that only grows --
+// no word written by an earlier call, and nothing else that ever lived at these addresses, can carry the current epoch
+int pnp_tags(vs_ctx* ctx, int iterations, hipStream_t s, unsigned long long** tag, unsigned* epoch) {
+  const size_t bytes = sizeof(unsigned long long) * (size_t)(iterations > 0 ? iterations : 1);
+  if (bytes > ctx->d_pnp_tag.cap || !ctx->d_pnp_tag.p) {
+    VS_TRY(vs_reserve(ctx, &ctx->d_pnp_tag, bytes));
+    VS_HIP(ctx, hipMemsetAsync(ctx->d_pnp_tag.p, 0, ctx->d_pnp_tag.cap, s));
+  }
+  ctx->pnp_epoch = ctx->pnp_epoch == 0xFFFFFFFFu ? 1u : ctx->pnp_epoch + 1u;
+  *tag = (unsigned long long*)ctx->d_pnp_tag.p;
+  *epoch = ctx->pnp_epoch;
+  return VS_OK;
+}
+
+// diagnostic stamps of the next launch (nullptr unless vs_pnp_profile switched them on)
+int pnp_stamps(vs_ctx* ctx, int iterations, hipStream_t s, unsigned long long** stamps) {
+  *stamps = nullptr;
+  if (!ctx->pnp_profile) return VS_OK;
+  const size_t bytes = sizeof(unsigned long long) * 8 * (size_t)(iterations + 1);
+  VS_TRY(vs_reserve(ctx, &ctx->d_pnp_stamps, bytes));
+  VS_HIP(ctx, hipMemsetAsync(ctx->d_pnp_stamps.p, 0, bytes, s));
+  ctx->pnp_profile_h = iterations;
+  *stamps = (unsigned long long*)ctx->d_pnp_stamps.p;
+  return VS_OK;
+}
 }  // namespace vsba
+
+// diagnostic hooks (not part of the stable ABI): phase stamps of pnp_ransac_kernel.  vs_pnp_profile_read synchronises and
+// returns the stamps of the newest profiled launch as microseconds since the launch's first stamp: rows 0 .. H-1 =
+// hypotheses (start, sampled, refined, published), row H = the finishing workgroup (start, winner known, inliers listed,
+// results written, refinement done); 8 doubles per row, zero = not reached.  Returns the number of rows.
+VS_API int vs_pnp_profile(vs_ctx* ctx, int enable) {
+  if (!ctx) return VS_EINVAL;
+  ctx->pnp_profile = enable != 0;
+  return VS_OK;
+}
+VS_API int vs_pnp_profile_read(vs_ctx* ctx, double* out, int cap_rows) {
+  if (!ctx || !out) return VS_EINVAL;
+  const int rows = ctx->pnp_profile_h + 1;
+  if (!ctx->d_pnp_stamps.p || ctx->pnp_profile_h <= 0 || cap_rows < rows) return 0;
+  std::vector<unsigned long long> h((size_t)rows * 8);
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(h.data(), ctx->d_pnp_stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+    return vs_fail(ctx, VS_EHIP, "%s: read-back failed", "vs_pnp_profile_read");
+  unsigned long long t0 = ~0ull;
+  for (unsigned long long v : h)
+    if (v && v < t0) t0 = v;
+  for (size_t i = 0; i < h.size(); ++i) out[i] = h[i] ? (double)(h[i] - t0) * 0.01 : 0.0;  // wall_clock64: 100 MHz
+  return rows;
+}
 
 VS_API int vs_pnp_ransac(vs_ctx* ctx, const double* obj, const double* img, int n, double fx, double fy, double cx,
                          double cy, const double* pose0, int iterations, double reproj_err, double confidence,
@@ -542,9 +668,7 @@ VS_API int vs_pnp_ransac(vs_ctx* ctx, const double* obj, const double* img, int 
   const size_t off_res = off_img + up(sizeof(double) * 2 * (size_t)n);
   const size_t off_inl = off_res + 256;
   const size_t off_cam = off_inl + up(sizeof(int) * (size_t)n);
-  const size_t off_pose = off_cam + up(sizeof(double) * kCamStride * (size_t)H);
-  const size_t off_good = off_pose + up(sizeof(double) * 12 * (size_t)H);
-  const size_t total = off_good + up(sizeof(int) * (size_t)H);
+  const size_t total = off_cam + up(sizeof(double) * kPnpModel * (size_t)H);
   VS_TRY(vs_reserve(ctx, &ctx->d_xy_in, total));
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, off_cam));
   VS_HIP(ctx, hipStreamSynchronize(s));
@@ -574,16 +698,15 @@ VS_API int vs_pnp_ransac(vs_ctx* ctx, const double* obj, const double* img, int 
   quat_to_w2n(P.cam0, P.cam0 + 3, P.cam0 + 7);
   P.result = (double*)(d + off_res);
   P.inl_out = (int*)(d + off_inl);
-  P.cam_out = (double*)(d + off_cam);
-  P.pose_out = (double*)(d + off_pose);
-  P.good_out = (int*)(d + off_good);
-  hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(H), dim3(64), 0, s, P);
-  VS_LAUNCH_CHECK(ctx, "pnp_hypothesis_kernel");
-  hipLaunchKernelGGL(pnp_finish_kernel, dim3(1), dim3(kPnpFinish), 0, s, P);
-  VS_LAUNCH_CHECK(ctx, "pnp_finish_kernel");
+  P.model_out = (double*)(d + off_cam);
+  VS_TRY(pnp_tags(ctx, H, s, &P.tag, &P.epoch));
+  VS_TRY(pnp_stamps(ctx, H, s, &P.stamps));
+  hipLaunchKernelGGL(pnp_ransac_kernel, dim3(pnp_grid(H)), dim3(kPnpFinish), 0, s, P);
+  VS_LAUNCH_CHECK(ctx, "pnp_ransac_kernel");
   VS_HIP(ctx, hipMemcpyAsync(h + off_res, d + off_res, off_cam - off_res, hipMemcpyDeviceToHost, s));
   VS_HIP(ctx, hipStreamSynchronize(s));
   const double* res = (const double*)(h + off_res);
+  if (res[16] < 0.0) return vs_fail(ctx, VS_EHIP, "%s: the hypothesis workgroups did not report", "vs_pnp_ransac");
   if (res[16] != 0.0) {
     const int m = (int)res[17];
     *found = 1;

@@ -73,7 +73,7 @@ struct track_front {
 struct track_layout {
   size_t xyz, mapdesc;
   track_front f[2];  // two sets of per-frame buffers (the synchronous entry point uses set 0 only)
-  size_t flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part, H, box, mst, pnp_cam, pnp_pose, pnp_good, pnp_res, pnp_inl,
+  size_t flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part, H, box, mst, pnp_cam, pnp_res, pnp_inl,
       push_idx, push_uv, rb_end, total;
   int cap_obs;
 };
@@ -103,7 +103,7 @@ track_layout track_layout_of(int P, int F, int max_kp, int H) {
   }
   // read-back block: [LM state x2 | flags | PnP result | both camera buffers] is fetched with one copy per frame
   L.mst = take(2 * sizeof(mo_state));
-  L.flags = take(4 * sizeof(int));
+  L.flags = take(2 * 4 * sizeof(int));  // two sets of {capacity exceeded, matches, key points, -}: one per per-frame buffer set
   L.pnp_res = take(sizeof(double) * 20);
   L.cam0 = take(sizeof(double) * kCamStride * (size_t)(F + 1));
   L.cam1 = take(sizeof(double) * kCamStride * (size_t)(F + 1));
@@ -115,9 +115,7 @@ track_layout track_layout_of(int P, int F, int max_kp, int H) {
   L.part = take(sizeof(double) * 8 * (size_t)F);
   L.H = take(sizeof(double) * 42 * (size_t)F);
   L.box = take(sizeof(unsigned long long) * 2 * kMoPersistCameras * 8);  // mailboxes of ba_motion_persistent
-  L.pnp_cam = take(sizeof(double) * kCamStride * (size_t)H);
-  L.pnp_pose = take(sizeof(double) * 12 * (size_t)H);
-  L.pnp_good = take(sizeof(int) * (size_t)H);
+  L.pnp_cam = take(sizeof(double) * kPnpModel * (size_t)H);
   L.pnp_inl = take(sizeof(int) * (size_t)(per > 0 ? per : 1));
   L.push_idx = take(sizeof(int) * (size_t)(per > 0 ? per : 1));
   L.push_uv = take(sizeof(double) * 2 * (size_t)(per > 0 ? per : 1));
@@ -149,9 +147,9 @@ track_layout layout_of(const vs_ctx* ctx) {
 
 constexpr size_t kPinRb = 4096;  // pinned staging: 1024 LM start state, 2048 record, 4096 read-back
 
-// Front half of a frame on stream `s`: image upload, detect+describe, match against the map -- enqueue only, no host
-// synchronisation.  Ends with ev_front[set] recorded on `s`.
-int track_front_half(vs_ctx* ctx, int set, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
+// Front half of a frame on stream `s`: image upload, detect+describe, match against the map, append of the matches as the
+// observations of free-camera slot `slot` -- enqueue only, no host synchronisation.  Ends with ev_front[set] recorded on `s`.
+int track_front_half(vs_ctx* ctx, int set, int slot, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
                      hipStream_t s) {
   auto& T = ctx->track;
   const track_layout L = layout_of(ctx);
@@ -167,27 +165,31 @@ int track_front_half(vs_ctx* ctx, int set, const uint8_t* bgr, int w, int h_img,
   // two: no matches): the front half needs no host synchronisation, the count reaches the host with the frame's results
   VS_TRY(vs_match_ratio_dev_n(ctx, d + L.mapdesc, T.n_points, d + F.fdesc, T.max_kp, (const int*)(d + F.fn), ratio, d + F.mq,
                               d + F.mt, d + F.md, d + F.M, s));
+  // The new frame's observations are appended here, in the FRONT half: the rows lie behind everything the motion-only
+  // solve of the previous frame reads (cameras up to its own), cam_start[slot] was written by the previous frame's append on
+  // this same stream, and the counts go to this buffer set's own flag words -- so in pipelined use the append (and the
+  // dispatch gap behind it) is off the critical path, the chain of back halves.
+  int* flags = (int*)(d + L.flags) + 4 * set;
+  hipLaunchKernelGGL(track_append_kernel, dim3(8), dim3(256), 0, s, (const double*)(d + L.xyz), (const float*)(d + F.fxy),
+                     (const int*)(d + F.mq), (const int*)(d + F.mt), (const int*)(d + F.M), (double*)(d + L.moX),
+                     (double*)(d + L.moUV), (int*)(d + L.cam_start), slot, L.cap_obs, flags, (const int*)(d + F.fn));
+  VS_LAUNCH_CHECK(ctx, "track_append_kernel");
   VS_HIP(ctx, hipEventRecord(T.ev_front[set], s));
   return VS_OK;
 }
 
-// Back half, enqueue only (context stream): wait for the front half, append the observations, PnP-RANSAC from the
+// Back half, enqueue only (context stream): wait for the front half, PnP-RANSAC from the
 // previous pose, motion-only BA over the k free poses, one read-back copy.  *steps_out = LM launches enqueued.
 int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   auto& T = ctx->track;
   const auto& Q = T.params[set];
   const track_layout L = layout_of(ctx);
-  const track_front& F = L.f[set];
   hipStream_t s = ctx->stream;
   uint8_t* d = (uint8_t*)ctx->d_track.p;
   uint8_t* hp = (uint8_t*)ctx->h_track.p;
   const int H = T.pnp_iters > 0 ? T.pnp_iters : 1;
-  const int slot = T.n_frames, k = T.n_frames + 1;  // new free-camera slot / pose index
+  const int k = T.n_frames + 1;  // pose index of the new frame
   VS_HIP(ctx, hipStreamWaitEvent(s, T.ev_front[set], 0));
-  hipLaunchKernelGGL(track_append_kernel, dim3(8), dim3(256), 0, s, (const double*)(d + L.xyz), (const float*)(d + F.fxy),
-                     (const int*)(d + F.mq), (const int*)(d + F.mt), (const int*)(d + F.M), (double*)(d + L.moX),
-                     (double*)(d + L.moUV), (int*)(d + L.cam_start), slot, L.cap_obs, (int*)(d + L.flags), (const int*)(d + F.fn));
-  VS_LAUNCH_CHECK(ctx, "track_append_kernel");
   double* cam0 = (double*)(d + L.cam0);
   double* cam1 = (double*)(d + L.cam1);
   // ---- PnP-RANSAC from the previous pose; its result becomes the new pose's record in both state buffers
@@ -196,7 +198,7 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   A.obj = (const double*)(d + L.moX) + 3 * (size_t)T.obs_used;
   A.img = (const double*)(d + L.moUV) + 2 * (size_t)T.obs_used;
   A.n = 0;
-  A.n_dev = (const int*)(d + L.flags) + 1;
+  A.n_dev = (const int*)(d + L.flags) + 4 * set + 1;
   A.iters_lm = Q.lm_iterations;
   A.iterations = T.pnp_iters;
   A.fx = T.K[0];
@@ -207,21 +209,19 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   A.confidence = Q.confidence;
   A.seed = Q.seed;
   memcpy(A.cam0, T.last_rec, sizeof A.cam0);
-  A.cam_out = (double*)(d + L.pnp_cam);
-  A.pose_out = (double*)(d + L.pnp_pose);
-  A.good_out = (int*)(d + L.pnp_good);
+  A.model_out = (double*)(d + L.pnp_cam);
   A.result = (double*)(d + L.pnp_res);
   A.inl_out = (int*)(d + L.pnp_inl);
   A.rec_out[0] = cam0 + (size_t)k * kCamStride;
   A.rec_out[1] = cam1 + (size_t)k * kCamStride;
-  const bool lm_on_device = T.pnp_iters > 0 && Q.lm_iterations > 0;  // pnp_finish_kernel resets the LM records itself
+  const bool lm_on_device = T.pnp_iters > 0 && Q.lm_iterations > 0;  // pnp_ransac_kernel's finishing workgroup resets the LM records itself
   A.lm_init = lm_on_device ? reinterpret_cast<mo_state*>(d + L.mst) : nullptr;
   A.lm_cur = T.cur;
   if (T.pnp_iters > 0) {
-    hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(H), dim3(64), 0, s, A);
-    VS_LAUNCH_CHECK(ctx, "pnp_hypothesis_kernel");
-    hipLaunchKernelGGL(pnp_finish_kernel, dim3(1), dim3(kPnpFinish), 0, s, A);
-    VS_LAUNCH_CHECK(ctx, "pnp_finish_kernel");
+    VS_TRY(pnp_tags(ctx, H, s, &A.tag, &A.epoch));
+    VS_TRY(pnp_stamps(ctx, H, s, &A.stamps));
+    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(pnp_grid(H)), dim3(kPnpFinish), 0, s, A);
+    VS_LAUNCH_CHECK(ctx, "pnp_ransac_kernel");
   } else {  // no PnP: the previous pose is the start
     memcpy(hp + 2048, T.last_rec, sizeof T.last_rec);
     VS_HIP(ctx, hipMemcpyAsync(A.rec_out[0], hp + 2048, sizeof T.last_rec, hipMemcpyHostToDevice, s));
@@ -328,7 +328,7 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
     if (fin.done || *step > 1 + lm * 10) break;
     VS_TRY(track_ba_batch(ctx, set, step));
   }
-  const int* rb_flags = (const int*)(rb + (L.flags - L.mst));
+  const int* rb_flags = (const int*)(rb + (L.flags - L.mst)) + 4 * set;
   const double* rb_res = (const double*)(rb + (L.pnp_res - L.mst));
   const int M = rb_flags[1], n_kp = rb_flags[2];
   if (rb_flags[0]) return vs_fail(ctx, VS_ENOMEM, "%s: observation capacity of the period exceeded", "vs_track_frame");
@@ -357,6 +357,7 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   *n_poses_out = k + 1;
   *n_matches = M;
   if (n_kp_out) *n_kp_out = n_kp;
+  if (T.pnp_iters > 0 && rb_res[16] < 0.0) return vs_fail(ctx, VS_EHIP, "%s: the PnP hypothesis workgroups did not report", "vs_track_frame");
   if (pnp_found) *pnp_found = T.pnp_iters > 0 && rb_res[16] != 0.0 ? (int)rb_res[17] : 0;  // inliers of the PnP model
   return VS_OK;
 }
@@ -393,7 +394,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   memcpy(h + L.mapdesc, desc, 32 * (size_t)n_points);
   VS_HIP(ctx, hipMemcpyAsync(d, h, up, hipMemcpyHostToDevice, s));
   VS_HIP(ctx, hipMemsetAsync(d + L.cam_start, 0, sizeof(int) * (size_t)(max_frames + 2), s));
-  VS_HIP(ctx, hipMemsetAsync(d + L.flags, 0, 4 * sizeof(int), s));
+  VS_HIP(ctx, hipMemsetAsync(d + L.flags, 0, 2 * 4 * sizeof(int), s));
   VS_HIP(ctx, hipMemsetAsync(d + L.box, 0, sizeof(unsigned long long) * 2 * kMoPersistCameras * 8, s));
   double rec[kCamStride];
   rec_from_pose(key_pose, rec);
@@ -448,7 +449,7 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   VS_HIP(ctx, hipSetDevice(ctx->device));
   auto& T = ctx->track;
   T.params[0] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
-  VS_TRY(track_front_half(ctx, 0, bgr, w, h_img, stride, thr, ratio, ctx->stream));
+  VS_TRY(track_front_half(ctx, 0, T.n_frames, bgr, w, h_img, stride, thr, ratio, ctx->stream));
   int step = 0;
   VS_TRY(track_back_enqueue(ctx, 0, &step));
   VS_TRY(track_ba_batch(ctx, 0, &step));
@@ -541,7 +542,8 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
     submitted = T.next_set;
     T.next_set ^= 1;
     T.params[submitted] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
-    VS_TRY(track_front_half(ctx, submitted, bgr, w, h_img, stride, thr, ratio, T.front_stream));
+    // its free-camera slot: behind the frames tracked so far and the one whose back half is still running
+    VS_TRY(track_front_half(ctx, submitted, T.n_frames + (solve >= 0 ? 1 : 0), bgr, w, h_img, stride, thr, ratio, T.front_stream));
   }
   T.pending = -1;
   T.pending_step = -1;
