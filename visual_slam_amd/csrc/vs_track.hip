@@ -2,10 +2,28 @@
 #include "vs_ba_internal.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 
 using namespace vsba;
 
 namespace {
+// developer aid (VS_TRACK_TIMING=1): host-side phase times of the pipelined entry point, printed by vs_track_end
+struct track_timing {
+  bool on = getenv("VS_TRACK_TIMING") != nullptr;
+  double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long n = 0;
+  std::chrono::steady_clock::time_point t;
+  void start() {
+    if (on) t = std::chrono::steady_clock::now();
+  }
+  void lap(int i) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    sum[i] += std::chrono::duration<double, std::micro>(now - t).count();
+    t = now;
+  }
+} g_tt;
 
 // ------------------------------------------------------------------------------------------------ tracking session
 // appends the new frame's observations to the period's camera-major arrays: obs i = (map point mq[i], keypoint mt[i])
@@ -435,6 +453,11 @@ VS_API int vs_track_end(vs_ctx* ctx) {
   ctx->track.active = 0;
   ctx->track.pending = -1;
   ctx->track.pending_step = -1;
+  if (g_tt.on && g_tt.n) {
+    fprintf(stderr, "[vs_track timing] per pipelined call over %ld calls: front enqueue %.1f us, wait+finish %.1f, PnP enqueue %.1f, BA+copy enqueue %.1f\n",
+            g_tt.n, g_tt.sum[0] / g_tt.n, g_tt.sum[1] / g_tt.n, g_tt.sum[2] / g_tt.n, g_tt.sum[3] / g_tt.n);
+    g_tt = track_timing();
+  }
   return VS_OK;
 }
 
@@ -537,6 +560,7 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
     VS_TRY(track_back_enqueue(ctx, solve, &step));
     VS_TRY(track_ba_batch(ctx, solve, &step));
   }
+  g_tt.start();
   int submitted = -1;
   if (bgr) {
     submitted = T.next_set;
@@ -547,17 +571,22 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
   }
   T.pending = -1;
   T.pending_step = -1;
+  g_tt.lap(0);  // front half enqueued
   if (solve >= 0) {
     VS_TRY(track_back_finish(ctx, solve, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out,
                              match_q, match_t));
     *has_result = 1;
   }
+  g_tt.lap(1);  // previous back half waited for and handed out
   if (submitted >= 0) {
     int next_step = 0;
     T.pending = submitted;  // from here on the frame counts as pending, whatever happens below
     VS_TRY(track_back_enqueue(ctx, submitted, &next_step));
+    g_tt.lap(2);  // PnP enqueued
     VS_TRY(track_ba_batch(ctx, submitted, &next_step));
+    g_tt.lap(3);  // BA + read-back enqueued
     T.pending_step = next_step;
   }
+  ++g_tt.n;
   return VS_OK;
 }
