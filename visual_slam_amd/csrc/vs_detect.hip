@@ -92,7 +92,8 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
                                                                    uint16_t* __restrict__ box_out,
                                                                    uint32_t* __restrict__ raw, int band_cap,
                                                                    int* __restrict__ bandcnt, int* __restrict__ bandhist,
-                                                                   uint32_t magic_w, uint32_t magic_w4, uint32_t magic_gpr) {
+                                                                   uint32_t magic_w, uint32_t magic_w4, uint32_t magic_gpr,
+                                                                   int* __restrict__ framehist) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_bhist[256];  // scores of this band's survivors (the cap of select_describe_kernel needs their histogram)
   if (threadIdx.x < 256) s_bhist[threadIdx.x] = 0;
@@ -266,7 +267,34 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
     }
   }
   __syncthreads();
-  if (tid < 256) bandhist[(size_t)blockIdx.x * 256 + tid] = s_bhist[tid];
+  // What the cap of select_describe_kernel needs, in the form that makes it cheap there: the band's histogram as SUFFIX
+  // sums, c[s] = survivors of this band with score >= s -- "how many score above the cut / equal to it" is then two words
+  // per band instead of a 256-bin row (240 dependent row reads per select workgroup made a frame over the cap cost twice a
+  // frame under it).  One wave, four bins per lane, no further barrier.  The band's plain histogram goes into the frame's
+  // with integer atomics (order-independent, so still bit-exact): only the bins that occur, a handful per band.
+  if (tid >= 64 && tid < 320) {
+    const int c = s_bhist[tid - 64];
+    if (c) atomicAdd(&framehist[tid - 64], c);
+  }
+  if (tid < 64) {
+    int v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // lane l holds bins 255 - 4l - k, k = 0..3: descending score order
+      v[k] = s_bhist[255 - 4 * lane - k];
+      sum += v[k];
+    }
+    int run = wave_incl_scan(sum, lane) - sum;  // survivors with a score above this lane's bins
+    int4 out;
+    run += v[0];
+    out.w = run;  // bin 255 - 4l
+    run += v[1];
+    out.z = run;
+    run += v[2];
+    out.y = run;
+    run += v[3];
+    out.x = run;  // bin 252 - 4l
+    *reinterpret_cast<int4*>(bandhist + (size_t)blockIdx.x * 256 + 252 - 4 * lane) = out;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------- select + describe
@@ -302,14 +330,16 @@ __device__ __forceinline__ void brief_wave(const uint16_t* __restrict__ box, int
 template <bool DO_BRIEF>
 __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const uint32_t* __restrict__ raw, int band_cap,
                                                                        const int* __restrict__ bandcnt,
-                                                                       const int* __restrict__ bandhist, int nbands,
+                                                                       const int* __restrict__ bandhist,
+                                                                       const int* __restrict__ framehist,
+                                                                       int* __restrict__ framehist_next, int nbands,
                                                                        int max_kp, const uint16_t* __restrict__ box,
                                                                        int w, float* __restrict__ xy,
                                                                        uint8_t* __restrict__ score,
                                                                        uint8_t* __restrict__ desc,
                                                                        int* __restrict__ n_out) {
   __shared__ int s_tmp[8];
-  __shared__ int s_hist[256], s_before[256];
+  __shared__ int s_hist[256];
   __shared__ int s_wcnt[kSelThreads / 64];
   __shared__ uint32_t s_sel[kSelThreads];  // (pos << 0) stored separately below
   __shared__ int s_pos[kSelThreads];
@@ -328,37 +358,38 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const uint
 
   int cut = 0, quota = 0, base = before, eq_before = 0;
   const bool over = total > max_kp;
+  if (band == 0) framehist_next[tid] = 0;  // the table the NEXT frame's bands add into (this frame's is framehist)
   if (over) {
-    // histogram of every survivor's score, and of the survivors in earlier bands: sums of the per-band histograms that
-    // detect_band_kernel left behind (thread = score bin; round 1 had every band re-scan every survivor: 80 us on a
-    // frame over the cap).  Then cut = the score at which the cap is reached, quota = how many of score == cut fit.
+    // framehist[s] = survivors of the whole frame with score s; its suffix sums ge[s] = survivors with score >= s are
+    // non-increasing in s.  cut = the score at which the cap is reached = the largest s with ge[s] > max_kp (0 if none);
+    // quota = how many of score == cut still fit.  Thread t holds bin 255 - t.
     static_assert(kSelThreads == 256, "one thread per score bin");
-    {
-      int all = 0, bef = 0;
-      for (int b0 = 0; b0 < nbands; b0 += 8) {
-        int v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = b0 + u < nbands ? bandhist[(size_t)(b0 + u) * 256 + tid] : 0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          all += v[u];
-          bef += b0 + u < band ? v[u] : 0;
-        }
-      }
-      s_hist[tid] = all;
-      s_before[tid] = bef;
-    }
+    const int hv = framehist[255 - tid];
+    const int incl = wave_incl_scan(hv, lane);
+    if (lane == 63) s_wcnt[wave] = incl;
     __syncthreads();
-    int above = 0;
-    cut = 255;
-    while (cut > 0 && above + s_hist[cut] <= max_kp) {  // every thread walks the same 256-entry table
-      above += s_hist[cut];
-      --cut;
-    }
+    int ge = incl;
+    for (int k = 0; k < wave; ++k) ge += s_wcnt[k];
+    s_hist[255 - tid] = ge;
+    __syncthreads();
+    const unsigned long long bal = __ballot(ge > max_kp);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int nabove = 0;
+    for (int k = 0; k < kSelThreads / 64; ++k) nabove += s_wcnt[k];
+    cut = max(nabove - 1, 0);
+    const int above = cut < 255 ? s_hist[cut + 1] : 0;   // survivors with score > cut
     quota = max_kp - above;
-    int gt_before = 0;
-    for (int s = cut + 1; s < 256; ++s) gt_before += s_before[s];
-    eq_before = s_before[cut];
+    __syncthreads();  // s_wcnt is reused by the selection loop below
+    // the same two numbers for the bands before this one, from their suffix-sum rows: two words per band
+    int gt_part = 0, ge_part = 0;
+    for (int b = tid; b < band; b += kSelThreads) {
+      ge_part += bandhist[(size_t)b * 256 + cut];
+      gt_part += cut < 255 ? bandhist[(size_t)b * 256 + cut + 1] : 0;
+    }
+    const int gt_before = block_sum(gt_part, s_tmp);
+    const int ge_before = block_sum(ge_part, s_tmp);
+    eq_before = ge_before - gt_before;
     base = gt_before + min(eq_before, quota);
   }
   if (band == 0 && tid == 0) *n_out = over ? max_kp : total;
@@ -528,9 +559,24 @@ int upload_image(vs_ctx* ctx, vs_buf* dst, const uint8_t* src, int row_bytes, in
   return VS_OK;
 }
 
+// the frame's suffix-sum score table: two of them, used alternately -- the bands of frame f add into table f & 1, which the
+// select kernel of frame f - 1 zeroed (zero when allocated)
+int frame_tables(vs_ctx* ctx, hipStream_t s, int** cur, int** next) {
+  if (!ctx->d_framehist.p) {
+    VS_TRY(vs_reserve(ctx, &ctx->d_framehist, 2 * 256 * sizeof(int)));
+    VS_HIP(ctx, hipMemsetAsync(ctx->d_framehist.p, 0, 2 * 256 * sizeof(int), s));
+    VS_HIP(ctx, hipStreamSynchronize(s));  // launches on the context's other streams must see the zeros, too
+  }
+  ctx->det_parity ^= 1;
+  *cur = (int*)ctx->d_framehist.p + 256 * ctx->det_parity;
+  *next = (int*)ctx->d_framehist.p + 256 * (ctx->det_parity ^ 1);
+  return VS_OK;
+}
+
 template <bool FROM_BGR, bool DO_BOX, bool WRITE_GRAY>
 int launch_detect(vs_ctx* ctx, hipStream_t s, const uint8_t* d_img, int pitch, int w, int h, int thr, int border,
-                  uint8_t* d_gray, uint16_t* d_box, uint32_t* d_raw, int band_cap, int* d_bandcnt, int* d_bandhist) {
+                  uint8_t* d_gray, uint16_t* d_box, uint32_t* d_raw, int band_cap, int* d_bandcnt, int* d_bandhist,
+                  int* d_framehist) {
   const int nbands = (h + kBand - 1) / kBand;
   const size_t lds = detect_lds_bytes(w, DO_BOX);
   auto fn = detect_band_kernel<FROM_BGR, DO_BOX, WRITE_GRAY>;
@@ -538,7 +584,7 @@ int launch_detect(vs_ctx* ctx, hipStream_t s, const uint8_t* d_img, int pitch, i
     VS_HIP(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int w4 = (w + 3) & ~3;
   hipLaunchKernelGGL(fn, dim3(nbands), dim3(kDetThreads), lds, s, d_img, pitch, w, h, thr, border, d_gray, d_box, d_raw,
-                     band_cap, d_bandcnt, d_bandhist, div_magic(w), div_magic(w4), div_magic(w4 >> 2));
+                     band_cap, d_bandcnt, d_bandhist, div_magic(w), div_magic(w4), div_magic(w4 >> 2), d_framehist);
   VS_LAUNCH_CHECK(ctx, "detect_band_kernel");
   return VS_OK;
 }
@@ -579,25 +625,27 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   uint8_t* res = (uint8_t*)ctx->d_xy.p;
   const uint8_t* d_img = (const uint8_t*)(from_bgr ? ctx->d_bgr.p : ctx->d_gray.p);
   hipStream_t s = ctx->stream;
+  int *fh = nullptr, *fh_next = nullptr;
+  VS_TRY(frame_tables(ctx, s, &fh, &fh_next));
   if (from_bgr) {
     VS_TRY((launch_detect<true, true, false>(ctx, s, d_img, pitch, w, h, thr, border, nullptr, (uint16_t*)ctx->d_box.p,
-                                             (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p)));
+                                             (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p, fh)));
   } else if (describe) {
     VS_TRY((launch_detect<false, true, false>(ctx, s, d_img, pitch, w, h, thr, border, nullptr, (uint16_t*)ctx->d_box.p,
-                                              (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p)));
+                                              (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p, fh)));
   } else {
     VS_TRY((launch_detect<false, false, false>(ctx, s, d_img, pitch, w, h, thr, border, nullptr, nullptr,
-                                               (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p)));
+                                               (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p, fh)));
   }
   if (describe) {
     hipLaunchKernelGGL(select_describe_kernel<true>, dim3(nbands), dim3(kSelThreads), 0, s, (const uint32_t*)ctx->d_raw.p,
-                       band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, nbands, max_kp, (const uint16_t*)ctx->d_box.p, w,
-                       (float*)(res + L.off_xy), res + L.off_score, res + L.off_desc, (int*)res);
+                       band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, (const int*)fh, fh_next, nbands, max_kp,
+                       (const uint16_t*)ctx->d_box.p, w, (float*)(res + L.off_xy), res + L.off_score, res + L.off_desc, (int*)res);
   } else {
     hipLaunchKernelGGL(select_describe_kernel<false>, dim3(nbands), dim3(kSelThreads), 0, s,
-                       (const uint32_t*)ctx->d_raw.p, band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, nbands, max_kp,
-                       (const uint16_t*)nullptr, w, (float*)(res + L.off_xy), res + L.off_score, (uint8_t*)nullptr,
-                       (int*)res);
+                       (const uint32_t*)ctx->d_raw.p, band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, (const int*)fh,
+                       fh_next, nbands, max_kp, (const uint16_t*)nullptr, w, (float*)(res + L.off_xy), res + L.off_score,
+                       (uint8_t*)nullptr, (int*)res);
   }
   VS_LAUNCH_CHECK(ctx, "select_describe_kernel");
   const size_t bytes = describe ? L.total : L.off_desc;
@@ -660,12 +708,14 @@ VS_API int vs_detect_describe_bgr_dev(vs_ctx* ctx, const void* d_bgr, int w, int
   VS_TRY(vs_reserve(ctx, &ctx->d_raw, sizeof(uint32_t) * (size_t)nbands * band_cap));
   VS_TRY(vs_reserve(ctx, &ctx->d_bandcnt, sizeof(int) * (size_t)nbands));
   VS_TRY(vs_reserve(ctx, &ctx->d_hist, sizeof(int) * 256 * (size_t)nbands));
+  int *fh = nullptr, *fh_next = nullptr;
+  VS_TRY(frame_tables(ctx, s, &fh, &fh_next));
   VS_TRY((launch_detect<true, true, false>(ctx, s, (const uint8_t*)d_bgr, pitch, w, h, thr, VS_BRIEF_BORDER, nullptr,
                                            (uint16_t*)ctx->d_box.p, (uint32_t*)ctx->d_raw.p, band_cap,
-                                           (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p)));
+                                           (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p, fh)));
   hipLaunchKernelGGL(select_describe_kernel<true>, dim3(nbands), dim3(kSelThreads), 0, s, (const uint32_t*)ctx->d_raw.p,
-                     band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, nbands, max_kp, (const uint16_t*)ctx->d_box.p, w,
-                     (float*)d_xy, (uint8_t*)d_score, (uint8_t*)d_desc, (int*)d_n_out);
+                     band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, (const int*)fh, fh_next, nbands, max_kp,
+                     (const uint16_t*)ctx->d_box.p, w, (float*)d_xy, (uint8_t*)d_score, (uint8_t*)d_desc, (int*)d_n_out);
   VS_LAUNCH_CHECK(ctx, "select_describe_kernel");
   return VS_OK;
 }
