@@ -125,9 +125,9 @@ class Context:
         bgr = np.ascontiguousarray(bgr, np.uint8)
         h, w, c = bgr.shape
         assert c == 3
-        xy = np.zeros((max(max_kp, 1), 2), np.float32)
-        sc = np.zeros(max(max_kp, 1), np.uint8)
-        desc = np.zeros((max(max_kp, 1), 32), np.uint8)
+        xy = np.empty((max(max_kp, 1), 2), np.float32)  # only the first n rows are written, and only those are handed out
+        sc = np.empty(max(max_kp, 1), np.uint8)
+        desc = np.empty((max(max_kp, 1), 32), np.uint8)
         n = C.c_int(0)
         self._chk(self._lib.vs_detect_describe_bgr(self._h, ptr(bgr, c_u8p), w, h, 3 * w, thr, max_kp, ptr(xy, c_f32p),
                                                    ptr(sc, c_u8p), ptr(desc, c_u8p), C.byref(n)))

@@ -171,6 +171,31 @@ int vs_desc_adopt(vs_ctx* ctx, const uint8_t* h, int n, const void* dev_src, con
   return VS_OK;
 }
 
+int vs_desc_slot_for_output(vs_ctx* ctx, size_t bytes, vs_desc_entry** slot) {
+  *slot = nullptr;
+  if (bytes > VS_DESC_CACHE_MAX_BYTES) return VS_OK;
+  vs_desc_entry* lru = &ctx->desc_cache[0];
+  for (vs_desc_entry& e : ctx->desc_cache)
+    if (e.stamp < lru->stamp) lru = &e;
+  lru->host = nullptr;  // invalid until adopted
+  lru->n = 0;
+  lru->stamp = ++ctx->desc_stamp;
+  VS_TRY(vs_reserve(ctx, &lru->dev, bytes));
+  VS_TRY(vs_reserve_pinned(ctx, &lru->shadow, bytes));
+  *slot = lru;
+  return VS_OK;
+}
+
+void vs_desc_adopt_slot(vs_ctx* ctx, vs_desc_entry* slot, const uint8_t* h, int n, const uint8_t* host_src) {
+  if (n <= 0) return;
+  for (vs_desc_entry& e : ctx->desc_cache)  // the host array may have been bound to another slot before: one binding only
+    if (&e != slot && e.host == h) e.host = nullptr;
+  memcpy(slot->shadow.p, host_src, (size_t)VS_DESC_BYTES * n);
+  slot->host = h;
+  slot->n = n;
+  slot->stamp = ++ctx->desc_stamp;
+}
+
 // pinned host memory for callers that want DMA without a staging copy (frames decoded straight into it)
 VS_API int vs_host_alloc(vs_ctx* ctx, size_t bytes, void** out) {
   if (!ctx || !out) return VS_EINVAL;

@@ -312,7 +312,7 @@ __device__ __forceinline__ int block_sum(int v, int* s_tmp /* >= 4 ints */) {
 
 // one wave evaluates the 256 tests of one keypoint: test k = 64*round + lane; a ballot packs 64 bits = 8 bytes
 __device__ __forceinline__ void brief_wave(const uint16_t* __restrict__ box, int w, int x, int y,
-                                           uint8_t* __restrict__ out32, int lane) {
+                                           uint8_t* __restrict__ out32, int lane, uint8_t* __restrict__ mirror32 = nullptr) {
   unsigned long long* out = reinterpret_cast<unsigned long long*>(out32);
   int a[4], b[4];
 #pragma unroll
@@ -324,7 +324,11 @@ __device__ __forceinline__ void brief_wave(const uint16_t* __restrict__ box, int
   unsigned long long m[4];
 #pragma unroll
   for (int rnd = 0; rnd < 4; ++rnd) m[rnd] = __ballot(a[rnd] < b[rnd]);
-  if (lane < 4) out[lane] = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
+  if (lane < 4) {
+    const unsigned long long v = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
+    out[lane] = v;
+    if (mirror32) reinterpret_cast<unsigned long long*>(mirror32)[lane] = v;
+  }
 }
 
 template <bool DO_BRIEF>
@@ -337,7 +341,12 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const uint
                                                                        int w, float* __restrict__ xy,
                                                                        uint8_t* __restrict__ score,
                                                                        uint8_t* __restrict__ desc,
-                                                                       int* __restrict__ n_out) {
+                                                                       int* __restrict__ n_out, uint8_t* __restrict__ host_block,
+                                                                       unsigned h_off_score, unsigned h_off_xy,
+                                                                       unsigned h_off_desc) {
+  // host_block != nullptr: a pinned host block laid out like the device result block; every result word is written there as
+  // well (a few tens of KB over PCIe straight from the kernel), so the host entry point needs no copy launch behind this one
+  float* const h_xy = host_block ? reinterpret_cast<float*>(host_block + h_off_xy) : nullptr;
   __shared__ int s_tmp[8];
   __shared__ int s_hist[256];
   __shared__ int s_wcnt[kSelThreads / 64];
@@ -392,7 +401,10 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const uint
     eq_before = ge_before - gt_before;
     base = gt_before + min(eq_before, quota);
   }
-  if (band == 0 && tid == 0) *n_out = over ? max_kp : total;
+  if (band == 0 && tid == 0) {
+    *n_out = over ? max_kp : total;
+    if (host_block) *reinterpret_cast<int*>(host_block) = over ? max_kp : total;
+  }
 
   int running = 0, eq_running = eq_before;
   for (int start = 0; start < nb; start += kSelThreads) {
@@ -435,6 +447,11 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const uint
       xy[2 * (size_t)pos] = (float)x;
       xy[2 * (size_t)pos + 1] = (float)y;
       if (score) score[pos] = (uint8_t)(e & 255u);
+      if (host_block) {
+        h_xy[2 * (size_t)pos] = (float)x;
+        h_xy[2 * (size_t)pos + 1] = (float)y;
+        host_block[h_off_score + pos] = (uint8_t)(e & 255u);
+      }
       s_sel[local] = e;
       s_pos[local] = pos;
     }
@@ -442,7 +459,8 @@ __global__ __launch_bounds__(kSelThreads) void select_describe_kernel(const uint
     if (DO_BRIEF) {
       for (int k = wave; k < tot; k += kSelThreads / 64) {
         const uint32_t ee = s_sel[k];
-        brief_wave(box, w, (ee >> 8) & 4095u, ee >> 20, desc + (size_t)s_pos[k] * VS_DESC_BYTES, lane);
+        brief_wave(box, w, (ee >> 8) & 4095u, ee >> 20, desc + (size_t)s_pos[k] * VS_DESC_BYTES, lane,
+                   host_block ? host_block + h_off_desc + (size_t)s_pos[k] * VS_DESC_BYTES : nullptr);
       }
     }
     running += tot;
@@ -627,6 +645,13 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   hipStream_t s = ctx->stream;
   int *fh = nullptr, *fh_next = nullptr;
   VS_TRY(frame_tables(ctx, s, &fh, &fh_next));
+  // descriptors are written straight into the least recently used slot of the descriptor cache (when they fit one)
+  vs_desc_entry* slot = nullptr;
+  uint8_t* d_desc_out = res + L.off_desc;
+  if (describe) {
+    VS_TRY(vs_desc_slot_for_output(ctx, (size_t)cap * VS_DESC_BYTES, &slot));
+    if (slot) d_desc_out = (uint8_t*)slot->dev.p;
+  }
   if (from_bgr) {
     VS_TRY((launch_detect<true, true, false>(ctx, s, d_img, pitch, w, h, thr, border, nullptr, (uint16_t*)ctx->d_box.p,
                                              (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p, fh)));
@@ -640,17 +665,17 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   if (describe) {
     hipLaunchKernelGGL(select_describe_kernel<true>, dim3(nbands), dim3(kSelThreads), 0, s, (const uint32_t*)ctx->d_raw.p,
                        band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, (const int*)fh, fh_next, nbands, max_kp,
-                       (const uint16_t*)ctx->d_box.p, w, (float*)(res + L.off_xy), res + L.off_score, res + L.off_desc, (int*)res);
+                       (const uint16_t*)ctx->d_box.p, w, (float*)(res + L.off_xy), res + L.off_score, d_desc_out, (int*)res,
+                       (uint8_t*)ctx->h_pin.p, (unsigned)L.off_score, (unsigned)L.off_xy, (unsigned)L.off_desc);
   } else {
     hipLaunchKernelGGL(select_describe_kernel<false>, dim3(nbands), dim3(kSelThreads), 0, s,
                        (const uint32_t*)ctx->d_raw.p, band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, (const int*)fh,
                        fh_next, nbands, max_kp, (const uint16_t*)nullptr, w, (float*)(res + L.off_xy), res + L.off_score,
-                       (uint8_t*)nullptr, (int*)res);
+                       (uint8_t*)nullptr, (int*)res, (uint8_t*)ctx->h_pin.p, (unsigned)L.off_score, (unsigned)L.off_xy,
+                       (unsigned)L.off_desc);
   }
   VS_LAUNCH_CHECK(ctx, "select_describe_kernel");
-  const size_t bytes = describe ? L.total : L.off_desc;
-  VS_HIP(ctx, hipMemcpyAsync(ctx->h_pin.p, res, bytes, hipMemcpyDeviceToHost, s));
-  VS_HIP(ctx, hipStreamSynchronize(s));
+  VS_HIP(ctx, hipStreamSynchronize(s));  // the results are in the pinned block already (written by the kernel itself)
   const uint8_t* hp = (const uint8_t*)ctx->h_pin.p;
   const int n = *(const int*)hp;
   if (n < 0 || n > cap) return vs_fail(ctx, VS_EHIP, "%s: device returned an impossible keypoint count", fn);
@@ -658,8 +683,9 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   if (score) memcpy(score, hp + L.off_score, (size_t)n);
   if (describe) {
     memcpy(desc, hp + L.off_desc, (size_t)n * VS_DESC_BYTES);
-    // the matcher will be handed `desc` next: keep the device copy so it is not uploaded again
-    VS_TRY(vs_desc_adopt(ctx, desc, n, res + L.off_desc, hp + L.off_desc));
+    // the matcher will be handed `desc` next: the kernel wrote the descriptors into a descriptor-cache slot, which now
+    // becomes the resident copy of `desc` -- no upload later, no device copy now
+    if (slot) vs_desc_adopt_slot(ctx, slot, desc, n, hp + L.off_desc);
   }
   *n_out = n;
   return VS_OK;
@@ -715,7 +741,8 @@ VS_API int vs_detect_describe_bgr_dev(vs_ctx* ctx, const void* d_bgr, int w, int
                                            (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p, fh)));
   hipLaunchKernelGGL(select_describe_kernel<true>, dim3(nbands), dim3(kSelThreads), 0, s, (const uint32_t*)ctx->d_raw.p,
                      band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, (const int*)fh, fh_next, nbands, max_kp,
-                     (const uint16_t*)ctx->d_box.p, w, (float*)d_xy, (uint8_t*)d_score, (uint8_t*)d_desc, (int*)d_n_out);
+                     (const uint16_t*)ctx->d_box.p, w, (float*)d_xy, (uint8_t*)d_score, (uint8_t*)d_desc, (int*)d_n_out,
+                     (uint8_t*)nullptr, 0u, 0u, 0u);
   VS_LAUNCH_CHECK(ctx, "select_describe_kernel");
   return VS_OK;
 }

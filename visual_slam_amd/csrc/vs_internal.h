@@ -126,6 +126,10 @@ struct vs_ctx {
 int vs_desc_resident(vs_ctx* ctx, const uint8_t* h, int n, int role, const void** dev_out);
 // registers a device-side descriptor set that equals the host array `h`; host_src = the bytes just copied into `h`
 int vs_desc_adopt(vs_ctx* ctx, const uint8_t* h, int n, const void* dev_src, const uint8_t* host_src);
+// a cache slot (the least recently used one) whose device buffer holds `bytes`, for a producer kernel to write a descriptor
+// set into; *slot = nullptr if the set is too large to be cached.  vs_desc_adopt_slot then binds it to the host array.
+int vs_desc_slot_for_output(vs_ctx* ctx, size_t bytes, vs_desc_entry** slot);
+void vs_desc_adopt_slot(vs_ctx* ctx, vs_desc_entry* slot, const uint8_t* h, int n, const uint8_t* host_src);
 // true if `p` is pinned (hipHostMalloc / hipHostRegister) host memory
 bool vs_is_pinned(const void* p);
 
