@@ -219,6 +219,27 @@ int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int 
  * lm_iterations = 0 appends only.  Neither the period's observations nor its points are rebuilt or uploaded again. */
 int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx /*[m]*/, const double* uv /*[m][2]*/, int m,
                         const double* pose16, int lm_iterations, double huber_delta, double* poses_out, int* n_poses_out);
+/* The same, for the class API driven call by call WITHOUT giving up the residency of the front half and the PnP: the three
+ * calls below together are one vs_track_frame, cut where the reference's call sequence needs values on the host
+ * (src/v2/main.py:181-214).  The key frame's descriptors given to vs_track_begin must be the map points' descriptors.
+ *   vs_track_front       Frame.process_frame + FeatureMatcher.match_features (main.py:181,185): upload, detect + describe,
+ *                        match the map points (queries) against the frame (train), append the matches as the new frame's
+ *                        observations; ONE synchronisation.  Returns key points, descriptors and the matches
+ *                        (match_q = map point index, match_t = key point index, match_d = Hamming distance).
+ *   vs_track_back_begin  cv2.solvePnPRansac (main.py:196-197): PnP-RANSAC from the period's previous pose on those matches
+ *                        and, enqueued right behind it, the motion-only BA over all poses (LocalBA.py:195-229); returns when
+ *                        the PnP outcome is in (pose16 = camera-to-world 4x4, the inlier indices into the match list).
+ *   vs_track_back_end    BundleAdjustment.motionOnlyBundleAdjustement (main.py:213-214): waits for that BA and returns all
+ *                        poses of the period.
+ * A front half that is not followed up (the caller went another way) costs nothing: the next frame overwrites its rows.
+ * The caller is responsible for passing the same matches and start pose on to the rest of the API as the device used
+ * (visual_slam_amd/map.py checks exactly that and otherwise restarts the period from the map). */
+int vs_track_front(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int thr, double ratio,
+                   float* xy_out /*[max_kp][2]*/, uint8_t* desc_out /*[max_kp][32]*/, int* n_kp_out,
+                   int32_t* match_q /*[n_points]*/, int32_t* match_t, int32_t* match_d, int* n_matches);
+int vs_track_back_begin(vs_ctx* ctx, double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations,
+                        double huber_delta, int* found, double* pose16, int32_t* inliers /*[n_matches]*/, int* n_inliers);
+int vs_track_back_end(vs_ctx* ctx, double* poses_out /*[n_frames+1][16]*/, int* n_poses_out);
 int vs_track_end(vs_ctx* ctx);
 
 /* ---- A9-A16: bundle adjustment ------------------------------------------------------------------------------

@@ -432,18 +432,32 @@ def test_class_api_keeps_the_tracking_period_resident(vs, oracle):
         ref_poses, _ = harness.track_sequence_api(frames, depth0, context=vs)
     finally:
         Map.use_device_mirror = True
-    pushed = []
-    orig = vs.track_push_frame
+    # how the frames reach the resident period: the first one host-fed (vs_track_push_frame: the period does not exist before
+    # the first motionOnlyBundleAdjustement), every later one detected, matched and PnP-ed inside the period (vs_track_front /
+    # vs_track_back_begin) and only collected by the BA call (vs_track_back_end); the period is begun once, never rebuilt
+    calls = {"push": [], "front": 0, "back_begin": 0, "back_end": 0, "begin": 0}
+    orig = {n: getattr(vs, n) for n in ("track_push_frame", "track_front", "track_back_begin", "track_back_end", "track_begin")}
 
-    def spy(*a, **k):
-        pushed.append(len(a[0]))
-        return orig(*a, **k)
-    vs.track_push_frame = spy
+    def spy(name, key, record=None):
+        def f(*a, **k):
+            if record is not None:
+                calls[key].append(record(a))
+            else:
+                calls[key] += 1
+            return orig[name](*a, **k)
+        return f
+    vs.track_push_frame = spy("track_push_frame", "push", lambda a: len(a[0]))
+    vs.track_front = spy("track_front", "front")
+    vs.track_back_begin = spy("track_back_begin", "back_begin")
+    vs.track_back_end = spy("track_back_end", "back_end")
+    vs.track_begin = spy("track_begin", "begin")
     try:
         poses, _ = harness.track_sequence_api(frames, depth0, context=vs)
     finally:
-        del vs.track_push_frame
-    assert len(pushed) == len(frames) - 1 and min(pushed) > 50      # one incremental push per frame, never a rebuild
+        for n in orig:
+            delattr(vs, n)
+    assert calls["begin"] == 1 and len(calls["push"]) == 1 and min(calls["push"]) > 50, calls
+    assert calls["back_begin"] == calls["back_end"] == len(frames) - 2, calls
     rel = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(poses, ref_poses))
     assert rel <= 1e-9, rel
     # edits behind the mirror's back restart the period instead of using stale device state

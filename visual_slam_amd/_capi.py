@@ -99,6 +99,11 @@ SIGNATURES = {
                                            C.c_double, C.c_uint64, C.c_int, C.c_double, c_intp, c_f64p, c_intp, c_intp,
                                            c_intp, c_f32p, c_u8p, c_intp, c_i32p, c_i32p]),
     "vs_track_push_frame": (C.c_int, [c_ctxp, c_i32p, c_f64p, C.c_int, c_f64p, C.c_int, C.c_double, c_f64p, c_intp]),
+    "vs_track_front": (C.c_int, [c_ctxp, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, c_f32p, c_u8p, c_intp, c_i32p,
+                                 c_i32p, c_i32p, c_intp]),
+    "vs_track_back_begin": (C.c_int, [c_ctxp, C.c_double, C.c_double, C.c_uint64, C.c_int, C.c_double, c_intp, c_f64p, c_i32p,
+                                      c_intp]),
+    "vs_track_back_end": (C.c_int, [c_ctxp, c_f64p, c_intp]),
     "vs_track_end": (C.c_int, [c_ctxp]),
     "vs_ba_solve": (C.c_int, [c_ctxp, C.POINTER(BAProblem), C.POINTER(BAResult)]),
     "vs_ba_debug_cholesky": (C.c_int, [c_ctxp, c_f64p, C.c_int, c_f64p, c_f64p, c_intp]),

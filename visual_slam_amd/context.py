@@ -333,6 +333,49 @@ class Context:
                                                 ptr(t["poses"], c_f64p), C.byref(npo)))
         return t["poses"][:npo.value].reshape(-1, 4, 4).copy()
 
+    # ---- the resident period fed by the class API: one vs_track_frame cut where main.py:181-214 needs values on the host
+    def track_front(self, bgr, thr=20, ratio=0.8):
+        """Front half (vs_track_front): detect + describe `bgr`, match the period's map points against it, append the
+        matches.  -> dict(xy [n,2] float32, desc [n,32] uint8, match_q, match_t, match_d [M] int32) -- fresh arrays."""
+        t = self._track
+        if t is None:
+            raise VsError(-1, "track_front: no tracking period (call track_begin)")
+        bgr = np.ascontiguousarray(bgr, np.uint8)
+        h, w, _ = bgr.shape
+        kp, P = t["max_kp"], t["P"]
+        xy, desc = np.empty((kp, 2), np.float32), np.empty((kp, 32), np.uint8)
+        m = np.empty((3, max(P, 1)), np.int32)
+        nk, nm = C.c_int(0), C.c_int(0)
+        self._chk(self._lib.vs_track_front(self._h, ptr(bgr, c_u8p), w, h, 3 * w, int(thr), float(ratio), ptr(xy, c_f32p),
+                                           ptr(desc, c_u8p), C.byref(nk), m[0].ctypes.data, m[1].ctypes.data,
+                                           m[2].ctypes.data, C.byref(nm)))
+        n, M = nk.value, nm.value
+        return dict(xy=xy[:n], desc=desc[:n], match_q=m[0, :M], match_t=m[1, :M], match_d=m[2, :M])
+
+    def track_back_begin(self, seed=0, reproj_err=8.0, confidence=0.99, lm_iterations=10,
+                         huber_delta=float(np.sqrt(5.991))):
+        """PnP-RANSAC on the front half's matches + (enqueued behind it) the motion-only BA; returns the PnP outcome:
+        dict(found, pose [4,4] camera-to-world, inliers [m] int32 indices into the match list)."""
+        t = self._track
+        if t is None:
+            raise VsError(-1, "track_back_begin: no tracking period (call track_begin)")
+        pose = np.empty(16)
+        inl = np.empty(max(t["P"], 1), np.int32)
+        found, ni = C.c_int(0), C.c_int(0)
+        self._chk(self._lib.vs_track_back_begin(self._h, float(reproj_err), float(confidence), int(seed), int(lm_iterations),
+                                                float(huber_delta), C.byref(found), ptr(pose, c_f64p), ptr(inl, c_i32p),
+                                                C.byref(ni)))
+        return dict(found=bool(found.value), pose=pose.reshape(4, 4), inliers=inl[:ni.value])
+
+    def track_back_end(self):
+        """Waits for the BA behind track_back_begin -> poses [n+1,4,4] of the period (pose 0 = key frame)."""
+        t = self._track
+        if t is None:
+            raise VsError(-1, "track_back_end: no tracking period (call track_begin)")
+        npo = C.c_int(0)
+        self._chk(self._lib.vs_track_back_end(self._h, ptr(t["poses"], c_f64p), C.byref(npo)))
+        return t["poses"][:npo.value].reshape(-1, 4, 4).copy()
+
     def track_end(self):
         self._chk(self._lib.vs_track_end(self._h))
         self._track = None

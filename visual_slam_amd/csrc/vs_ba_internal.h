@@ -157,6 +157,8 @@ struct pnp_args {
   double* model_out;   // [H][kPnpModel]: rows of [R|t] (camera-to-world, 12), the record re-derived from it (19), pad; 256-byte rows
   unsigned long long* tag;  // [H] (call epoch << 32) | inlier count of hypothesis h, published when its model is complete
   unsigned epoch;      // this call's epoch (never 0; words of earlier calls never carry it)
+  double* host_result;  // optional pinned mirror of `result` [20] (class-API period), or nullptr
+  int* host_inl;        // ... and of inl_out
   unsigned long long* stamps;  // diagnostic (vs_pnp_profile): wall-clock stamps [H + 1][8] of the roles' phases, or nullptr
   double* result;      // [20]: pose 4x4, found, inliers, best hypothesis, hypotheses used
   int* inl_out;        // [n]

@@ -86,6 +86,8 @@ VS_API int vs_destroy(vs_ctx* ctx) {
   if (ctx->h_pin.p) (void)hipHostFree(ctx->h_pin.p);
   if (ctx->h_pin_big.p) (void)hipHostFree(ctx->h_pin_big.p);
   if (ctx->h_track.p) (void)hipHostFree(ctx->h_track.p);
+  if (ctx->h_api.p) (void)hipHostFree(ctx->h_api.p);
+  if (ctx->track.ev_api) (void)hipEventDestroy(ctx->track.ev_api);
   for (hipEvent_t e : ctx->track.ev_front)
     if (e) (void)hipEventDestroy(e);
   if (ctx->ev_shard) (void)hipEventDestroy(ctx->ev_shard);

@@ -720,8 +720,9 @@ VS_API int vs_detect_describe_bgr(vs_ctx* ctx, const uint8_t* bgr, int w, int h,
                        "vs_detect_describe_bgr");
 }
 
-VS_API int vs_detect_describe_bgr_dev(vs_ctx* ctx, const void* d_bgr, int w, int h, int pitch, int thr, int max_kp,
-                                      void* d_xy, void* d_score, void* d_desc, void* d_n_out, void* stream) {
+int vs_detect_describe_dev_mirror(vs_ctx* ctx, const void* d_bgr, int w, int h, int pitch, int thr, int max_kp, void* d_xy,
+                                  void* d_score, void* d_desc, void* d_n_out, void* stream, uint8_t* h_block,
+                                  unsigned h_off_score, unsigned h_off_xy, unsigned h_off_desc) {
   VS_TRY(check_image(ctx, d_bgr, w, h, pitch, 3, "vs_detect_describe_bgr_dev"));
   if ((pitch & 3) || ((uintptr_t)d_bgr & 3) || ((uintptr_t)d_desc & 7))
     return vs_fail(ctx, VS_EINVAL, "%s: pitch and base must be multiples of 4 bytes, desc of 8", "vs_detect_describe_bgr_dev");
@@ -742,9 +743,15 @@ VS_API int vs_detect_describe_bgr_dev(vs_ctx* ctx, const void* d_bgr, int w, int
   hipLaunchKernelGGL(select_describe_kernel<true>, dim3(nbands), dim3(kSelThreads), 0, s, (const uint32_t*)ctx->d_raw.p,
                      band_cap, (const int*)ctx->d_bandcnt.p, (const int*)ctx->d_hist.p, (const int*)fh, fh_next, nbands, max_kp,
                      (const uint16_t*)ctx->d_box.p, w, (float*)d_xy, (uint8_t*)d_score, (uint8_t*)d_desc, (int*)d_n_out,
-                     (uint8_t*)nullptr, 0u, 0u, 0u);
+                     h_block, h_off_score, h_off_xy, h_off_desc);
   VS_LAUNCH_CHECK(ctx, "select_describe_kernel");
   return VS_OK;
+}
+
+VS_API int vs_detect_describe_bgr_dev(vs_ctx* ctx, const void* d_bgr, int w, int h, int pitch, int thr, int max_kp,
+                                      void* d_xy, void* d_score, void* d_desc, void* d_n_out, void* stream) {
+  return vs_detect_describe_dev_mirror(ctx, d_bgr, w, h, pitch, thr, max_kp, d_xy, d_score, d_desc, d_n_out, stream, nullptr, 0u,
+                                       0u, 0u);
 }
 
 VS_API int vs_brief256(vs_ctx* ctx, const uint8_t* gray, int w, int h, int stride, const float* xy, int n,

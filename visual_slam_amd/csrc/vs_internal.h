@@ -84,7 +84,7 @@ struct vs_ctx {
   vs_desc_entry desc_cache[VS_DESC_CACHE];
   uint64_t desc_stamp = 0;
   // tracking session (vs_track_*): one key-frame period resident on the device
-  vs_buf d_track, h_track;
+  vs_buf d_track, h_track, h_api;  // h_api: pinned block the class-API entry points' kernels mirror their results into
   struct {
     int active = 0, n_points = 0, cap_frames = 0, max_kp = 0, pnp_iters = 0;
     int n_frames = 0;   // frames tracked so far in this period (pose index of the newest one)
@@ -101,6 +101,9 @@ struct vs_ctx {
     int pending = -1;   // buffer set of the frame whose front half is done and whose back half is not, or -1
     int pending_step = -1;  // >= 0: that frame's back half is enqueued already, this many LM launches so far
     int next_set = 0;
+    // class-API feeding (vs_track_front / vs_track_back_begin / vs_track_back_end): 0 idle, 1 front half done, 2 back half running
+    int api_stage = 0, api_step = 0, api_matches = 0;
+    hipEvent_t ev_api = nullptr;  // recorded behind the PnP kernel of vs_track_back_begin
     struct {
       double reproj_err, confidence, huber;
       unsigned long long seed;
@@ -193,8 +196,15 @@ static inline int vs_reserve_pinned(vs_ctx* ctx, vs_buf* b, size_t bytes) {
 
 static inline hipStream_t vs_pick_stream(vs_ctx* ctx, void* s) { return s ? (hipStream_t)s : ctx->stream; }
 // vs_match_ratio_dev with the number of train rows read on the device (at most nt of them); vs_match.hip
+// h_mirror: optional pinned host block [count (4 ints) | mq | mt | md], h_stride ints apart, written by the kernel as well
 int vs_match_ratio_dev_n(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, const int* nt_dev, double ratio,
-                         void* d_match_q, void* d_match_t, void* d_match_d, void* d_n_out, void* stream);
+                         void* d_match_q, void* d_match_t, void* d_match_d, void* d_n_out, void* stream, int32_t* h_mirror,
+                         int h_stride);
+// vs_detect_describe_bgr_dev with an optional pinned host block [n | pad 16][score][xy][desc] (offsets as given) that the
+// select kernel writes as well; vs_detect.hip
+int vs_detect_describe_dev_mirror(vs_ctx* ctx, const void* d_bgr, int w, int h, int pitch, int thr, int max_kp, void* d_xy,
+                                  void* d_score, void* d_desc, void* d_n_out, void* stream, uint8_t* h_block,
+                                  unsigned h_off_score, unsigned h_off_xy, unsigned h_off_desc);
 
 // implemented in vs_match.hip / vs_detect.hip / vs_ba.hip
 void vs_ctx_free_buffers(vs_ctx* ctx);

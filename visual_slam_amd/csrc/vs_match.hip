@@ -286,10 +286,16 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
 __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int2* __restrict__ idx, const int2* __restrict__ dist,
                                                               int nq, double ratio, int32_t* __restrict__ mq,
                                                               int32_t* __restrict__ mt, int32_t* __restrict__ md,
-                                                              int32_t* __restrict__ n_out, const int* __restrict__ nt_dev) {
+                                                              int32_t* __restrict__ n_out, const int* __restrict__ nt_dev,
+                                                              int32_t* __restrict__ h_mirror, int h_stride) {
+  // h_mirror != nullptr: pinned host block [count (4 ints) | mq (h_stride) | mt (h_stride) | md (h_stride)] that receives
+  // every result word as well (the tracking period fed by the class API reads matches without a copy launch)
   __shared__ int wave_cnt[16];
   if (nt_dev && *nt_dev < 2) {  // fewer than two train rows: no second neighbour, no match (frame.py:30 could not unpack (m, n))
-    if (threadIdx.x == 0) *n_out = 0;
+    if (threadIdx.x == 0) {
+      *n_out = 0;
+      if (h_mirror) h_mirror[0] = 0;
+    }
     return;
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -319,11 +325,19 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int2* __restr
       mq[pos] = q;
       mt[pos] = i2.x;
       md[pos] = d2.x;
+      if (h_mirror) {
+        h_mirror[4 + pos] = q;
+        h_mirror[4 + h_stride + pos] = i2.x;
+        h_mirror[4 + 2 * h_stride + pos] = d2.x;
+      }
     }
     running += total;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *n_out = running;
+  if (threadIdx.x == 0) {
+    *n_out = running;
+    if (h_mirror) h_mirror[0] = running;
+  }
 }
 
 // chunk_len trains per workgroup (split into kWaves sub-ranges of sub_len), nchunks workgroups along y.
@@ -558,7 +572,8 @@ VS_API int vs_match_profile_read(vs_ctx* ctx, float* kernel_ms) {
 // nt_dev != nullptr: at most nt train rows, the actual count is read on the device (internal: vs_track.hip matches a frame
 // whose key-point count the host has not seen)
 int vs_match_ratio_dev_n(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, const int* nt_dev, double ratio,
-                         void* d_match_q, void* d_match_t, void* d_match_d, void* d_n_out, void* stream) {
+                         void* d_match_q, void* d_match_t, void* d_match_d, void* d_n_out, void* stream, int32_t* h_mirror,
+                         int h_stride) {
   VS_TRY(check_args(ctx, d_q, nq, d_t, nt, "vs_match_ratio_dev"));
   if (!d_n_out || (nq > 0 && (!d_match_q || !d_match_t || !d_match_d)))
     return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_match_ratio_dev");
@@ -573,14 +588,14 @@ int vs_match_ratio_dev_n(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
   VS_TRY(knn2_dev_impl(ctx, d_q, nq, d_t, nt, ms->idx.p, ms->dist.p, false, s, nt_dev));
   hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, s, (const int2*)ms->idx.p,
                      (const int2*)ms->dist.p, nq, ratio, (int32_t*)d_match_q, (int32_t*)d_match_t,
-                     (int32_t*)d_match_d, (int32_t*)d_n_out, nt_dev);
+                     (int32_t*)d_match_d, (int32_t*)d_n_out, nt_dev, h_mirror, h_stride);
   VS_LAUNCH_CHECK(ctx, "ratio_compact_kernel");
   return VS_OK;
 }
 
 VS_API int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, double ratio,
                               void* d_match_q, void* d_match_t, void* d_match_d, void* d_n_out, void* stream) {
-  return vs_match_ratio_dev_n(ctx, d_q, nq, d_t, nt, nullptr, ratio, d_match_q, d_match_t, d_match_d, d_n_out, stream);
+  return vs_match_ratio_dev_n(ctx, d_q, nq, d_t, nt, nullptr, ratio, d_match_q, d_match_t, d_match_d, d_n_out, stream, nullptr, 0);
 }
 
 VS_API int vs_hamming_knn2(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx,

@@ -516,6 +516,12 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
       P.result[17] = 0.0;
       P.result[18] = -1.0;
       P.result[19] = (double)s_best[1];
+      if (P.host_result) {
+        P.host_result[16] = s_best[2] ? -1.0 : 0.0;
+        P.host_result[17] = 0.0;
+        P.host_result[18] = -1.0;
+        P.host_result[19] = (double)s_best[1];
+      }
     }
     if (P.rec_out[0] && tid < kCamStride) {
       P.rec_out[0][tid] = P.cam0[tid];
@@ -541,7 +547,10 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
     __syncthreads();
     int off = s_base + __popcll(bal & ((1ull << lane) - 1));
     for (int w = 0; w < wv; ++w) off += s_cnt[w];
-    if (in) P.inl_out[off] = i;
+    if (in) {
+      P.inl_out[off] = i;
+      if (P.host_inl) P.host_inl[off] = i;
+    }
     __syncthreads();
     if (tid == 0) s_base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     __syncthreads();
@@ -582,6 +591,15 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
     P.result[17] = (double)m;
     P.result[18] = (double)best;
     P.result[19] = (double)s_best[1];
+    if (P.host_result) {  // the class-API period reads the PnP outcome from pinned memory, without a copy launch
+      for (int k = 0; k < 12; ++k) P.host_result[k] = pose[k];
+      P.host_result[12] = P.host_result[13] = P.host_result[14] = 0.0;
+      P.host_result[15] = 1.0;
+      P.host_result[16] = 1.0;
+      P.host_result[17] = (double)m;
+      P.host_result[18] = (double)best;
+      P.host_result[19] = (double)s_best[1];
+    }
     pnp_stamp(P, srow, 3);
   }
 }

@@ -167,8 +167,27 @@ constexpr size_t kPinRb = 4096;  // pinned staging: 1024 LM start state, 2048 re
 
 // Front half of a frame on stream `s`: image upload, detect+describe, match against the map, append of the matches as the
 // observations of free-camera slot `slot` -- enqueue only, no host synchronisation.  Ends with ev_front[set] recorded on `s`.
+// pinned block of the class-API entry points (vs_track_front / vs_track_back_begin): what the kernels mirror to the host
+struct api_layout {
+  size_t det, det_score, det_xy, det_desc, match, match_stride, pnp_res, pnp_inl, total;
+};
+api_layout api_layout_of(int P, int max_kp) {
+  api_layout A;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  A.det = 0;
+  A.det_score = 16;
+  A.det_xy = A.det_score + (((size_t)max_kp + 15) & ~(size_t)15);
+  A.det_desc = A.det_xy + (size_t)max_kp * 8;
+  A.match = up(A.det_desc + (size_t)max_kp * VS_DESC_BYTES);
+  A.match_stride = ((size_t)P + 3) & ~(size_t)3;  // ints
+  A.pnp_res = up(A.match + 16 + 3 * 4 * A.match_stride);
+  A.pnp_inl = A.pnp_res + 256;
+  A.total = up(A.pnp_inl + 4 * (size_t)P);
+  return A;
+}
+
 int track_front_half(vs_ctx* ctx, int set, int slot, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
-                     hipStream_t s) {
+                     hipStream_t s, bool mirror = false) {
   auto& T = ctx->track;
   const track_layout L = layout_of(ctx);
   const track_front& F = L.f[set];
@@ -178,11 +197,14 @@ int track_front_half(vs_ctx* ctx, int set, int slot, const uint8_t* bgr, int w, 
   VS_TRY(vs_reserve(ctx, img, (size_t)pitch * h_img + 16));
   if (stride == pitch) VS_HIP(ctx, hipMemcpyAsync(img->p, bgr, (size_t)pitch * h_img, hipMemcpyHostToDevice, s));
   else VS_HIP(ctx, hipMemcpy2DAsync(img->p, pitch, bgr, stride, 3 * (size_t)w, h_img, hipMemcpyHostToDevice, s));
-  VS_TRY(vs_detect_describe_bgr_dev(ctx, img->p, w, h_img, pitch, thr, T.max_kp, d + F.fxy, d + F.fscore, d + F.fdesc, d + F.fn, s));
+  const api_layout AL = api_layout_of(T.n_points, T.max_kp);
+  uint8_t* hb = mirror ? (uint8_t*)ctx->h_api.p : nullptr;
+  VS_TRY(vs_detect_describe_dev_mirror(ctx, img->p, w, h_img, pitch, thr, T.max_kp, d + F.fxy, d + F.fscore, d + F.fdesc, d + F.fn, s,
+                                       hb, (unsigned)AL.det_score, (unsigned)AL.det_xy, (unsigned)AL.det_desc));
   // the matcher is launched for max_kp train rows at most and reads the actual key-point count on the device (fewer than
   // two: no matches): the front half needs no host synchronisation, the count reaches the host with the frame's results
   VS_TRY(vs_match_ratio_dev_n(ctx, d + L.mapdesc, T.n_points, d + F.fdesc, T.max_kp, (const int*)(d + F.fn), ratio, d + F.mq,
-                              d + F.mt, d + F.md, d + F.M, s));
+                              d + F.mt, d + F.md, d + F.M, s, hb ? (int32_t*)(hb + AL.match) : nullptr, (int)AL.match_stride));
   // The new frame's observations are appended here, in the FRONT half: the rows lie behind everything the motion-only
   // solve of the previous frame reads (cameras up to its own), cam_start[slot] was written by the previous frame's append on
   // this same stream, and the counts go to this buffer set's own flag words -- so in pipelined use the append (and the
@@ -235,6 +257,11 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   const bool lm_on_device = T.pnp_iters > 0 && Q.lm_iterations > 0;  // pnp_ransac_kernel's finishing workgroup resets the LM records itself
   A.lm_init = lm_on_device ? reinterpret_cast<mo_state*>(d + L.mst) : nullptr;
   A.lm_cur = T.cur;
+  if (T.api_stage == 1) {  // class-API period: the PnP outcome is read from pinned memory (vs_track_back_begin)
+    const api_layout AL = api_layout_of(T.n_points, T.max_kp);
+    A.host_result = (double*)((uint8_t*)ctx->h_api.p + AL.pnp_res);
+    A.host_inl = (int*)((uint8_t*)ctx->h_api.p + AL.pnp_inl);
+  }
   if (T.pnp_iters > 0) {
     VS_TRY(pnp_tags(ctx, H, s, &A.tag, &A.epoch));
     VS_TRY(pnp_stamps(ctx, H, s, &A.stamps));
@@ -326,7 +353,7 @@ int track_ba_batch(vs_ctx* ctx, int set, int* step) {
 
 // Back half, completion: synchronise, run further LM batches if the solve is not finished, hand out the results.
 int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found,
-                      float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t) {
+                      float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t, bool pnp_ran = true) {
   auto& T = ctx->track;
   const track_layout L = layout_of(ctx);
   const track_front& F = L.f[set];
@@ -375,8 +402,9 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   *n_poses_out = k + 1;
   *n_matches = M;
   if (n_kp_out) *n_kp_out = n_kp;
-  if (T.pnp_iters > 0 && rb_res[16] < 0.0) return vs_fail(ctx, VS_EHIP, "%s: the PnP hypothesis workgroups did not report", "vs_track_frame");
-  if (pnp_found) *pnp_found = T.pnp_iters > 0 && rb_res[16] != 0.0 ? (int)rb_res[17] : 0;  // inliers of the PnP model
+  if (pnp_ran && T.pnp_iters > 0 && rb_res[16] < 0.0)
+    return vs_fail(ctx, VS_EHIP, "%s: the PnP hypothesis workgroups did not report", "vs_track_frame");
+  if (pnp_found) *pnp_found = pnp_ran && T.pnp_iters > 0 && rb_res[16] != 0.0 ? (int)rb_res[17] : 0;  // inliers of the PnP model
   return VS_OK;
 }
 
@@ -405,6 +433,8 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(std::max(std::max(up, (size_t)1 << 16),
                                                                   kPinRb + (L.rb_end - L.mst) + 256 + 20 * (size_t)n_points),
                                                          sizeof(int) * (size_t)max_frames + 2048)));
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_api, api_layout_of(n_points, max_kp).total));
+  if (!T.ev_api) VS_HIP(ctx, hipEventCreateWithFlags(&T.ev_api, hipEventDisableTiming));
   VS_HIP(ctx, hipStreamSynchronize(s));
   uint8_t* h = (uint8_t*)ctx->h_track.p;
   uint8_t* d = (uint8_t*)ctx->d_track.p;
@@ -438,6 +468,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   T.pending = -1;
   T.pending_step = -1;
   T.next_set = 0;
+  T.api_stage = 0;
   T.K[0] = fx;
   T.K[1] = fy;
   T.K[2] = cx;
@@ -453,6 +484,7 @@ VS_API int vs_track_end(vs_ctx* ctx) {
   ctx->track.active = 0;
   ctx->track.pending = -1;
   ctx->track.pending_step = -1;
+  ctx->track.api_stage = 0;
   if (g_tt.on && g_tt.n) {
     fprintf(stderr, "[vs_track timing] per pipelined call over %ld calls: front enqueue %.1f us, wait+finish %.1f, PnP enqueue %.1f, BA+copy enqueue %.1f\n",
             g_tt.n, g_tt.sum[0] / g_tt.n, g_tt.sum[1] / g_tt.n, g_tt.sum[2] / g_tt.n, g_tt.sum[3] / g_tt.n);
@@ -491,6 +523,8 @@ VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const doub
   if (m < 0 || (m > 0 && (!point_idx || !uv)) || !pose16 || lm_iterations < 0 || !poses_out || !n_poses_out)
     return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_push_frame");
   if (T.pending >= 0) return vs_fail(ctx, VS_EINVAL, "%s: a pipelined frame is pending (flush it first)", "vs_track_push_frame");
+  if (T.api_stage == 2) return vs_fail(ctx, VS_EINVAL, "%s: a back half is running (vs_track_back_end first)", "vs_track_push_frame");
+  T.api_stage = 0;  // a front half nobody followed up on: its rows are overwritten below
   if (T.n_frames >= T.cap_frames) return vs_fail(ctx, VS_ENOMEM, "%s: the period holds max_frames frames already", "vs_track_push_frame");
   if (m > T.n_points) return vs_fail(ctx, VS_EINVAL, "%s: more observations than map points", "vs_track_push_frame");
   for (int i = 0; i < m; ++i)
@@ -534,7 +568,7 @@ VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const doub
   int step = 0, n_matches = 0;
   VS_TRY(track_ba_batch(ctx, 0, &step));
   return track_back_finish(ctx, 0, &step, poses_out, n_poses_out, &n_matches, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr);
+                           nullptr, false);
 }
 
 VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
@@ -589,4 +623,86 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
   }
   ++g_tt.n;
   return VS_OK;
+}
+
+// ---- The same period driven call by call through the reference's class API (src/v2/main.py:181-214), without giving up the
+// residency: Frame.process_frame -> vs_track_front (upload, detect + describe, match against the key frame's map points,
+// append; ONE synchronisation, results mirrored into pinned memory by the kernels themselves); cv2.solvePnPRansac ->
+// vs_track_back_begin (PnP-RANSAC and, right behind it on the stream, the motion-only BA; returns as soon as the PnP outcome is
+// in); BundleAdjustment.motionOnlyBundleAdjustement -> vs_track_back_end (waits for the BA, which ran while the caller did
+// its bookkeeping).  The Python side (map.py, _PeriodMirror) checks that what the caller passes to each of these calls is
+// what the device already worked on, and otherwise starts the period afresh from the map.
+VS_API int vs_track_front(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio, float* xy_out,
+                          uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t, int32_t* match_d,
+                          int* n_matches) {
+  if (!ctx) return VS_EINVAL;
+  VS_TRY(track_check_frame(ctx, bgr, w, h_img, stride, 0, "vs_track_front"));
+  if (!xy_out || !desc_out || !n_kp_out || !match_q || !match_t || !match_d || !n_matches)
+    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_front");
+  auto& T = ctx->track;
+  if (T.pending >= 0 || T.api_stage == 2) return vs_fail(ctx, VS_EINVAL, "%s: a back half is still running", "vs_track_front");
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  VS_TRY(track_front_half(ctx, 0, T.n_frames, bgr, w, h_img, stride, thr, ratio, ctx->stream, true));
+  VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const api_layout AL = api_layout_of(T.n_points, T.max_kp);
+  const uint8_t* hb = (const uint8_t*)ctx->h_api.p;
+  const int n_kp = *(const int*)(hb + AL.det);
+  const int32_t* hm = (const int32_t*)(hb + AL.match);
+  const int M = hm[0];
+  if (n_kp < 0 || n_kp > T.max_kp || M < 0 || M > T.n_points)
+    return vs_fail(ctx, VS_EHIP, "%s: device returned impossible counts", "vs_track_front");
+  memcpy(xy_out, hb + AL.det_xy, sizeof(float) * 2 * (size_t)n_kp);
+  memcpy(desc_out, hb + AL.det_desc, (size_t)VS_DESC_BYTES * n_kp);
+  memcpy(match_q, hm + 4, sizeof(int32_t) * (size_t)M);
+  memcpy(match_t, hm + 4 + AL.match_stride, sizeof(int32_t) * (size_t)M);
+  memcpy(match_d, hm + 4 + 2 * AL.match_stride, sizeof(int32_t) * (size_t)M);
+  *n_kp_out = n_kp;
+  *n_matches = M;
+  T.api_stage = 1;
+  T.api_matches = M;
+  return VS_OK;
+}
+
+VS_API int vs_track_back_begin(vs_ctx* ctx, double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations,
+                               double huber_delta, int* found, double* pose16, int32_t* inliers, int* n_inliers) {
+  if (!ctx) return VS_EINVAL;
+  auto& T = ctx->track;
+  if (!T.active || T.api_stage != 1) return vs_fail(ctx, VS_EINVAL, "%s: no front half to continue (vs_track_front)", "vs_track_back_begin");
+  if (!found || !pose16 || !inliers || !n_inliers || lm_iterations < 0 || T.pnp_iters <= 0)
+    return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_back_begin");
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  T.params[0] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
+  int step = 0;
+  VS_TRY(track_back_enqueue(ctx, 0, &step));            // PnP-RANSAC; its outcome also goes to pinned memory
+  VS_HIP(ctx, hipEventRecord(T.ev_api, ctx->stream));
+  VS_TRY(track_ba_batch(ctx, 0, &step));                // the motion-only BA + read-back copy, right behind it
+  T.api_step = step;
+  T.api_stage = 2;
+  VS_HIP(ctx, hipEventSynchronize(T.ev_api));
+  const api_layout AL = api_layout_of(T.n_points, T.max_kp);
+  const double* res = (const double*)((const uint8_t*)ctx->h_api.p + AL.pnp_res);
+  if (res[16] < 0.0) return vs_fail(ctx, VS_EHIP, "%s: the PnP hypothesis workgroups did not report", "vs_track_back_begin");
+  *found = res[16] != 0.0;
+  *n_inliers = 0;
+  if (*found) {
+    const int m = (int)res[17];
+    if (m < 0 || m > T.api_matches) return vs_fail(ctx, VS_EHIP, "%s: device returned an impossible inlier count", "vs_track_back_begin");
+    memcpy(pose16, res, 16 * sizeof(double));
+    memcpy(inliers, (const uint8_t*)ctx->h_api.p + AL.pnp_inl, sizeof(int32_t) * (size_t)m);
+    *n_inliers = m;
+  } else {
+    pose_from_rec(T.last_rec, pose16);  // nothing found: the guess, as cv2 leaves rvec / tvec untouched
+  }
+  return VS_OK;
+}
+
+VS_API int vs_track_back_end(vs_ctx* ctx, double* poses_out, int* n_poses_out) {
+  if (!ctx) return VS_EINVAL;
+  auto& T = ctx->track;
+  if (!T.active || T.api_stage != 2) return vs_fail(ctx, VS_EINVAL, "%s: no back half is running (vs_track_back_begin)", "vs_track_back_end");
+  if (!poses_out || !n_poses_out) return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_back_end");
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  int step = T.api_step, n_matches = 0, pnp_found = 0;
+  T.api_stage = 0;
+  return track_back_finish(ctx, 0, &step, poses_out, n_poses_out, &n_matches, &pnp_found, nullptr, nullptr, nullptr, nullptr, nullptr);
 }

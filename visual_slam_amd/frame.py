@@ -7,6 +7,8 @@ matcher uses the Hamming norm.  Everything else -- argument order, return tuples
 reference line by line (cited per method).
 """
 from collections.abc import Sequence
+from functools import partial as _partial
+from operator import itemgetter as _itemgetter
 
 import numpy as np
 
@@ -27,18 +29,24 @@ def imread(path):
         return None
 
 
-class DMatch:
-    """The fields of cv2.DMatch the reference reads (frame.py:33-47, main.py:187-188,210)."""
-    __slots__ = ("queryIdx", "trainIdx", "imgIdx", "distance")
+class DMatch(tuple):
+    """The fields of cv2.DMatch the reference reads (frame.py:33-47, main.py:187-188,210): queryIdx, trainIdx, imgIdx,
+    distance.  A tuple underneath (read-only fields): the tracking loop builds one per match per frame, and a tuple with
+    C-level accessors is created and read at twice the speed of an object with Python-level attributes."""
+    __slots__ = ()
+    queryIdx = property(_itemgetter(0))
+    trainIdx = property(_itemgetter(1))
+    imgIdx = property(_itemgetter(2))
+    distance = property(_itemgetter(3))
 
-    def __init__(self, queryIdx, trainIdx, distance, imgIdx=0):
-        self.queryIdx = int(queryIdx)
-        self.trainIdx = int(trainIdx)
-        self.imgIdx = int(imgIdx)
-        self.distance = float(distance)
+    def __new__(cls, queryIdx, trainIdx, distance, imgIdx=0):
+        return tuple.__new__(cls, (int(queryIdx), int(trainIdx), int(imgIdx), float(distance)))
 
     def __repr__(self):
-        return "DMatch(queryIdx=%d, trainIdx=%d, distance=%g)" % (self.queryIdx, self.trainIdx, self.distance)
+        return "DMatch(queryIdx=%d, trainIdx=%d, distance=%g)" % (self[0], self[1], self[3])
+
+
+_dmatch_from_row = _partial(tuple.__new__, DMatch)  # (queryIdx, trainIdx, imgIdx, distance) -> DMatch, no Python frame
 
 
 class MatchList(Sequence):
@@ -55,16 +63,11 @@ class MatchList(Sequence):
         return int(self.query_idx.shape[0])
 
     def __iter__(self):
-        # the reference's callers iterate `for m in matches: m[0].queryIdx` (main.py:187-188,210): build the objects
-        # from plain Python scalars in one pass instead of one NumPy scalar conversion per attribute
-        new = DMatch.__new__
-        for q, t, d in zip(self.query_idx.tolist(), self.train_idx.tolist(), self.distance.tolist()):
-            m = new(DMatch)
-            m.queryIdx = q
-            m.trainIdx = t
-            m.imgIdx = 0
-            m.distance = float(d)
-            yield [m]
+        # the reference's callers iterate `for m in matches: m[0].queryIdx` (main.py:187-188,210): all rows are built in one
+        # pass from plain Python scalars (no NumPy scalar conversion per attribute, no Python-level constructor per match)
+        n = len(self)
+        rows = zip(self.query_idx.tolist(), self.train_idx.tolist(), [0] * n, self.distance.astype(np.float64).tolist())
+        return iter([[m] for m in map(_dmatch_from_row, rows)])
 
     def __getitem__(self, i):
         if isinstance(i, slice):
@@ -89,6 +92,15 @@ class FeatureExtractor:
         """img: BGR uint8 [H, W, 3] -> (keypoints float32 [N, 2] as cv2.KeyPoint_convert gives them, descriptors uint8
         [N, 32]).  One upload, two kernel launches (vs_detect_describe_bgr)."""
         ctx = self._ctx or default_context()
+        own = ctx._track_owner
+        if own is not None:
+            # a local map's tracking period is resident on this context (map.py, _PeriodMirror): the frame is detected,
+            # described AND matched against the key frame there, in one chain with one synchronisation; match_features
+            # below recognises the pair and hands the matches out without touching the GPU again
+            r = own.speculate_front(img, self.threshold, self.max_keypoints)
+            if r is not None:
+                self.last_scores = None
+                return r
         xy, score, desc = ctx.detect_describe_bgr(img, self.threshold, self.max_keypoints)
         self.last_scores = score
         return xy, desc
@@ -104,6 +116,12 @@ class FeatureMatcher:
         """knnMatch(desc1, desc2, k=2) + Lowe's ratio test, survivors in query order.
         Returns (matches, pts1, ft1, pts2, ft2) exactly as frame.py:49."""
         ctx = self._ctx or default_context()
+        own = ctx._track_owner
+        if own is not None and own.spec is not None:
+            hit = own.spec_matches(kp1, desc1, kp2, desc2, ratio)
+            if hit is not None:  # key frame x the frame in flight: the resident period matched them already
+                mq, mt, md = hit
+                return MatchList(mq, mt, md), kp1[mq], desc1[mq], kp2[mt], desc2[mt]
         desc1 = np.ascontiguousarray(desc1, np.uint8).reshape(-1, 32)
         desc2 = np.ascontiguousarray(desc2, np.uint8).reshape(-1, 32)
         if desc1.shape[0] > 0 and desc2.shape[0] < 2:

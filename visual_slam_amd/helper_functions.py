@@ -128,9 +128,19 @@ def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rve
     pose0 = np.eye(4)
     pose0[:3, :3] = c_T_w[:3, :3].T
     pose0[:3, 3] = -c_T_w[:3, :3].T @ c_T_w[:3, 3]
-    run = solver or (context or default_context()).pnp_ransac
-    r = run(obj, img, K4, pose0, iterations=int(iterationsCount), reproj_err=float(reprojectionError),
-            confidence=float(confidence), seed=int(seed))
+    r = None
+    if solver is None:
+        ctx = context or default_context()
+        own = ctx._track_owner
+        if own is not None and own.spec is not None and useExtrinsicGuess:
+            # the correspondences are the matches the resident period just produced and the guess is its previous pose:
+            # PnP-RANSAC runs there (no upload), with the motion-only BA enqueued right behind it
+            r = own.speculate_back(obj, img, K4, pose0, int(iterationsCount), float(reprojectionError), float(confidence),
+                                   int(seed))
+    if r is None:
+        run = solver or (context or default_context()).pnp_ransac
+        r = run(obj, img, K4, pose0, iterations=int(iterationsCount), reproj_err=float(reprojectionError),
+                confidence=float(confidence), seed=int(seed))
     w_T_c = r["pose"]
     R = w_T_c[:3, :3].T
     t = -R @ w_T_c[:3, 3]

@@ -17,6 +17,7 @@ observations and start pose (vs_track_push_frame) instead of rebuilding and re-u
 import copy
 
 import numpy as np
+from operator import itemgetter as _itemgetter
 
 
 _SOA_GENERATION = [0]  # every mirror ever built gets the next number: a cache key that, unlike id(), is never recycled
@@ -127,14 +128,84 @@ class _PeriodMirror:
         self.consumed = 0      # SoA batches consumed so far
         self.written = {}      # frame id -> pose array object this mirror wrote into the Frame
         self.state = None      # (points dict id, n_points, geometry counter, observation counter, key id, key pose value)
+        # Front half / PnP of the NEXT frame run inside the resident period when the period holds the key frame's real
+        # descriptors (see _begin): `key` = (uv, desc) arrays of the key frame as GetImagePointsWithFrameID hands them out,
+        # `spec` = what the device has already worked out for the frame in flight (see speculate_front / speculate_back)
+        self.key = None
+        self.max_kp = 0
+        self.xyz = None
+        self.spec = None
+        self.unused = 0        # front halves nobody followed up on (then no more are attempted for this map)
+        self.last_pose = None
+
+    kMaxKeypoints = 3000  # FeatureExtractor's default; an extractor with another cap takes the plain path
 
     def _begin(self, map_, soa, key_id, key_frame, cap):
         P = soa.n_points
-        self.ctx.track_begin(soa.xyz[:P], np.zeros((P, 32), np.uint8), np.asarray(key_frame.GetPose(), np.float64), self.K4,
-                             max_frames=cap, max_kp=2, pnp_iterations=0)
+        # The key frame's descriptors, one per map point in point order, make the period able to match a new frame and run
+        # PnP-RANSAC on the device (speculate_front / speculate_back).  They are there when every point of the local map
+        # is seen by the key frame -- the shape main.py:333-345 builds; otherwise the period only takes host-fed frames.
+        desc, key, max_kp, pnp = np.zeros((P, 32), np.uint8), None, 2, 0
+        try:
+            uv, kd, _, _ = map_.GetImagePointsWithFrameID(key_id)
+            if isinstance(kd, np.ndarray) and kd.dtype == np.uint8 and kd.shape == (P, 32) and len(uv) == P:
+                desc, key, max_kp, pnp = kd, (uv, kd), self.kMaxKeypoints, 100
+        except Exception:
+            pass
+        self.ctx.track_begin(soa.xyz[:P], desc, np.asarray(key_frame.GetPose(), np.float64), self.K4,
+                             max_frames=cap, max_kp=max_kp, pnp_iterations=pnp)
         self.ctx._track_owner = self
         self.cap, self.pushed, self.consumed, self.written = cap, [], 0, {}
+        self.key, self.max_kp, self.xyz, self.spec, self.unused = key, max_kp, np.array(soa.xyz[:P], np.float64), None, 0
+        self.last_pose = np.array(key_frame.GetPose(), np.float64)
         self.state = (id(map_.points_3d), P, map_._cell[0], map_._cell[1], key_id, np.array(key_frame.GetPose(), np.float64))
+
+    # ---- the frame in flight: FeatureExtractor.compute_features -> speculate_front, FeatureMatcher.match_features ->
+    # spec_matches, solvePnPRansac -> speculate_back, motionOnlyBundleAdjustement -> solve() collects.  Every step checks
+    # that the caller's arguments are what the device worked on; a caller that does anything else gets the plain path,
+    # and a back half that turns out not to match restarts the period from the map (solve()).
+    def _alive(self):
+        ctx = self.ctx
+        return getattr(ctx, "_track_owner", None) is self and ctx._track is not None and self.state is not None
+
+    def speculate_front(self, img, thr, max_kp):
+        """-> (xy, desc) of `img` computed inside the resident period, or None (no such period / not applicable)."""
+        if self.key is None or self.unused or not self._alive() or max_kp != self.max_kp or len(self.pushed) + 1 > self.cap:
+            return None
+        if self.spec is not None:
+            if self.spec["stage"] == 2:
+                return None  # a back half nobody collected: leave it to solve() to sort out
+            self.unused += 1  # the previous front half was never followed up: this caller's frames go elsewhere
+            self.spec = None
+            return None
+        r = self.ctx.track_front(img, thr, 0.8)
+        self.spec = dict(stage=1, matched=False, ratio=0.8, **r)
+        return r["xy"], r["desc"]
+
+    def spec_matches(self, kp1, desc1, kp2, desc2, ratio):
+        """The front half's matches if (kp1, desc1) is the key frame and (kp2, desc2) the frame in flight, else None."""
+        sp = self.spec
+        if sp is None or sp["stage"] != 1 or desc2 is not sp["desc"] or kp2 is not sp["xy"] or ratio != sp["ratio"]:
+            return None
+        uv, kd = self.key
+        if desc1 is not kd and not (getattr(desc1, "shape", None) == kd.shape and np.array_equal(desc1, kd)):
+            return None
+        sp["matched"] = True
+        return sp["match_q"], sp["match_t"], sp["match_d"]
+
+    def speculate_back(self, obj, img, K4, pose0, iterations, reproj_err, confidence, seed):
+        """PnP-RANSAC inside the period if the call is the one main.py:196-197 makes on the matches in flight, else None."""
+        sp = self.spec
+        if (sp is None or sp["stage"] != 1 or not sp["matched"] or not self._alive() or iterations != 100
+                or tuple(float(v) for v in K4) != self.K4):
+            return None
+        mq, mt = sp["match_q"], sp["match_t"]
+        if (obj.shape != (len(mq), 3) or img.shape != (len(mq), 2) or len(mq) < 5 or not np.array_equal(obj, self.xyz[mq])
+                or not np.array_equal(img, sp["xy"][mt]) or float(np.abs(pose0 - self.last_pose).max()) > 1e-9):
+            return None
+        r = self.ctx.track_back_begin(seed=seed, reproj_err=reproj_err, confidence=confidence)
+        sp["stage"], sp["pnp"] = 2, r
+        return r
 
     def solve(self, map_, huber_delta, max_iterations):
         """Appends what is new and runs the motion-only BA; returns poses [n_frames,4,4] in map.frames order, or None if
@@ -177,6 +248,27 @@ class _PeriodMirror:
                 if b is not None and b[0] >= self.consumed:
                     fresh = True  # observations of an already sent frame arrived later
                     break
+        sp, self.spec = self.spec, None
+        if sp is not None and sp["stage"] == 2 and getattr(ctx, "_track_owner", None) is self and ctx._track is not None:
+            # A back half is running on the device (speculate_back).  It is this call's solve iff exactly one new frame
+            # arrived with the very matches and (to rounding: the caller took the pose through rvec / tvec) the PnP pose.
+            poses = None
+            todo = frames[1 + len(self.pushed):]
+            if not fresh and len(todo) == 1:
+                fid, f = todo[0]
+                b = rows.get(fid)
+                if b is not None and b[0] >= self.consumed and b[2] == len(sp["match_q"]):
+                    slot_, _, uv_, _ = soa.arrays()
+                    sl, obs = slot_[b[1]:b[1] + b[2]], uv_[b[1]:b[1] + b[2]]
+                    if (np.array_equal(sl, sp["match_q"]) and np.array_equal(obs, sp["xy"][sp["match_t"]])
+                            and float(np.abs(np.asarray(f.GetPose(), np.float64) - sp["pnp"]["pose"]).max()) <= 1e-9):
+                        poses = ctx.track_back_end()
+                        self.pushed.append(fid)
+                        self.consumed = len(soa.batches)
+                        self.last_pose = np.array(poses[-1])
+            if poses is not None:
+                return poses
+            fresh = True  # the device solved something else than the caller built: start the period afresh from the map
         if fresh:
             if ctx._track is not None and getattr(ctx, "_track_owner", None) is None:
                 return None  # the context's resident period was opened explicitly (Context.track_begin): not ours to end
@@ -205,6 +297,7 @@ class _PeriodMirror:
                                          lm_iterations=max_iterations if last else 0, huber_delta=huber_delta)
             self.pushed.append(fid)
         self.consumed = len(soa.batches)
+        self.last_pose = np.array(poses[-1])
         return poses
 
     def wrote(self, fid, pose):
@@ -451,8 +544,11 @@ class Map:
         if (self._soa_points_obj is pts and s.n_obs >= 0 and s.n_points == len(pts) and self._soa_cell[0] == c[0]
                 and self._soa_cell[1] == c[1] and hasattr(image_points, "__getitem__") and hasattr(descriptors, "__getitem__")):
             try:
-                slots = np.fromiter((s.point_slot[pid] for pid in point_ids), dtype=np.int32)
-                n = slots.shape[0]
+                n = len(point_ids)
+                if n > 1:  # one C-level lookup for the whole batch
+                    slots = np.array(_itemgetter(*(point_ids.tolist() if isinstance(point_ids, np.ndarray) else point_ids))(s.point_slot), np.int32)
+                else:
+                    slots = np.fromiter((s.point_slot[pid] for pid in point_ids), dtype=np.int32)
                 new_frame = s.fid_rows.get(fid, 0) == 0
             except (KeyError, TypeError):
                 slots, n, new_frame = None, 0, False

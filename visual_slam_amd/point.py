@@ -48,8 +48,11 @@ class Point:
 
     def _adopt(self, cell):
         """Called by a Map that starts holding this point."""
-        if all(c is not cell for c in self._cells):
-            self._cells = self._cells + (cell,)
+        cells = self._cells
+        if not cells:
+            self._cells = (cell,)
+        elif all(c is not cell for c in cells):
+            self._cells = cells + (cell,)
 
     def __copy__(self):
         q = Point.__new__(Point)
