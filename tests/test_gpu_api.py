@@ -535,3 +535,82 @@ def test_resident_tracking_survives_frames_without_key_points(vs, oracle):
         assert np.allclose(r2["poses"][1], r1["poses"][1], atol=5e-3)  # the first frame's pose only moves within the BA's reach
     finally:
         vs.track_end()
+
+
+def test_class_api_speculation_falls_back_when_the_caller_deviates(vs, oracle):
+    """The class API runs a frame's front half and PnP inside the resident period AHEAD of the calls that ask for them
+    (vs_track_front in process_frame, vs_track_back_begin in solvePnPRansac).  That is only valid while the caller passes
+    on exactly what the device used.  Here the caller deviates -- drops matches before PnP, ignores the PnP pose, edits the
+    match list between PnP and the BA, skips PnP altogether -- and every time the result must be that of the path that
+    rebuilds and uploads the whole problem (Map.use_device_mirror = False) driven the same way, to 1e-9."""
+    from visual_slam_amd import harness
+    from visual_slam_amd import helper_functions as hf
+    from visual_slam_amd.LocalBA import BundleAdjustment, Camera
+    from visual_slam_amd.frame import FeatureExtractor, FeatureMatcher, Frame
+    from visual_slam_amd.map import Map
+    from visual_slam_amd.point import Point
+    frames, depth0 = harness.load_sequence(9)
+    fx, fy, cx, cy = ICL_NUIM_K
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+
+    def drive():
+        extractor, matcher, camera = FeatureExtractor(context=vs), FeatureMatcher(context=vs), Camera(*ICL_NUIM_K)
+        key = Frame(frames[0], None, 0)
+        key.AddPose(np.eye(4))
+        key.SetAsKeyFrame()
+        kp0, ft0, _ = key.process_frame(extractor)
+        m = Map()
+        m.AddFrame(0, key)
+        for i, (X, uv, d) in enumerate(zip(harness.backproject(kp0, depth0), kp0, ft0)):
+            pt = Point(location=X, id=i + 1)
+            pt.AddFrame(frame=key, uv=uv, descriptor=d)
+            m.AddPoint3D(point_id=i + 1, point_3d=pt)
+        for k in range(1, len(frames)):
+            cur = Frame(frames[k], None, k)
+            kp_cur, ft_cur, _ = cur.process_frame(extractor)
+            kp_prev, ft_prev, known_3d, point_ids = m.GetImagePointsWithFrameID(0)
+            matches, _, _, cur_pts, cur_fts = matcher.match_features(kp_prev, ft_prev, kp_cur, ft_cur)
+            q = matches.query_idx
+            if k == 3:                      # fewer correspondences than the device matched
+                q, cur_pts, cur_fts = q[:-10], cur_pts[:-10], cur_fts[:-10]
+            prev_pose = np.asarray(m.GetFrame(k - 1).GetPose(), np.float64)
+            pose = prev_pose
+            if k != 6:                      # k == 6: no PnP at all
+                c_T_w = np.linalg.inv(prev_pose)
+                ok, rvec, tvec, _ = hf.solvePnPRansac(known_3d[q], cur_pts, K, None, hf.Rtorvec(c_T_w[:3, :3]), c_T_w[:3, 3],
+                                                      useExtrinsicGuess=True, context=vs, seed=k)
+                if ok and k != 4:           # k == 4: the PnP pose is ignored
+                    pose = np.linalg.inv(np.asarray(hf.transformMatrix(rvec, tvec)))
+            if k == 5:                      # the match list is edited between PnP and the BA
+                q, cur_pts, cur_fts = q[5:], cur_pts[5:], cur_fts[5:]
+            m.AddParentAndPose(parent_id=k - 1, frame_id=k, frame_obj=cur, rel_pose_trans=np.eye(4), pose=pose)
+            m.AddPointToFrameCorrespondences(point_ids=[point_ids[i] for i in q.tolist()], image_points=cur_pts,
+                                             descriptors=cur_fts, frame_obj=cur)
+            BundleAdjustment(camera, context=vs).motionOnlyBundleAdjustement(m)
+        return np.stack([m.GetFrame(k).GetPose() for k in range(len(frames))])
+
+    Map.use_device_mirror = False
+    try:
+        ref = drive()
+    finally:
+        Map.use_device_mirror = True
+    calls = {"begin": 0, "back_end": 0}
+    orig_begin, orig_end = vs.track_begin, vs.track_back_end
+
+    def begin(*a, **k):
+        calls["begin"] += 1
+        return orig_begin(*a, **k)
+
+    def end(*a, **k):
+        calls["back_end"] += 1
+        return orig_end(*a, **k)
+    vs.track_begin, vs.track_back_end = begin, end
+    try:
+        got = drive()
+    finally:
+        del vs.track_begin, vs.track_back_end
+    rel = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(got, ref))
+    assert rel <= 1e-9, rel
+    # frames 2, 7 and 8 follow the reference's sequence to the letter: collected from the device; 4 and 5 had a back half in
+    # flight that did not match what the caller then built: the period was started afresh both times
+    assert calls["back_end"] >= 2 and calls["begin"] >= 3, calls
