@@ -144,19 +144,32 @@ def test_noise_free_converges_to_ground_truth(vs):
     assert np.allclose(g["poses"], w["poses_gt"], atol=1e-6) and np.allclose(g["points"], w["points_gt"], atol=1e-5)
 
 
-def _oracle_sensitivity(oracle, w, max_iterations, reps=6):
-    """How far the ORACLE's own LM path moves when its inputs move by one ulp: per-trial and per-iteration relative
-    spread of chi2 over `reps` runs whose observations are perturbed by +-1.1e-16 relative.  This is the conditioning of
-    the scene's LM path -- an implementation with a different (equally valid) summation order cannot be expected to stay
-    closer to the oracle than the oracle stays to itself."""
+def _oracle_sensitivity(oracle, w, max_iterations, reps=3):
+    """How far the ORACLE's own LM path moves under perturbations that leave the problem the same to rounding: per-trial
+    and per-iteration relative spread of chi2 over runs with (a) the observations, (b) the points, (c) the poses moved by
+    one ulp (+-1.1e-16 relative) and (d) the observations summed in another order (a permutation of the edge list).  This is
+    the conditioning of the scene's LM path -- an implementation with a different (equally valid) summation order cannot
+    be expected to stay closer to the oracle than the oracle stays to itself.  Round 2 perturbed the observations only: that
+    does not touch the state the normal equations are built at and under-reports the spread by three orders of magnitude
+    on some scenes (seed 6, trial 0: 2.4e-14 against 4.8e-11 for a mere reordering of the edges -- and 4.8e-11 is exactly
+    how far the HIP solver is from the oracle there; profiles/r03_seed6_sensitivity.txt)."""
     base = oracle.ba_solve(*_args(w), max_iterations=max_iterations)
     rng = np.random.default_rng(1234)
     it_spread = np.zeros(len(base["chi2_trace"]))
     tr_spread = np.zeros(len(base["trial_trace"]))
     same_path = True
-    for _ in range(reps):
-        w2 = dict(w)
-        w2["obs_uv"] = w["obs_uv"] * (1.0 + (rng.integers(0, 2, w["obs_uv"].shape) * 2 - 1) * 1.1e-16)
+
+    def ulp(x):
+        return x * (1.0 + (rng.integers(0, 2, x.shape) * 2 - 1) * 1.1e-16)
+
+    def variants():
+        for _ in range(reps):
+            yield dict(w, obs_uv=ulp(w["obs_uv"]))
+            yield dict(w, points=ulp(w["points"]))
+            yield dict(w, poses=ulp(w["poses"]))
+            p = rng.permutation(len(w["obs_pose"]))
+            yield dict(w, obs_pose=w["obs_pose"][p], obs_point=w["obs_point"][p], obs_uv=w["obs_uv"][p])
+    for w2 in variants():
         o2 = oracle.ba_solve(*_args(w2), max_iterations=max_iterations)
         n = min(len(it_spread), len(o2["chi2_trace"]))
         it_spread[:n] = np.maximum(it_spread[:n], np.abs(o2["chi2_trace"][:n] - base["chi2_trace"][:n]) / np.abs(base["chi2_trace"][:n]))
@@ -172,8 +185,8 @@ def _oracle_sensitivity(oracle, w, max_iterations, reps=6):
 def test_rejected_steps_and_termination(vs, oracle, seed, st, sd, sp):
     """A terrible start forces rejected trials (lambda growth, restore) in both implementations; seed 1 also terminates.
     Lock step is asserted PER TRIAL (lambda used, trial chi2, gain ratio, Cholesky verdict) -- not only per iteration --
-    with a tolerance derived from the scene's own conditioning: the oracle re-run on inputs perturbed by one ulp
-    (_oracle_sensitivity).  Round 1 found seed 7 apart by 1.4e-7 at iteration 1 while seeds 1/3/6 stay at 1e-10..1e-14;
+    with a tolerance derived from the scene's own conditioning: the oracle re-run on inputs perturbed by one ulp and on
+    a reordered edge list (_oracle_sensitivity).  Round 1 found seed 7 apart by 1.4e-7 at iteration 1 while seeds 1/3/6 stay at 1e-10..1e-14;
     the oracle itself moves by 1e-7..2e-7 there under a one-ulp perturbation (profiles/r02_seed7_sensitivity.txt), i.e.
     the scene is ill-conditioned, the reject/restore path is not at fault: every accept/reject decision and every
     Cholesky verdict below is identical."""
@@ -189,7 +202,7 @@ def test_rejected_steps_and_termination(vs, oracle, seed, st, sd, sp):
     # iteration 0 starts from identical states: tight
     assert np.isclose(g["chi2_trace"][0], o["chi2_trace"][0], rtol=1e-9)
     # per-trial lock step while the oracle's own path is reproducible (spread < 1e-3): decisions identical, values within
-    # 100 x the oracle's self-spread (floor 1e-9)
+    # 20 x the oracle's self-spread (floor 1e-12: the spread is a maximum over a dozen runs, not a bound)
     gt, ot = g["trial_trace"], o["trial_trace"]
     n = min(len(gt), len(ot))
     live = n
@@ -202,7 +215,7 @@ def test_rejected_steps_and_termination(vs, oracle, seed, st, sd, sp):
     assert np.array_equal(gt[:live, 3], ot[:live, 3])                       # Cholesky verdict of every trial
     assert np.array_equal(gt[:live, 2] > 0, ot[:live, 2] > 0)               # accept / reject decision of every trial
     for k in range(live):
-        tol = max(1e-9, 100.0 * tr_spread[:k + 1].max())
+        tol = max(1e-12, 20.0 * tr_spread[:k + 1].max())
         assert np.isclose(gt[k, 0], ot[k, 0], rtol=tol), ("lambda", k, gt[k], ot[k], tol)
         if np.isfinite(ot[k, 1]) and abs(ot[k, 1]) < 1e300:
             assert np.isclose(gt[k, 1], ot[k, 1], rtol=tol), ("trial chi2", k, gt[k], ot[k], tol)
@@ -210,7 +223,7 @@ def test_rejected_steps_and_termination(vs, oracle, seed, st, sd, sp):
         assert g["trials"] == o["trials"] and g["iterations"] == o["iterations"] and g["terminated"] == o["terminated"]
     # per-iteration traces within the same band
     for k in range(min(len(g["chi2_trace"]), len(o["chi2_trace"]), 4)):
-        tol = max(1e-9, 100.0 * it_spread[:k + 1].max())
+        tol = max(1e-12, 20.0 * it_spread[:k + 1].max())
         assert np.isclose(g["chi2_trace"][k], o["chi2_trace"][k], rtol=tol), (k, g["chi2_trace"][k], o["chi2_trace"][k], tol)
 
 
