@@ -7,7 +7,7 @@ that the loose contract would hide.
 import numpy as np
 import pytest
 
-from visual_slam_amd.workloads import ba_workload
+from visual_slam_amd.workloads import ICL_NUIM_K, ba_workload
 
 pytestmark = pytest.mark.gpu
 HUBER = float(np.sqrt(5.991))
@@ -445,3 +445,38 @@ def test_scale_edges_with_the_camera_role_split_over_workgroups(vs, oracle):
         se = (list(range(0, nc - 1)), list(range(1, nc)), meas)
         _compare(vs.ba_solve(*_args(w), scale_edges=se), oracle.ba_solve(*_args(w), scale_edges=se))
         _compare(vs.ba_solve(*_args(w)), oracle.ba_solve(*_args(w)))
+
+
+def test_large_problem_structure_passes_on_several_host_threads(vs):
+    """Problems with >= 400 000 observations build their structure (counts, active points, Hpl blocks, per-camera lists) on
+    several host threads -- each takes a range of the point-grouped observation list.  The same scene with its
+    observations shuffled is not grouped: it falls back to the sequential passes (and the sorted copy).  Both must give
+    the same solve; and the threaded one must still reject a bad index."""
+    r = np.random.default_rng(11)
+    n_cams, n_points, window = 40, 45000, 10
+    fx, fy, cx, cy = ICL_NUIM_K
+    poses = np.tile(np.eye(4), (n_cams, 1, 1))
+    poses[:, 0, 3] = 0.1 * np.arange(n_cams)
+    start = r.integers(0, n_cams - window + 1, n_points)
+    pts = np.stack([0.1 * (start + window / 2) + r.uniform(-1, 1, n_points), r.uniform(-1.2, 1.2, n_points), r.uniform(2.5, 5.5, n_points)], 1)
+    cam = (start[:, None] + np.arange(window)[None, :]).astype(np.int32).ravel()
+    pt = np.repeat(np.arange(n_points, dtype=np.int32), window)
+    pc = pts[pt] - poses[cam, :3, 3]
+    uv = np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy], 1) + r.normal(0, 0.5, (len(cam), 2))
+    poses0 = poses.copy()
+    poses0[1:, :3, 3] += r.normal(0, 0.01, (n_cams - 1, 3))
+    pts0 = pts + r.normal(0, 0.03, pts.shape)
+    fixed = np.zeros(n_cams, np.uint8)
+    fixed[0] = 1
+    pfix = np.zeros(n_points, np.uint8)
+    pfix[::97] = 1  # some fixed points: inactive where only fixed cameras see them
+    assert len(cam) >= 400000
+    a = vs.ba_solve(poses0, fixed, pts0, pfix, cam, pt, uv, ICL_NUIM_K, max_iterations=2)
+    perm = r.permutation(len(cam))
+    b = vs.ba_solve(poses0, fixed, pts0, pfix, cam[perm], pt[perm], uv[perm], ICL_NUIM_K, max_iterations=2)
+    assert a["trials"] == b["trials"] and np.allclose(a["chi2_trace"], b["chi2_trace"], rtol=1e-10)
+    assert np.allclose(a["poses"], b["poses"], rtol=0, atol=1e-10) and np.allclose(a["points"], b["points"], rtol=0, atol=1e-9)
+    bad = cam.copy()
+    bad[len(bad) // 2] = n_cams
+    with pytest.raises(Exception):
+        vs.ba_solve(poses0, fixed, pts0, pfix, bad, pt, uv, ICL_NUIM_K, max_iterations=1)

@@ -41,6 +41,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 using namespace vsba;
@@ -2723,18 +2724,92 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   int* cam_start = W.cam_start.data();
   int n_obs = 0, n_hpl = 0, prev_pt = -1;
   bool grouped = true;  // observations arrive grouped by point in ascending order (as the reference adds its edges)
-  for (int o = 0; o < p->n_obs; ++o) {
-    const int ci = p->obs_pose[o], pj = p->obs_point[o];
-    if (ci < 0 || ci >= F || pj < 0 || pj >= P) return vs_fail(ctx, VS_EINVAL, "%s: observation index out of range", "vs_ba_solve");
-    grouped &= pj >= prev_pt;
-    prev_pt = pj;
-    const int cs = pose_slot[ci], ls = pt_slot[pj];
-    if (cs < 0 && ls < 0) continue;  // fixed camera and fixed point: not part of the problem
-    cnt[pj + 1]++;
-    ++n_obs;
-    if (cs >= 0) {
-      cam_start[cs + 1]++;
-      n_hpl += ls >= 0;
+  // large problems (the scaled run: 2 000 000 observations) spread both structure passes over a few host threads
+  static const int kThreadsEnv = getenv("VS_BA_THREADS") ? atoi(getenv("VS_BA_THREADS")) : 0;  // developer aid
+  int T = p->n_obs >= 400000 ? std::max(1, std::min(kThreadsEnv > 0 ? kThreadsEnv : 12, (int)std::thread::hardware_concurrency())) : 1;
+  auto par_for = [](int nt, auto&& body) {  // body(t, nt) on nt threads, the caller's included
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back([&body, t, nt] { body(t, nt); });
+    body(0, nt);
+    for (std::thread& x : th) x.join();
+  };
+  auto pass1_sequential = [&]() -> int {
+    n_obs = n_hpl = 0;
+    prev_pt = -1;
+    grouped = true;
+    for (int o = 0; o < p->n_obs; ++o) {
+      const int ci = p->obs_pose[o], pj = p->obs_point[o];
+      if (ci < 0 || ci >= F || pj < 0 || pj >= P) return vs_fail(ctx, VS_EINVAL, "%s: observation index out of range", "vs_ba_solve");
+      grouped &= pj >= prev_pt;
+      prev_pt = pj;
+      const int cs = pose_slot[ci], ls = pt_slot[pj];
+      if (cs < 0 && ls < 0) continue;  // fixed camera and fixed point: not part of the problem
+      cnt[pj + 1]++;
+      ++n_obs;
+      if (cs >= 0) {
+        cam_start[cs + 1]++;
+        n_hpl += ls >= 0;
+      }
+    }
+    return VS_OK;
+  };
+  if (T == 1) {
+    VS_TRY(pass1_sequential());
+  } else {
+    // Threads take ranges of the observation list that begin and end where the point changes, so -- when the list is grouped
+    // by point, which large problems are -- no two threads count for the same point and no atomics are needed.  A list
+    // that turns out not to be grouped is counted again, sequentially.
+    struct part1 {
+      std::vector<int> cam;
+      int n_obs = 0, n_hpl = 0, first = -1, last = -1;
+      bool grouped = true, bad = false;
+    };
+    std::vector<part1> parts((size_t)T);
+    par_for(T, [&](int t, int nt) {
+      part1& R = parts[(size_t)t];
+      R.cam.assign((size_t)nfp + 1, 0);
+      int o0 = (int)((long long)p->n_obs * t / nt), o1 = (int)((long long)p->n_obs * (t + 1) / nt);
+      // move both ends forward to the next change of point (the previous thread finishes the point it is in)
+      auto pt_ok = [&](int o) { return p->obs_point[o] >= 0 && p->obs_point[o] < P; };
+      while (o0 > 0 && o0 < p->n_obs && pt_ok(o0) && pt_ok(o0 - 1) && p->obs_point[o0] == p->obs_point[o0 - 1]) ++o0;
+      while (o1 > 0 && o1 < p->n_obs && pt_ok(o1) && pt_ok(o1 - 1) && p->obs_point[o1] == p->obs_point[o1 - 1]) ++o1;
+      int prev = -1;
+      for (int o = o0; o < o1; ++o) {
+        const int ci = p->obs_pose[o], pj = p->obs_point[o];
+        if (ci < 0 || ci >= F || pj < 0 || pj >= P) {
+          R.bad = true;
+          return;
+        }
+        if (R.first < 0) R.first = pj;
+        R.grouped &= pj >= prev;
+        prev = pj;
+        const int cs = pose_slot[ci], ls = pt_slot[pj];
+        if (cs < 0 && ls < 0) continue;
+        cnt[pj + 1]++;
+        ++R.n_obs;
+        if (cs >= 0) {
+          R.cam[(size_t)cs + 1]++;
+          R.n_hpl += ls >= 0;
+        }
+      }
+      R.last = prev;
+    });
+    for (const part1& R : parts) {
+      if (R.bad) return vs_fail(ctx, VS_EINVAL, "%s: observation index out of range", "vs_ba_solve");
+      // strictly greater across ranges: a point that shows up in two ranges was counted by two threads at once
+      grouped &= R.grouped && (R.first < 0 || R.first > prev_pt);
+      if (R.last >= 0) prev_pt = R.last;
+      n_obs += R.n_obs;
+      n_hpl += R.n_hpl;
+      for (int c = 0; c <= nfp; ++c) cam_start[c] += R.cam[(size_t)c];
+    }
+    if (!grouped) {  // not grouped by point: the ranges may have raced on a point's counter
+      W.cnt.assign((size_t)P + 1, 0);
+      W.cam_start.assign((size_t)nfp + 1, 0);
+      cnt = W.cnt.data();
+      cam_start = W.cam_start.data();
+      VS_TRY(pass1_sequential());
+      T = 1;
     }
   }
   // active points = free points (even without observations: they still receive the lambda damping) + fixed points
@@ -2890,26 +2965,29 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   memcpy(h_pose_slot, pose_slot, sizeof(int) * F);
   memcpy(h_pt_slot, pt_slot, sizeof(int) * P);
   memcpy(h_cstart, cam_start, sizeof(int) * ((size_t)nfp + 1));
+  // the observation records of the identity case are plain copies (48 MB at 2 000 000 observations): split over the threads
   if (identity) {
-    memcpy(h_ocam, q.obs_pose, sizeof(int) * (size_t)n_obs);
-    memcpy(h_opt, q.obs_point, sizeof(int) * (size_t)n_obs);
-    memcpy(h_uv, q.obs_uv, sizeof(double) * 2 * (size_t)n_obs);
-    if (h_info) memcpy(h_info, q.obs_info, sizeof(double) * 3 * (size_t)n_obs);
+    par_for(T, [&](int t, int nt) {
+      const size_t a = (size_t)((long long)n_obs * t / nt), b = (size_t)((long long)n_obs * (t + 1) / nt);
+      memcpy(h_ocam + a, q.obs_pose + a, sizeof(int) * (b - a));
+      memcpy(h_opt + a, q.obs_point + a, sizeof(int) * (b - a));
+      memcpy(h_uv + 2 * a, q.obs_uv + 2 * a, sizeof(double) * 2 * (b - a));
+      if (h_info) memcpy(h_info + 3 * a, q.obs_info + 3 * a, sizeof(double) * 3 * (b - a));
+    });
   }
-  W.cfill.assign(cam_start, cam_start + nfp + 1);
-  W.seen_by.assign(F ? F : 1, -1);  // seen_by[camera] = last free point with an observation from that free camera
-  int* cfill = W.cfill.data();
-  int* seen_by = W.seen_by.data();
   int mmax = 1, dups = 0, a_idx = 0, k_hpl = 0;
-  for (int j = 0; j < P; ++j) {
+  // one point: its active-point record, its sorted observation records, its Hpl blocks and the per-camera lists.  The
+  // running positions (active index, Hpl block index, per-camera fill positions) are the caller's: sequential for small
+  // problems; for large ones every thread takes a range of points whose starting positions a counting pass fixed.
+  auto do_point = [&](int j, int& a_i, int& k_h, int* cf, int* seen, int& mmax_, int& dups_) {
     const int i0 = cnt[j], i1 = cnt[j + 1], ls = pt_slot[j];
-    if (i0 == i1 && ls < 0) continue;
-    h_act[a_idx] = j;
-    h_ptstart[a_idx] = i0;
-    ++a_idx;
+    if (i0 == i1 && ls < 0) return;
+    h_act[a_i] = j;
+    h_ptstart[a_i] = i0;
+    ++a_i;
     int mf = 0;
     unsigned long long mask = 0ull;
-    if (ls >= 0) h_fps[ls] = k_hpl;
+    if (ls >= 0) h_fps[ls] = k_h;
     for (int i = i0; i < i1; ++i) {
       const int o = identity ? i : order[i];
       const int cam = q.obs_pose[o];
@@ -2927,22 +3005,79 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       }
       int blk = -1;
       if (cs >= 0) {
-        h_cpt[cfill[cs]] = j;
-        h_cobs[cfill[cs]++] = i;
+        h_cpt[cf[cs]] = j;
+        h_cobs[cf[cs]++] = i;
         if (ls >= 0) {
           ++mf;
-          dups |= seen_by[cam] == j;  // same camera twice: the ordered-rounds path of ba_schur
-          seen_by[cam] = j;
-          blk = k_hpl;
-          h_fpl[k_hpl++] = cs;
+          dups_ |= seen[cam] == j;  // same camera twice: the ordered-rounds path of ba_schur
+          seen[cam] = j;
+          blk = k_h;
+          h_fpl[k_h++] = cs;
           mask |= 1ull << ((cs / kTileCams) & 63);
         }
       }
       h_ohpl[i] = blk;
     }
     if (ls >= 0) {
-      mmax = std::max(mmax, mf);
+      mmax_ = std::max(mmax_, mf);
       if (h_mask) h_mask[ls] = mask;
+    }
+  };
+  if (T == 1) {
+    W.cfill.assign(cam_start, cam_start + nfp + 1);
+    W.seen_by.assign(F ? F : 1, -1);  // seen_by[camera] = last free point with an observation from that free camera
+    for (int j = 0; j < P; ++j) do_point(j, a_idx, k_hpl, W.cfill.data(), W.seen_by.data(), mmax, dups);
+  } else {
+    // counting pass per range of points: active points, Hpl blocks, observations per free camera
+    struct part2 {
+      std::vector<int> cam, seen;
+      int act = 0, hpl = 0, mmax = 1, dups = 0;
+    };
+    std::vector<part2> parts((size_t)T);
+    par_for(T, [&](int t, int nt) {
+      part2& R = parts[(size_t)t];
+      R.cam.assign((size_t)nfp + 1, 0);
+      const int j0 = (int)((long long)P * t / nt), j1 = (int)((long long)P * (t + 1) / nt);
+      for (int j = j0; j < j1; ++j) {
+        const int i0 = cnt[j], i1 = cnt[j + 1], ls = pt_slot[j];
+        if (i0 == i1 && ls < 0) continue;
+        ++R.act;
+        for (int i = i0; i < i1; ++i) {
+          const int cs = pose_slot[q.obs_pose[identity ? i : order[i]]];
+          if (cs >= 0) {
+            R.cam[(size_t)cs]++;
+            R.hpl += ls >= 0;
+          }
+        }
+      }
+    });
+    // starting positions of every range (exclusive prefix over the ranges; per camera on top of the camera's own start)
+    int act0 = 0, hpl0 = 0;
+    std::vector<int> cam_run(cam_start, cam_start + nfp + 1);
+    for (part2& R : parts) {
+      const int a = R.act, h = R.hpl;
+      R.act = act0;
+      R.hpl = hpl0;
+      act0 += a;
+      hpl0 += h;
+      for (int c = 0; c < nfp; ++c) {
+        const int k = R.cam[(size_t)c];
+        R.cam[(size_t)c] = cam_run[(size_t)c];
+        cam_run[(size_t)c] += k;
+      }
+    }
+    par_for(T, [&](int t, int nt) {
+      part2& R = parts[(size_t)t];
+      R.seen.assign(F ? F : 1, -1);
+      const int j0 = (int)((long long)P * t / nt), j1 = (int)((long long)P * (t + 1) / nt);
+      int a_i = R.act, k_h = R.hpl;
+      for (int j = j0; j < j1; ++j) do_point(j, a_i, k_h, R.cam.data(), R.seen.data(), R.mmax, R.dups);
+    });
+    a_idx = act0;
+    k_hpl = hpl0;
+    for (const part2& R : parts) {
+      mmax = std::max(mmax, R.mmax);
+      dups |= R.dups;
     }
   }
   h_ptstart[n_act] = n_obs;
@@ -2954,7 +3089,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
     W.seen_by.assign(F ? F : 1, -1);
     W.seen_cnt.assign(F ? F : 1, 0);
-    seen_by = W.seen_by.data();
+    int* seen_by = W.seen_by.data();
     int* seen_cnt = W.seen_cnt.data();
     for (int a = 0; a < n_act; ++a)
       for (int i = h_ptstart[a]; i < h_ptstart[a + 1]; ++i) {
