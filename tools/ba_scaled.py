@@ -52,6 +52,9 @@ def main():
     from visual_slam_amd.context import Context
     ctx = Context()
     kw = dict(huber_delta=np.sqrt(5.991), max_iterations=a.iters)
+    if os.environ.get("PINNED", "1") == "1":  # the observation arrays in pinned memory: DMA-ed from where they lie
+        for k in ("obs_pose", "obs_point", "obs_uv"):
+            w[k] = ctx.pin(np.ascontiguousarray(w[k]))
     args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
     g = ctx.ba_solve(*args, **kw)
     t0 = time.perf_counter()

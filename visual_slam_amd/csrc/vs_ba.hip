@@ -2966,7 +2966,10 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   memcpy(h_pt_slot, pt_slot, sizeof(int) * P);
   memcpy(h_cstart, cam_start, sizeof(int) * ((size_t)nfp + 1));
   // the observation records of the identity case are plain copies (48 MB at 2 000 000 observations): split over the threads
-  if (identity) {
+  // ... unless the caller keeps them in pinned memory (Context.pinned_empty / vs_host_alloc): then they are DMA-ed from
+  // where they lie, behind the arena upload (large problems only: the three pointer queries cost a few microseconds)
+  const bool direct_obs = identity && T > 1 && !q.obs_info && vs_is_pinned(q.obs_uv) && vs_is_pinned(q.obs_pose) && vs_is_pinned(q.obs_point);
+  if (identity && !direct_obs) {
     par_for(T, [&](int t, int nt) {
       const size_t a = (size_t)((long long)n_obs * t / nt), b = (size_t)((long long)n_obs * (t + 1) / nt);
       memcpy(h_ocam + a, q.obs_pose + a, sizeof(int) * (b - a));
@@ -3094,7 +3097,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     for (int a = 0; a < n_act; ++a)
       for (int i = h_ptstart[a]; i < h_ptstart[a + 1]; ++i) {
         if (h_ohpl[i] < 0) continue;
-        const int cam = h_ocam[i];
+        const int cam = identity ? q.obs_pose[i] : h_ocam[i];
         seen_cnt[cam] = seen_by[cam] == h_act[a] ? seen_cnt[cam] + 1 : 0;
         seen_by[cam] = h_act[a];
         h_fpr[h_ohpl[i]] = seen_cnt[cam];
@@ -3202,6 +3205,11 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   const bool nothing = (np + 3 * nfl == 0) || q.max_iterations == 0;
   const auto t_filled = now();
   VS_HIP(ctx, hipMemcpyAsync(A.base, A.host, upload_bytes, hipMemcpyHostToDevice, s));
+  if (direct_obs) {
+    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_cam, q.obs_pose, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, s));
+    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_pt, q.obs_point, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, s));
+    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_uv, q.obs_uv, sizeof(double) * 2 * (size_t)n_obs, hipMemcpyHostToDevice, s));
+  }
   // both state buffers start identical (fixed cameras / points are never rewritten in the trial buffer's points)
   VS_HIP(ctx, hipMemcpyAsync(D.cam[1], D.cam[0], sizeof(double) * (size_t)F * kCamStride, hipMemcpyDeviceToDevice, s));
   VS_HIP(ctx, hipMemcpyAsync(D.pts[1], D.pts[0], sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToDevice, s));
