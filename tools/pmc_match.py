@@ -3,7 +3,7 @@ Passes (each its own process, counters only, no trace domains):
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d out/fetch -o p -- python3 bench.py --no-frames --no-cpu-baseline --steps 20 --warmup 5
   rocprofv3 --pmc WRITE_SIZE ...                 -d out/write
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE ... -d out/sq
-usage: python tools/pmc_match.py out > profiles/r02_pmc_match.json"""
+usage: python tools/pmc_match.py out > profiles/r03_pmc_match.json"""
 import csv
 import glob
 import json
@@ -40,8 +40,9 @@ out = {
         "algorithmic_bytes_streamed_model": 32.0 * nq * nt,
         "compulsory_bytes": 32 * (nq + nt) + int(write_kb * 1024),
         "note": "FETCH_SIZE on gfx950 under-reports wide coalesced streaming reads by exactly 2x (MI355X_MICROARCH.md, HBM); "
-                "this kernel mixes 16-B/lane query loads with scalar (s_load_dwordx16) train loads, an uncalibrated "
-                "pattern, so both the raw value and the 2x upper bound are given.  WRITE_SIZE = the per-chunk partial rows "
+                "this kernel mixes 16-B/lane query loads with coalesced 32-B/lane train-row loads that are staged through "
+                "LDS (64 rows per wave at a time), an uncalibrated pattern, so both the raw value and the 2x upper bound are "
+                "given.  WRITE_SIZE = the per-chunk partial rows "
                 "(32 chunks x 40 tiles x 256 x 8 B, write-through) + the 160 KB of results.",
     },
 }

@@ -1,6 +1,6 @@
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_r02
+O=$R/gpurun_out/prof_r03
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/bench -o bench -- python3 $R/bench.py --single-stream --steps 20 --warmup 5 > $O/bench_under_rocprof.log 2>&1
@@ -17,4 +17,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg
 python3 tools/trace_by_grid.py $O/cfg4/cfg4_kernel_trace.csv > $O/cfg4_by_grid.csv
 timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 > $O/bench.log 2>&1
 tail -1 $O/bench.log | cut -c1-200
+python3 tools/trace_timeline.py $O/resident/resident_kernel_trace.csv 0.90 70 > $O/tracking_timeline.txt
+python3 tools/pnp_stamps.py > $O/pnp_stamps.txt 2>&1
+python3 tools/ba_sensitivity.py > $O/seed6_sensitivity.txt 2>&1
 rm -f $O/*/*_kernel_trace.csv $O/*/*agent_info.csv
