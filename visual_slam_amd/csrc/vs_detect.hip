@@ -20,7 +20,10 @@
 
 namespace {
 
-constexpr int kBand = 2;         // image rows per workgroup
+#ifndef VS_DET_BAND
+#define VS_DET_BAND 2
+#endif
+constexpr int kBand = VS_DET_BAND;  // image rows per workgroup (2: 240 workgroups at 640x480; 3 and 4 measured slower, see profiles/tried_and_dropped.md)
 constexpr int kHalo = 4;         // 3 (circle radius) + 1 (NMS neighbour)
 constexpr int kDetThreads = 1024; // 16 waves: 4 per SIMD hide the LDS latency of the box / score phases
 constexpr int kStageUnroll = 2; // staging groups per thread with their loads in flight together
