@@ -476,6 +476,9 @@ def test_large_problem_structure_passes_on_several_host_threads(vs):
     b = vs.ba_solve(poses0, fixed, pts0, pfix, cam[perm], pt[perm], uv[perm], ICL_NUIM_K, max_iterations=2)
     assert a["trials"] == b["trials"] and np.allclose(a["chi2_trace"], b["chi2_trace"], rtol=1e-10)
     assert np.allclose(a["poses"], b["poses"], rtol=0, atol=1e-10) and np.allclose(a["points"], b["points"], rtol=0, atol=1e-9)
+    # observation arrays in pinned memory are DMA-ed from where they lie instead of being copied into the arena first
+    c = vs.ba_solve(poses0, fixed, pts0, pfix, vs.pin(cam), vs.pin(pt), vs.pin(uv), ICL_NUIM_K, max_iterations=2)
+    assert np.array_equal(a["poses"], c["poses"]) and np.array_equal(a["points"], c["points"]) and np.array_equal(a["chi2_trace"], c["chi2_trace"])
     bad = cam.copy()
     bad[len(bad) // 2] = n_cams
     with pytest.raises(Exception):
