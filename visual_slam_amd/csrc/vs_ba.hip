@@ -40,6 +40,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <thread>
 #include <vector>
@@ -874,6 +875,127 @@ __global__ __launch_bounds__(256) void ba_schur_tile(ba_dev D) {
   }
 }
 
+// Banded windows beyond one tile (a sliding window of key frames: every point is seen from a few NEIGHBOURING cameras).
+// The host orders the contributing free points by their lowest camera slot and cuts that order into slabs; when the
+// cameras of every slab span at most kWinCams slots, the slab's whole contribution is a dense kWinN x kWinN block of S
+// that starts at camera w0 - and the sum over its points is one matrix product
+//     S_win -= [Y_1 Y_2 ...] [H_1 H_2 ...]^T,   Y_l = H_l Dinv_l  (6 wlen x 3 per point, zero rows for absent cameras)
+// with K = 3 per point.  That is what the FP64 matrix cores are for: v_mfma_f64_16x16x4_f64 over the lower 16 x 16
+// tiles of the window (21 for 16 cameras, dealt round-robin to the four waves, 8 accumulator VGPRs per tile), four k per
+// instruction = 4/3 points.  A batch of kWinBatch points is staged as two zero-padded K x kWinN panels in LDS (row stride
+// kWinStride: the four k rows an operand read touches fall on disjoint banks); VALU work is only the staging (Y = H Dinv,
+// nine FMAs per camera row) and the right-hand side.  Per element the points arrive in the sorted order and the slabs are
+// summed in slab order by ba_reduce_window: deterministic, no atomics.  The window slab is 74 KB instead of np^2 doubles.
+constexpr int kWinCams = 16, kWinN = 6 * kWinCams, kWinBatch = 8, kWinK = 3 * kWinBatch, kWinStride = kWinN + 16;
+constexpr int kWinSlabElems = kWinN * kWinN + kWinN, kWinPerMax = 512, kWinTilesPerWave = 6;
+typedef double win_d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void ba_schur_window(ba_dev D) {
+  __shared__ __attribute__((aligned(16))) double sY[kWinK * kWinStride];
+  __shared__ __attribute__((aligned(16))) double sH[kWinK * kWinStride];
+  __shared__ double sD[kWinBatch][12];
+  __shared__ int sRec[kWinPerMax][3];  // point slot, first Hpl block, blocks
+  __shared__ int sMap[kWinBatch][kWinCams];
+  if (D.st->done) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = blockIdx.x, i0 = s * D.win_per, n = min(D.win_per, D.win_n - i0);
+  const int w0 = D.win_w0[s], wlen = D.win_len[s], ncol = 6 * wlen, ntr = (ncol + 15) >> 4;
+  const int ntiles = ntr * (ntr + 1) / 2;
+  for (int i = tid; i < n; i += 256) {
+    const int l = D.win_order[i0 + i], b = D.fp_start[l];
+    sRec[i][0] = l;
+    sRec[i][1] = b;
+    sRec[i][2] = D.fp_start[l + 1] - b;
+  }
+  for (int i = tid; i < kWinK * kWinStride; i += 256) sY[i] = sH[i] = 0.0;  // the padding columns stay zero
+  if (tid < kWinBatch * kWinCams) (&sMap[0][0])[tid] = -1;
+  // this wave's tiles: t = wv, wv + 4, ... of the lower triangle, enumerated row by row
+  int toff_a[kWinTilesPerWave], toff_b[kWinTilesPerWave];
+  win_d4 acc[kWinTilesPerWave];
+#pragma unroll
+  for (int q = 0; q < kWinTilesPerWave; ++q) {
+    const int t = 4 * q + wv;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    toff_a[q] = t < ntiles ? 16 * ti : -1;
+    toff_b[q] = 16 * tj;
+    acc[q] = win_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  double racc = 0.0;
+  const int krow = lane >> 4, kcol = lane & 15;
+  __syncthreads();
+  for (int b0 = 0; b0 < n; b0 += kWinBatch) {
+    const int nb = min(kWinBatch, n - b0);
+    // A: camera maps of the batch (thread = (point, block)), Dinv and Dinv bl
+    if (tid < kWinBatch * kWinCams) {
+      const int pb = tid >> 4, i = tid & 15;
+      if (pb < nb && i < sRec[b0 + pb][2]) {
+        const int blk = sRec[b0 + pb][1] + i;
+        sMap[pb][D.fp_slot[blk] - w0] = blk;
+      }
+    } else if (tid < kWinBatch * kWinCams + kWinBatch * 12) {
+      const int pb = (tid - kWinBatch * kWinCams) / 12, k = (tid - kWinBatch * kWinCams) - 12 * pb;
+      if (pb < nb) {
+        const int l = sRec[b0 + pb][0];
+        sD[pb][k] = k < 9 ? D.Dinv[9 * (size_t)l + k] : D.Dbl[3 * (size_t)l + k - 9];
+      }
+    }
+    __syncthreads();
+    // B: the panels - cell group = (point, window camera, block row): three k of H and of Y = H Dinv, or zeros
+    for (int t = tid; t < kWinBatch * ncol; t += 256) {
+      const int pb = t / ncol, col = t - pb * ncol, wc = col / 6, ar = col - 6 * wc;
+      const int blk = pb < nb ? sMap[pb][wc] : -1;
+      double h0 = 0.0, h1 = 0.0, h2 = 0.0, y0 = 0.0, y1 = 0.0, y2 = 0.0;
+      if (blk >= 0) {
+        const double* B = D.Hpl + 18 * (size_t)blk + 3 * ar;
+        h0 = B[0];
+        h1 = B[1];
+        h2 = B[2];
+        const double* sd = sD[pb];
+        y0 = h0 * sd[0] + h1 * sd[3] + h2 * sd[6];
+        y1 = h0 * sd[1] + h1 * sd[4] + h2 * sd[7];
+        y2 = h0 * sd[2] + h1 * sd[5] + h2 * sd[8];
+      }
+      const int o = 3 * pb * kWinStride + col;
+      sH[o] = h0;
+      sH[o + kWinStride] = h1;
+      sH[o + 2 * kWinStride] = h2;
+      sY[o] = y0;
+      sY[o + kWinStride] = y1;
+      sY[o + 2 * kWinStride] = y2;
+    }
+    __syncthreads();
+    // C: matrix cores; the right-hand side on the first threads; the maps of the next batch cleared
+    const int nk = (3 * nb + 3) >> 2;
+    for (int ks = 0; ks < nk; ++ks) {
+      const int o = (4 * ks + krow) * kWinStride + kcol;
+#pragma unroll
+      for (int q = 0; q < kWinTilesPerWave; ++q) {
+        if (toff_a[q] < 0) continue;  // wave-uniform
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(sY[o + toff_a[q]], sH[o + toff_b[q]], acc[q], 0, 0, 0);
+      }
+    }
+    if (tid < ncol) {
+      for (int pb = 0; pb < nb; ++pb) {
+        const int o = 3 * pb * kWinStride + tid;
+        racc += sH[o] * sD[pb][9] + sH[o + kWinStride] * sD[pb][10] + sH[o + 2 * kWinStride] * sD[pb][11];
+      }
+    } else if (tid >= 128 && tid < 128 + kWinBatch * kWinCams) {
+      (&sMap[0][0])[tid - 128] = -1;
+    }
+    __syncthreads();
+  }
+  double* out = D.slab + (size_t)s * kWinSlabElems;
+#pragma unroll
+  for (int q = 0; q < kWinTilesPerWave; ++q) {
+    if (toff_a[q] < 0) continue;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) out[(size_t)(toff_a[q] + krow + 4 * v) * kWinN + toff_b[q] + kcol] = acc[q][v];
+  }
+  if (tid < ncol) out[kWinN * kWinN + tid] = racc;
+}
+
 // Windows of at most kTileCams free cameras (one tile; BASELINE cfg4, the driver's local BA): the tile kernel's camera
 // maps, masks and chunk lists are not needed, and its chain of dependent global loads (mask -> list -> slots -> blocks)
 // is what a workgroup with 8 points spends its time on.  Here the Hpl blocks of a point are read where they lie
@@ -1113,6 +1235,51 @@ __global__ __launch_bounds__(64 * kRedSplit) void ba_reduce(ba_dev D) {
   } else {
     D.bs[i - np * np] = base - acc;
   }
+}
+
+// The window slabs (ba_schur_window) summed into S and bs: thread = element of the lower block triangle (a diagonal 6 x 6
+// block takes its upper half from the mirrored element: the tiles above the diagonal are not produced).  The slabs are
+// ordered by their first camera, so those whose window can hold both cameras of an element are the range
+// [win_first[row camera - kWinCams + 1], win_first[column camera + 1]) of the host's table (win_first[c] = first slab
+// that starts at camera c or later); they are added in slab order.
+__global__ __launch_bounds__(256) void ba_reduce_window(ba_dev D) {
+  const lm_state st = *D.st;
+  if (st.done) return;
+  const int np = D.np;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= np * np + np) return;
+  const lin_view L = lin_of(D, st.cur);
+  int r, c;
+  double base;
+  if (i < np * np) {
+    r = i / np;
+    c = i - r * np;
+    base = L.Hpp[i];
+    if (r == c) base += st.lambda;
+    if (r / 6 < c / 6) {  // above the block diagonal: never read
+      D.S[i] = base;
+      return;
+    }
+    if (r < c) {
+      const int t = r;
+      r = c;
+      c = t;
+    }
+  } else {
+    r = c = i - np * np;
+    base = L.bp[r];
+  }
+  const int cr = r / 6, cc = c / 6;
+  const int s0 = D.win_first[max(cr - kWinCams + 1, 0)], s1 = D.win_first[cc + 1];
+  double acc = 0.0;
+  for (int s = s0; s < s1; ++s) {
+    const int w0 = D.win_w0[s];
+    if (cr >= w0 + D.win_len[s]) continue;
+    const double* slab = D.slab + (size_t)s * kWinSlabElems;
+    acc += i < np * np ? slab[(size_t)(r - 6 * w0) * kWinN + (c - 6 * w0)] : slab[kWinN * kWinN + (r - 6 * w0)];
+  }
+  if (i < np * np) D.S[i] = base - acc;
+  else D.bs[r] = base - acc;
 }
 
 // ------------------------------------------------------------------------------------------------ dense solve
@@ -2606,11 +2773,13 @@ int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& 
 // tuning / test hooks (not part of the stable ABI; per context, vs_tuning in vs_internal.h): Schur kernel of single-tile
 // windows (0 automatic = ba_schur_small with the linearisation of accepted states folded into the trial, 1 = the general
 // tile kernel, 2 = ba_schur_small with a linearisation launch per iteration), points per workgroup and the cap on the
-// number of slabs of ba_schur_small; motion-only form (0 = one launch where it applies, 1 = one launch per LM step)
+// number of slabs of ba_schur_small (from 64 points up the value sets the slab size of ba_schur_window instead; 3 = banded
+// windows of several tiles on the tile kernel, not on ba_schur_window); motion-only form (0 = one launch where it applies, 1 = one launch per LM step)
 VS_API int vs_tune_ba(vs_ctx* ctx, int schur_variant, int points_per_workgroup, int max_slabs, int motion_variant) {
   if (!ctx) return VS_EINVAL;
-  if (schur_variant >= 0 && schur_variant <= 2) ctx->tune.schur_variant = schur_variant;
-  if (points_per_workgroup > 0) ctx->tune.small_per = points_per_workgroup;
+  if (schur_variant >= 0 && schur_variant <= 3) ctx->tune.schur_variant = schur_variant;
+  if (points_per_workgroup >= 64) ctx->tune.win_per = points_per_workgroup;  // ba_schur_window's slabs are never that small
+  else if (points_per_workgroup > 0) ctx->tune.small_per = points_per_workgroup;
   if (max_slabs > 0) ctx->tune.small_ns_cap = max_slabs;
   if (motion_variant == 0 || motion_variant == 1) ctx->tune.motion_variant = motion_variant;
   return VS_OK;
@@ -2703,12 +2872,20 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     return std::chrono::duration<double, std::micro>(b - a).count();
   };
   const auto t_begin = now();
+  double lap_us[8] = {0};  // VS_BA_TIMING: stretches of the arena fill
+  auto t_lap = t_begin;
+  auto lap = [&](int k) {
+    if (!timing) return;
+    const auto t = now();
+    lap_us[k] += us(t_lap, t);
+    t_lap = t;
+  };
   // ---- structure (host).  Pass 1 over the observations: index validation, active observations per point and per free
   // camera, number of Hpl blocks -- every array size is known after it, so pass 2 writes the device arrays straight into
   // the pinned arena.  Scratch vectors are kept per host thread (no allocation in the steady state).
   const int F = p->n_poses, P = p->n_points;
   static thread_local struct {
-    std::vector<int> pose_slot, pt_slot, cnt, fill, order, cam_start, cfill, seen_by, seen_cnt;
+    std::vector<int> pose_slot, pt_slot, cnt, fill, order, cam_start, cfill, seen_by, seen_cnt, wlo, whi, wcnt;
   } W;
   W.pose_slot.resize(F ? F : 1);
   W.pt_slot.resize(P ? P : 1);
@@ -2727,11 +2904,9 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   // large problems (the scaled run: 2 000 000 observations) spread both structure passes over a few host threads
   static const int kThreadsEnv = getenv("VS_BA_THREADS") ? atoi(getenv("VS_BA_THREADS")) : 0;  // developer aid
   int T = p->n_obs >= 400000 ? std::max(1, std::min(kThreadsEnv > 0 ? kThreadsEnv : 12, (int)std::thread::hardware_concurrency())) : 1;
-  auto par_for = [](int nt, auto&& body) {  // body(t, nt) on nt threads, the caller's included
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back([&body, t, nt] { body(t, nt); });
-    body(0, nt);
-    for (std::thread& x : th) x.join();
+  auto par_for = [ctx](int nt, auto&& body) {  // body(t, nt) on nt threads of the context's pool, the caller's included
+    using B = std::remove_reference_t<decltype(body)>;
+    ctx->pool.run(nt, [](void* a, int t, int n) { (*static_cast<B*>(a))(t, n); }, (void*)&body);
   };
   // (the loops are written out, not shared through a lambda: the closure's indirections cost 10 us at 20 000 observations)
   if (T == 1) {
@@ -2773,35 +2948,54 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       int n_obs = 0, n_hpl = 0, first = -1, last = -1;
       bool grouped = true, bad = false;
     };
-    std::vector<part1> parts((size_t)T);
-    par_for(T, [&](int t, int nt) {
-      part1& R = parts[(size_t)t];
-      R.cam.assign((size_t)nfp + 1, 0);
-      int o0 = (int)((long long)p->n_obs * t / nt), o1 = (int)((long long)p->n_obs * (t + 1) / nt);
-      // move both ends forward to the next change of point (the previous thread finishes the point it is in)
-      auto pt_ok = [&](int o) { return p->obs_point[o] >= 0 && p->obs_point[o] < P; };
-      while (o0 > 0 && o0 < p->n_obs && pt_ok(o0) && pt_ok(o0 - 1) && p->obs_point[o0] == p->obs_point[o0 - 1]) ++o0;
-      while (o1 > 0 && o1 < p->n_obs && pt_ok(o1) && pt_ok(o1 - 1) && p->obs_point[o1] == p->obs_point[o1 - 1]) ++o1;
-      int prev = -1;
-      for (int o = o0; o < o1; ++o) {
-        const int ci = p->obs_pose[o], pj = p->obs_point[o];
-        if (ci < 0 || ci >= F || pj < 0 || pj >= P) {
-          R.bad = true;
-          return;
+    // (more ranges than threads, handed out through a counter: a thread that loses its core for a while does not hold
+    // up the pass; inside a range everything lives in locals -- the closure's references would be re-read after each store)
+    const int nchunk = 4 * T;
+    std::vector<part1> parts((size_t)nchunk);
+    std::atomic<int> next1{0};
+    par_for(T, [&](int, int) {
+      const int* const op = p->obs_pose;
+      const int* const oq = p->obs_point;
+      const int* const pose_slot_ = pose_slot;
+      const int* const pt_slot_ = pt_slot;
+      int* const cnt_ = cnt;
+      const int n_all = p->n_obs, F_ = F, P_ = P, nfp_ = nfp;
+      for (int ch = next1.fetch_add(1); ch < nchunk; ch = next1.fetch_add(1)) {
+        part1& R = parts[(size_t)ch];
+        R.cam.assign((size_t)nfp_ + 1, 0);
+        int* const rcam = R.cam.data();
+        int o0 = (int)((long long)n_all * ch / nchunk), o1 = (int)((long long)n_all * (ch + 1) / nchunk);
+        // move both ends forward to the next change of point (the previous range finishes the point it is in)
+        auto pt_ok = [=](int o) { return oq[o] >= 0 && oq[o] < P_; };
+        while (o0 > 0 && o0 < n_all && pt_ok(o0) && pt_ok(o0 - 1) && oq[o0] == oq[o0 - 1]) ++o0;
+        while (o1 > 0 && o1 < n_all && pt_ok(o1) && pt_ok(o1 - 1) && oq[o1] == oq[o1 - 1]) ++o1;
+        int prev = -1, first = -1, n_o = 0, n_h = 0;
+        bool grp = true, bad = false;
+        for (int o = o0; o < o1; ++o) {
+          const int ci = op[o], pj = oq[o];
+          if (ci < 0 || ci >= F_ || pj < 0 || pj >= P_) {
+            bad = true;
+            break;
+          }
+          if (first < 0) first = pj;
+          grp &= pj >= prev;
+          prev = pj;
+          const int cs = pose_slot_[ci], ls = pt_slot_[pj];
+          if (cs < 0 && ls < 0) continue;
+          cnt_[pj + 1]++;
+          ++n_o;
+          if (cs >= 0) {
+            rcam[cs + 1]++;
+            n_h += ls >= 0;
+          }
         }
-        if (R.first < 0) R.first = pj;
-        R.grouped &= pj >= prev;
-        prev = pj;
-        const int cs = pose_slot[ci], ls = pt_slot[pj];
-        if (cs < 0 && ls < 0) continue;
-        cnt[pj + 1]++;
-        ++R.n_obs;
-        if (cs >= 0) {
-          R.cam[(size_t)cs + 1]++;
-          R.n_hpl += ls >= 0;
-        }
+        R.first = first;
+        R.last = prev;
+        R.n_obs = n_o;
+        R.n_hpl = n_h;
+        R.grouped = grp;
+        R.bad = bad;
       }
-      R.last = prev;
     });
     for (const part1& R : parts) {
       if (R.bad) return vs_fail(ctx, VS_EINVAL, "%s: observation index out of range", "vs_ba_solve");
@@ -2891,13 +3085,14 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   cam_split = std::min(cam_split, 8);
 
   const auto t_struct = now();
+  t_lap = t_struct;
   // ---- arena: [uploaded constants | state | system]
   vs_ba_problem const& q = *p;
   size_t need = (1u << 20) + sizeof(int) * ((size_t)F + P + 3 * (size_t)n_act + 4 * (size_t)n_obs + 2 * (size_t)nfp +
                                             2 * (size_t)n_cam_obs + 2 * (size_t)q.n_scale + nfl + 64) +
                 sizeof(double) * (5 * (size_t)n_obs + (size_t)q.n_scale + 2 * (size_t)F * kCamStride + 6 * (size_t)P +
                                   2 * (size_t)np * np + 8 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
-                                  9 * (size_t)nfl + (tiled_possible ? 4 * (size_t)nfl : 0) + (size_t)(ns_bound ? ns_bound : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
+                                  9 * (size_t)nfl + (tiled_possible ? 5 * (size_t)nfl + nfp + 4096 : 0) + (size_t)(ns_bound ? ns_bound : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
                                   2 * (size_t)q.max_iterations + 64) +
                 256 * 64 + sizeof(int) * (3 * (size_t)n_obs + nfl + 16) + (sizeof(double) * 27 * 8 + 8) * (size_t)nfp + 1024 +
                 sizeof(double) * (64 + (size_t)F * kCamStride + 3 * (size_t)P + 2 * (size_t)q.max_iterations) + 512 +
@@ -2910,6 +3105,21 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   A.host = (uint8_t*)ctx->h_pin_big.p;
   ba_dev D;
   memset(&D, 0, sizeof D);
+  // Observation arrays that the caller keeps in pinned memory (Context.pinned_empty / vs_host_alloc) and that need no
+  // reordering are DMA-ed from where they lie, started NOW so that the transfer runs beside the host passes below; they
+  // sit in front of the uploaded part of the arena.  (Large problems only: the three pointer queries cost microseconds.)
+  const bool direct_obs = identity && T > 1 && !q.obs_info && vs_is_pinned(q.obs_uv) && vs_is_pinned(q.obs_pose) && vs_is_pinned(q.obs_point);
+  size_t upload_begin = 0;
+  if (direct_obs) {
+    D.o_cam = A.take<int>(n_obs);
+    D.o_pt = A.take<int>(n_obs);
+    D.o_uv = A.take<double>(2 * (size_t)n_obs);
+    A.off = (A.off + 255) & ~(size_t)255;
+    upload_begin = A.off;
+    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_cam, q.obs_pose, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, s));
+    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_pt, q.obs_point, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, s));
+    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_uv, q.obs_uv, sizeof(double) * 2 * (size_t)n_obs, hipMemcpyHostToDevice, s));
+  }
   D.n_poses = F;
   D.n_points = P;
   D.n_obs = n_obs;
@@ -2928,14 +3138,16 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.cy = q.cy;
   D.huber = q.huber_delta;
   D.dcs = q.dcs_phi;
-  int *h_pose_slot, *h_pt_slot, *h_act, *h_ptstart, *h_ocam, *h_opt, *h_cstart, *h_cobs, *h_scp, *h_scc;
-  double *h_uv, *h_info = nullptr, *h_scm, *h_cam0, *h_pts0;
+  int *h_pose_slot, *h_pt_slot, *h_act, *h_ptstart, *h_ocam = nullptr, *h_opt = nullptr, *h_cstart, *h_cobs, *h_scp, *h_scc;
+  double *h_uv = nullptr, *h_info = nullptr, *h_scm, *h_cam0, *h_pts0;
   D.pose_slot = A.take<int>(F, &h_pose_slot);
   D.pt_slot = A.take<int>(P, &h_pt_slot);
   D.act_pt = A.take<int>(n_act, &h_act);
   D.pt_start = A.take<int>(n_act + 1, &h_ptstart);
-  D.o_cam = A.take<int>(n_obs, &h_ocam);
-  D.o_pt = A.take<int>(n_obs, &h_opt);
+  if (!direct_obs) {
+    D.o_cam = A.take<int>(n_obs, &h_ocam);
+    D.o_pt = A.take<int>(n_obs, &h_opt);
+  }
   D.cam_start = A.take<int>(nfp + 1, &h_cstart);
   D.cam_obs = A.take<int>(n_cam_obs, &h_cobs);
   int* h_cpt;
@@ -2952,7 +3164,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.fp_slot = A.take<int>(n_hpl, &h_fpl);
   unsigned long long* h_mask = nullptr;
   if (tiled_possible) D.fp_mask = A.take<unsigned long long>(nfl, &h_mask);
-  D.o_uv = A.take<double>(2 * (size_t)n_obs, &h_uv);
+  if (!direct_obs) D.o_uv = A.take<double>(2 * (size_t)n_obs, &h_uv);
   if (D.has_info) D.o_info = A.take<double>(3 * (size_t)n_obs, &h_info);
   D.sc_meas = A.take<double>(q.n_scale, &h_scm);
   double *h_mx = nullptr, *h_muv = nullptr, *h_minfo = nullptr;
@@ -2984,6 +3196,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.cam_split = cam_split;
   if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
 
+  lap(0);  // reserve + carve
   // ---- pass 2 over the observations in point order, straight into the pinned arena: the active points, the sorted
   // observation records, the Hpl blocks (observations whose point AND camera are free, stored contiguously per free
   // point), the per-camera lists, the camera-tile mask of every free point (tiled Schur) and duplicate cameras per point
@@ -2993,7 +3206,6 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   // the observation records of the identity case are plain copies (48 MB at 2 000 000 observations): split over the threads
   // ... unless the caller keeps them in pinned memory (Context.pinned_empty / vs_host_alloc): then they are DMA-ed from
   // where they lie, behind the arena upload (large problems only: the three pointer queries cost a few microseconds)
-  const bool direct_obs = identity && T > 1 && !q.obs_info && vs_is_pinned(q.obs_uv) && vs_is_pinned(q.obs_pose) && vs_is_pinned(q.obs_point);
   if (identity && !direct_obs) {
     par_for(T, [&](int t, int nt) {
       const size_t a = (size_t)((long long)n_obs * t / nt), b = (size_t)((long long)n_obs * (t + 1) / nt);
@@ -3003,19 +3215,28 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       if (h_info) memcpy(h_info + 3 * a, q.obs_info + 3 * a, sizeof(double) * 3 * (b - a));
     });
   }
+  lap(1);  // slot tables, observation records
   int mmax = 1, dups = 0, a_idx = 0, k_hpl = 0;
   // one point: its active-point record, its sorted observation records, its Hpl blocks and the per-camera lists.  The
   // running positions (active index, Hpl block index, per-camera fill positions) are the caller's: sequential for small
   // problems; for large ones every thread takes a range of points whose starting positions a counting pass fixed.
   // (captures BY VALUE: with the arena pointers captured by reference every store through an int* could alias them and they
   // were re-read from the closure after each one -- arena fill 43 -> 69 us at cfg4)
+  // lowest / highest camera slot of every free point (banded-window plan below)
+  int *wlo = nullptr, *whi = nullptr;
+  if (tiled_possible && ntile > 1 && ctx->tune.schur_variant != 3) {
+    W.wlo.resize((size_t)nfl);
+    W.whi.resize((size_t)nfl);
+    wlo = W.wlo.data();
+    whi = W.whi.data();
+  }
   auto do_point = [=](int j, int& a_i, int& k_h, int* cf, int* seen, int& mmax_, int& dups_) {
     const int i0 = cnt[j], i1 = cnt[j + 1], ls = pt_slot[j];
     if (i0 == i1 && ls < 0) return;
     h_act[a_i] = j;
     h_ptstart[a_i] = i0;
     ++a_i;
-    int mf = 0;
+    int mf = 0, lo = INT_MAX, hi = -1;
     unsigned long long mask = 0ull;
     if (ls >= 0) h_fps[ls] = k_h;
     for (int i = i0; i < i1; ++i) {
@@ -3044,6 +3265,8 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
           blk = k_h;
           h_fpl[k_h++] = cs;
           mask |= 1ull << ((cs / kTileCams) & 63);
+          lo = std::min(lo, cs);
+          hi = std::max(hi, cs);
         }
       }
       h_ohpl[i] = blk;
@@ -3051,6 +3274,10 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     if (ls >= 0) {
       mmax_ = std::max(mmax_, mf);
       if (h_mask) h_mask[ls] = mask;
+      if (wlo) {
+        wlo[ls] = lo;  // INT_MAX / -1: seen from fixed cameras only, contributes nothing
+        whi[ls] = hi;
+      }
     }
   };
   if (T == 1) {
@@ -3063,22 +3290,37 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       std::vector<int> cam, seen;
       int act = 0, hpl = 0, mmax = 1, dups = 0;
     };
-    std::vector<part2> parts((size_t)T);
-    par_for(T, [&](int t, int nt) {
-      part2& R = parts[(size_t)t];
-      R.cam.assign((size_t)nfp + 1, 0);
-      const int j0 = (int)((long long)P * t / nt), j1 = (int)((long long)P * (t + 1) / nt);
-      for (int j = j0; j < j1; ++j) {
-        const int i0 = cnt[j], i1 = cnt[j + 1], ls = pt_slot[j];
-        if (i0 == i1 && ls < 0) continue;
-        ++R.act;
-        for (int i = i0; i < i1; ++i) {
-          const int cs = pose_slot[q.obs_pose[identity ? i : order[i]]];
-          if (cs >= 0) {
-            R.cam[(size_t)cs]++;
-            R.hpl += ls >= 0;
+    const int nchunk = 4 * T;  // handed out through a counter, as in pass 1
+    std::vector<part2> parts((size_t)nchunk);
+    std::atomic<int> next2{0};
+    par_for(T, [&](int, int) {
+      const int* const cnt_ = cnt;
+      const int* const pt_slot_ = pt_slot;
+      const int* const pose_slot_ = pose_slot;
+      const int* const op = q.obs_pose;
+      const int* const order_ = order;
+      const bool identity_ = identity;
+      const int P_ = P, nfp_ = nfp;
+      for (int ch = next2.fetch_add(1); ch < nchunk; ch = next2.fetch_add(1)) {
+        part2& R = parts[(size_t)ch];
+        R.cam.assign((size_t)nfp_ + 1, 0);
+        int* const rcam = R.cam.data();
+        const int j0 = (int)((long long)P_ * ch / nchunk), j1 = (int)((long long)P_ * (ch + 1) / nchunk);
+        int act = 0, hpl = 0;
+        for (int j = j0; j < j1; ++j) {
+          const int i0 = cnt_[j], i1 = cnt_[j + 1], ls = pt_slot_[j];
+          if (i0 == i1 && ls < 0) continue;
+          ++act;
+          for (int i = i0; i < i1; ++i) {
+            const int cs = pose_slot_[op[identity_ ? i : order_[i]]];
+            if (cs >= 0) {
+              rcam[cs]++;
+              hpl += ls >= 0;
+            }
           }
         }
+        R.act = act;
+        R.hpl = hpl;
       }
     });
     // starting positions of every range (exclusive prefix over the ranges; per camera on top of the camera's own start)
@@ -3096,12 +3338,20 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
         cam_run[(size_t)c] += k;
       }
     }
-    par_for(T, [&](int t, int nt) {
-      part2& R = parts[(size_t)t];
-      R.seen.assign(F ? F : 1, -1);
-      const int j0 = (int)((long long)P * t / nt), j1 = (int)((long long)P * (t + 1) / nt);
-      int a_i = R.act, k_h = R.hpl;
-      for (int j = j0; j < j1; ++j) do_point(j, a_i, k_h, R.cam.data(), R.seen.data(), R.mmax, R.dups);
+    std::atomic<int> next3{0};
+    par_for(T, [&](int, int) {
+      const int P_ = P, F_ = F;
+      for (int ch = next3.fetch_add(1); ch < nchunk; ch = next3.fetch_add(1)) {
+        part2& R = parts[(size_t)ch];
+        R.seen.assign(F_ ? F_ : 1, -1);
+        const int j0 = (int)((long long)P_ * ch / nchunk), j1 = (int)((long long)P_ * (ch + 1) / nchunk);
+        int a_i = R.act, k_h = R.hpl, mm = 1, dd = 0;
+        int* const cf = R.cam.data();
+        int* const seen = R.seen.data();
+        for (int j = j0; j < j1; ++j) do_point(j, a_i, k_h, cf, seen, mm, dd);
+        R.mmax = mm;
+        R.dups = dd;
+      }
     });
     a_idx = act0;
     k_hpl = hpl0;
@@ -3110,6 +3360,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       dups |= R.dups;
     }
   }
+  lap(2);  // per-point pass
   h_ptstart[n_act] = n_obs;
   h_fps[nfl] = k_hpl;
   int max_rank = 0;
@@ -3131,6 +3382,52 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
         max_rank = std::max(max_rank, seen_cnt[cam]);
       }
   }
+  // ---- banded window?  (several tiles, no duplicates): the contributing free points ordered by their lowest camera slot
+  // and cut into slabs; taken when the cameras of every slab span at most kWinCams slots (ba_schur_window)
+  lap(3);
+  const auto t_win0 = now();
+  bool win = false;
+  int win_n = 0, win_per = 0, ns_win = 0;
+  if (tiled_possible && !dups && ntile > 1 && ctx->tune.schur_variant != 3) {
+    W.wcnt.assign((size_t)nfp + 1, 0);
+    int* const wcnt = W.wcnt.data();
+    for (int l = 0; l < nfl; ++l)
+      if (whi[l] >= 0) ++wcnt[wlo[l] + 1];
+    for (int c = 0; c < nfp; ++c) wcnt[c + 1] += wcnt[c];
+    win_n = wcnt[nfp];
+    if (win_n > 0) {
+      int* h_word;
+      D.win_order = A.take<int>(nfl, &h_word);
+      for (int l = 0; l < nfl; ++l)
+        if (whi[l] >= 0) h_word[wcnt[wlo[l]]++] = l;  // stable: equal keys stay in point order
+      // three workgroups per CU (LDS), at least 64 points each
+      const int target = 3 * std::max(ctx->prop.multiProcessorCount, 64);
+      win_per = std::min(kWinPerMax, std::max(64, (win_n + target - 1) / target));
+      if (ctx->tune.win_per > 0) win_per = std::min(kWinPerMax, ctx->tune.win_per);
+      ns_win = (win_n + win_per - 1) / win_per;
+      int *h_w0, *h_wl, *h_wf;
+      D.win_w0 = A.take<int>(ns_win, &h_w0);
+      D.win_len = A.take<int>(ns_win, &h_wl);
+      D.win_first = A.take<int>(nfp + 1, &h_wf);
+      if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
+      win = true;
+      for (int sl = 0; sl < ns_win && win; ++sl) {
+        const int a = sl * win_per, b = std::min(a + win_per, win_n);
+        const int lo = wlo[h_word[a]];  // sorted by it
+        int hi = lo;
+        for (int i = a; i < b; ++i) hi = std::max(hi, whi[h_word[i]]);
+        h_w0[sl] = lo;
+        h_wl[sl] = hi - lo + 1;
+        win = hi - lo + 1 <= kWinCams;
+      }
+      for (int c = 0, sl = 0; c <= nfp; ++c) {  // first slab that starts at camera c or later
+        while (sl < ns_win && h_w0[sl] < c) ++sl;
+        h_wf[c] = sl;
+      }
+    }
+  }
+  lap(4);  // window plan
+  const double win_plan_us = us(t_win0, now());
   const size_t upload_bytes = A.off;
   const bool tiled = tiled_possible && !dups;
   const bool small = tiled && small_possible;
@@ -3140,6 +3437,12 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   // workgroups on one CU take turns at its LDS in the product phase (measured 14-15 us per launch at 286 workgroups on
   // 256 CUs against 10 us alone); a workgroup with a few more points costs less than that.
   if (spec) ns = std::max(1, std::min(ns, std::max(ctx->prop.multiProcessorCount, 64) - nfp * cam_split));
+  if (win) {
+    ns = ns_win;
+    D.win = 1;
+    D.win_per = win_per;
+    D.win_n = win_n;
+  }
   D.ns = ns;
   D.mmax = mmax;
   D.dups = dups;
@@ -3166,7 +3469,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     D.bl1 = A.take<double>(3 * (size_t)nfl);
     D.Hpl1 = A.take<double>(18 * (size_t)n_hpl);
   }
-  D.slab = A.take<double>((size_t)(ns ? ns : 1) * slab_elems);
+  D.slab = win ? A.take<double>((size_t)ns * kWinSlabElems) : A.take<double>((size_t)(ns ? ns : 1) * slab_elems);
   D.S = A.take<double>((size_t)np * np);
   D.bs = A.take<double>(np);
   D.xp = A.take<double>(np);
@@ -3230,13 +3533,9 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   h_st->need_lin = 1;
   h_st->ni = 2.0;
   const bool nothing = (np + 3 * nfl == 0) || q.max_iterations == 0;
+  lap(5);  // states
   const auto t_filled = now();
-  VS_HIP(ctx, hipMemcpyAsync(A.base, A.host, upload_bytes, hipMemcpyHostToDevice, s));
-  if (direct_obs) {
-    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_cam, q.obs_pose, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, s));
-    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_pt, q.obs_point, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, s));
-    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_uv, q.obs_uv, sizeof(double) * 2 * (size_t)n_obs, hipMemcpyHostToDevice, s));
-  }
+  VS_HIP(ctx, hipMemcpyAsync(A.base + upload_begin, A.host + upload_begin, upload_bytes - upload_begin, hipMemcpyHostToDevice, s));
   // both state buffers start identical (fixed cameras / points are never rewritten in the trial buffer's points)
   VS_HIP(ctx, hipMemcpyAsync(D.cam[1], D.cam[0], sizeof(double) * (size_t)F * kCamStride, hipMemcpyDeviceToDevice, s));
   VS_HIP(ctx, hipMemcpyAsync(D.pts[1], D.pts[0], sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToDevice, s));
@@ -3284,15 +3583,23 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
         VS_LAUNCH_CHECK(ctx, "ba_schur_small");
       } else {
         if (ntile > 1) hipLaunchKernelGGL(ba_dinv, dim3((unsigned)((nfl + 255) / 256)), dim3(256), 0, s, D);  // single tile: fused
-        hipLaunchKernelGGL(ba_schur_tile, dim3(ns, ntile * (ntile + 1) / 2), dim3(256), tile_lds, s, D);  // lower triangle
-        VS_LAUNCH_CHECK(ctx, "ba_schur_tile");
+        if (win) {
+          hipLaunchKernelGGL(ba_schur_window, dim3(ns), dim3(256), 0, s, D);
+          VS_LAUNCH_CHECK(ctx, "ba_schur_window");
+        } else {
+          hipLaunchKernelGGL(ba_schur_tile, dim3(ns, ntile * (ntile + 1) / 2), dim3(256), tile_lds, s, D);  // lower triangle
+          VS_LAUNCH_CHECK(ctx, "ba_schur_tile");
+        }
       }
     } else if (ns > 0) {
       if (lds_slab) hipLaunchKernelGGL(ba_schur<true>, dim3(ns), dim3(kSchurThreads), schur_lds, s, D);
       else hipLaunchKernelGGL(ba_schur<false>, dim3(ns), dim3(kSchurThreads), schur_lds, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_schur");
     }
-    if (np > 0) {
+    if (np > 0 && win) {
+      hipLaunchKernelGGL(ba_reduce_window, dim3((unsigned)((slab_elems + 255) / 256)), dim3(256), 0, s, D);
+      VS_LAUNCH_CHECK(ctx, "ba_reduce_window");
+    } else if (np > 0) {
       hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 63) / 64)), dim3(64 * kRedSplit), 0, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_reduce");
     }
@@ -3323,7 +3630,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
         if (hms->terminated != 3) break;
         // the camera workgroups did not meet (the device was shared with long-running foreign work, or is smaller than it
         // reports): restore the start state from the pinned arena mirror and run the launch-per-step form once instead
-        VS_HIP(ctx, hipMemcpyAsync(A.base, A.host, upload_bytes, hipMemcpyHostToDevice, s));
+        VS_HIP(ctx, hipMemcpyAsync(A.base + upload_begin, A.host + upload_begin, upload_bytes - upload_begin, hipMemcpyHostToDevice, s));
         VS_HIP(ctx, hipMemcpyAsync(D.cam[1], D.cam[0], sizeof(double) * (size_t)F * kCamStride, hipMemcpyDeviceToDevice, s));
         VS_HIP(ctx, hipMemcpyAsync(D.pts[1], D.pts[0], sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToDevice, s));
         persistent = false;
@@ -3398,8 +3705,11 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     VS_HIP(ctx, hipStreamSynchronize(s));
   }
   if (timing)
-    fprintf(stderr, "vs_ba_solve: structure %.1f us, arena fill %.1f us, upload + kernels %.1f us, read-back %.1f us (upload %zu B)\n",
-            us(t_begin, t_struct), us(t_struct, t_filled), us(t_filled, t_solved), us(t_solved, now()), upload_bytes);
+    fprintf(stderr, "vs_ba_solve: structure %.1f us, arena fill %.1f us, upload + kernels %.1f us, read-back %.1f us (upload %zu B; window plan %.1f us inside the fill, %d slabs)\n",
+            us(t_begin, t_struct), us(t_struct, t_filled), us(t_filled, t_solved), us(t_solved, now()), upload_bytes, win_plan_us, win ? ns : 0);
+  if (timing)
+    fprintf(stderr, "  fill: reserve + carve %.1f, tables + records %.1f, per-point pass %.1f, ranks %.1f, window plan %.1f, states %.1f us (%d threads)\n", lap_us[0],
+            lap_us[1], lap_us[2], lap_us[3], lap_us[4], lap_us[5], T);
   res->iterations = hst->it;
   res->trials = hst->trials;
   res->not_pd = hst->not_pd;

@@ -41,6 +41,9 @@ struct ba_dev {
   double* Dbl;     // [nfl][3] (Hll + lambda I)^-1 bl (tiled Schur)
   int ntile;       // tiles of kTileCams cameras per side (tiled Schur), 0 otherwise
   int small;       // 1: ba_schur_small produced the slabs (single tile, lower block triangle only)
+  int win, win_per, win_n;  // 1: ba_schur_window (banded window); points per slab; contributing free points
+  const int *win_order, *win_w0, *win_len;  // their order by lowest camera slot; per slab: first camera slot, cameras
+  const int* win_first;  // [nfp + 1] first slab whose window starts at this camera slot or later
   int cam_split;   // workgroups that share one camera in the linearisation's camera role
   double* cam_part;       // [nfp][cam_split][27] their partial sums
   unsigned* cam_ticket;   // [nfp] arrival counters

@@ -48,6 +48,57 @@ VS_API int vs_create(vs_ctx** out, int device) {
   return VS_OK;
 }
 
+void vs_pool::run(int n, void (*f)(void*, int, int), void* a) {
+  if (n <= 1) {
+    f(a, 0, 1);
+    return;
+  }
+  {
+    std::lock_guard<std::mutex> lk(m);
+    while ((int)th.size() < n - 1) {
+      const int id = (int)th.size() + 1;
+      const unsigned seen0 = gen;  // a worker born now waits for the NEXT generation
+      th.emplace_back([this, id, seen0] {
+        unsigned seen = seen0;
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+          cv_work.wait(lk, [&] { return stop || gen != seen; });
+          if (stop) return;
+          seen = gen;
+          if (id >= nt) continue;  // not part of this run
+          void (*const f_)(void*, int, int) = fn;
+          void* const a_ = arg;
+          const int nt_ = nt;
+          lk.unlock();
+          f_(a_, id, nt_);
+          lk.lock();
+          if (--pending == 0) cv_done.notify_one();
+        }
+      });
+    }
+    fn = f;
+    arg = a;
+    nt = n;
+    pending = n - 1;
+    ++gen;
+  }
+  cv_work.notify_all();
+  f(a, 0, n);
+  std::unique_lock<std::mutex> lk(m);
+  cv_done.wait(lk, [&] { return pending == 0; });
+}
+
+void vs_pool::shutdown() {
+  {
+    std::lock_guard<std::mutex> lk(m);
+    stop = true;
+  }
+  cv_work.notify_all();
+  for (std::thread& t : th)
+    if (t.joinable()) t.join();
+  th.clear();
+}
+
 static void free_dev(vs_buf* b) {
   if (b->p) (void)hipFree(b->p);  // teardown: nothing useful can be done with an error here
   b->p = nullptr;

@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/vslam_hip.h"
@@ -49,9 +52,10 @@ struct vs_tuning {
   int match_target_blocks = 0;  // 0: automatic plan (plan_chunks); > 0: fixed number of workgroups
   int match_tstage = 1;         // train rows staged through LDS into VGPRs (1) or fed from SGPRs (0)
   bool match_profile = false;   // HIP events around every match launch (bench.py)
-  int schur_variant = 0;        // single-tile windows: 0 ba_schur_small + speculative linearisation, 1 tile kernel, 2 ba_schur_small + linearise launch
+  int schur_variant = 0;        // single-tile windows: 0 ba_schur_small + speculative linearisation, 1 tile kernel, 2 ba_schur_small + linearise launch; 3: as 0, and banded windows of several tiles on ba_schur_tile instead of ba_schur_window
   int small_per = 0;            // points per ba_schur_small workgroup (0: kSmallPts)
   int small_ns_cap = 512;       // cap on its slab count
+  int win_per = 0;              // banded large windows: points per ba_schur_window workgroup (0: automatic)
   int motion_variant = 0;       // 0: one-launch motion-only solve where it applies, 1: one launch per LM step
 };
 struct vs_prof_rec {
@@ -59,6 +63,23 @@ struct vs_prof_rec {
 };
 
 constexpr int VS_AUX_STREAMS = 2;
+
+// Host worker threads of a context (the structure passes of large bundle adjustments): created on first use, parked on a
+// condition variable between uses -- starting a dozen std::threads per pass cost 0.3-0.4 ms each time.  run(nt, fn, arg) calls
+// fn(arg, t, nt) for t = 0 .. nt-1, t = 0 on the caller, and returns when all have finished.  One run at a time.
+struct vs_pool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  void (*fn)(void*, int, int) = nullptr;
+  void* arg = nullptr;
+  int nt = 0, pending = 0;
+  unsigned gen = 0;
+  bool stop = false;
+  void run(int n, void (*f)(void*, int, int), void* a);
+  void shutdown();
+  ~vs_pool() { shutdown(); }
+};
 
 struct vs_ctx {
   int device = 0;
@@ -120,6 +141,7 @@ struct vs_ctx {
   vs_buf d_pnp_stamps;      // diagnostic phase stamps of the newest PnP launch (vs_pnp_profile)
   bool pnp_profile = false;
   int pnp_profile_h = 0;
+  vs_pool pool;
   int mo_persist_cap = -1;  // camera workgroups of ba_motion_persistent the device keeps resident together (-1: not asked yet)
 };
 
