@@ -483,3 +483,86 @@ def test_large_problem_structure_passes_on_several_host_threads(vs):
     bad[len(bad) // 2] = n_cams
     with pytest.raises(Exception):
         vs.ba_solve(poses0, fixed, pts0, pfix, bad, pt, uv, ICL_NUIM_K, max_iterations=1)
+
+
+def _sliding_window_scene(n_cams, n_points, window, seed):
+    """cameras on a 0.1 m-spaced track, every point seen from `window` consecutive cameras starting at a random one: the
+    co-visibility of key-frame bundle adjustment (a banded reduced system)."""
+    r = np.random.default_rng(seed)
+    fx, fy, cx, cy = ICL_NUIM_K
+    poses = np.tile(np.eye(4), (n_cams, 1, 1))
+    poses[:, 0, 3] = 0.1 * np.arange(n_cams)
+    start = r.integers(0, n_cams - window + 1, n_points)
+    pts = np.stack([0.1 * (start + window / 2) + r.uniform(-1, 1, n_points), r.uniform(-1.2, 1.2, n_points), r.uniform(2.5, 5.5, n_points)], 1)
+    cam = (start[:, None] + np.arange(window)[None, :]).astype(np.int32).ravel()
+    pt = np.repeat(np.arange(n_points, dtype=np.int32), window)
+    pc = pts[pt] - poses[cam, :3, 3]
+    uv = np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy], 1) + r.normal(0, 0.5, (len(cam), 2))
+    bad = r.random(len(uv)) < 0.02
+    uv[bad] += r.uniform(-50, 50, (int(bad.sum()), 2))
+    poses0 = poses.copy()
+    poses0[1:, :3, 3] += r.normal(0, 0.01, (n_cams - 1, 3))
+    fixed = np.zeros(n_cams, np.uint8)
+    fixed[0] = 1
+    return dict(poses=poses0, pose_fixed=fixed, points=pts + r.normal(0, 0.03, pts.shape), point_fixed=np.zeros(n_points, np.uint8),
+                obs_pose=cam, obs_point=pt, obs_uv=uv, K=ICL_NUIM_K, poses_gt=poses)
+
+
+def test_banded_windows_on_the_matrix_cores_agree_with_the_tile_kernel_and_the_oracle(vs, oracle):
+    """Windows of more than ten free cameras whose points are seen from neighbouring cameras only: the points are ordered
+    by their lowest camera, every slab's contribution is one dense window of S accumulated with FP64 MFMA
+    (ba_schur_window), the slabs are summed by ba_reduce_window and -- without scale edges -- the banded system is
+    factorised by ba_chol_band in one launch.  vs_tune_ba variant 3 keeps such problems on the tile kernel and the dense
+    factorisation: both must agree with the oracle, and with each other to rounding."""
+    cases = [(24, 3000, 10, 1), (100, 1500, 10, 6), (40, 4000, 14, 2), (13, 400, 5, 5)]
+    try:
+        for n_cams, n_points, window, seed in cases:
+            w = _sliding_window_scene(n_cams, n_points, window, seed)
+            w["point_fixed"][::53] = 1                    # some fixed points
+            w["obs_pose"][w["obs_point"] == 7] = 0        # a free point seen from the fixed camera only (duplicates too)
+            vs.tune_ba(schur_variant=0)
+            a = vs.ba_solve(*_args(w), max_iterations=4)
+            vs.tune_ba(schur_variant=3)
+            b = vs.ba_solve(*_args(w), max_iterations=4)
+            o = oracle.ba_solve(*_args(w), max_iterations=4)
+            _compare(a, o)
+            _compare(b, o)
+            assert np.abs(a["poses"] - b["poses"]).max() < 1e-11 and np.abs(a["points"] - b["points"]).max() < 1e-11
+        # with scale edges the camera Hessian is no longer banded: windowed Schur complement, dense factorisation
+        w = _sliding_window_scene(30, 2500, 10, 9)
+        idx = np.arange(1, 30)
+        meas = [float(np.linalg.norm(w["poses_gt"][i][:3, 3] - w["poses_gt"][i - 1][:3, 3]) * (1.0 + 0.01 * (i % 3))) for i in idx]
+        se = ((idx - 1).tolist(), idx.tolist(), meas)
+        se_far = ([0, 2], [29, 25], [2.95, 2.31])     # ... including pairs far outside any window
+        for edges in (se, se_far):
+            vs.tune_ba(schur_variant=0)
+            _compare(vs.ba_solve(*_args(w), max_iterations=4, scale_edges=edges), oracle.ba_solve(*_args(w), max_iterations=4, scale_edges=edges))
+    finally:
+        vs.tune_ba(schur_variant=0)
+
+
+def test_banded_cholesky_is_bitwise_the_dense_factorisation(vs):
+    """ba_chol_band (one launch, a window of the band sliding through LDS) performs the dense panel / update kernels'
+    subtractions in their order and skips only exact zeros: same bits, also for a band that is not a multiple of the panel
+    width and one wider than the kernel takes (dense path both times); an indefinite matrix is rejected."""
+    r = np.random.default_rng(0)
+    try:
+        for n, cams_band in ((594, 11), (594, 16), (300, 5), (132, 3), (600, 1), (594, 17)):
+            M = np.zeros((n, n))
+            for a in range(n // 6):
+                for b in range(max(0, a - cams_band + 1), a + 1):
+                    M[6 * a:6 * a + 6, 6 * b:6 * b + 6] = r.normal(size=(6, 6))
+            S = M + M.T
+            S += np.eye(n) * (np.abs(S).sum(1).max() + 1.0)
+            rhs = r.normal(size=n)
+            vs.tune_ba(schur_variant=0)
+            ok1, x1 = vs.debug_cholesky(S, rhs)
+            vs.tune_ba(schur_variant=3)
+            ok2, x2 = vs.debug_cholesky(S, rhs)
+            assert ok1 and ok2 and np.array_equal(x1, x2)
+            assert np.abs(x1 - np.linalg.solve(S, rhs)).max() < 1e-12
+        vs.tune_ba(schur_variant=0)
+        S[300, 300] = -1.0
+        assert not vs.debug_cholesky(S, rhs)[0]
+    finally:
+        vs.tune_ba(schur_variant=0)

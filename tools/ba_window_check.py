@@ -1,5 +1,5 @@
 """Banded windows of several tiles: ba_schur_window (FP64 matrix cores, points ordered by lowest camera) against the tile
-kernel (vs_tune_ba variant 3) and the CPU oracle on sliding-window scenes; timing of both at the scaled size.
+kernel (vs_tune_ba variant 3) and the CPU oracle on sliding-window scenes; median of five solves each; --big adds the scaled size.
   python tools/ba_window_check.py [--big]"""
 import _env  # noqa: F401
 import sys
@@ -16,9 +16,12 @@ def run(ctx, w, iters, variant):
     args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
     kw = dict(huber_delta=np.sqrt(5.991), max_iterations=iters)
     g = ctx.ba_solve(*args, **kw)
-    t0 = time.perf_counter()
-    g = ctx.ba_solve(*args, **kw)
-    return g, (time.perf_counter() - t0) * 1e3
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        g = ctx.ba_solve(*args, **kw)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return g, float(np.median(ts))
 
 
 def main():

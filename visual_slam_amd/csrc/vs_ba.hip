@@ -43,6 +43,7 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 using namespace vsba;
@@ -895,9 +896,9 @@ __global__ __launch_bounds__(256) void ba_schur_window(ba_dev D) {
   __shared__ __attribute__((aligned(16))) double sH[kWinK * kWinStride];
   __shared__ double sD[kWinBatch][12];
   __shared__ int sRec[kWinPerMax][3];  // point slot, first Hpl block, blocks
-  __shared__ int sMap[kWinBatch][kWinCams];
+  __shared__ unsigned sMask[kWinBatch];  // window cameras that see the point
   if (D.st->done) return;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the tile tests below are branches, not masks
   const int s = blockIdx.x, i0 = s * D.win_per, n = min(D.win_per, D.win_n - i0);
   const int w0 = D.win_w0[s], wlen = D.win_len[s], ncol = 6 * wlen, ntr = (ncol + 15) >> 4;
   const int ntiles = ntr * (ntr + 1) / 2;
@@ -908,7 +909,7 @@ __global__ __launch_bounds__(256) void ba_schur_window(ba_dev D) {
     sRec[i][2] = D.fp_start[l + 1] - b;
   }
   for (int i = tid; i < kWinK * kWinStride; i += 256) sY[i] = sH[i] = 0.0;  // the padding columns stay zero
-  if (tid < kWinBatch * kWinCams) (&sMap[0][0])[tid] = -1;
+  if (tid < kWinBatch) sMask[tid] = 0u;
   // this wave's tiles: t = wv, wv + 4, ... of the lower triangle, enumerated row by row
   int toff_a[kWinTilesPerWave], toff_b[kWinTilesPerWave];
   win_d4 acc[kWinTilesPerWave];
@@ -918,78 +919,142 @@ __global__ __launch_bounds__(256) void ba_schur_window(ba_dev D) {
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
     const int tj = t - ti * (ti + 1) / 2;
-    toff_a[q] = t < ntiles ? 16 * ti : -1;
-    toff_b[q] = 16 * tj;
+    toff_a[q] = __builtin_amdgcn_readfirstlane(16 * ti);
+    toff_b[q] = __builtin_amdgcn_readfirstlane(16 * tj);
     acc[q] = win_d4{0.0, 0.0, 0.0, 0.0};
   }
+  const int nq = __builtin_amdgcn_readfirstlane(wv < ntiles ? (ntiles - 1 - wv) / 4 + 1 : 0);  // this wave's tiles: q < nq
   double racc = 0.0;
   const int krow = lane >> 4, kcol = lane & 15;
+  // Staging tasks (point of the batch, Hpl block of the point, block row): kWinBatch * kWinCams * 6 = 3 per thread.  Their
+  // global loads -- camera slot and the three values of the row -- are issued one batch ahead and land while the matrix
+  // cores work on the current one; the same goes for Dinv and Dinv bl (thread = one of the twelve values of a point).
+  constexpr int kTasks = kWinBatch * kWinCams * 6 / 256;
+  static_assert(kTasks * 256 == kWinBatch * kWinCams * 6, "three staging tasks per thread");
+  int pslot[kTasks];     // camera slot of the task's block: the raw loaded value -- arithmetic on it here would wait for the load
+  unsigned pvalid = 0u;  // bit k: task k has a block
+  double ph[kTasks][3];  // the row of the Hpl block
+  double pd = 0.0;
   __syncthreads();
-  for (int b0 = 0; b0 < n; b0 += kWinBatch) {
+  auto prefetch = [&](int b0) {
     const int nb = min(kWinBatch, n - b0);
-    // A: camera maps of the batch (thread = (point, block)), Dinv and Dinv bl
-    if (tid < kWinBatch * kWinCams) {
-      const int pb = tid >> 4, i = tid & 15;
+#pragma unroll
+    for (int k = 0; k < kTasks; ++k) {
+      const int t = tid + 256 * k;
+      const int pb = t / (kWinCams * 6), rem = t - pb * (kWinCams * 6), i = rem / 6, ar = rem - 6 * i;
+      pvalid &= ~(1u << k);
       if (pb < nb && i < sRec[b0 + pb][2]) {
         const int blk = sRec[b0 + pb][1] + i;
-        sMap[pb][D.fp_slot[blk] - w0] = blk;
+        const double* B = D.Hpl + 18 * (size_t)blk + 3 * ar;
+        pvalid |= 1u << k;
+        pslot[k] = D.fp_slot[blk];
+        ph[k][0] = B[0];
+        ph[k][1] = B[1];
+        ph[k][2] = B[2];
       }
-    } else if (tid < kWinBatch * kWinCams + kWinBatch * 12) {
-      const int pb = (tid - kWinBatch * kWinCams) / 12, k = (tid - kWinBatch * kWinCams) - 12 * pb;
+    }
+    if (tid < kWinBatch * 12) {
+      const int pb = tid / 12, k = tid - 12 * pb;
       if (pb < nb) {
         const int l = sRec[b0 + pb][0];
-        sD[pb][k] = k < 9 ? D.Dinv[9 * (size_t)l + k] : D.Dbl[3 * (size_t)l + k - 9];
+        pd = k < 9 ? D.Dinv[9 * (size_t)l + k] : D.Dbl[3 * (size_t)l + k - 9];
       }
     }
-    __syncthreads();
-    // B: the panels - cell group = (point, window camera, block row): three k of H and of Y = H Dinv, or zeros
-    for (int t = tid; t < kWinBatch * ncol; t += 256) {
-      const int pb = t / ncol, col = t - pb * ncol, wc = col / 6, ar = col - 6 * wc;
-      const int blk = pb < nb ? sMap[pb][wc] : -1;
-      double h0 = 0.0, h1 = 0.0, h2 = 0.0, y0 = 0.0, y1 = 0.0, y2 = 0.0;
-      if (blk >= 0) {
-        const double* B = D.Hpl + 18 * (size_t)blk + 3 * ar;
-        h0 = B[0];
-        h1 = B[1];
-        h2 = B[2];
-        const double* sd = sD[pb];
-        y0 = h0 * sd[0] + h1 * sd[3] + h2 * sd[6];
-        y1 = h0 * sd[1] + h1 * sd[4] + h2 * sd[7];
-        y2 = h0 * sd[2] + h1 * sd[5] + h2 * sd[8];
-      }
-      const int o = 3 * pb * kWinStride + col;
-      sH[o] = h0;
-      sH[o + kWinStride] = h1;
-      sH[o + 2 * kWinStride] = h2;
-      sY[o] = y0;
-      sY[o + kWinStride] = y1;
-      sY[o + 2 * kWinStride] = y2;
-    }
-    __syncthreads();
-    // C: matrix cores; the right-hand side on the first threads; the maps of the next batch cleared
-    const int nk = (3 * nb + 3) >> 2;
-    for (int ks = 0; ks < nk; ++ks) {
-      const int o = (4 * ks + krow) * kWinStride + kcol;
+  };
+  prefetch(0);
+#ifdef VS_WIN_STAMPS
+  long long tsA = 0, tsB = 0, tsP = 0, tsC = 0, ts0 = __builtin_readcyclecounter(), tsStart = ts0;
+#define VS_WIN_LAP(x) { const long long t_ = __builtin_readcyclecounter(); x += t_ - ts0; ts0 = t_; }
+#else
+#define VS_WIN_LAP(x)
+#endif
+  for (int b0 = 0; b0 < n; b0 += kWinBatch) {
+    const int nb = min(kWinBatch, n - b0);
+    // A: which window cameras see each point; Dinv, Dinv bl
 #pragma unroll
-      for (int q = 0; q < kWinTilesPerWave; ++q) {
-        if (toff_a[q] < 0) continue;  // wave-uniform
-        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(sY[o + toff_a[q]], sH[o + toff_b[q]], acc[q], 0, 0, 0);
+    for (int k = 0; k < kTasks; ++k) {
+      const int t = tid + 256 * k;
+      if ((pvalid >> k & 1u) && t % 6 == 0) atomicOr(&sMask[t / (kWinCams * 6)], 1u << (pslot[k] - w0));
+    }
+    if (tid < kWinBatch * 12) sD[tid / 12][tid % 12] = pd;
+    __syncthreads();
+    VS_WIN_LAP(tsA)
+    // B: the panels.  Present (point, camera) rows from the prefetched values (three k of H and of Y = H Dinv), absent
+    // ones -- and the points beyond the end of the slab -- zeroed.
+#pragma unroll
+    for (int k = 0; k < kTasks; ++k) {
+      const int t = tid + 256 * k;
+      const int pb = t / (kWinCams * 6);
+      if (pvalid >> k & 1u) {
+        const double* sd = sD[pb];
+        const double h0 = ph[k][0], h1 = ph[k][1], h2 = ph[k][2];
+        const int o = 3 * pb * kWinStride + 6 * (pslot[k] - w0) + t % 6;
+        sH[o] = h0;
+        sH[o + kWinStride] = h1;
+        sH[o + 2 * kWinStride] = h2;
+        sY[o] = h0 * sd[0] + h1 * sd[3] + h2 * sd[6];
+        sY[o + kWinStride] = h0 * sd[1] + h1 * sd[4] + h2 * sd[7];
+        sY[o + 2 * kWinStride] = h0 * sd[2] + h1 * sd[5] + h2 * sd[8];
       }
+    }
+    for (int t = tid; t < kWinBatch * ncol; t += 256) {
+      const int pb = t / ncol, col = t - pb * ncol;
+      if (pb < nb && (sMask[pb] >> (col / 6) & 1u)) continue;
+      const int o = 3 * pb * kWinStride + col;
+      sH[o] = sH[o + kWinStride] = sH[o + 2 * kWinStride] = 0.0;
+      sY[o] = sY[o + kWinStride] = sY[o + 2 * kWinStride] = 0.0;
+    }
+    VS_WIN_LAP(tsB)
+    if (b0 + kWinBatch < n) prefetch(b0 + kWinBatch);
+    __syncthreads();
+    VS_WIN_LAP(tsP)
+    // C: matrix cores; the right-hand side on the first threads; the masks cleared for the next batch
+    const int nk = (3 * nb + 3) >> 2;
+    // (one copy of the loop per tile count: with the count tested inside, the compiler issues every operand read right in
+    // front of its own MFMA and waits for it there)
+    auto mma = [&](auto nq_) {
+      constexpr int NQ = decltype(nq_)::value;
+      for (int ks = 0; ks < nk; ++ks) {
+        const int o = (4 * ks + krow) * kWinStride + kcol;
+        double av[NQ], bv[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          av[q] = sY[o + toff_a[q]];
+          bv[q] = sH[o + toff_b[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc[q], 0, 0, 0);
+      }
+    };
+    switch (nq) {
+      case 1: mma(std::integral_constant<int, 1>{}); break;
+      case 2: mma(std::integral_constant<int, 2>{}); break;
+      case 3: mma(std::integral_constant<int, 3>{}); break;
+      case 4: mma(std::integral_constant<int, 4>{}); break;
+      case 5: mma(std::integral_constant<int, 5>{}); break;
+      case 6: mma(std::integral_constant<int, 6>{}); break;
+      default: break;
     }
     if (tid < ncol) {
       for (int pb = 0; pb < nb; ++pb) {
         const int o = 3 * pb * kWinStride + tid;
         racc += sH[o] * sD[pb][9] + sH[o + kWinStride] * sD[pb][10] + sH[o + 2 * kWinStride] * sD[pb][11];
       }
-    } else if (tid >= 128 && tid < 128 + kWinBatch * kWinCams) {
-      (&sMap[0][0])[tid - 128] = -1;
+    } else if (tid >= 128 && tid < 128 + kWinBatch) {
+      sMask[tid - 128] = 0u;
     }
     __syncthreads();
+    VS_WIN_LAP(tsC)
   }
+#ifdef VS_WIN_STAMPS
+  if (tid == 0 && (s == 0 || s == 100 || s == 400))
+    printf("slab %d: %d points, window %d; cycles A(wait loads + masks) %lld, B(panels) %lld, prefetch issue + barrier %lld, C(mfma) %lld, total %lld\n", s, n, wlen,
+           tsA, tsB, tsP, tsC, (long long)__builtin_readcyclecounter() - tsStart);
+#endif
   double* out = D.slab + (size_t)s * kWinSlabElems;
 #pragma unroll
   for (int q = 0; q < kWinTilesPerWave; ++q) {
-    if (toff_a[q] < 0) continue;
+    if (q >= nq) break;
 #pragma unroll
     for (int v = 0; v < 4; ++v) out[(size_t)(toff_a[q] + krow + 4 * v) * kWinN + toff_b[q] + kcol] = acc[q][v];
   }
@@ -1726,6 +1791,209 @@ __global__ __launch_bounds__(256) void ba_chol_update(ba_dev D, int j0, int nbw)
     }
 }
 
+// Banded systems (ba_schur_window's windows: S[r][c] = 0 for r - c >= band): the whole factorisation in ONE launch.  A
+// window of W = nbw + band rows and columns of the lower triangle (plus the rhs as its last row) lives in LDS and slides
+// down the diagonal: factorise the window's first nbw columns exactly as ba_chol_panel does, update the rest of the
+// window exactly as ba_chol_update does (per element the same subtractions in the same order, so L is bit-identical to
+// the dense path's; what lies outside the band is an exact zero there and is simply not visited here), write the panel to
+// HBM, move the window up-left by nbw and read the next nbw rows, which no earlier column has touched.  That replaces
+// 2 n / nbw launches whose dependent hand-overs were the cost (25 x (22 + 7) us at 594 unknowns) by one.
+constexpr int kBandMax = 6 * kWinCams, kBandNbw = 24, kBandW = kBandNbw + kBandMax;
+constexpr int kBandShift = ((kBandW - kBandNbw + 1) * (kBandW - kBandNbw) + kPanelThreads - 1) / kPanelThreads;
+constexpr int kBandFetch = (kBandNbw * kBandW + kBandNbw + kPanelThreads - 1) / kPanelThreads;
+constexpr size_t kBandLds = sizeof(double) * ((size_t)(kBandW + 1) * ((kBandW + 1) | 1) + kBandNbw) + 64;
+
+__global__ __launch_bounds__(kPanelThreads) void ba_chol_band(ba_dev D, int band) {
+  extern __shared__ __attribute__((aligned(16))) double s_mem[];
+  if (D.st->done) return;
+  const int n = D.np, tid = threadIdx.x;
+  constexpr int nbw = kBandNbw;
+  const int W = nbw + band, ld = (kBandW + 1) | 1;
+  double* A = s_mem;                                  // [W + 1][ld]: window rows, then the rhs row at index W
+  double* rinv = s_mem + (size_t)(kBandW + 1) * ld;   // [nbw]
+  int* s_flag = reinterpret_cast<int*>(rinv + nbw);
+  {
+    const int R0 = min(W, n);
+    for (int e = tid; e < (R0 + 1) * R0; e += kPanelThreads) {
+      const int r = e / R0, c = e - r * R0;
+      A[(r < R0 ? r : W) * ld + c] = (c <= r || r == R0) ? chol_row(D, r < R0 ? r : n)[c] : 0.0;
+    }
+  }
+  if (tid == 0) {
+    *s_flag = 0;
+    *D.chol_fail = 0;
+  }
+  __syncthreads();
+  for (int j0 = 0; j0 < n; j0 += nbw) {
+    const int w = min(nbw, n - j0), R = min(W, n - j0);  // panel columns, window rows (local row R stands for the rhs)
+    // the rows that enter the window after this step, requested now: global rows j0 + R .. j0 + w + R' - 1
+    const int Rn = min(W, n - j0 - w), fresh = max(Rn - (R - w), 0);  // next window's rows; how many of them are new
+    double fv[kBandFetch];
+#pragma unroll
+    for (int k = 0; k < kBandFetch; ++k) {
+      const int e = tid + kPanelThreads * k;
+      fv[k] = 0.0;
+      if (e < fresh * W) {
+        const int fr = e / W, c = e - fr * W, lr = R - w + fr;  // row / column in the NEXT window
+        if (c <= lr) fv[k] = D.S[(size_t)(j0 + w + lr) * n + j0 + w + c];
+      } else if (e < fresh * W + fresh) {
+        fv[k] = D.bs[j0 + w + (R - w) + (e - fresh * W)];
+      }
+    }
+    for (int b0 = 0; b0 < w; b0 += 6) {
+      if (tid == 0) {
+        double L[6][6], ri[6];
+        int good = 1;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c <= r; ++c) L[r][c] = A[(b0 + r) * ld + b0 + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          const double d = L[c][c];
+          if (!(d > 0.0)) good = 0;
+          double r = __builtin_amdgcn_rsq(d);
+          r = r * (1.5 - 0.5 * d * r * r);
+          r = r * (1.5 - 0.5 * d * r * r);
+          double l = d * r;
+          l = l + 0.5 * r * (d - l * l);
+          L[c][c] = l;
+          ri[c] = r;
+#pragma unroll
+          for (int i = c + 1; i < 6; ++i) L[i][c] = L[i][c] * r;
+#pragma unroll
+          for (int i = c + 1; i < 6; ++i)
+#pragma unroll
+            for (int k = c + 1; k <= i; ++k) L[i][k] -= L[i][c] * L[k][c];
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+#pragma unroll
+          for (int c = 0; c <= r; ++c) A[(b0 + r) * ld + b0 + c] = L[r][c];
+          rinv[b0 + r] = ri[r];
+        }
+        if (!good) *s_flag = 1;
+      }
+      __syncthreads();
+      if (*s_flag) break;  // uniform
+      for (int i = b0 + 6 + tid; i <= R; i += kPanelThreads) {
+        double* row = A + (i < R ? i : W) * ld;
+        double a[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) a[c] = row[b0 + c];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double v = a[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) v -= a[k] * A[(b0 + c) * ld + b0 + k];
+          a[c] = v * rinv[b0 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) row[b0 + c] = a[c];
+      }
+      __syncthreads();
+      const int wc = w - b0 - 6;
+      if (wc > 0) {
+        for (int e = tid; e < (R + 1 - b0 - 6) * wc; e += kPanelThreads) {
+          const int i = b0 + 6 + e / wc, c = b0 + 6 + e % wc;
+          if (c > i && i < R) continue;  // strictly upper part (the rhs row keeps all columns)
+          double* row = A + (i < R ? i : W) * ld;
+          double acc = row[c];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc -= row[b0 + k] * A[c * ld + b0 + k];
+          row[c] = acc;
+        }
+        __syncthreads();
+      }
+    }
+    if (*s_flag) {
+      if (tid == 0) *D.chol_fail = 1;
+      return;
+    }
+    // the rest of the window: 4 x 4 register tiles over rows w .. R (R = rhs) and columns w .. R - 1, lower triangle
+    {
+      const int tr_n = (R - w + 1 + 3) >> 2, tc_n = (R - w + 3) >> 2;
+      for (int t = tid; t < tr_n * tc_n; t += kPanelThreads) {
+        const int tr = t / tc_n, tc = t - tr * tc_n;
+        const int r0 = w + 4 * tr, c0 = w + 4 * tc;
+        if (c0 > r0 + 3 && r0 + 3 < R) continue;  // wholly above the diagonal and without the rhs row
+        const double* rp[4];
+        const double* cp[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int i = min(r0 + a, R);
+          rp[a] = A + (i < R ? i : W) * ld;
+          cp[a] = A + min(c0 + a, R - 1) * ld;
+        }
+        double acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = rp[a][min(c0 + b, R - 1)];
+        for (int k = 0; k < w; ++k) {
+          double rv[4], cv[4];
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            rv[a] = rp[a][k];
+            cv[a] = cp[a][k];
+          }
+#pragma unroll
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] -= rv[a] * cv[b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const int i = r0 + a, c = c0 + b;
+            if (i > R || c >= R || (c > i && i < R)) continue;
+            const_cast<double*>(rp[a])[c] = acc[a][b];
+          }
+      }
+    }
+    // the finished panel (and its part of the forward-substituted rhs) to HBM
+    for (int e = tid; e < (R + 1) * w; e += kPanelThreads) {
+      const int i = e / w, c = e - i * w;
+      if (c <= i || i == R) chol_row(D, i < R ? j0 + i : n)[j0 + c] = A[(i < R ? i : W) * ld + c];
+    }
+    for (int c = tid; c < w; c += kPanelThreads) D.rinv[j0 + c] = rinv[c];
+    __syncthreads();
+    if (j0 + w >= n) break;
+    // slide: (i, c) -> (i - w, c - w) through registers, then the fresh rows
+    double mv[kBandShift];
+    const int keep_r = R - w + 1, keep_c = R - w;  // rows w .. R (rhs last), columns w .. R - 1
+#pragma unroll
+    for (int k = 0; k < kBandShift; ++k) {
+      const int e = tid + kPanelThreads * k;
+      if (e < keep_r * keep_c) {
+        const int i = w + e / keep_c, c = w + e % keep_c;
+        mv[k] = A[(i < R ? i : W) * ld + c];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kBandShift; ++k) {
+      const int e = tid + kPanelThreads * k;
+      if (e < keep_r * keep_c) {
+        const int i = w + e / keep_c, c = w + e % keep_c;
+        A[(i < R ? i - w : W) * ld + c - w] = mv[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kBandFetch; ++k) {
+      const int e = tid + kPanelThreads * k;
+      if (e < fresh * W) {
+        const int fr = e / W, c = e - fr * W, lr = R - w + fr;
+        if (c <= lr) A[lr * ld + c] = fv[k];
+      } else if (e < fresh * W + fresh) {
+        A[W * ld + (R - w) + (e - fresh * W)] = fv[k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nbw) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   lm_state* st = D.st;
@@ -1737,19 +2005,30 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
     for (int i = tid; i < n; i += kPanelThreads) x[i] = D.bs[i];
     __syncthreads();
     // blocks of nbw rows from the bottom: triangular solve inside the block (wave 0), then one matvec for the rows above
+    // (the block's triangle and pivots are brought into LDS first: read from global memory inside the serial loop, every
+    // one of its steps waited for a round trip.  A banded system -- D.band -- has nothing but zeros above row k0 - band.)
+    double* T = x + n;  // [nbw][nbw + 1] rows k0 .. k1-1 of L, columns k0 .. k1-1; then the reciprocal pivots
+    double* ri = T + nbw * (nbw + 1);
     for (int k1 = n; k1 > 0;) {
-      const int k0 = k1 - ((k1 % nbw) ? (k1 % nbw) : nbw);
+      const int k0 = k1 - ((k1 % nbw) ? (k1 % nbw) : nbw), bw = k1 - k0;
+      for (int e = tid; e < bw * bw; e += kPanelThreads) {
+        const int k = e / bw, i = e - k * bw;
+        if (i < k) T[k * (nbw + 1) + i] = D.S[(size_t)(k0 + k) * n + k0 + i];
+      }
+      if (tid < bw) ri[tid] = D.rinv[k0 + tid];
+      __syncthreads();
       if (tid < 64) {
         for (int k = k1 - 1; k >= k0; --k) {
-          const double xk = x[k] * D.rinv[k];
+          const double xk = x[k] * ri[k - k0];
           wave_lds_sync();
           if (tid == 0) x[k] = xk;
-          for (int i = k0 + tid; i < k; i += 64) x[i] -= D.S[(size_t)k * n + i] * xk;
+          for (int i = k0 + tid; i < k; i += 64) x[i] -= T[(k - k0) * (nbw + 1) + i - k0] * xk;
           wave_lds_sync();
         }
       }
       __syncthreads();
-      for (int i = tid; i < k0; i += kPanelThreads) {
+      const int i_lo = D.band > 0 ? max(k0 - D.band, 0) : 0;
+      for (int i = i_lo + tid; i < k0; i += kPanelThreads) {
         double v = x[i];
         for (int k = k1 - 1; k >= k0; --k) v -= D.S[(size_t)k * n + i] * x[k];
         x[i] = v;
@@ -2728,7 +3007,7 @@ int plan_solve(vs_ctx* ctx, int np, solve_plan* P) {
     // widest panel (24 / 12 / 6 columns) whose rows j0..n fit in LDS
     for (int w : {24, 12, 6}) {
       const size_t b = sizeof(double) * ((size_t)(np + 1) * (w | 1) + w) + 64;
-      if (b <= 150 * 1024 && sizeof(double) * (size_t)np + 64 <= 150 * 1024) {
+      if (b <= 150 * 1024 && sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64 <= 150 * 1024) {
         P->nbw = w;
         P->panel_lds = b;
         break;
@@ -2736,7 +3015,8 @@ int plan_solve(vs_ctx* ctx, int np, solve_plan* P) {
     }
     if (P->nbw) {
       VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->panel_lds));
-      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * (size_t)np + 64)));
+      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64)));
+      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds));
     }
   }
   if (P->lds_bytes > 64 * 1024)
@@ -2748,6 +3028,9 @@ int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& 
   const int np = D.np;
   if (P.lds) {
     hipLaunchKernelGGL(ba_solve_block, dim3(1), dim3(kSolveBlock), P.lds_bytes, s, D);
+  } else if (P.nbw == kBandNbw && D.band > 0 && D.band <= kBandMax) {
+    hipLaunchKernelGGL(ba_chol_band, dim3(1), dim3(kPanelThreads), kBandLds, s, D, D.band);
+    hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64, s, D, P.nbw);
   } else if (P.nbw > 0) {
     for (int j0 = 0; j0 < np; j0 += P.nbw) {
       const int w = std::min(P.nbw, np - j0);
@@ -2758,7 +3041,7 @@ int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& 
         hipLaunchKernelGGL(ba_chol_update, dim3(T, T), dim3(256), 0, s, D, j0, w);
       }
     }
-    hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * (size_t)np + 64, s, D, P.nbw);
+    hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64, s, D, P.nbw);
   } else {
     hipLaunchKernelGGL(ba_solve<false>, dim3(1), dim3(kSolveThreads), P.lds_bytes, s, D);
   }
@@ -2837,6 +3120,17 @@ VS_API int vs_ba_debug_cholesky(vs_ctx* ctx, const double* S, int n, const doubl
   VS_HIP(ctx, hipMemcpyAsync(D.bs, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
   VS_HIP(ctx, hipMemcpyAsync(D.bp, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
   VS_HIP(ctx, hipMemsetAsync(D.chol_fail, 0, 16, s));
+  if (ctx->tune.schur_variant != 3) {  // a banded matrix takes the banded factorisation, as vs_ba_solve's banded windows do
+    int band = 0;
+    for (int r = 0; r < n; ++r)
+      for (int c = 0; c <= r - band; ++c)
+        if (S[(size_t)r * n + c] != 0.0) {
+          band = r - c + 1;
+          break;
+        }
+    band = (band + 5) / 6 * 6;
+    if (band <= kBandMax) D.band = band;
+  }
   solve_plan P;
   VS_TRY(plan_solve(ctx, n, &P));
   VS_TRY(launch_solve(ctx, s, D, P));
@@ -3387,7 +3681,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   lap(3);
   const auto t_win0 = now();
   bool win = false;
-  int win_n = 0, win_per = 0, ns_win = 0;
+  int win_n = 0, win_per = 0, ns_win = 0, win_cams = 0;
   if (tiled_possible && !dups && ntile > 1 && ctx->tune.schur_variant != 3) {
     W.wcnt.assign((size_t)nfp + 1, 0);
     int* const wcnt = W.wcnt.data();
@@ -3400,9 +3694,9 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       D.win_order = A.take<int>(nfl, &h_word);
       for (int l = 0; l < nfl; ++l)
         if (whi[l] >= 0) h_word[wcnt[wlo[l]]++] = l;  // stable: equal keys stay in point order
-      // three workgroups per CU (LDS), at least 64 points each
-      const int target = 3 * std::max(ctx->prop.multiProcessorCount, 64);
-      win_per = std::min(kWinPerMax, std::max(64, (win_n + target - 1) / target));
+      // two workgroups per CU (registers), all resident at once; at least 32 points each
+      const int target = 2 * std::max(ctx->prop.multiProcessorCount, 64);
+      win_per = std::min(kWinPerMax, std::max(32, (win_n + target - 1) / target));
       if (ctx->tune.win_per > 0) win_per = std::min(kWinPerMax, ctx->tune.win_per);
       ns_win = (win_n + win_per - 1) / win_per;
       int *h_w0, *h_wl, *h_wf;
@@ -3419,6 +3713,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
         h_w0[sl] = lo;
         h_wl[sl] = hi - lo + 1;
         win = hi - lo + 1 <= kWinCams;
+        win_cams = std::max(win_cams, hi - lo + 1);
       }
       for (int c = 0, sl = 0; c <= nfp; ++c) {  // first slab that starts at camera c or later
         while (sl < ns_win && h_w0[sl] < c) ++sl;
@@ -3442,6 +3737,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     D.win = 1;
     D.win_per = win_per;
     D.win_n = win_n;
+    if (q.n_scale == 0) D.band = 6 * win_cams;  // scale edges couple arbitrary camera pairs in Hpp: dense factorisation then
   }
   D.ns = ns;
   D.mmax = mmax;

@@ -44,6 +44,7 @@ struct ba_dev {
   int win, win_per, win_n;  // 1: ba_schur_window (banded window); points per slab; contributing free points
   const int *win_order, *win_w0, *win_len;  // their order by lowest camera slot; per slab: first camera slot, cameras
   const int* win_first;  // [nfp + 1] first slab whose window starts at this camera slot or later
+  int band;  // > 0: S[r][c] = 0 for r - c >= band (banded windows without scale edges): ba_chol_band instead of the panel launches
   int cam_split;   // workgroups that share one camera in the linearisation's camera role
   double* cam_part;       // [nfp][cam_split][27] their partial sums
   unsigned* cam_ticket;   // [nfp] arrival counters
