@@ -85,8 +85,10 @@ class Context:
 
     def tune_ba(self, schur_variant=-1, points_per_workgroup=0, max_slabs=0, motion_variant=-1):
         """BA knobs (vs_tune_ba; negative / zero = leave as it is): Schur kernel of single-tile windows (0 automatic,
-        1 tile kernel, 2 ba_schur_small + linearise launch), its points per workgroup and slab cap; motion-only form
-        (0 one launch where it applies, 1 one launch per LM step)."""
+        1 tile kernel, 2 ba_schur_small + linearise launch; 3 = as 0, and banded windows of several tiles stay on the tile
+        kernel and the dense factorisation instead of ba_schur_window / ba_chol_band), its points per workgroup (from 64
+        up: the slab size of ba_schur_window) and slab cap; motion-only form (0 one launch where it applies, 1 one launch
+        per LM step)."""
         self._chk(self._lib.vs_tune_ba(self._h, int(schur_variant), int(points_per_workgroup), int(max_slabs),
                                        int(motion_variant)))
 

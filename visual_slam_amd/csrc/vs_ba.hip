@@ -23,10 +23,14 @@
 //                     wave w owns the row cameras w, w+4, w+8, lane (block row, column camera) owns 6 elements per row
 //                     camera -- fixed ownership, no atomics, no LDS read-modify-write; Hpl blocks staged 8 points per
 //                     barrier (ba_schur<LDS_SLAB> remains for duplicate observations of one camera: LDS atomics there)
+//   ba_schur_window   windows of several tiles whose points are seen from neighbouring cameras only (a banded system): the
+//                     points ordered by lowest camera, workgroup = slab of that order, the slab's dense 96 x 96 window of S
+//                     accumulated on the FP64 matrix cores from two K x 96 LDS panels; ba_reduce_window sums the slabs
 //   ba_reduce         S = Hpp + lambda I - sum of slabs, rhs likewise (four slab groups per element, fixed order)
 //   dense solve       n <= 126: ba_solve_block, one workgroup, [S | rhs] in LDS, blocked by the 6x6 camera blocks,
 //                     blocked back-substitution, trial camera states;  beyond: ba_chol_panel + ba_chol_update per block
-//                     column in HBM, then ba_chol_finish;  ba_solve<false> (element-wise, one workgroup) is the last
+//                     column in HBM -- banded systems: ba_chol_band, the same arithmetic in one launch -- then
+//                     ba_chol_finish;  ba_solve<false> (element-wise, one workgroup) is the last
 //                     resort when even a 6-column panel does not fit in LDS
 //   ba_point_trial    8 lanes per point: back-substitution x_l = Dinv (bl - sum Hpl^T x_p) with the sum split over the
 //                     lanes, trial point, robust chi2 of the trial state, fixed-order block reduction
