@@ -2659,6 +2659,7 @@ static_assert(kMoObsRegs * kMoThreads == kMoPersistObs, "register capacity of ba
 template <bool OVF>
 __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int max_steps) {
 #pragma clang fp contract(fast)
+  __builtin_amdgcn_s_setprio(3);  // the critical path of pipelined tracking; the other stream's kernels are throughput work
   __shared__ double s_all[kMoRows][29];
   __shared__ double s_grp[kRedGroups][28];
   __shared__ double s_sum[28];

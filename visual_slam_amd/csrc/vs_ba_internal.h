@@ -170,6 +170,13 @@ struct pnp_args {
   double* rec_out[2];  // tracking session: camera record of the result (the guess if nothing was found), or nullptr
   mo_state* lm_init;   // tracking session: the two motion-only LM records to reset for the solve that follows, or nullptr
   int lm_cur;          // ... their state-buffer index
+  // chained tracking (vs_track_frame_pipelined): what the host would know only after the previous frame's results are read
+  // on the device instead, so that this launch can be enqueued while the previous back half is still running
+  const int* off_dev;        // row offset of this frame's correspondences in obj / img, or nullptr (obj / img point at them)
+  const double* guess_dev[2];  // the guess: the previous frame's camera record in either state buffer (the one `cur` names), or nullptr (cam0)
+  const mo_state* cur_dev;   // record whose `cur` is the state-buffer index, or nullptr (lm_cur)
+  const unsigned* front_tag_dev;  // word the frame's front half (another stream) sets to front_tag when its append is complete:
+  unsigned front_tag;             // ... every workgroup waits for it here instead of a stream-level event wait in front of the launch
 };
 
 __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step);

@@ -25,6 +25,8 @@ namespace {
 
 
 __device__ inline int pnp_count(const pnp_args& P) { return P.n_dev ? *P.n_dev : P.n; }
+// (chained tracking: pnp_ransac_kernel has resolved guess_dev[0] and lm_cur from the device-side state at its entry)
+__device__ inline double pnp_guess(const pnp_args& P, int k) { return P.guess_dev[0] ? P.guess_dev[0][k] : P.cam0[k]; }
 
 __device__ inline unsigned long long splitmix64(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -408,7 +410,7 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
   wave_lds_sync();
   if (lane == 0) pnp_stamp(P, h, 1);
   double cam[kCamStride];
-  for (int k = 0; k < kCamStride; ++k) cam[k] = P.cam0[k];
+  for (int k = 0; k < kCamStride; ++k) cam[k] = pnp_guess(P, k);
   pnp_lm<3, 1, 1>(P, idx, 5, lane & 7, 8, cam, nullptr, min(P.iters_lm, kPnpHypIters));
   if (lane == 0) pnp_stamp(P, h, 2);
   // the model is handed on as a 4x4 pose (as the sequential algorithm does): re-derive the record from that matrix
@@ -524,8 +526,8 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
       }
     }
     if (P.rec_out[0] && tid < kCamStride) {
-      P.rec_out[0][tid] = P.cam0[tid];
-      P.rec_out[1][tid] = P.cam0[tid];
+      P.rec_out[0][tid] = pnp_guess(P, tid);
+      P.rec_out[1][tid] = pnp_guess(P, tid);
     }
     return;
   }
@@ -605,8 +607,41 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
 }
 
 __global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(pnp_args P) {
+  // chains of dependent FP64 instructions on single waves: when the next frame's detector shares the CUs (pipelined tracking),
+  // the issue arbiter should serve these waves first
+  __builtin_amdgcn_s_setprio(3);
   const int nhw = (int)gridDim.x - 1;
+  if (P.front_tag_dev) {
+    // chained tracking: the correspondences come from the front half on another stream.  Its last workgroup publishes the
+    // frame's tag (agent-scope release behind everybody's rows); the wait is bounded -- the front half was enqueued before
+    // this launch and its kernels do not depend on it -- and a workgroup that gives up leaves the launch (the finishing one
+    // reports the hypotheses as missing, which the host turns into an error).
+    __shared__ int s_front;
+    if (threadIdx.x == 0) {
+      int ok = 0;
+      for (int it = 0; it < (1 << 22) && !ok; ++it) {
+        ok = __hip_atomic_load(P.front_tag_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == P.front_tag;
+        if (!ok) __builtin_amdgcn_s_sleep(4);
+      }
+      s_front = ok;
+    }
+    __syncthreads();
+    if (!s_front) {
+      if ((int)blockIdx.x == nhw && threadIdx.x == 0) {
+        P.result[16] = -1.0;
+        if (P.host_result) P.host_result[16] = -1.0;
+      }
+      return;
+    }
+  }
   P.n = pnp_count(P);
+  if (P.off_dev) {  // chained tracking: one round trip for the three device-side scalars, all requested together
+    const int off = *P.off_dev, cur = P.cur_dev->cur & 1;
+    P.obj += 3 * (size_t)off;
+    P.img += 2 * (size_t)off;
+    P.lm_cur = cur;
+    P.guess_dev[0] = P.guess_dev[cur];
+  }
   if ((int)blockIdx.x < nhw) pnp_hypothesis_role(P, nhw);
   else pnp_finish_role(P);
 }

@@ -29,7 +29,8 @@ struct track_timing {
 // appends the new frame's observations to the period's camera-major arrays: obs i = (map point mq[i], keypoint mt[i])
 __global__ __launch_bounds__(256) void track_append_kernel(const double* xyz, const float* fxy, const int* mq, const int* mt,
                                                            const int* d_M, double* mo_X, double* mo_uv, int* cam_start,
-                                                           int slot, int cap_obs, int* flags, const int* d_nkp) {
+                                                           int slot, int cap_obs, int* flags, const int* d_nkp,
+                                                           unsigned* front_sync, unsigned front_tag) {
   const int base = cam_start[slot];
   int M = *d_M;
   if (base + M > cap_obs) {
@@ -49,6 +50,27 @@ __global__ __launch_bounds__(256) void track_append_kernel(const double* xyz, co
     flags[1] = M;  // the count PnP and the host see (clamped)
     flags[2] = *d_nkp;  // the frame's key-point count: the host reads it with the results, not in the middle of the frame
   }
+  // "this frame's rows are complete": the workgroup that arrives last publishes the frame's tag.  A chained back half
+  // (pnp_ransac_kernel on the other stream) waits for that word instead of for an event in front of its launch.
+  __threadfence();  // this thread's rows are visible device-wide before its workgroup is counted
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(front_sync, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_store(front_sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next frame's append counts from zero
+      __hip_atomic_store(front_sync + 64, front_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// chained back halves: the read-back block goes to pinned host memory from a kernel of ours, followed by the frame's tag
+// (system-scope release) -- the host polls the tag.  One short launch instead of a copy command + an event record, both of
+// which are barrier packets on the chain of back halves.
+__global__ __launch_bounds__(256) void track_publish_kernel(const uint4* src, uint4* dst, int n16, unsigned* tag_word, unsigned tag) {
+  for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(tag_word, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // host-fed variant (vs_track_push_frame): obs i = (map point idx[i], image point uv[i]) as the caller matched them
@@ -92,7 +114,7 @@ struct track_layout {
   size_t xyz, mapdesc;
   track_front f[2];  // two sets of per-frame buffers (the synchronous entry point uses set 0 only)
   size_t flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part, H, box, mst, pnp_cam, pnp_res, pnp_inl,
-      push_idx, push_uv, rb_end, total;
+      push_idx, push_uv, rb_end, front_sync, total;
   int cap_obs;
 };
 
@@ -135,6 +157,7 @@ track_layout track_layout_of(int P, int F, int max_kp, int H) {
   L.box = take(sizeof(unsigned long long) * 2 * kMoPersistCameras * 8);  // mailboxes of ba_motion_persistent
   L.pnp_cam = take(sizeof(double) * kPnpModel * (size_t)H);
   L.pnp_inl = take(sizeof(int) * (size_t)(per > 0 ? per : 1));
+  L.front_sync = take(512);  // [0] arrival counter of track_append_kernel, [64] tag of the newest complete front half
   L.push_idx = take(sizeof(int) * (size_t)(per > 0 ? per : 1));
   L.push_uv = take(sizeof(double) * 2 * (size_t)(per > 0 ? per : 1));
   L.total = off;
@@ -210,17 +233,36 @@ int track_front_half(vs_ctx* ctx, int set, int slot, const uint8_t* bgr, int w, 
   // this same stream, and the counts go to this buffer set's own flag words -- so in pipelined use the append (and the
   // dispatch gap behind it) is off the critical path, the chain of back halves.
   int* flags = (int*)(d + L.flags) + 4 * set;
+  if (++T.front_seq == 0) ++T.front_seq;  // never the zero the word starts with
+  T.front_tag[set] = T.front_seq;
   hipLaunchKernelGGL(track_append_kernel, dim3(8), dim3(256), 0, s, (const double*)(d + L.xyz), (const float*)(d + F.fxy),
                      (const int*)(d + F.mq), (const int*)(d + F.mt), (const int*)(d + F.M), (double*)(d + L.moX),
-                     (double*)(d + L.moUV), (int*)(d + L.cam_start), slot, L.cap_obs, flags, (const int*)(d + F.fn));
+                     (double*)(d + L.moUV), (int*)(d + L.cam_start), slot, L.cap_obs, flags, (const int*)(d + F.fn),
+                     (unsigned*)(d + L.front_sync), T.front_tag[set]);
   VS_LAUNCH_CHECK(ctx, "track_append_kernel");
   VS_HIP(ctx, hipEventRecord(T.ev_front[set], s));
   return VS_OK;
 }
 
+size_t rb_len(const track_layout& L) { return (L.rb_end - L.mst + 255) & ~(size_t)255; }
+size_t rb_stride(const track_layout& L) { return rb_len(L) + 256; }  // the block, then the word track_publish_kernel tags it with
+
+// May the back half of pose k be enqueued before the previous one's results are known?  Only the form that needs no host
+// decision in between: PnP on, LM on, the motion-only solve in one launch.
+bool track_can_chain(vs_ctx* ctx, int set, int k) {
+  const auto& T = ctx->track;
+  const int lm = T.params[set].lm_iterations;
+  static const bool off = getenv("VS_TRACK_NOCHAIN") != nullptr;  // developer aid: A/B against the host-paced form
+  if (off) return false;
+  return T.mst_both && T.pnp_iters > 0 && lm > 0 && mo_persistent_ok(ctx, k, 1 + lm * 10);
+}
+
 // Back half, enqueue only (context stream): wait for the front half, PnP-RANSAC from the
 // previous pose, motion-only BA over the k free poses, one read-back copy.  *steps_out = LM launches enqueued.
-int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
+// `k` is the pose index of the new frame.  chained: the previous frame's back half may still be running -- the row offset of
+// the correspondences, the guess (the previous pose, in the state buffer its solve ended on) and that buffer's index are read
+// by the PnP kernel on the device instead of being passed from the host.
+int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out, int k, bool chained = false) {
   auto& T = ctx->track;
   const auto& Q = T.params[set];
   const track_layout L = layout_of(ctx);
@@ -228,15 +270,14 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   uint8_t* d = (uint8_t*)ctx->d_track.p;
   uint8_t* hp = (uint8_t*)ctx->h_track.p;
   const int H = T.pnp_iters > 0 ? T.pnp_iters : 1;
-  const int k = T.n_frames + 1;  // pose index of the new frame
-  VS_HIP(ctx, hipStreamWaitEvent(s, T.ev_front[set], 0));
+  if (!chained) VS_HIP(ctx, hipStreamWaitEvent(s, T.ev_front[set], 0));  // chained: the PnP kernel waits for the front half's tag itself
   double* cam0 = (double*)(d + L.cam0);
   double* cam1 = (double*)(d + L.cam1);
   // ---- PnP-RANSAC from the previous pose; its result becomes the new pose's record in both state buffers
   pnp_args A;
   memset(&A, 0, sizeof A);
-  A.obj = (const double*)(d + L.moX) + 3 * (size_t)T.obs_used;
-  A.img = (const double*)(d + L.moUV) + 2 * (size_t)T.obs_used;
+  A.obj = (const double*)(d + L.moX) + (chained ? 0 : 3 * (size_t)T.obs_used);
+  A.img = (const double*)(d + L.moUV) + (chained ? 0 : 2 * (size_t)T.obs_used);
   A.n = 0;
   A.n_dev = (const int*)(d + L.flags) + 4 * set + 1;
   A.iters_lm = Q.lm_iterations;
@@ -249,6 +290,14 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   A.confidence = Q.confidence;
   A.seed = Q.seed;
   memcpy(A.cam0, T.last_rec, sizeof A.cam0);
+  if (chained) {
+    A.off_dev = (const int*)(d + L.cam_start) + (k - 1);  // written by the previous frames' appends
+    A.guess_dev[0] = cam0 + (size_t)(k - 1) * kCamStride;
+    A.guess_dev[1] = cam1 + (size_t)(k - 1) * kCamStride;
+    A.cur_dev = reinterpret_cast<const mo_state*>(d + L.mst);  // a finished solve leaves its record in both slots
+    A.front_tag_dev = (const unsigned*)(d + L.front_sync) + 64;
+    A.front_tag = T.front_tag[set];
+  }
   A.model_out = (double*)(d + L.pnp_cam);
   A.result = (double*)(d + L.pnp_res);
   A.inl_out = (int*)(d + L.pnp_inl);
@@ -285,11 +334,10 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out) {
   return VS_OK;
 }
 
-ba_dev track_ba_dev(vs_ctx* ctx, int set) {
+ba_dev track_ba_dev(vs_ctx* ctx, int set, int k) {
   auto& T = ctx->track;
   const track_layout L = layout_of(ctx);
   uint8_t* d = (uint8_t*)ctx->d_track.p;
-  const int k = T.n_frames + 1;
   ba_dev D;
   memset(&D, 0, sizeof D);
   D.n_poses = k + 1;
@@ -317,16 +365,18 @@ ba_dev track_ba_dev(vs_ctx* ctx, int set) {
 }
 
 // enqueues up to one batch of LM launches followed by the read-back copy; returns the number of launches so far
-int track_ba_batch(vs_ctx* ctx, int set, int* step) {
+// chained: the read-back goes to the buffer set's own pinned block and ev_back[set] is recorded behind it (the host waits for
+// that event, not for the stream, which holds the next back half already)
+int track_ba_batch(vs_ctx* ctx, int set, int* step, int k, bool chained = false) {
   auto& T = ctx->track;
   const track_layout L = layout_of(ctx);
   hipStream_t s = ctx->stream;
   uint8_t* d = (uint8_t*)ctx->d_track.p;
-  uint8_t* rb = (uint8_t*)ctx->h_track.p + kPinRb;
-  const int lm = T.params[set].lm_iterations, k = T.n_frames + 1;
+  uint8_t* rb = (uint8_t*)ctx->h_track.p + kPinRb + (chained ? (size_t)(1 + set) * rb_stride(L) : 0);
+  const int lm = T.params[set].lm_iterations;
   if (lm > 0) {
     if (*step == 0) T.solve_epoch = T.solve_epoch % 0xFFFFF + 1;  // 1 .. 2^20 - 1: never the zero the mailboxes start with
-    const ba_dev D = track_ba_dev(ctx, set);
+    const ba_dev D = track_ba_dev(ctx, set, k);
     const int max_steps = 1 + lm * 10;
     // Launches after the one that finds the solve finished are predicated no-ops of ~5 us each on the critical path of the
     // frame, and consecutive frames of a stream need about the same number of LM steps: the first batch is as long as the
@@ -337,7 +387,9 @@ int track_ba_batch(vs_ctx* ctx, int set, int* step) {
       else hipLaunchKernelGGL(ba_motion_persistent<true>, dim3(k), dim3(kMoThreads), 0, s, D, max_steps);
       VS_LAUNCH_CHECK(ctx, "ba_motion_persistent");
       *step = max_steps + 2;  // nothing left to enqueue
+      T.mst_both = 1;
     } else {
+      T.mst_both = 0;
       int batch = std::min(max_steps + 1 - *step, lm + 2);
       if (*step == 0 && T.lm_steps_hint > 0) batch = std::min(batch, std::max(3, T.lm_steps_hint + 1));
       for (int b = 0; b < batch; ++b, ++*step) {
@@ -347,31 +399,57 @@ int track_ba_batch(vs_ctx* ctx, int set, int* step) {
     }
   }
   // one copy brings back everything the host wants; if the solve needs another batch it is simply repeated
-  VS_HIP(ctx, hipMemcpyAsync(rb, d + L.mst, L.rb_end - L.mst, hipMemcpyDeviceToHost, s));
+  if (chained) {
+    if (++T.back_seq == 0) ++T.back_seq;
+    T.back_tag[set] = T.back_seq;
+    hipLaunchKernelGGL(track_publish_kernel, dim3(1), dim3(256), 0, s, (const uint4*)(d + L.mst), (uint4*)rb, (int)(rb_len(L) / 16),
+                       (unsigned*)(rb + rb_len(L)), T.back_tag[set]);
+    VS_LAUNCH_CHECK(ctx, "track_publish_kernel");
+  } else {
+    VS_HIP(ctx, hipMemcpyAsync(rb, d + L.mst, L.rb_end - L.mst, hipMemcpyDeviceToHost, s));
+  }
   return VS_OK;
 }
 
 // Back half, completion: synchronise, run further LM batches if the solve is not finished, hand out the results.
 int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found,
-                      float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t, bool pnp_ran = true) {
+                      float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t, bool pnp_ran = true,
+                      bool chained = false) {
   auto& T = ctx->track;
   const track_layout L = layout_of(ctx);
   const track_front& F = L.f[set];
-  hipStream_t s = ctx->stream;
+  // chained: the context's stream holds the next back half already -- wait for this one's event, and fetch the optional
+  // per-frame arrays on another stream (this buffer set is not written again before the next call)
+  hipStream_t s = chained ? ctx->aux_stream[0] : ctx->stream;
   uint8_t* d = (uint8_t*)ctx->d_track.p;
-  const uint8_t* rb = (const uint8_t*)ctx->h_track.p + kPinRb;
+  const uint8_t* rb = (const uint8_t*)ctx->h_track.p + kPinRb + (chained ? (size_t)(1 + set) * rb_stride(L) : 0);
   const mo_state* rb_st = (const mo_state*)rb;
   const int lm = T.params[set].lm_iterations, k = T.n_frames + 1;
   mo_state fin;
   memset(&fin, 0, sizeof fin);
   fin.cur = T.cur;
   for (;;) {
-    VS_HIP(ctx, hipStreamSynchronize(s));
+    if (chained) {
+      // the tag behind the block, written by track_publish_kernel with a system-scope release
+      const volatile unsigned* tag = (const volatile unsigned*)(rb + rb_len(L));
+      const auto t0 = std::chrono::steady_clock::now();
+      for (unsigned spins = 0; __atomic_load_n(tag, __ATOMIC_ACQUIRE) != T.back_tag[set]; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+          (void)hipStreamSynchronize(ctx->stream);
+          if (__atomic_load_n(tag, __ATOMIC_ACQUIRE) == T.back_tag[set]) break;
+          return vs_fail(ctx, VS_EHIP, "%s: the back half did not publish its results", "vs_track_frame_pipelined");
+        }
+      }
+    } else {
+      VS_HIP(ctx, hipStreamSynchronize(s));
+    }
     if (lm == 0) break;
     fin = rb_st[(*step - 1) & 1];
     if (fin.terminated == 3) return vs_fail(ctx, VS_EHIP, "%s: the camera workgroups of the motion-only solve did not rendezvous", "vs_track_frame");
     if (fin.done || *step > 1 + lm * 10) break;
-    VS_TRY(track_ba_batch(ctx, set, step));
+    if (chained) return vs_fail(ctx, VS_EHIP, "%s: the one-launch motion-only solve returned unfinished", "vs_track_frame_pipelined");
+    VS_TRY(track_ba_batch(ctx, set, step, k));
   }
   const int* rb_flags = (const int*)(rb + (L.flags - L.mst)) + 4 * set;
   const double* rb_res = (const double*)(rb + (L.pnp_res - L.mst));
@@ -431,7 +509,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   const size_t up = L.f[0].fxy;  // [xyz | mapdesc] are uploaded
   // pinned staging: [control block kPinRb | read-back block | push staging: idx + uv of one frame]
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(std::max(std::max(up, (size_t)1 << 16),
-                                                                  kPinRb + (L.rb_end - L.mst) + 256 + 20 * (size_t)n_points),
+                                                                  kPinRb + 3 * rb_stride(L) + 256 + 20 * (size_t)n_points),
                                                          sizeof(int) * (size_t)max_frames + 2048)));
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_api, api_layout_of(n_points, max_kp).total));
   if (!T.ev_api) VS_HIP(ctx, hipEventCreateWithFlags(&T.ev_api, hipEventDisableTiming));
@@ -443,6 +521,8 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   VS_HIP(ctx, hipMemcpyAsync(d, h, up, hipMemcpyHostToDevice, s));
   VS_HIP(ctx, hipMemsetAsync(d + L.cam_start, 0, sizeof(int) * (size_t)(max_frames + 2), s));
   VS_HIP(ctx, hipMemsetAsync(d + L.flags, 0, 2 * 4 * sizeof(int), s));
+  VS_HIP(ctx, hipMemsetAsync(d + L.mst, 0, 2 * sizeof(mo_state), s));  // state buffer 0 holds the estimate
+  VS_HIP(ctx, hipMemsetAsync(d + L.front_sync, 0, 512, s));
   VS_HIP(ctx, hipMemsetAsync(d + L.box, 0, sizeof(unsigned long long) * 2 * kMoPersistCameras * 8, s));
   double rec[kCamStride];
   rec_from_pose(key_pose, rec);
@@ -467,6 +547,8 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   T.solve_epoch = 0;
   T.pending = -1;
   T.pending_step = -1;
+  T.pending_chained = 0;
+  T.mst_both = 1;
   T.next_set = 0;
   T.api_stage = 0;
   T.K[0] = fx;
@@ -506,8 +588,8 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   T.params[0] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
   VS_TRY(track_front_half(ctx, 0, T.n_frames, bgr, w, h_img, stride, thr, ratio, ctx->stream));
   int step = 0;
-  VS_TRY(track_back_enqueue(ctx, 0, &step));
-  VS_TRY(track_ba_batch(ctx, 0, &step));
+  VS_TRY(track_back_enqueue(ctx, 0, &step, T.n_frames + 1));
+  VS_TRY(track_ba_batch(ctx, 0, &step, T.n_frames + 1));
   return track_back_finish(ctx, 0, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out, match_q, match_t);
 }
 
@@ -535,7 +617,7 @@ VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const doub
   hipStream_t s = ctx->stream;
   uint8_t* d = (uint8_t*)ctx->d_track.p;
   uint8_t* hp = (uint8_t*)ctx->h_track.p;
-  uint8_t* stage = hp + kPinRb + ((L.rb_end - L.mst + 255) & ~(size_t)255);
+  uint8_t* stage = hp + kPinRb + 3 * rb_stride(L);
   T.params[0] = {0.0, 0.0, huber_delta, 0ull, lm_iterations};
   const int slot = T.n_frames, k = T.n_frames + 1;
   if (m > 0) {
@@ -566,7 +648,7 @@ VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const doub
     VS_HIP(ctx, hipMemcpyAsync(d + L.mst, h_st, 256, hipMemcpyHostToDevice, s));
   }
   int step = 0, n_matches = 0;
-  VS_TRY(track_ba_batch(ctx, 0, &step));
+  VS_TRY(track_ba_batch(ctx, 0, &step, k));
   return track_back_finish(ctx, 0, &step, poses_out, n_poses_out, &n_matches, nullptr, nullptr, nullptr, nullptr, nullptr,
                            nullptr, false);
 }
@@ -584,41 +666,60 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
   if (!T.active) return vs_fail(ctx, VS_EINVAL, "%s: no tracking period (call vs_track_begin)", "vs_track_frame_pipelined");
   if (bgr) VS_TRY(track_check_frame(ctx, bgr, w, h_img, stride, lm_iterations, "vs_track_frame_pipelined"));
   VS_HIP(ctx, hipSetDevice(ctx->device));
-  // The back half of the previous frame is on the GPU already (enqueued at the end of the previous call, the moment its
-  // inputs were known) and runs while this frame's front half is prepared.  When its results are in, the back half of
-  // THIS frame is enqueued before returning: the round trip through the caller (return, next call) is off the GPU's
-  // critical path, which is the chain of back halves.
+  // The back half of the previous frame is on the GPU already.  Chained form (PnP on, LM on, the motion-only solve in one
+  // launch): the back half of THIS frame goes onto the context's stream right behind it, before the previous one's results
+  // are known -- the PnP kernel reads the row offset of its correspondences, its guess and the state-buffer index on the
+  // device -- so the GPU passes from one back half to the next without the host in between (the host round trip and the
+  // dispatch of the next kernel onto an idle queue were ~20 us per frame on the chain of back halves, which is the critical
+  // path).  The previous frame's results are then awaited through the event behind ITS read-back copy.  Otherwise (a solve
+  // that may need further LM batches decided on the host): the back half is enqueued once the previous results are in.
   const int solve = T.pending;
+  const bool solve_chained = solve >= 0 && T.pending_chained;
   int step = T.pending_step >= 0 ? T.pending_step : 0;
   if (solve >= 0 && T.pending_step < 0) {
-    VS_TRY(track_back_enqueue(ctx, solve, &step));
-    VS_TRY(track_ba_batch(ctx, solve, &step));
+    VS_TRY(track_back_enqueue(ctx, solve, &step, T.n_frames + 1));
+    VS_TRY(track_ba_batch(ctx, solve, &step, T.n_frames + 1));
   }
   g_tt.start();
-  int submitted = -1;
+  int submitted = -1, next_step = 0;
+  bool chain = false;
   if (bgr) {
     submitted = T.next_set;
     T.next_set ^= 1;
     T.params[submitted] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
-    // its free-camera slot: behind the frames tracked so far and the one whose back half is still running
-    VS_TRY(track_front_half(ctx, submitted, T.n_frames + (solve >= 0 ? 1 : 0), bgr, w, h_img, stride, thr, ratio, T.front_stream));
+    // its pose index: behind the frames tracked so far and the one whose back half is still running
+    const int k_new = T.n_frames + (solve >= 0 ? 2 : 1);
+    VS_TRY(track_front_half(ctx, submitted, k_new - 1, bgr, w, h_img, stride, thr, ratio, T.front_stream));
+    g_tt.lap(0);  // front half enqueued
+    chain = (solve < 0 || solve_chained) && track_can_chain(ctx, submitted, k_new);
+    if (chain) {
+      VS_TRY(track_back_enqueue(ctx, submitted, &next_step, k_new, true));
+      VS_TRY(track_ba_batch(ctx, submitted, &next_step, k_new, true));
+      g_tt.lap(2);
+    }
   }
   T.pending = -1;
   T.pending_step = -1;
-  g_tt.lap(0);  // front half enqueued
+  T.pending_chained = 0;
   if (solve >= 0) {
-    VS_TRY(track_back_finish(ctx, solve, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out,
-                             match_q, match_t));
+    const int rc = track_back_finish(ctx, solve, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out,
+                                     match_q, match_t, true, solve_chained);
+    if (rc != VS_OK) {
+      if (chain) (void)hipStreamSynchronize(ctx->stream);  // the next back half is on the stream already: let it drain
+      return rc;
+    }
     *has_result = 1;
   }
   g_tt.lap(1);  // previous back half waited for and handed out
   if (submitted >= 0) {
-    int next_step = 0;
     T.pending = submitted;  // from here on the frame counts as pending, whatever happens below
-    VS_TRY(track_back_enqueue(ctx, submitted, &next_step));
-    g_tt.lap(2);  // PnP enqueued
-    VS_TRY(track_ba_batch(ctx, submitted, &next_step));
-    g_tt.lap(3);  // BA + read-back enqueued
+    T.pending_chained = chain;
+    if (!chain) {
+      VS_TRY(track_back_enqueue(ctx, submitted, &next_step, T.n_frames + 1));
+      g_tt.lap(2);  // PnP enqueued
+      VS_TRY(track_ba_batch(ctx, submitted, &next_step, T.n_frames + 1));
+      g_tt.lap(3);  // BA + read-back enqueued
+    }
     T.pending_step = next_step;
   }
   ++g_tt.n;
@@ -673,9 +774,9 @@ VS_API int vs_track_back_begin(vs_ctx* ctx, double pnp_reproj_err, double pnp_co
   VS_HIP(ctx, hipSetDevice(ctx->device));
   T.params[0] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
   int step = 0;
-  VS_TRY(track_back_enqueue(ctx, 0, &step));            // PnP-RANSAC; its outcome also goes to pinned memory
+  VS_TRY(track_back_enqueue(ctx, 0, &step, T.n_frames + 1));  // PnP-RANSAC; its outcome also goes to pinned memory
   VS_HIP(ctx, hipEventRecord(T.ev_api, ctx->stream));
-  VS_TRY(track_ba_batch(ctx, 0, &step));                // the motion-only BA + read-back copy, right behind it
+  VS_TRY(track_ba_batch(ctx, 0, &step, T.n_frames + 1));      // the motion-only BA + read-back copy, right behind it
   T.api_step = step;
   T.api_stage = 2;
   VS_HIP(ctx, hipEventSynchronize(T.ev_api));
