@@ -33,8 +33,6 @@ VS_API int vs_create(vs_ctx** out, int device) {
   for (int i = 0; i < VS_AUX_STREAMS && e == hipSuccess; ++i) e = hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking);
   for (hipEvent_t& ev : ctx->track.ev_front)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-  for (hipEvent_t& ev : ctx->track.ev_back)
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
   if (e != hipSuccess) {
     vs_fail(nullptr, VS_EHIP, "vs_create: %s", hipGetErrorString(e));
     vs_destroy(ctx);
@@ -142,8 +140,6 @@ VS_API int vs_destroy(vs_ctx* ctx) {
   if (ctx->h_api.p) (void)hipHostFree(ctx->h_api.p);
   if (ctx->track.ev_api) (void)hipEventDestroy(ctx->track.ev_api);
   for (hipEvent_t e : ctx->track.ev_front)
-    if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : ctx->track.ev_back)
     if (e) (void)hipEventDestroy(e);
   if (ctx->ev_shard) (void)hipEventDestroy(ctx->ev_shard);
   if (ctx->ev_after) (void)hipEventDestroy(ctx->ev_after);

@@ -119,7 +119,6 @@ struct vs_ctx {
     // stream while the back half (PnP, BA) of frame k runs on the context's stream; two sets of per-frame buffers
     hipStream_t front_stream = nullptr;
     hipEvent_t ev_front[2] = {nullptr, nullptr};
-    hipEvent_t ev_back[2] = {nullptr, nullptr};  // behind the read-back copy of a chained back half (one per buffer set)
     int pending_chained = 0;  // the pending back half was enqueued with its inputs read on the device (see vs_track_frame_pipelined)
     unsigned front_seq = 0, front_tag[2] = {0, 0};  // tags of the front halves (track_append_kernel publishes them on the device)
     unsigned back_seq = 0, back_tag[2] = {0, 0};    // tags of the chained back halves' read-back blocks (track_publish_kernel)

@@ -114,7 +114,7 @@ struct track_layout {
   size_t xyz, mapdesc;
   track_front f[2];  // two sets of per-frame buffers (the synchronous entry point uses set 0 only)
   size_t flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part, H, box, mst, pnp_cam, pnp_res, pnp_inl,
-      push_idx, push_uv, rb_end, front_sync, total;
+      push_idx, push_uv, rb_end, front_sync, init_end, total;
   int cap_obs;
 };
 
@@ -148,16 +148,18 @@ track_layout track_layout_of(int P, int F, int max_kp, int H) {
   L.cam0 = take(sizeof(double) * kCamStride * (size_t)(F + 1));
   L.cam1 = take(sizeof(double) * kCamStride * (size_t)(F + 1));
   L.rb_end = off;
-  L.moX = take(sizeof(double) * 3 * (size_t)L.cap_obs);
-  L.moUV = take(sizeof(double) * 2 * (size_t)L.cap_obs);
+  // initialised by vs_track_begin together with the block above: ONE upload of a host-built image [mst .. init_end)
   L.cam_start = take(sizeof(int) * (size_t)(F + 2));
   L.slot_pose = take(sizeof(int) * (size_t)(F + 1));
+  L.box = take(sizeof(unsigned long long) * 2 * kMoPersistCameras * 8);  // mailboxes of ba_motion_persistent
+  L.front_sync = take(512);  // [0] arrival counter of track_append_kernel, [64] tag of the newest complete front half
+  L.init_end = off;
+  L.moX = take(sizeof(double) * 3 * (size_t)L.cap_obs);
+  L.moUV = take(sizeof(double) * 2 * (size_t)L.cap_obs);
   L.part = take(sizeof(double) * 8 * (size_t)F);
   L.H = take(sizeof(double) * 42 * (size_t)F);
-  L.box = take(sizeof(unsigned long long) * 2 * kMoPersistCameras * 8);  // mailboxes of ba_motion_persistent
   L.pnp_cam = take(sizeof(double) * kPnpModel * (size_t)H);
   L.pnp_inl = take(sizeof(int) * (size_t)(per > 0 ? per : 1));
-  L.front_sync = take(512);  // [0] arrival counter of track_append_kernel, [64] tag of the newest complete front half
   L.push_idx = take(sizeof(int) * (size_t)(per > 0 ? per : 1));
   L.push_uv = take(sizeof(double) * 2 * (size_t)(per > 0 ? per : 1));
   L.total = off;
@@ -365,8 +367,8 @@ ba_dev track_ba_dev(vs_ctx* ctx, int set, int k) {
 }
 
 // enqueues up to one batch of LM launches followed by the read-back copy; returns the number of launches so far
-// chained: the read-back goes to the buffer set's own pinned block and ev_back[set] is recorded behind it (the host waits for
-// that event, not for the stream, which holds the next back half already)
+// chained: the read-back goes to the buffer set's own pinned block through track_publish_kernel, which tags it (the host polls
+// that tag; it cannot wait for the stream, which holds the next back half already)
 int track_ba_batch(vs_ctx* ctx, int set, int* step, int k, bool chained = false) {
   auto& T = ctx->track;
   const track_layout L = layout_of(ctx);
@@ -503,38 +505,39 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   VS_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   auto& T = ctx->track;
+  // the one synchronisation of this call: the staging is free to be rewritten (or reallocated), the buffers are idle
   VS_HIP(ctx, hipStreamSynchronize(T.front_stream));
+  VS_HIP(ctx, hipStreamSynchronize(s));
   const track_layout L = track_layout_of(n_points, max_frames, max_kp, pnp_iterations > 0 ? pnp_iterations : 1);
   VS_TRY(vs_reserve(ctx, &ctx->d_track, L.total));
   const size_t up = L.f[0].fxy;  // [xyz | mapdesc] are uploaded
-  // pinned staging: [control block kPinRb | read-back block | push staging: idx + uv of one frame]
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(std::max(std::max(up, (size_t)1 << 16),
-                                                                  kPinRb + 3 * rb_stride(L) + 256 + 20 * (size_t)n_points),
-                                                         sizeof(int) * (size_t)max_frames + 2048)));
+  const size_t init = L.init_end - L.mst;  // the control image: LM records, flags, both camera buffers, counters, mailboxes
+  // pinned staging: [control block kPinRb | three read-back blocks | push staging: idx + uv of one frame], and at least the
+  // map + the control image of this call
+  const size_t map_at = (kPinRb + 3 * rb_stride(L) + 256 + 20 * (size_t)n_points + 255) & ~(size_t)255;
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_track, std::max(map_at + up + init + 512, (size_t)1 << 16)));
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_api, api_layout_of(n_points, max_kp).total));
   if (!T.ev_api) VS_HIP(ctx, hipEventCreateWithFlags(&T.ev_api, hipEventDisableTiming));
-  VS_HIP(ctx, hipStreamSynchronize(s));
-  uint8_t* h = (uint8_t*)ctx->h_track.p;
+  uint8_t* h = (uint8_t*)ctx->h_track.p + map_at;
   uint8_t* d = (uint8_t*)ctx->d_track.p;
   memcpy(h + L.xyz, xyz, sizeof(double) * 3 * (size_t)n_points);
   memcpy(h + L.mapdesc, desc, 32 * (size_t)n_points);
-  VS_HIP(ctx, hipMemcpyAsync(d, h, up, hipMemcpyHostToDevice, s));
-  VS_HIP(ctx, hipMemsetAsync(d + L.cam_start, 0, sizeof(int) * (size_t)(max_frames + 2), s));
-  VS_HIP(ctx, hipMemsetAsync(d + L.flags, 0, 2 * 4 * sizeof(int), s));
-  VS_HIP(ctx, hipMemsetAsync(d + L.mst, 0, 2 * sizeof(mo_state), s));  // state buffer 0 holds the estimate
-  VS_HIP(ctx, hipMemsetAsync(d + L.front_sync, 0, 512, s));
-  VS_HIP(ctx, hipMemsetAsync(d + L.box, 0, sizeof(unsigned long long) * 2 * kMoPersistCameras * 8, s));
+  // the control image, built here and uploaded with one copy: everything zero (LM records: state buffer 0 holds the
+  // estimate; flags; counters; mailboxes: no word carries a tag) except the key frame's record in both camera buffers and
+  // the slot table (free-camera slot c = pose c + 1, pose 0 is the fixed key frame)
+  uint8_t* hi = h + up;
+  memset(hi, 0, init);
   double rec[kCamStride];
   rec_from_pose(key_pose, rec);
-  VS_HIP(ctx, hipStreamSynchronize(s));  // the pinned mirror is reused below
-  if (sizeof(int) * (size_t)max_frames + 1024 > ctx->h_track.cap) return vs_fail(ctx, VS_ENOMEM, "%s: staging too small", "vs_track_begin");
-  memcpy(h, rec, sizeof rec);
-  int* sp = (int*)(h + 1024);
-  for (int c = 0; c < max_frames; ++c) sp[c] = c + 1;  // free-camera slot c = pose c + 1 (pose 0 is the fixed key frame)
-  VS_HIP(ctx, hipMemcpyAsync(d + L.cam0, h, sizeof rec, hipMemcpyHostToDevice, s));
-  VS_HIP(ctx, hipMemcpyAsync(d + L.cam1, h, sizeof rec, hipMemcpyHostToDevice, s));
-  VS_HIP(ctx, hipMemcpyAsync(d + L.slot_pose, sp, sizeof(int) * (size_t)max_frames, hipMemcpyHostToDevice, s));
-  VS_HIP(ctx, hipStreamSynchronize(s));
+  memcpy(hi + (L.cam0 - L.mst), rec, sizeof rec);
+  memcpy(hi + (L.cam1 - L.mst), rec, sizeof rec);
+  int* sp = (int*)(hi + (L.slot_pose - L.mst));
+  for (int c = 0; c < max_frames; ++c) sp[c] = c + 1;
+  VS_HIP(ctx, hipMemcpyAsync(d, h, up, hipMemcpyHostToDevice, s));
+  VS_HIP(ctx, hipMemcpyAsync(d + L.mst, hi, init, hipMemcpyHostToDevice, s));
+  // no wait here: the frames' back halves run on this stream, and the front halves' stream is ordered behind the uploads
+  VS_HIP(ctx, hipEventRecord(T.ev_api, s));
+  VS_HIP(ctx, hipStreamWaitEvent(T.front_stream, T.ev_api, 0));
   T.active = 1;
   T.n_points = n_points;
   T.cap_frames = max_frames;
