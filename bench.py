@@ -322,6 +322,27 @@ def ba_leg(ctx, cpu=True):
     return out
 
 
+def ba_scaled_leg(ctx):
+    """SURVEY 8d's scaled bundle adjustment (not a BASELINE config): 100 cameras x 200 000 points, 2 000 000 residuals, a
+    banded 594 x 594 reduced system, 3 LM iterations -- the BA size at which bytes move.  Observation arrays in pinned memory."""
+    from visual_slam_amd.workloads import ba_sliding_window_workload
+    w = ba_sliding_window_workload()
+    for k in ("obs_pose", "obs_point", "obs_uv"):
+        w[k] = ctx.pin(np.ascontiguousarray(w[k]))
+    args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
+    g = ctx.ba_solve(*args, max_iterations=3)
+    med, ts = median_time(lambda: ctx.ba_solve(*args, max_iterations=3), 7, warm=1)
+    n_res, trials = len(w["obs_pose"]), max(int(g["trials"]), 1)
+    return {"workload": "SURVEY 8d: 100 cameras x 200000 points, sliding window of 10, 2000000 residuals, 3 LM iterations",
+            "ms_per_solve": med * 1e3, "ms_per_solve_min": min(ts) * 1e3, "repetitions": len(ts), "statistic": "median",
+            "lm_trials": trials, "mresiduals_per_s": n_res * trials / med / 1e6,
+            "hbm_GBps_at_178B_per_residual": 178.0 * n_res * trials / med / 1e9,
+            "chi2": [float(g["chi2_initial"]), float(g["chi2_final"])],
+            "note": "whole vs_ba_solve call: host structure passes (worker pool) + upload + kernels (banded Schur complement "
+                    "on the FP64 matrix cores, banded Cholesky in one launch) + read-back; checked against the CPU oracle by "
+                    "tools/ba_scaled.py --check (profiles/r03_ba_scaled.log)"}
+
+
 def frames_leg(ctx, cpu=True):
     """frames/s of the 640x480 ICL-NUIM stream (detect+describe -> match -> PnP-RANSAC -> motion-only BA), GPU path and -- as the
     checker/baseline only -- the CPU oracle through the same harness.  GPU legs: medians of 20 repetitions (minima
@@ -727,6 +748,10 @@ def main():
                     "launch_floor_us_per_trial": lb["launch_floor_us_per_trial"]}
             except Exception as e:
                 line["local_ba"] = {"error": repr(e)}
+            try:
+                line["local_ba_scaled"] = ba_scaled_leg(ctx)
+            except Exception as e:
+                line["local_ba_scaled"] = {"error": repr(e)}
         if not args.no_frames:
             try:
                 line["frames"] = frames_leg(ctx, cpu=cpu)

@@ -10,33 +10,11 @@ import time
 
 import numpy as np
 
-from visual_slam_amd.workloads import ICL_NUIM_K  # noqa: E402
+from visual_slam_amd.workloads import ICL_NUIM_K, ba_sliding_window_workload  # noqa: E402,F401
 
 
 def scene(n_cams, n_points, window, seed=3):
-    """cameras on a straight 0.1 m-spaced track looking down +z, points 2.5-5.5 m ahead; point j is observed by `window`
-    consecutive cameras starting at a random one (sliding-window visibility as key-frame BA has it)."""
-    r = np.random.default_rng(seed)
-    fx, fy, cx, cy = ICL_NUIM_K
-    poses = np.tile(np.eye(4), (n_cams, 1, 1))
-    poses[:, 0, 3] = 0.1 * np.arange(n_cams)
-    start = r.integers(0, n_cams - window + 1, n_points)
-    centre = 0.1 * (start + window / 2)
-    pts = np.stack([centre + r.uniform(-1.0, 1.0, n_points), r.uniform(-1.2, 1.2, n_points), r.uniform(2.5, 5.5, n_points)], 1)
-    cam = (start[:, None] + np.arange(window)[None, :]).astype(np.int32)            # [P, window]
-    pt = np.repeat(np.arange(n_points, dtype=np.int32)[:, None], window, 1)
-    pc = pts[pt.ravel()] - poses[cam.ravel(), :3, 3]
-    uv = np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy], 1)
-    uv += r.normal(0, 0.5, uv.shape)
-    bad = r.random(len(uv)) < 0.02
-    uv[bad] += r.uniform(-50, 50, (int(bad.sum()), 2))
-    poses0 = poses.copy()
-    poses0[1:, :3, 3] += r.normal(0, 0.01, (n_cams - 1, 3))
-    pts0 = pts + r.normal(0, 0.03, pts.shape)
-    fixed = np.zeros(n_cams, np.uint8)
-    fixed[0] = 1
-    return dict(poses=poses0, pose_fixed=fixed, points=pts0, point_fixed=np.zeros(n_points, np.uint8),
-                obs_pose=cam.ravel(), obs_point=pt.ravel(), obs_uv=uv, K=ICL_NUIM_K)
+    return ba_sliding_window_workload(n_cams, n_points, window, seed)
 
 
 def main():

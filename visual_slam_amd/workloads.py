@@ -113,3 +113,30 @@ def ba_workload(n_cams=10, n_points=2000, seed=3, noise_px=0.5, outlier_frac=0.0
     return dict(poses=poses0, pose_fixed=pose_fixed, points=pts0, point_fixed=np.zeros(n_points, np.uint8),
                 obs_pose=obs_pose, obs_point=obs_point, obs_uv=obs_uv, K=K, poses_gt=poses, points_gt=pts,
                 obs_uv_gt=obs_uv_gt)
+
+
+def ba_sliding_window_workload(n_cams=100, n_points=200000, window=10, seed=3):
+    """SURVEY 8d's scaled bundle adjustment: cameras on a straight 0.1 m-spaced track looking down +z, points 2.5-5.5 m
+    ahead; point j is observed by `window` consecutive cameras starting at a random one -- the co-visibility key-frame BA
+    has (a banded reduced camera system).  0.5 px noise, 2 % gross outliers, camera 0 fixed.  Observations grouped by point."""
+    r = np.random.default_rng(seed)
+    fx, fy, cx, cy = ICL_NUIM_K
+    poses = np.tile(np.eye(4), (n_cams, 1, 1))
+    poses[:, 0, 3] = 0.1 * np.arange(n_cams)
+    start = r.integers(0, n_cams - window + 1, n_points)
+    centre = 0.1 * (start + window / 2)
+    pts = np.stack([centre + r.uniform(-1.0, 1.0, n_points), r.uniform(-1.2, 1.2, n_points), r.uniform(2.5, 5.5, n_points)], 1)
+    cam = (start[:, None] + np.arange(window)[None, :]).astype(np.int32)            # [P, window]
+    pt = np.repeat(np.arange(n_points, dtype=np.int32)[:, None], window, 1)
+    pc = pts[pt.ravel()] - poses[cam.ravel(), :3, 3]
+    uv = np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy], 1)
+    uv += r.normal(0, 0.5, uv.shape)
+    bad = r.random(len(uv)) < 0.02
+    uv[bad] += r.uniform(-50, 50, (int(bad.sum()), 2))
+    poses0 = poses.copy()
+    poses0[1:, :3, 3] += r.normal(0, 0.01, (n_cams - 1, 3))
+    pts0 = pts + r.normal(0, 0.03, pts.shape)
+    fixed = np.zeros(n_cams, np.uint8)
+    fixed[0] = 1
+    return dict(poses=poses0, pose_fixed=fixed, points=pts0, point_fixed=np.zeros(n_points, np.uint8),
+                obs_pose=cam.ravel(), obs_point=pt.ravel(), obs_uv=uv, K=ICL_NUIM_K, poses_gt=poses)
