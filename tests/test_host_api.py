@@ -62,6 +62,43 @@ def test_matchlist_behaves_like_the_reference_list():
         ml[2]
 
 
+def test_match_rows_built_in_c_equal_the_python_stand_in():
+    """frame.py takes DMatch / rows() from visual_slam_amd._rows (CPython C API, compiled by build()) and falls back to its
+    Python classes; both must hand out the same list of one-element lists with the same field values and repr."""
+    from visual_slam_amd import frame as fr
+    _rows = pytest.importorskip("visual_slam_amd._rows")
+    r = np.random.default_rng(3)
+    q, t, d = (r.integers(0, 5000, 400).astype(np.int32) for _ in range(3))
+    a, b = _rows.rows(q, t, d), fr._py_rows(q, t, d)
+    assert fr.DMatch is _rows.DMatch and len(a) == len(b) == 400 and all(len(x) == 1 for x in a)
+    for x, y in zip(a, b):
+        assert (x[0].queryIdx, x[0].trainIdx, x[0].imgIdx, x[0].distance) == (y[0].queryIdx, y[0].trainIdx, y[0].imgIdx, y[0].distance)
+        assert repr(x[0]) == repr(y[0]) and isinstance(x[0].distance, float) and isinstance(x[0].queryIdx, int)
+    assert _rows.rows(q[:0], t[:0], d[:0]) == []
+    with pytest.raises(ValueError):
+        _rows.rows(q, t[:-1], d)
+    m = _rows.DMatch(queryIdx=3, trainIdx=4, distance=2.5)
+    assert (m.queryIdx, m.trainIdx, m.imgIdx, m.distance) == (3, 4, 0, 2.5)
+    ml = MatchList(q, t, d)
+    assert [m[0].trainIdx for m in ml] == t.tolist() and next(iter(ml)) is next(iter(ml))  # a real list underneath
+
+
+def test_rotation_vector_helpers_round_trip():
+    """Rtorvec / transformMatrix (helper_functions.py:269-278) in plain float arithmetic: against scipy over small, ordinary
+    and near-pi rotations; the 4x4 keeps the reference's np.matrix type."""
+    from scipy.spatial.transform import Rotation
+    from visual_slam_amd import helper_functions as hf
+    r = np.random.default_rng(0)
+    for _ in range(300):
+        v = r.normal(size=3) * r.choice([1e-9, 1e-3, 0.5, 3.1])
+        Rm = Rotation.from_rotvec(v).as_matrix()
+        T = hf.transformMatrix(v.reshape(3, 1), [1, 2, 3])
+        assert isinstance(T, np.matrix) and np.abs(np.asarray(T)[:3, :3] - Rm).max() < 1e-14
+        assert np.asarray(T)[:3, 3].tolist() == [1, 2, 3] and np.asarray(T)[3].tolist() == [0, 0, 0, 1]
+        rv = hf.Rtorvec(Rm)
+        assert rv.shape == (3, 1) and np.abs(Rotation.from_rotvec(rv.ravel()).as_matrix() - Rm).max() < 1e-13
+
+
 def test_isometry_helpers():
     R = np.array([[0.0, -1, 0], [1, 0, 0], [0, 0, 1]])
     T = Isometry3d(R, np.array([1.0, 2, 3]))

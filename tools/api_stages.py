@@ -74,6 +74,25 @@ def run():
         t = lap("motionOnlyBundleAdjustement (rest of the BA)", t)
 
 
+def timed(obj, name, label):
+    f = getattr(obj, name)
+
+    def g(*a, **k):
+        t0 = time.perf_counter()
+        try:
+            return f(*a, **k)
+        finally:
+            acc[label] = acc.get(label, 0.0) + (time.perf_counter() - t0)
+    setattr(obj, name, g)
+
+
+timed(ctx, "track_back_end", "  (inside: ctx.track_back_end)")
+timed(ctx, "track_back_begin", "  (inside: ctx.track_back_begin)")
+timed(ctx, "track_front", "  (inside: ctx.track_front)")
+from visual_slam_amd import map as _map  # noqa: E402
+timed(_map._PeriodMirror, "solve", "  (inside: _PeriodMirror.solve incl. track_back_end)")
+timed(_map._PeriodMirror, "speculate_back", "  (inside: _PeriodMirror.speculate_back incl. track_back_begin)")
+timed(_map._PeriodMirror, "speculate_front", "  (inside: _PeriodMirror.speculate_front incl. track_front)")
 for _ in range(3):
     run()
 acc.clear()

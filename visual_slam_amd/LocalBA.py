@@ -300,11 +300,12 @@ class BundleAdjustment:
             if poses is not None:
                 self._pose_ids = {fid: i for i, fid in enumerate(frame_ids)}
                 self.result = {"poses": poses, "points": None}
-                dev = map._dev
-                for i, frame_id in enumerate(frame_ids):
-                    new_pose = np.array(poses[i])
-                    map.UpdatePose(new_pose=new_pose, frame_id=frame_id)
-                    dev.wrote(frame_id, new_pose)
+                # every frame gets its own 4x4 (rows of one fresh copy: distinct memory, so an in-place edit of one pose by
+                # the caller touches no other); the mirror remembers which objects it wrote to recognise later edits
+                views = list(np.array(poses))
+                for f, new_pose in zip(map.frames.values(), views):
+                    f.UpdatePose(new_pose)
+                map._dev.written.update(zip(frame_ids, views))
                 return
         self._graph_from_soa(map, lambda fid_, f_: bool(f_.IsKeyFrame()), points_fixed=True, with_scale_edges=False)
         self.optimize()

@@ -1,0 +1,115 @@
+/* Host-side helper of the class API (CPython C API, no GPU): the Python objects the reference's tracking loop iterates
+ * over, built in C.
+ *
+ * `matches` is a list of one-element lists [[cv2.DMatch], ...] in the reference (src/v2/frame.py:33-47), and main.py
+ * walks it per frame (`[point_ids[m[0].queryIdx] for m in matches]`, main.py:187-188,210).  With ~420 matches per frame that
+ * is ~850 objects per frame; created from Python (tuple subclass + property(itemgetter)) they cost 130 us per frame of the
+ * class-API period -- more than the GPU's PnP.  Here: a DMatch type with C member descriptors and `rows()`, which builds
+ * the whole list of lists from the three int32 arrays in one call.  frame.py falls back to its Python classes if this
+ * module was not built. */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+#include <structmember.h>
+
+typedef struct {
+  PyObject_HEAD
+  int queryIdx, trainIdx, imgIdx;
+  double distance;
+} DMatchObject;
+
+static PyTypeObject DMatchType;
+
+static PyObject* dmatch_new(PyTypeObject* type, PyObject* args, PyObject* kw) {
+  static char* names[] = {"queryIdx", "trainIdx", "distance", "imgIdx", NULL};
+  int q = 0, t = 0, img = 0;
+  double d = 0.0;
+  if (!PyArg_ParseTupleAndKeywords(args, kw, "|iidi", names, &q, &t, &d, &img)) return NULL;
+  DMatchObject* m = (DMatchObject*)type->tp_alloc(type, 0);
+  if (!m) return NULL;
+  m->queryIdx = q;
+  m->trainIdx = t;
+  m->imgIdx = img;
+  m->distance = d;
+  return (PyObject*)m;
+}
+
+static PyObject* dmatch_repr(DMatchObject* m) {
+  char buf[128];
+  PyOS_snprintf(buf, sizeof buf, "DMatch(queryIdx=%d, trainIdx=%d, distance=%g)", m->queryIdx, m->trainIdx, m->distance);
+  return PyUnicode_FromString(buf);
+}
+
+static PyMemberDef dmatch_members[] = {
+    {"queryIdx", T_INT, offsetof(DMatchObject, queryIdx), 0, "index into the query (first) descriptor set"},
+    {"trainIdx", T_INT, offsetof(DMatchObject, trainIdx), 0, "index into the train (second) descriptor set"},
+    {"imgIdx", T_INT, offsetof(DMatchObject, imgIdx), 0, "train image index (always 0 here)"},
+    {"distance", T_DOUBLE, offsetof(DMatchObject, distance), 0, "Hamming distance"},
+    {NULL, 0, 0, 0, NULL}};
+
+static PyTypeObject DMatchType = {
+    PyVarObject_HEAD_INIT(NULL, 0).tp_name = "visual_slam_amd._rows.DMatch",
+    .tp_basicsize = sizeof(DMatchObject),
+    .tp_flags = Py_TPFLAGS_DEFAULT,
+    .tp_doc = "The fields of cv2.DMatch the reference reads: queryIdx, trainIdx, imgIdx, distance.",
+    .tp_new = dmatch_new,
+    .tp_repr = (reprfunc)dmatch_repr,
+    .tp_members = dmatch_members,
+};
+
+/* rows(query_idx, train_idx, distance) -> [[DMatch], ...]; the arguments are C-contiguous int32 buffers of one length */
+static PyObject* rows(PyObject* self, PyObject* args) {
+  Py_buffer bq, bt, bd;
+  if (!PyArg_ParseTuple(args, "y*y*y*", &bq, &bt, &bd)) return NULL;
+  PyObject* out = NULL;
+  if (bq.len != bt.len || bq.len != bd.len || bq.len % 4 != 0) {
+    PyErr_SetString(PyExc_ValueError, "rows: three int32 buffers of one length expected");
+    goto done;
+  }
+  {
+    const Py_ssize_t n = bq.len / 4;
+    const int32_t* q = (const int32_t*)bq.buf;
+    const int32_t* t = (const int32_t*)bt.buf;
+    const int32_t* d = (const int32_t*)bd.buf;
+    out = PyList_New(n);
+    if (!out) goto done;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+      DMatchObject* m = PyObject_New(DMatchObject, &DMatchType);
+      PyObject* inner = m ? PyList_New(1) : NULL;
+      if (!inner) {
+        Py_XDECREF((PyObject*)m);
+        Py_CLEAR(out);
+        goto done;
+      }
+      m->queryIdx = q[i];
+      m->trainIdx = t[i];
+      m->imgIdx = 0;
+      m->distance = (double)d[i];
+      PyList_SET_ITEM(inner, 0, (PyObject*)m);
+      PyList_SET_ITEM(out, i, inner);
+    }
+  }
+done:
+  PyBuffer_Release(&bq);
+  PyBuffer_Release(&bt);
+  PyBuffer_Release(&bd);
+  return out;
+}
+
+static PyMethodDef methods[] = {{"rows", rows, METH_VARARGS, "rows(query_idx, train_idx, distance: int32 buffers) -> [[DMatch], ...]"},
+                                {NULL, NULL, 0, NULL}};
+
+static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_rows", "match rows of the class API, built in C (no GPU)", -1, methods};
+
+PyMODINIT_FUNC PyInit__rows(void) {
+  if (PyType_Ready(&DMatchType) < 0) return NULL;
+  PyObject* m = PyModule_Create(&module);
+  if (!m) return NULL;
+  Py_INCREF(&DMatchType);
+  if (PyModule_AddObject(m, "DMatch", (PyObject*)&DMatchType) < 0) {
+    Py_DECREF(&DMatchType);
+    Py_DECREF(m);
+    return NULL;
+  }
+  return m;
+}

@@ -29,10 +29,10 @@ def imread(path):
         return None
 
 
-class DMatch(tuple):
+class _PyDMatch(tuple):
     """The fields of cv2.DMatch the reference reads (frame.py:33-47, main.py:187-188,210): queryIdx, trainIdx, imgIdx,
-    distance.  A tuple underneath (read-only fields): the tracking loop builds one per match per frame, and a tuple with
-    C-level accessors is created and read at twice the speed of an object with Python-level attributes."""
+    distance.  Pure-Python stand-in for visual_slam_amd._rows.DMatch (the C type build() compiles): a tuple underneath
+    with C-level accessors."""
     __slots__ = ()
     queryIdx = property(_itemgetter(0))
     trainIdx = property(_itemgetter(1))
@@ -46,7 +46,16 @@ class DMatch(tuple):
         return "DMatch(queryIdx=%d, trainIdx=%d, distance=%g)" % (self[0], self[1], self[3])
 
 
-_dmatch_from_row = _partial(tuple.__new__, DMatch)  # (queryIdx, trainIdx, imgIdx, distance) -> DMatch, no Python frame
+def _py_rows(query_idx, train_idx, distance):
+    n = len(query_idx)
+    rows = zip(query_idx.tolist(), train_idx.tolist(), [0] * n, distance.astype(np.float64).tolist())
+    return [[m] for m in map(_partial(tuple.__new__, _PyDMatch), rows)]
+
+
+try:  # the match rows built in C (visual_slam_amd/cext/_rows.c): 130 -> ~40 us per frame of the class-API tracking loop
+    from ._rows import DMatch, rows as _match_rows
+except ImportError:  # not built (a source checkout before __graft_entry__.build()): same behaviour, slower
+    DMatch, _match_rows = _PyDMatch, _py_rows
 
 
 class MatchList(Sequence):
@@ -55,19 +64,20 @@ class MatchList(Sequence):
     array consumers can use .query_idx / .train_idx / .distance directly and skip the Python objects."""
 
     def __init__(self, query_idx, train_idx, distance):
-        self.query_idx = np.asarray(query_idx, np.int32)
-        self.train_idx = np.asarray(train_idx, np.int32)
-        self.distance = np.asarray(distance, np.int32)
+        self.query_idx = np.ascontiguousarray(query_idx, np.int32)
+        self.train_idx = np.ascontiguousarray(train_idx, np.int32)
+        self.distance = np.ascontiguousarray(distance, np.int32)
+        self._rows = None
 
     def __len__(self):
         return int(self.query_idx.shape[0])
 
     def __iter__(self):
         # the reference's callers iterate `for m in matches: m[0].queryIdx` (main.py:187-188,210): all rows are built in one
-        # pass from plain Python scalars (no NumPy scalar conversion per attribute, no Python-level constructor per match)
-        n = len(self)
-        rows = zip(self.query_idx.tolist(), self.train_idx.tolist(), [0] * n, self.distance.astype(np.float64).tolist())
-        return iter([[m] for m in map(_dmatch_from_row, rows)])
+        # call, once (the reference's `matches` is a real list: iterating it twice yields the same objects)
+        if self._rows is None:
+            self._rows = _match_rows(self.query_idx, self.train_idx, self.distance)
+        return iter(self._rows)
 
     def __getitem__(self, i):
         if isinstance(i, slice):
@@ -76,7 +86,9 @@ class MatchList(Sequence):
             i += len(self)
         if not 0 <= i < len(self):
             raise IndexError(i)
-        return [DMatch(self.query_idx[i], self.train_idx[i], self.distance[i])]
+        if self._rows is not None:
+            return self._rows[i]
+        return [DMatch(int(self.query_idx[i]), int(self.train_idx[i]), float(self.distance[i]))]
 
 
 class FeatureExtractor:

@@ -4,6 +4,8 @@ triangulate() runs on the GPU (vs_triangulate_dlt); the rest are the reference's
 key-frame code of main.py:237-318 finds the names it imports.  RANSAC geometry (estimateEssential, estimateHomography,
 estimateRelativePose: cv2.findEssentialMat / recoverPose) is out of scope this round.
 """
+import math as _math
+
 import numpy as np
 
 from .context import default_context
@@ -62,48 +64,61 @@ def GetListDiff(kp1, kp2):
     return np.nonzero(~np.isin(a, b))[0].tolist()
 
 
-def Rtorvec(R):
-    """helper_functions.py:276-278 (cv2.Rodrigues(R)[0]): rotation matrix -> rotation vector [3,1].
-    Through the unit quaternion (largest-component branch, as Eigen / scipy do): accurate near 0 and near pi."""
-    m = np.asarray(R, np.float64)
-    m00, m11, m22 = m[0, 0], m[1, 1], m[2, 2]
-    tr = m00 + m11 + m22
-    if tr > 0.0:
-        s = np.sqrt(tr + 1.0) * 2.0
-        w, x, y, z = 0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s
-    elif m00 > m11 and m00 > m22:
-        s = np.sqrt(1.0 + m00 - m11 - m22) * 2.0
-        w, x, y, z = (m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s
-    elif m11 > m22:
-        s = np.sqrt(1.0 + m11 - m00 - m22) * 2.0
-        w, x, y, z = (m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s
-    else:
-        s = np.sqrt(1.0 + m22 - m00 - m11) * 2.0
-        w, x, y, z = (m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s
+def _quat_to_rvec(w, x, y, z):
     if w < 0.0:
         w, x, y, z = -w, -x, -y, -z
-    n = np.sqrt(x * x + y * y + z * z)
-    if n < 1e-12:
-        k = 2.0  # angle / sin(angle / 2) -> 2 for small angles
+    n = _math.sqrt(x * x + y * y + z * z)
+    k = 2.0 if n < 1e-12 else 2.0 * _math.atan2(n, w) / n  # angle / sin(angle / 2) -> 2 for small angles
+    return k * x, k * y, k * z
+
+
+def _rvec_of_rows(m):
+    """rotation matrix as nested lists of Python floats -> rotation vector (x, y, z).  Through the unit quaternion
+    (largest-component branch, as Eigen / scipy do): accurate near 0 and near pi.  Plain float arithmetic: the tracking
+    loop calls this twice per frame, and NumPy scalars cost a microsecond per operation."""
+    (m00, m01, m02), (m10, m11, m12), (m20, m21, m22) = m
+    tr = m00 + m11 + m22
+    if tr > 0.0:
+        s = _math.sqrt(tr + 1.0) * 2.0
+        return _quat_to_rvec(0.25 * s, (m21 - m12) / s, (m02 - m20) / s, (m10 - m01) / s)
+    if m00 > m11 and m00 > m22:
+        s = _math.sqrt(1.0 + m00 - m11 - m22) * 2.0
+        return _quat_to_rvec((m21 - m12) / s, 0.25 * s, (m01 + m10) / s, (m02 + m20) / s)
+    if m11 > m22:
+        s = _math.sqrt(1.0 + m11 - m00 - m22) * 2.0
+        return _quat_to_rvec((m02 - m20) / s, (m01 + m10) / s, 0.25 * s, (m12 + m21) / s)
+    s = _math.sqrt(1.0 + m22 - m00 - m11) * 2.0
+    return _quat_to_rvec((m10 - m01) / s, (m02 + m20) / s, (m12 + m21) / s, 0.25 * s)
+
+
+def Rtorvec(R):
+    """helper_functions.py:276-278 (cv2.Rodrigues(R)[0]): rotation matrix -> rotation vector [3,1]."""
+    x, y, z = _rvec_of_rows(np.asarray(R, np.float64).reshape(3, 3).tolist())
+    return np.array([[x], [y], [z]])
+
+
+def _rodrigues_rows(x, y, z):
+    """rotation vector -> rotation matrix rows (Python floats): I + a K + b K^2, K^2 = r r^T - |r|^2 I."""
+    th2 = x * x + y * y + z * z
+    th = _math.sqrt(th2)
+    if th < 1e-12:
+        a, b = 1.0, 0.5  # sin(th)/th, (1 - cos(th))/th^2
     else:
-        k = 2.0 * np.arctan2(n, w) / n
-    return np.array([[k * x], [k * y], [k * z]])
+        a, b = _math.sin(th) / th, (1.0 - _math.cos(th)) / th2
+    ax, ay, az = a * x, a * y, a * z
+    bxy, bxz, byz = b * x * y, b * x * z, b * y * z
+    return ([1.0 - b * (y * y + z * z), bxy - az, bxz + ay],
+            [bxy + az, 1.0 - b * (x * x + z * z), byz - ax],
+            [bxz - ay, byz + ax, 1.0 - b * (x * x + y * y)])
 
 
 def transformMatrix(rvec, tvec):
     """helper_functions.py:269-274: 4x4 from a rotation vector (Rodrigues) and a translation."""
-    r = np.asarray(rvec, np.float64).reshape(3)
-    th = np.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2])
-    T = np.eye(4)
-    if th < 1e-12:
-        a, b = 1.0, 0.5  # sin(th)/th, (1 - cos(th))/th^2
-    else:
-        a, b = np.sin(th) / th, (1.0 - np.cos(th)) / (th * th)
-    x, y, z = r
-    Kx = np.array([[0.0, -z, y], [z, 0.0, -x], [-y, x, 0.0]])
-    T[:3, :3] += a * Kx + b * (Kx @ Kx)
-    T[:3, 3] = np.asarray(tvec, np.float64).reshape(3)
-    return np.matrix(T)  # the reference returns np.matrix (main.py:202 slices it and squeezes with np.asarray)
+    x, y, z = np.asarray(rvec, np.float64).reshape(3).tolist()
+    tx, ty, tz = np.asarray(tvec, np.float64).reshape(3).tolist()
+    r0, r1, r2 = _rodrigues_rows(x, y, z)
+    # the reference returns np.matrix (main.py:202 slices it and squeezes with np.asarray)
+    return np.array([r0 + [tx], r1 + [ty], r2 + [tz], [0.0, 0.0, 0.0, 1.0]]).view(np.matrix)
 
 
 def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rvec=None, tvec=None,
@@ -122,12 +137,13 @@ def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rve
     Kmat = np.asarray(cameraMatrix, np.float64)
     K4 = (Kmat[0, 0], Kmat[1, 1], Kmat[0, 2], Kmat[1, 2])
     if useExtrinsicGuess and rvec is not None and tvec is not None:
-        c_T_w = np.asarray(transformMatrix(rvec, np.asarray(tvec, np.float64).reshape(3, 1)))
+        x, y, z = np.asarray(rvec, np.float64).reshape(3).tolist()
+        tx, ty, tz = np.asarray(tvec, np.float64).reshape(3).tolist()
+        (a, b, c), (d, e, f), (g, h, i) = _rodrigues_rows(x, y, z)  # world-to-camera rotation; the pose is its inverse
+        pose0 = np.array([[a, d, g, -(a * tx + d * ty + g * tz)], [b, e, h, -(b * tx + e * ty + h * tz)],
+                          [c, f, i, -(c * tx + f * ty + i * tz)], [0.0, 0.0, 0.0, 1.0]])
     else:
-        c_T_w = np.eye(4)
-    pose0 = np.eye(4)
-    pose0[:3, :3] = c_T_w[:3, :3].T
-    pose0[:3, 3] = -c_T_w[:3, :3].T @ c_T_w[:3, 3]
+        pose0 = np.eye(4)
     r = None
     if solver is None:
         ctx = context or default_context()
@@ -141,10 +157,10 @@ def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs=None, rve
         run = solver or (context or default_context()).pnp_ransac
         r = run(obj, img, K4, pose0, iterations=int(iterationsCount), reproj_err=float(reprojectionError),
                 confidence=float(confidence), seed=int(seed))
-    w_T_c = r["pose"]
-    R = w_T_c[:3, :3].T
-    t = -R @ w_T_c[:3, 3]
-    return bool(r["found"]), Rtorvec(R), t.reshape(3, 1), r["inliers"].astype(np.int32).reshape(-1, 1)
+    (a, b, c, px), (d, e, f, py), (g, h, i, pz) = np.asarray(r["pose"], np.float64)[:3].tolist()  # camera-to-world
+    x, y, z = _rvec_of_rows([[a, d, g], [b, e, h], [c, f, i]])                                       # ... inverted
+    tvec_out = np.array([[-(a * px + d * py + g * pz)], [-(b * px + e * py + h * pz)], [-(c * px + f * py + i * pz)]])
+    return bool(r["found"]), np.array([[x], [y], [z]]), tvec_out, r["inliers"].astype(np.int32).reshape(-1, 1)
 
 
 def _normalise(pts, K):

@@ -39,6 +39,7 @@ class _SoA:
         self.xyz_refs = []        # the location_3d object mirrored in each xyz row (identity check)
         self.batches = []         # chronological log of add_obs calls: (frame id or None for mixed ids, first row, rows)
         self.fid_rows = {}        # frame id -> number of observation rows carrying it
+        self.batch_data = []      # per batch: (slot int32[k], uv [k,2]) as they arrived (no concatenation needed to read one)
 
     def add_point(self, point_id, location):
         slot = self.n_points
@@ -66,8 +67,8 @@ class _SoA:
                     desc = None
             except (ValueError, TypeError):
                 desc = None
-        if not isinstance(frame_id, np.ndarray) and not np.isscalar(frame_id) and len(frame_id) == k and all(
-                f == frame_id[0] for f in frame_id):
+        if not isinstance(frame_id, np.ndarray) and not np.isscalar(frame_id) and len(frame_id) == k and (
+                frame_id.count(frame_id[0]) == k if isinstance(frame_id, list) else all(f == frame_id[0] for f in frame_id)):
             frame_id = frame_id[0]  # one id repeated (a point entering the map with its first observation)
         if np.ndim(frame_id) == 0:
             fids = np.full(k, frame_id, np.int64)
@@ -78,7 +79,9 @@ class _SoA:
             self.batches.append((None, self.n_obs, k))
             for f in fids.tolist():
                 self.fid_rows[f] = self.fid_rows.get(f, 0) + 1
-        self._chunks.append((np.asarray(slots, np.int32), fids, uv, desc))
+        slots = np.asarray(slots, np.int32)
+        self._chunks.append((slots, fids, uv, desc))
+        self.batch_data.append((slots, uv))
         self._cat = None
         self.n_obs += k
 
@@ -136,6 +139,7 @@ class _PeriodMirror:
         self.xyz = None
         self.spec = None
         self.unused = 0        # front halves nobody followed up on (then no more are attempted for this map)
+        self._bidx = None      # index over the mirror's batch log (see solve)
         self.last_pose = None
 
     kMaxKeypoints = 3000  # FeatureExtractor's default; an extractor with another cap takes the plain path
@@ -222,18 +226,30 @@ class _PeriodMirror:
         ids = [fid for fid, _ in frames[1:]]
         if len(set(ids)) != len(ids) or key_id in ids:
             return None
-        # which batches belong to which free frame: exactly one scalar-id batch per frame, none with mixed ids
-        free = set(ids)
+        # which batches belong to which free frame: exactly one scalar-id batch per frame, none with mixed ids.  The batch
+        # log of a mirror only grows, so the index over it is kept between calls and extended by the new entries.
+        bc = self._bidx
+        if bc is None or bc[0] != soa.gen or bc[1] > len(soa.batches):
+            bc = self._bidx = [soa.gen, 0, {}, set()]  # mirror generation, batches indexed, fid -> [(b, first, k)], ids in mixed batches
+        if bc[1] < len(soa.batches):
+            by_fid, mixed = bc[2], bc[3]
+            for b in range(bc[1], len(soa.batches)):
+                fid, first, k = soa.batches[b]
+                if fid is None:
+                    _, bf, _, _ = soa.arrays()
+                    mixed.update(np.unique(bf[first:first + k]).tolist())
+                else:
+                    by_fid.setdefault(fid, []).append((b, first, k))
+            bc[1] = len(soa.batches)
+        if bc[3] and not bc[3].isdisjoint(ids):
+            return None
         rows = {}
-        for b, (fid, first, k) in enumerate(soa.batches):
-            if fid is None:
-                _, bf, _, _ = soa.arrays()
-                if free.intersection(np.unique(bf[first:first + k]).tolist()):
+        for fid in ids:
+            got = bc[2].get(fid)
+            if got is not None:
+                if len(got) > 1:
                     return None
-            elif fid in free:
-                if fid in rows:
-                    return None
-                rows[fid] = (b, first, k)
+                rows[fid] = got[0]
         state = (id(map_.points_3d), P, map_._cell[0], map_._cell[1], key_id)
         fresh = (getattr(ctx, "_track_owner", None) is not self or ctx._track is None or self.state is None
                  or self.state[:5] != state or not np.array_equal(self.state[5], np.asarray(key_frame.GetPose(), np.float64))
@@ -258,8 +274,7 @@ class _PeriodMirror:
                 fid, f = todo[0]
                 b = rows.get(fid)
                 if b is not None and b[0] >= self.consumed and b[2] == len(sp["match_q"]):
-                    slot_, _, uv_, _ = soa.arrays()
-                    sl, obs = slot_[b[1]:b[1] + b[2]], uv_[b[1]:b[1] + b[2]]
+                    sl, obs = soa.batch_data[b[0]]
                     if (np.array_equal(sl, sp["match_q"]) and np.array_equal(obs, sp["xy"][sp["match_t"]])
                             and float(np.abs(np.asarray(f.GetPose(), np.float64) - sp["pnp"]["pose"]).max()) <= 1e-9):
                         poses = ctx.track_back_end()
@@ -278,7 +293,6 @@ class _PeriodMirror:
             while cap < len(ids) + 8:
                 cap *= 2
             self._begin(map_, soa, key_id, key_frame, cap)
-        slot, _, uv, _ = soa.arrays()
         poses = None
         todo = frames[1 + len(self.pushed):]
         if not todo:  # nothing new: re-run the solve on the last frame's state is not expressible -> general path
@@ -288,7 +302,8 @@ class _PeriodMirror:
             if b is None:
                 sl, obs = np.zeros(0, np.int32), np.zeros((0, 2))
             else:
-                sl, obs = slot[b[1]:b[1] + b[2]], np.asarray(uv[b[1]:b[1] + b[2]], np.float64)
+                sl, obs = soa.batch_data[b[0]]
+                obs = np.asarray(obs, np.float64)
                 if sl.size > 1 and not np.all(sl[1:] >= sl[:-1]):  # per-camera order of the general path: point-major
                     order = np.argsort(sl, kind="stable")
                     sl, obs = sl[order], obs[order]
@@ -461,16 +476,52 @@ class Map:
                 and self._soa_cell[0] + len(added) == c[0] and self._soa_cell[1] == c[1]
                 and all(hasattr(p, "_frames") for _, p in added)):
             return  # something else happened in between: soa() verifies and rebuilds
-        slots, fids, uvs, descs = [], [], [], []
-        for pid, p in added:
-            slot = s.add_point(pid, p.location_3d)
-            s.rev += p._rev
-            for f, (_, uv, d) in p.frames.items():  # observations attached before the point entered the map
-                slots.append(slot)
-                fids.append(f)
-                uvs.append(uv)
-                descs.append(d)
-        if slots:
+        if c[2] is not None:
+            c[2]()  # observation batches not yet written into the Point objects: the dicts below must be complete
+        n = len(added)
+        pts = [p for _, p in added]
+        locs = [p._loc for p in pts]
+        try:
+            rows = np.array(locs, np.float64).reshape(n, 3)  # one conversion for the batch
+        except (ValueError, TypeError):
+            rows = None
+        if rows is None:  # ragged / exotic locations: one by one
+            slots, fids, uvs, descs = [], [], [], []
+            for pid, p in added:
+                slot = s.add_point(pid, p.location_3d)
+                s.rev += p._rev
+                for f, (_, uv, d) in p._frames.items():
+                    slots.append(slot)
+                    fids.append(f)
+                    uvs.append(uv)
+                    descs.append(d)
+        else:
+            slot0 = s.n_points
+            if slot0 + n > s.xyz.shape[0]:
+                grown = np.zeros((max(256, 2 * s.xyz.shape[0], slot0 + n), 3))
+                grown[:slot0] = s.xyz[:slot0]
+                s.xyz = grown
+            s.xyz[slot0:slot0 + n] = rows
+            s.point_slot.update(zip([pid for pid, _ in added], range(slot0, slot0 + n)))
+            s.xyz_refs.extend(locs)
+            s.n_points += n
+            s.rev += sum([p._rev for p in pts])
+            frames = [p._frames for p in pts]  # observations attached before the points entered the map
+            if all([len(fr) == 1 for fr in frames]):  # the usual case: one observation each (main.py:130-135,312-318)
+                items = [next(iter(fr.items())) for fr in frames]
+                slots = range(slot0, slot0 + n)
+                fids = [it[0] for it in items]
+                uvs = [it[1][1] for it in items]
+                descs = [it[1][2] for it in items]
+            else:
+                slots, fids, uvs, descs = [], [], [], []
+                for k, fr in enumerate(frames):
+                    for f, (_, uv, d) in fr.items():
+                        slots.append(slot0 + k)
+                        fids.append(f)
+                        uvs.append(uv)
+                        descs.append(d)
+        if len(slots):
             s.add_obs(slots, fids, uvs, descs)
         self._soa_cell = (c[0], c[1])
 
