@@ -177,6 +177,13 @@ struct pnp_args {
   const mo_state* cur_dev;   // record whose `cur` is the state-buffer index, or nullptr (lm_cur)
   const unsigned* front_tag_dev;  // word the frame's front half (another stream) sets to front_tag when its append is complete:
   unsigned front_tag;             // ... every workgroup waits for it here instead of a stream-level event wait in front of the launch
+  // ... and the PREVIOUS frame's read-back rides along: the finishing workgroup, which has nothing to do until the hypotheses
+  // report, first copies that frame's result block to pinned host memory and tags it (what track_publish_kernel does)
+  const uint4* pub_src;
+  uint4* pub_dst;
+  int pub_n16;
+  unsigned* pub_tag_word;
+  unsigned pub_tag;
 };
 
 __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step);

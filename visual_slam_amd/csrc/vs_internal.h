@@ -119,6 +119,7 @@ struct vs_ctx {
     // stream while the back half (PnP, BA) of frame k runs on the context's stream; two sets of per-frame buffers
     hipStream_t front_stream = nullptr;
     hipEvent_t ev_front[2] = {nullptr, nullptr};
+    int pending_published = 0;  // ... and its read-back block is on its way to the host (a kernel that publishes it has been enqueued)
     int pending_chained = 0;  // the pending back half was enqueued with its inputs read on the device (see vs_track_frame_pipelined)
     unsigned front_seq = 0, front_tag[2] = {0, 0};  // tags of the front halves (track_append_kernel publishes them on the device)
     unsigned back_seq = 0, back_tag[2] = {0, 0};    // tags of the chained back halves' read-back blocks (track_publish_kernel)

@@ -611,6 +611,12 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(pnp_args P) {
   // the issue arbiter should serve these waves first
   __builtin_amdgcn_s_setprio(3);
   const int nhw = (int)gridDim.x - 1;
+  if (P.pub_src && (int)blockIdx.x == nhw) {  // the previous frame's results to the host, before anything here overwrites them
+    for (int i = threadIdx.x; i < P.pub_n16; i += kPnpFinish) P.pub_dst[i] = P.pub_src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(P.pub_tag_word, P.pub_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (P.front_tag_dev) {
     // chained tracking: the correspondences come from the front half on another stream.  Its last workgroup publishes the
     // frame's tag (agent-scope release behind everybody's rows); the wait is bounded -- the front half was enqueued before

@@ -264,7 +264,7 @@ bool track_can_chain(vs_ctx* ctx, int set, int k) {
 // `k` is the pose index of the new frame.  chained: the previous frame's back half may still be running -- the row offset of
 // the correspondences, the guess (the previous pose, in the state buffer its solve ended on) and that buffer's index are read
 // by the PnP kernel on the device instead of being passed from the host.
-int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out, int k, bool chained = false) {
+int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out, int k, bool chained = false, int publish_set = -1) {
   auto& T = ctx->track;
   const auto& Q = T.params[set];
   const track_layout L = layout_of(ctx);
@@ -299,6 +299,14 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out, int k, bool chained
     A.cur_dev = reinterpret_cast<const mo_state*>(d + L.mst);  // a finished solve leaves its record in both slots
     A.front_tag_dev = (const unsigned*)(d + L.front_sync) + 64;
     A.front_tag = T.front_tag[set];
+    if (publish_set >= 0) {  // the previous frame's read-back rides on this launch's finishing workgroup
+      uint8_t* rbp = (uint8_t*)ctx->h_track.p + kPinRb + (size_t)(1 + publish_set) * rb_stride(L);
+      A.pub_src = (const uint4*)(d + L.mst);
+      A.pub_dst = (uint4*)rbp;
+      A.pub_n16 = (int)(rb_len(L) / 16);
+      A.pub_tag_word = (unsigned*)(rbp + rb_len(L));
+      A.pub_tag = T.back_tag[publish_set];
+    }
   }
   A.model_out = (double*)(d + L.pnp_cam);
   A.result = (double*)(d + L.pnp_res);
@@ -402,14 +410,25 @@ int track_ba_batch(vs_ctx* ctx, int set, int* step, int k, bool chained = false)
   }
   // one copy brings back everything the host wants; if the solve needs another batch it is simply repeated
   if (chained) {
+    // the block is published later: by the next frame's PnP launch (its finishing workgroup idles while the hypotheses
+    // run), or by track_publish below when no chained frame follows
     if (++T.back_seq == 0) ++T.back_seq;
     T.back_tag[set] = T.back_seq;
-    hipLaunchKernelGGL(track_publish_kernel, dim3(1), dim3(256), 0, s, (const uint4*)(d + L.mst), (uint4*)rb, (int)(rb_len(L) / 16),
-                       (unsigned*)(rb + rb_len(L)), T.back_tag[set]);
-    VS_LAUNCH_CHECK(ctx, "track_publish_kernel");
   } else {
     VS_HIP(ctx, hipMemcpyAsync(rb, d + L.mst, L.rb_end - L.mst, hipMemcpyDeviceToHost, s));
   }
+  return VS_OK;
+}
+
+// the read-back block of a chained back half to its pinned block, tagged (when no later PnP launch carries it)
+int track_publish(vs_ctx* ctx, int set) {
+  auto& T = ctx->track;
+  const track_layout L = layout_of(ctx);
+  uint8_t* d = (uint8_t*)ctx->d_track.p;
+  uint8_t* rb = (uint8_t*)ctx->h_track.p + kPinRb + (size_t)(1 + set) * rb_stride(L);
+  hipLaunchKernelGGL(track_publish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint4*)(d + L.mst), (uint4*)rb,
+                     (int)(rb_len(L) / 16), (unsigned*)(rb + rb_len(L)), T.back_tag[set]);
+  VS_LAUNCH_CHECK(ctx, "track_publish_kernel");
   return VS_OK;
 }
 
@@ -696,10 +715,16 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
     g_tt.lap(0);  // front half enqueued
     chain = (solve < 0 || solve_chained) && track_can_chain(ctx, submitted, k_new);
     if (chain) {
-      VS_TRY(track_back_enqueue(ctx, submitted, &next_step, k_new, true));
+      const bool carry = solve_chained && !T.pending_published;  // frame k's read-back rides on frame k+1's PnP launch
+      VS_TRY(track_back_enqueue(ctx, submitted, &next_step, k_new, true, carry ? solve : -1));
+      if (carry) T.pending_published = 1;
       VS_TRY(track_ba_batch(ctx, submitted, &next_step, k_new, true));
       g_tt.lap(2);
     }
+  }
+  if (solve_chained && !T.pending_published) {  // nobody carries it (flush, or a frame that cannot be chained)
+    VS_TRY(track_publish(ctx, solve));
+    T.pending_published = 1;
   }
   T.pending = -1;
   T.pending_step = -1;
@@ -717,6 +742,7 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
   if (submitted >= 0) {
     T.pending = submitted;  // from here on the frame counts as pending, whatever happens below
     T.pending_chained = chain;
+    T.pending_published = 0;
     if (!chain) {
       VS_TRY(track_back_enqueue(ctx, submitted, &next_step, T.n_frames + 1));
       g_tt.lap(2);  // PnP enqueued
