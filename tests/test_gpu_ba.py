@@ -547,7 +547,8 @@ def test_banded_cholesky_is_bitwise_the_dense_factorisation(vs):
     width and one wider than the kernel takes (dense path both times); an indefinite matrix is rejected."""
     r = np.random.default_rng(0)
     try:
-        for n, cams_band in ((594, 11), (594, 16), (300, 5), (132, 3), (600, 1), (594, 17)):
+        # (1194 unknowns: the dense path's panels are 12 columns wide there, the banded one's always 24 -- same bits)
+        for n, cams_band in ((594, 11), (594, 16), (300, 5), (132, 3), (600, 1), (594, 17), (1194, 9)):
             M = np.zeros((n, n))
             for a in range(n // 6):
                 for b in range(max(0, a - cams_band + 1), a + 1):

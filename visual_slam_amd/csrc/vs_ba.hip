@@ -3001,6 +3001,7 @@ struct solve_plan {
   size_t lds_bytes = 0;
   int nbw = 0;             // otherwise: panel width of the blocked HBM factorisation (0: element-wise last resort)
   size_t panel_lds = 0;
+  bool band_ok = false;    // ba_chol_band + ba_chol_finish fit (any np up to ~18 000 unknowns): taken when the system is banded
 };
 
 int plan_solve(vs_ctx* ctx, int np, solve_plan* P) {
@@ -3008,6 +3009,7 @@ int plan_solve(vs_ctx* ctx, int np, solve_plan* P) {
   P->lds_bytes = 32 + (P->lds ? sizeof(double) * ((size_t)(np + 1) * ((np + 1) | 1) + 2 * (size_t)np + 4) : 0);
   P->nbw = 0;
   P->panel_lds = 0;
+  P->band_ok = false;
   if (!P->lds) {
     // widest panel (24 / 12 / 6 columns) whose rows j0..n fit in LDS
     for (int w : {24, 12, 6}) {
@@ -3018,8 +3020,10 @@ int plan_solve(vs_ctx* ctx, int np, solve_plan* P) {
         break;
       }
     }
-    if (P->nbw) {
-      VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->panel_lds));
+    if (P->nbw) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_panel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->panel_lds));
+    // the banded factorisation keeps a window of the band in LDS whatever np is; the back substitution keeps x (np doubles)
+    P->band_ok = sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64 <= 150 * 1024;
+    if (P->nbw || P->band_ok) {
       VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64)));
       VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds));
     }
@@ -3033,9 +3037,9 @@ int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& 
   const int np = D.np;
   if (P.lds) {
     hipLaunchKernelGGL(ba_solve_block, dim3(1), dim3(kSolveBlock), P.lds_bytes, s, D);
-  } else if (P.nbw == kBandNbw && D.band > 0 && D.band <= kBandMax) {
+  } else if (P.band_ok && D.band > 0 && D.band <= kBandMax) {
     hipLaunchKernelGGL(ba_chol_band, dim3(1), dim3(kPanelThreads), kBandLds, s, D, D.band);
-    hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64, s, D, P.nbw);
+    hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64, s, D, kBandNbw);
   } else if (P.nbw > 0) {
     for (int j0 = 0; j0 < np; j0 += P.nbw) {
       const int w = std::min(P.nbw, np - j0);
