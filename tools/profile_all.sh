@@ -20,4 +20,7 @@ tail -1 $O/bench.log | cut -c1-200
 python3 tools/trace_timeline.py $O/resident/resident_kernel_trace.csv 0.90 70 > $O/tracking_timeline.txt
 python3 tools/pnp_stamps.py > $O/pnp_stamps.txt 2>&1
 python3 tools/ba_sensitivity.py > $O/seed6_sensitivity.txt 2>&1
+python3 tools/chain_gaps.py $O/resident/resident_kernel_trace.csv > $O/tracking_chain.txt 2>&1
+python3 tools/api_stages.py 2>&1 | grep -v Warning > $O/class_api_stages.txt
+python3 tools/ba_window_check.py --big > $O/ba_window_check.txt 2>&1
 rm -f $O/*/*_kernel_trace.csv $O/*/*agent_info.csv

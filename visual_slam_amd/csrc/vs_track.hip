@@ -570,6 +570,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   T.pending = -1;
   T.pending_step = -1;
   T.pending_chained = 0;
+  T.pending_published = 0;
   T.mst_both = 1;
   T.next_set = 0;
   T.api_stage = 0;
