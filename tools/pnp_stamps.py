@@ -34,6 +34,7 @@ for profile in (0, 1):
     print("profile=%d: %.1f us per frame (frame by frame)" % (profile, dt / 19 * 1e6))
 for k, r in enumerate(rows):
     hyp, fin = r[:H], r[H]
+    print('   after LM (medians): record %.1f, stored %.1f, scored %.1f, published %.1f' % tuple(statistics.median(hyp[:, c] - hyp[:, 2]) for c in (4, 5, 6, 3)))
     lm = hyp[:, 2] - hyp[:, 1]
     print("frame %2d  hyp: start %.1f..%.1f  sample %.1f  LM med %.1f max %.1f  published: first10 max %.1f, all max %.1f | "
           "fin: start %.1f  winner %.1f  listed %.1f  LM done %.1f  end %.1f"

@@ -421,6 +421,7 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
   }
   quat_from_pose(m, cam + 3);
   quat_to_w2n(cam, cam + 3, cam + 7);
+  if (lane == 0) pnp_stamp(P, h, 4);
   // the model leaves as ONE wave-wide write-through store: [pose rows 12 | record 19 | pad] = 32 doubles, lane l stores
   // word l (through LDS: every lane holds the whole model, a store needs lane-indexed words).  One store instruction = one
   // round trip to wait for before the tag; 31 scalar write-through stores by one lane cost ~12 us here.
@@ -432,6 +433,7 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
   }
   wave_lds_sync();
   if (lane < kPnpModel) st_wt(P.model_out + (size_t)h * kPnpModel + lane, rec[lane]);
+  if (lane == 0) pnp_stamp(P, h, 5);
   int good = 0;
   for (int i0 = 0; i0 < P.n; i0 += 64) {
     const int i = i0 + lane;
@@ -445,6 +447,7 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
     }
     good += __popcll(__ballot(in));
   }
+  if (lane == 0) pnp_stamp(P, h, 6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the model has left this compute unit before the word that announces it
   if (lane == 0) {
     __hip_atomic_store(&P.tag[h], tag_hi | (unsigned long long)(unsigned)good, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
