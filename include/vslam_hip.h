@@ -208,7 +208,8 @@ int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, in
  * frame.  The parameters given with a frame are the ones used for it.  Results are identical to vs_track_frame.
  * With PnP and LM on and the motion-only solve in one launch, frame k+1's back half is enqueued too, behind frame k's and
  * before frame k's results are known (its kernels read what they need from frame k on the device and wait for their own
- * front half through a tagged word): the GPU passes from one back half to the next without the host in between. */
+ * front half through a tagged word): the GPU passes from one back half to the next without the host in between.
+ * Consecutive back halves alternate between the context's stream and vs_aux_stream(ctx, 1). */
 int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, int thr, double ratio,
                              double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations,
                              double huber_delta, int* has_result, double* poses_out, int* n_poses_out, int* n_matches,

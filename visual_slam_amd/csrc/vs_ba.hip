@@ -2972,6 +2972,16 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
     g_state[0] = st;
     g_state[1] = st;
   }
+  // chained tracking: "every camera's record and the LM state are final" as a tagged word -- the next frame's PnP launch
+  // (another stream) is already resident and waits for it.  Thread 0 is the only writer of this workgroup's global results.
+  if (D.mo_done && tid == 0) {
+    __threadfence();
+    const unsigned prev = __hip_atomic_fetch_add(D.mo_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (unsigned)nfp - 1u) {
+      __hip_atomic_store(D.mo_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(D.mo_done + 64, D.mo_done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 template __global__ void ba_motion_persistent<false>(ba_dev D, int max_steps);

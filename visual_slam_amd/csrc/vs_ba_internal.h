@@ -65,6 +65,8 @@ struct ba_dev {
   double *mo_part, *mo_H;                // [2][nfp][4] per-camera partials by step parity; [nfp][42] H upper + b
   unsigned long long* mo_box;            // ba_motion_persistent: [2][kMoPersistCameras][8] tagged mailbox words
   unsigned mo_epoch;                     // ... tag of this solve (20 bits), so that words of an earlier solve never match
+  unsigned* mo_done;                     // chained tracking: [0] arrival counter, [64] tag published when every camera workgroup is through (nullptr: none)
+  unsigned mo_done_tag;
 };
 
 // motion-only LM state (double-buffered by launch parity, see vs_ba.hip)
@@ -177,6 +179,8 @@ struct pnp_args {
   const mo_state* cur_dev;   // record whose `cur` is the state-buffer index, or nullptr (lm_cur)
   const unsigned* front_tag_dev;  // word the frame's front half (another stream) sets to front_tag when its append is complete:
   unsigned front_tag;             // ... every workgroup waits for it here instead of a stream-level event wait in front of the launch
+  const unsigned* back_tag_dev;   // likewise the previous frame's motion-only solve, which runs on ANOTHER stream: this launch is
+  unsigned back_tag;              // resident and has sampled when that solve ends (nullptr: stream order already says so)
   // ... and the PREVIOUS frame's read-back rides along: the finishing workgroup, which has nothing to do until the hypotheses
   // report, first copies that frame's result block to pinned host memory and tags it (what track_publish_kernel does)
   const uint4* pub_src;

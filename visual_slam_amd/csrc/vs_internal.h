@@ -123,6 +123,7 @@ struct vs_ctx {
     int pending_chained = 0;  // the pending back half was enqueued with its inputs read on the device (see vs_track_frame_pipelined)
     unsigned front_seq = 0, front_tag[2] = {0, 0};  // tags of the front halves (track_append_kernel publishes them on the device)
     unsigned back_seq = 0, back_tag[2] = {0, 0};    // tags of the chained back halves' read-back blocks (track_publish_kernel)
+    unsigned ba_seq = 0, ba_tag[2] = {0, 0};        // tags the chained back halves' motion-only solves publish on the device when they are through
     int mst_both = 0;  // both LM records on the device name the state buffer of the newest estimate (fresh period, or the last solve ran in one launch)
     int pending = -1;   // buffer set of the frame whose front half is done and whose back half is not, or -1
     int pending_step = -1;  // >= 0: that frame's back half is enqueued already, this many LM launches so far

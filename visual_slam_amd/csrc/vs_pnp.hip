@@ -25,7 +25,25 @@ namespace {
 
 
 __device__ inline int pnp_count(const pnp_args& P) { return P.n_dev ? *P.n_dev : P.n; }
-// (chained tracking: pnp_ransac_kernel has resolved guess_dev[0] and lm_cur from the device-side state at its entry)
+// bounded, sleeping poll of a tagged word (nullptr: nothing to wait for); acquire: what the publisher wrote is visible after it
+__device__ inline bool pnp_wait_tag(const unsigned* word, unsigned tag) {
+  if (!word) return true;
+  for (int it = 0; it < (1 << 22); ++it) {
+    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // one cache invalidation, when the word has arrived -- not one per poll
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(16);
+  }
+  return false;
+}
+// chained tracking: the state-buffer index of the previous solve and with it the guess (valid once that solve has ended)
+__device__ inline void pnp_resolve_guess(pnp_args& P) {
+  const int cur = P.cur_dev->cur & 1;
+  P.lm_cur = cur;
+  P.guess_dev[0] = P.guess_dev[cur];
+}
+// (chained tracking: guess_dev[0] and lm_cur have been resolved from the device-side state by then)
 __device__ inline double pnp_guess(const pnp_args& P, int k) { return P.guess_dev[0] ? P.guess_dev[0][k] : P.cam0[k]; }
 
 __device__ inline unsigned long long splitmix64(unsigned long long x) {
@@ -409,6 +427,15 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
   }
   wave_lds_sync();
   if (lane == 0) pnp_stamp(P, h, 1);
+  if (P.off_dev) {  // chained tracking: sampled; now the previous frame's solve has to be through
+    // one poller per workgroup (its four hypotheses sample in step): a hundred waves polling one word slowed the solve they wait for
+    __shared__ int s_back;
+    __syncthreads();
+    if (threadIdx.x == 0) s_back = pnp_wait_tag(P.back_tag_dev, P.back_tag);
+    __syncthreads();
+    if (!s_back) return;  // the tags stay unpublished
+    pnp_resolve_guess(P);
+  }
   double cam[kCamStride];
   for (int k = 0; k < kCamStride; ++k) cam[k] = pnp_guess(P, k);
   pnp_lm<3, 1, 1>(P, idx, 5, lane & 7, 8, cam, nullptr, min(P.iters_lm, kPnpHypIters));
@@ -614,42 +641,37 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(pnp_args P) {
   // the issue arbiter should serve these waves first
   __builtin_amdgcn_s_setprio(3);
   const int nhw = (int)gridDim.x - 1;
-  if (P.pub_src && (int)blockIdx.x == nhw) {  // the previous frame's results to the host, before anything here overwrites them
-    for (int i = threadIdx.x; i < P.pub_n16; i += kPnpFinish) P.pub_dst[i] = P.pub_src[i];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(P.pub_tag_word, P.pub_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (P.front_tag_dev) {
-    // chained tracking: the correspondences come from the front half on another stream.  Its last workgroup publishes the
-    // frame's tag (agent-scope release behind everybody's rows); the wait is bounded -- the front half was enqueued before
-    // this launch and its kernels do not depend on it -- and a workgroup that gives up leaves the launch (the finishing one
-    // reports the hypotheses as missing, which the host turns into an error).
+  // chained tracking: the correspondences come from the front half on another stream, the guess from the previous frame's
+  // motion-only solve on yet another.  Their last workgroups publish tagged words (agent-scope release behind everybody's
+  // results); the waits are bounded -- both were enqueued before this launch and neither depends on it -- and whoever gives up
+  // leaves the launch (the finishing workgroup then reports the hypotheses as missing, which the host turns into an error).
+  // Order: front half -> count and row offset -> [hypotheses: sampling] -> previous solve -> guess.  The launch is resident
+  // and has sampled by the time the previous solve ends.
+  const bool fin = (int)blockIdx.x == nhw;
+  if (P.front_tag_dev || (fin && P.back_tag_dev)) {
     __shared__ int s_front;
-    if (threadIdx.x == 0) {
-      int ok = 0;
-      for (int it = 0; it < (1 << 22) && !ok; ++it) {
-        ok = __hip_atomic_load(P.front_tag_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == P.front_tag;
-        if (!ok) __builtin_amdgcn_s_sleep(4);
-      }
-      s_front = ok;
-    }
+    if (threadIdx.x == 0) s_front = pnp_wait_tag(P.front_tag_dev, P.front_tag) && (!fin || pnp_wait_tag(P.back_tag_dev, P.back_tag));
     __syncthreads();
     if (!s_front) {
-      if ((int)blockIdx.x == nhw && threadIdx.x == 0) {
+      if (fin && threadIdx.x == 0) {
         P.result[16] = -1.0;
         if (P.host_result) P.host_result[16] = -1.0;
       }
       return;
     }
   }
+  if (fin && P.pub_src) {  // the previous frame's results to the host, before anything here overwrites them
+    for (int i = threadIdx.x; i < P.pub_n16; i += kPnpFinish) P.pub_dst[i] = P.pub_src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(P.pub_tag_word, P.pub_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   P.n = pnp_count(P);
-  if (P.off_dev) {  // chained tracking: one round trip for the three device-side scalars, all requested together
-    const int off = *P.off_dev, cur = P.cur_dev->cur & 1;
+  if (P.off_dev) {
+    const int off = *P.off_dev;
     P.obj += 3 * (size_t)off;
     P.img += 2 * (size_t)off;
-    P.lm_cur = cur;
-    P.guess_dev[0] = P.guess_dev[cur];
+    if (fin) pnp_resolve_guess(P);  // (the hypothesis waves do it after their sampling, behind their own wait)
   }
   if ((int)blockIdx.x < nhw) pnp_hypothesis_role(P, nhw);
   else pnp_finish_role(P);

@@ -114,7 +114,7 @@ struct track_layout {
   size_t xyz, mapdesc;
   track_front f[2];  // two sets of per-frame buffers (the synchronous entry point uses set 0 only)
   size_t flags, cam0, cam1, moX, moUV, cam_start, slot_pose, part, H, box, mst, pnp_cam, pnp_res, pnp_inl,
-      push_idx, push_uv, rb_end, front_sync, init_end, total;
+      push_idx, push_uv, rb_end, front_sync, back_sync, init_end, total;
   int cap_obs;
 };
 
@@ -153,6 +153,7 @@ track_layout track_layout_of(int P, int F, int max_kp, int H) {
   L.slot_pose = take(sizeof(int) * (size_t)(F + 1));
   L.box = take(sizeof(unsigned long long) * 2 * kMoPersistCameras * 8);  // mailboxes of ba_motion_persistent
   L.front_sync = take(512);  // [0] arrival counter of track_append_kernel, [64] tag of the newest complete front half
+  L.back_sync = take(512);   // [0] arrival counter of ba_motion_persistent's workgroups, [64] tag of the newest finished solve
   L.init_end = off;
   L.moX = take(sizeof(double) * 3 * (size_t)L.cap_obs);
   L.moUV = take(sizeof(double) * 2 * (size_t)L.cap_obs);
@@ -246,6 +247,11 @@ int track_front_half(vs_ctx* ctx, int set, int slot, const uint8_t* bgr, int w, 
   return VS_OK;
 }
 
+// Chained back halves alternate between two streams (buffer set 0: the context's, set 1: an auxiliary one): the PnP launch of
+// frame k+1 does not queue behind frame k's solve -- it is resident, has waited for its front half and sampled when that
+// solve publishes its tag.
+hipStream_t track_back_stream(vs_ctx* ctx, int set, bool chained) { return chained && set ? ctx->aux_stream[1] : ctx->stream; }
+
 size_t rb_len(const track_layout& L) { return (L.rb_end - L.mst + 255) & ~(size_t)255; }
 size_t rb_stride(const track_layout& L) { return rb_len(L) + 256; }  // the block, then the word track_publish_kernel tags it with
 
@@ -268,7 +274,7 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out, int k, bool chained
   auto& T = ctx->track;
   const auto& Q = T.params[set];
   const track_layout L = layout_of(ctx);
-  hipStream_t s = ctx->stream;
+  hipStream_t s = track_back_stream(ctx, set, chained);
   uint8_t* d = (uint8_t*)ctx->d_track.p;
   uint8_t* hp = (uint8_t*)ctx->h_track.p;
   const int H = T.pnp_iters > 0 ? T.pnp_iters : 1;
@@ -299,6 +305,10 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out, int k, bool chained
     A.cur_dev = reinterpret_cast<const mo_state*>(d + L.mst);  // a finished solve leaves its record in both slots
     A.front_tag_dev = (const unsigned*)(d + L.front_sync) + 64;
     A.front_tag = T.front_tag[set];
+    if (publish_set >= 0) {  // a chained frame is in flight on the other stream: its solve announces its end on the device
+      A.back_tag_dev = (const unsigned*)(d + L.back_sync) + 64;
+      A.back_tag = T.ba_tag[publish_set];
+    }
     if (publish_set >= 0) {  // the previous frame's read-back rides on this launch's finishing workgroup
       uint8_t* rbp = (uint8_t*)ctx->h_track.p + kPinRb + (size_t)(1 + publish_set) * rb_stride(L);
       A.pub_src = (const uint4*)(d + L.mst);
@@ -344,7 +354,7 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out, int k, bool chained
   return VS_OK;
 }
 
-ba_dev track_ba_dev(vs_ctx* ctx, int set, int k) {
+ba_dev track_ba_dev(vs_ctx* ctx, int set, int k, bool chained = false) {
   auto& T = ctx->track;
   const track_layout L = layout_of(ctx);
   uint8_t* d = (uint8_t*)ctx->d_track.p;
@@ -371,6 +381,12 @@ ba_dev track_ba_dev(vs_ctx* ctx, int set, int k) {
   D.st = reinterpret_cast<lm_state*>(d + L.mst);
   D.mo_box = reinterpret_cast<unsigned long long*>(d + L.box);
   D.mo_epoch = (unsigned)T.solve_epoch & 0xFFFFFu;
+  if (chained) {  // the solve announces its end on the device (the next frame's PnP launch, on the other stream, waits for it)
+    if (++T.ba_seq == 0) ++T.ba_seq;
+    T.ba_tag[set] = T.ba_seq;
+    D.mo_done = (unsigned*)(d + L.back_sync);
+    D.mo_done_tag = T.ba_tag[set];
+  }
   return D;
 }
 
@@ -380,13 +396,13 @@ ba_dev track_ba_dev(vs_ctx* ctx, int set, int k) {
 int track_ba_batch(vs_ctx* ctx, int set, int* step, int k, bool chained = false) {
   auto& T = ctx->track;
   const track_layout L = layout_of(ctx);
-  hipStream_t s = ctx->stream;
+  hipStream_t s = track_back_stream(ctx, set, chained);
   uint8_t* d = (uint8_t*)ctx->d_track.p;
   uint8_t* rb = (uint8_t*)ctx->h_track.p + kPinRb + (chained ? (size_t)(1 + set) * rb_stride(L) : 0);
   const int lm = T.params[set].lm_iterations;
   if (lm > 0) {
     if (*step == 0) T.solve_epoch = T.solve_epoch % 0xFFFFF + 1;  // 1 .. 2^20 - 1: never the zero the mailboxes start with
-    const ba_dev D = track_ba_dev(ctx, set, k);
+    const ba_dev D = track_ba_dev(ctx, set, k, chained);
     const int max_steps = 1 + lm * 10;
     // Launches after the one that finds the solve finished are predicated no-ops of ~5 us each on the critical path of the
     // frame, and consecutive frames of a stream need about the same number of LM steps: the first batch is as long as the
@@ -426,7 +442,7 @@ int track_publish(vs_ctx* ctx, int set) {
   const track_layout L = layout_of(ctx);
   uint8_t* d = (uint8_t*)ctx->d_track.p;
   uint8_t* rb = (uint8_t*)ctx->h_track.p + kPinRb + (size_t)(1 + set) * rb_stride(L);
-  hipLaunchKernelGGL(track_publish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const uint4*)(d + L.mst), (uint4*)rb,
+  hipLaunchKernelGGL(track_publish_kernel, dim3(1), dim3(256), 0, track_back_stream(ctx, set, true), (const uint4*)(d + L.mst), (uint4*)rb,
                      (int)(rb_len(L) / 16), (unsigned*)(rb + rb_len(L)), T.back_tag[set]);
   VS_LAUNCH_CHECK(ctx, "track_publish_kernel");
   return VS_OK;
@@ -526,6 +542,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   auto& T = ctx->track;
   // the one synchronisation of this call: the staging is free to be rewritten (or reallocated), the buffers are idle
   VS_HIP(ctx, hipStreamSynchronize(T.front_stream));
+  VS_HIP(ctx, hipStreamSynchronize(ctx->aux_stream[1]));
   VS_HIP(ctx, hipStreamSynchronize(s));
   const track_layout L = track_layout_of(n_points, max_frames, max_kp, pnp_iterations > 0 ? pnp_iterations : 1);
   VS_TRY(vs_reserve(ctx, &ctx->d_track, L.total));
@@ -557,6 +574,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   // no wait here: the frames' back halves run on this stream, and the front halves' stream is ordered behind the uploads
   VS_HIP(ctx, hipEventRecord(T.ev_api, s));
   VS_HIP(ctx, hipStreamWaitEvent(T.front_stream, T.ev_api, 0));
+  VS_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream[1], T.ev_api, 0));  // chained back halves of buffer set 1 run there
   T.active = 1;
   T.n_points = n_points;
   T.cap_frames = max_frames;
@@ -585,6 +603,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
 VS_API int vs_track_end(vs_ctx* ctx) {
   if (!ctx) return VS_EINVAL;
   if (ctx->track.front_stream) (void)hipStreamSynchronize(ctx->track.front_stream);
+  (void)hipStreamSynchronize(ctx->aux_stream[1]);
   (void)hipStreamSynchronize(ctx->stream);
   ctx->track.active = 0;
   ctx->track.pending = -1;
@@ -734,7 +753,10 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
     const int rc = track_back_finish(ctx, solve, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out,
                                      match_q, match_t, true, solve_chained);
     if (rc != VS_OK) {
-      if (chain) (void)hipStreamSynchronize(ctx->stream);  // the next back half is on the stream already: let it drain
+      if (chain) {  // the next back half is enqueued already: let it drain
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->aux_stream[1]);
+      }
       return rc;
     }
     *has_result = 1;

@@ -195,6 +195,10 @@ class _PeriodMirror:
         if desc1 is not kd and not (getattr(desc1, "shape", None) == kd.shape and np.array_equal(desc1, kd)):
             return None
         sp["matched"] = True
+        # what the caller is expected to hand to solvePnPRansac (main.py:189-197): the key frame's 3-D points and this
+        # frame's image points of the matches -- gathered once, here
+        sp["obj_expect"] = self.xyz[sp["match_q"]]
+        sp["img_expect"] = sp["xy"][sp["match_t"]]
         return sp["match_q"], sp["match_t"], sp["match_d"]
 
     def speculate_back(self, obj, img, K4, pose0, iterations, reproj_err, confidence, seed):
@@ -203,9 +207,9 @@ class _PeriodMirror:
         if (sp is None or sp["stage"] != 1 or not sp["matched"] or not self._alive() or iterations != 100
                 or tuple(float(v) for v in K4) != self.K4):
             return None
-        mq, mt = sp["match_q"], sp["match_t"]
-        if (obj.shape != (len(mq), 3) or img.shape != (len(mq), 2) or len(mq) < 5 or not np.array_equal(obj, self.xyz[mq])
-                or not np.array_equal(img, sp["xy"][mt]) or float(np.abs(pose0 - self.last_pose).max()) > 1e-9):
+        mq = sp["match_q"]
+        if (obj.shape != (len(mq), 3) or img.shape != (len(mq), 2) or len(mq) < 5 or not np.array_equal(obj, sp["obj_expect"])
+                or not np.array_equal(img, sp["img_expect"]) or float(np.abs(pose0 - self.last_pose).max()) > 1e-9):
             return None
         r = self.ctx.track_back_begin(seed=seed, reproj_err=reproj_err, confidence=confidence)
         sp["stage"], sp["pnp"] = 2, r
@@ -275,7 +279,7 @@ class _PeriodMirror:
                 b = rows.get(fid)
                 if b is not None and b[0] >= self.consumed and b[2] == len(sp["match_q"]):
                     sl, obs = soa.batch_data[b[0]]
-                    if (np.array_equal(sl, sp["match_q"]) and np.array_equal(obs, sp["xy"][sp["match_t"]])
+                    if (np.array_equal(sl, sp["match_q"]) and np.array_equal(obs, sp["img_expect"])
                             and float(np.abs(np.asarray(f.GetPose(), np.float64) - sp["pnp"]["pose"]).max()) <= 1e-9):
                         poses = ctx.track_back_end()
                         self.pushed.append(fid)
