@@ -488,6 +488,22 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int srow = P.iterations;  // diagnostic row of the finishing workgroup
   if (tid == 0) pnp_stamp(P, srow, 0);
+  // this workgroup's share of the correspondences (thread t: t, t + 256) is requested now and is in registers long before the
+  // hypotheses report: the inlier listing below then starts without a round trip
+  constexpr int kListPre = 2;
+  double lX[kListPre][3], lU[kListPre][2];
+#pragma unroll
+  for (int j = 0; j < kListPre; ++j) {
+    const int i = kPnpFinish * j + tid;
+    lX[j][0] = lX[j][1] = lX[j][2] = lU[j][0] = lU[j][1] = 0.0;
+    if (i < P.n) {
+      lX[j][0] = P.obj[3 * (size_t)i];
+      lX[j][1] = P.obj[3 * (size_t)i + 1];
+      lX[j][2] = P.obj[3 * (size_t)i + 2];
+      lU[j][0] = P.img[2 * (size_t)i];
+      lU[j][1] = P.img[2 * (size_t)i + 1];
+    }
+  }
   if (P.lm_init && tid == 64) {  // the motion-only solve that follows starts from fresh LM records (no upload in between)
     mo_state z;
     memset(&z, 0, sizeof z);
@@ -564,12 +580,25 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
   double cam[kCamStride];
   for (int k = 0; k < kCamStride; ++k) cam[k] = P.model_out[(size_t)best * kPnpModel + 12 + k];
   // ordered inlier list of the best model
-  for (int i0 = 0; i0 < P.n; i0 += kPnpFinish) {
+  for (int i0 = 0, j = 0; i0 < P.n; i0 += kPnpFinish, ++j) {
     const int i = i0 + tid;
     bool in = false;
     if (i < P.n) {
-      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+      double X[3], uv[2];
+      if (j < kListPre) {
+        // (static indices only: a register array indexed by the loop counter would go to scratch)
+        X[0] = j == 0 ? lX[0][0] : lX[1][0];
+        X[1] = j == 0 ? lX[0][1] : lX[1][1];
+        X[2] = j == 0 ? lX[0][2] : lX[1][2];
+        uv[0] = j == 0 ? lU[0][0] : lU[1][0];
+        uv[1] = j == 0 ? lU[0][1] : lU[1][1];
+      } else {
+        X[0] = P.obj[3 * (size_t)i];
+        X[1] = P.obj[3 * (size_t)i + 1];
+        X[2] = P.obj[3 * (size_t)i + 2];
+        uv[0] = P.img[2 * (size_t)i];
+        uv[1] = P.img[2 * (size_t)i + 1];
+      }
       double eu, ev, pc[3];
       pnp_err(P, cam, X, uv, eu, ev, pc);
       in = eu * eu + ev * ev <= P.thr2;
