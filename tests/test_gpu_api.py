@@ -653,3 +653,47 @@ def test_track_front_back_entry_points_equal_track_frame(vs, oracle):
         poses = vs.track_back_end()
         assert np.array_equal(poses, r["poses"]), k
     vs.track_end()
+
+
+def test_pipelined_tracking_mixes_chained_and_host_paced_frames(vs):
+    """vs_track_frame_pipelined chains a frame's back half on the device (enqueued before the previous results are known,
+    alternating streams, tagged words instead of events) only when no host decision can be needed in between: PnP on, LM on,
+    one-launch solve.  A stream whose frames switch the LM off and on again, blank frames (no matches: PnP finds nothing)
+    and optional per-frame outputs must give, frame for frame, what the frame-by-frame entry point gives -- bit for bit."""
+    from visual_slam_amd import harness
+    from visual_slam_amd.workloads import ICL_NUIM_K
+    frames, depth0 = harness.load_sequence(12)
+    blank = np.full_like(frames[0], 90)
+    seq = [frames[1], frames[2], frames[3], blank, frames[4], frames[5], frames[6], frames[7], frames[8], frames[9]]
+    lms = [10, 10, 0, 10, 10, 0, 0, 10, 10, 10]      # 0: cannot be chained (and leaves a solve that is not one launch behind it)
+    xy0, _, desc0 = vs.detect_describe_bgr(frames[0], 20, 3000)
+
+    def run(pipelined, **kw):
+        vs.track_begin(harness.backproject(xy0, depth0), desc0, np.eye(4), ICL_NUIM_K, max_frames=len(seq), pnp_iterations=100)
+        outs = []
+        try:
+            if pipelined:
+                for k, (img, lm) in enumerate(list(zip(seq, lms)) + [(None, 10)]):
+                    r = vs.track_frame_pipelined(img, seed=k + 1, lm_iterations=lm, **kw)
+                    if r is not None:
+                        outs.append(r)
+            else:
+                for k, (img, lm) in enumerate(zip(seq, lms)):
+                    outs.append(vs.track_frame(img, seed=k + 1, lm_iterations=lm, **kw))
+        finally:
+            vs.track_end()
+        return outs
+
+    ref = run(False, want_keypoints=True, want_matches=True)
+    for kw in (dict(want_keypoints=True, want_matches=True), dict(want_keypoints=False, want_matches=False)):
+        got = run(True, **kw)
+        assert len(got) == len(ref) == len(seq)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a["poses"], b["poses"]) and a["n_matches"] == b["n_matches"] and a["pnp_found"] == b["pnp_found"]
+            if kw["want_keypoints"]:
+                assert np.array_equal(a["xy"], b["xy"]) and np.array_equal(a["desc"], b["desc"])
+                assert np.array_equal(a["match_q"], b["match_q"]) and np.array_equal(a["match_t"], b["match_t"])
+    assert ref[3]["n_matches"] == 0 and ref[3]["pnp_found"] == 0   # the blank frame
+    # and a second period right behind it on the same context (tags and tickets carry over)
+    again = run(True, want_keypoints=False, want_matches=False)
+    assert all(np.array_equal(a["poses"], b["poses"]) for a, b in zip(ref, again))

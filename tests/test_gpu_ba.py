@@ -514,7 +514,7 @@ def test_banded_windows_on_the_matrix_cores_agree_with_the_tile_kernel_and_the_o
     (ba_schur_window), the slabs are summed by ba_reduce_window and -- without scale edges -- the banded system is
     factorised by ba_chol_band in one launch.  vs_tune_ba variant 3 keeps such problems on the tile kernel and the dense
     factorisation: both must agree with the oracle, and with each other to rounding."""
-    cases = [(24, 3000, 10, 1), (100, 1500, 10, 6), (40, 4000, 14, 2), (13, 400, 5, 5)]
+    cases = [(24, 3000, 10, 1), (100, 1500, 10, 6), (40, 4000, 14, 2), (13, 400, 5, 5), (12, 30, 4, 8), (17, 70, 16, 9)]
     try:
         for n_cams, n_points, window, seed in cases:
             w = _sliding_window_scene(n_cams, n_points, window, seed)
