@@ -1311,44 +1311,77 @@ __global__ __launch_bounds__(64 * kRedSplit) void ba_reduce(ba_dev D) {
 // ordered by their first camera, so those whose window can hold both cameras of an element are the range
 // [win_first[row camera - kWinCams + 1], win_first[column camera + 1]) of the host's table (win_first[c] = first slab
 // that starts at camera c or later); they are added in slab order.
+constexpr int kRedWinGroups = 4, kRedWinElems = 256 / kRedWinGroups, kRedWinInFlight = 8;
 __global__ __launch_bounds__(256) void ba_reduce_window(ba_dev D) {
+  extern __shared__ int s_win[];  // [ns][2]: first camera, cameras (one level of dependent loads less per slab)
+  __shared__ double s_part[kRedWinGroups][kRedWinElems];
   const lm_state st = *D.st;
   if (st.done) return;
-  const int np = D.np;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= np * np + np) return;
-  const lin_view L = lin_of(D, st.cur);
-  int r, c;
-  double base;
-  if (i < np * np) {
-    r = i / np;
-    c = i - r * np;
-    base = L.Hpp[i];
-    if (r == c) base += st.lambda;
-    if (r / 6 < c / 6) {  // above the block diagonal: never read
-      D.S[i] = base;
-      return;
-    }
-    if (r < c) {
-      const int t = r;
-      r = c;
-      c = t;
-    }
-  } else {
-    r = c = i - np * np;
-    base = L.bp[r];
+  const int np = D.np, ns = D.ns;
+  for (int k = threadIdx.x; k < ns; k += 256) {
+    s_win[2 * k] = D.win_w0[k];
+    s_win[2 * k + 1] = D.win_len[k];
   }
-  const int cr = r / 6, cc = c / 6;
-  const int s0 = D.win_first[max(cr - kWinCams + 1, 0)], s1 = D.win_first[cc + 1];
+  __syncthreads();
+  // thread = (element e of this workgroup, group g): the element's slab range is cut into chunks of kRedWinInFlight slabs,
+  // group g adds the chunks g, g + 4, ... in order with all loads of a chunk in flight; the groups are added in group
+  // order -- a fixed order, and 32 independent loads per element instead of a chain of ~60 round trips
+  const int e = threadIdx.x % kRedWinElems, g = threadIdx.x / kRedWinElems;
+  const int i = blockIdx.x * kRedWinElems + e;
+  const bool live = i < np * np + np;
+  const bool mat = i < np * np;
+  int r = 0, c = 0;
+  bool upper = false;
+  if (live) {
+    if (mat) {
+      r = i / np;
+      c = i - r * np;
+      upper = r / 6 < c / 6;  // above the block diagonal: never read, no slab contribution
+      if (r < c) {
+        const int t = r;
+        r = c;
+        c = t;
+      }
+    } else {
+      r = c = i - np * np;
+    }
+  }
   double acc = 0.0;
-  for (int s = s0; s < s1; ++s) {
-    const int w0 = D.win_w0[s];
-    if (cr >= w0 + D.win_len[s]) continue;
-    const double* slab = D.slab + (size_t)s * kWinSlabElems;
-    acc += i < np * np ? slab[(size_t)(r - 6 * w0) * kWinN + (c - 6 * w0)] : slab[kWinN * kWinN + (r - 6 * w0)];
+  if (live && !upper) {
+    const int cr = r / 6, cc = c / 6;
+    const int s0 = D.win_first[max(cr - kWinCams + 1, 0)], s1 = D.win_first[cc + 1];
+    for (int sb = s0 + g * kRedWinInFlight; sb < s1; sb += kRedWinGroups * kRedWinInFlight) {
+      double v[kRedWinInFlight];
+      bool use[kRedWinInFlight];
+#pragma unroll
+      for (int u = 0; u < kRedWinInFlight; ++u) {
+        const int s = min(sb + u, s1 - 1);
+        const int w0 = s_win[2 * s];
+        use[u] = sb + u < s1 && cr < w0 + s_win[2 * s + 1];
+        const double* slab = D.slab + (size_t)s * kWinSlabElems;
+        // (an unused slab still gets a valid address: its own first element)
+        const size_t off = !use[u] ? 0 : mat ? (size_t)(r - 6 * w0) * kWinN + (c - 6 * w0) : (size_t)kWinN * kWinN + (r - 6 * w0);
+        v[u] = slab[off];
+      }
+#pragma unroll
+      for (int u = 0; u < kRedWinInFlight; ++u)
+        if (use[u]) acc += v[u];
+    }
   }
-  if (i < np * np) D.S[i] = base - acc;
-  else D.bs[r] = base - acc;
+  s_part[g][e] = acc;
+  __syncthreads();
+  if (g != 0 || !live) return;
+  acc = s_part[0][e];
+#pragma unroll
+  for (int k = 1; k < kRedWinGroups; ++k) acc += s_part[k][e];
+  const lin_view L = lin_of(D, st.cur);
+  if (mat) {
+    double base = L.Hpp[i];
+    if (i / np == i % np) base += st.lambda;
+    D.S[i] = base - acc;
+  } else {
+    D.bs[i - np * np] = L.bp[i - np * np] - acc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ dense solve
@@ -3912,7 +3945,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       VS_LAUNCH_CHECK(ctx, "ba_schur");
     }
     if (np > 0 && win) {
-      hipLaunchKernelGGL(ba_reduce_window, dim3((unsigned)((slab_elems + 255) / 256)), dim3(256), 0, s, D);
+      hipLaunchKernelGGL(ba_reduce_window, dim3((unsigned)((slab_elems + kRedWinElems - 1) / kRedWinElems)), dim3(256), sizeof(int) * 2 * (size_t)ns, s, D);
       VS_LAUNCH_CHECK(ctx, "ba_reduce_window");
     } else if (np > 0) {
       hipLaunchKernelGGL(ba_reduce, dim3((unsigned)((slab_elems + 63) / 64)), dim3(64 * kRedSplit), 0, s, D);
