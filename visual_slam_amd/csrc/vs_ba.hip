@@ -3751,12 +3751,14 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       win_per = std::min(kWinPerMax, std::max(32, (win_n + target - 1) / target));
       if (ctx->tune.win_per > 0) win_per = std::min(kWinPerMax, ctx->tune.win_per);
       ns_win = (win_n + win_per - 1) / win_per;
+      if (sizeof(int) * 2 * (size_t)ns_win > 48 * 1024) ns_win = 0;  // ba_reduce_window keeps the slab windows in LDS: beyond ~3 million points the tile path
       int *h_w0, *h_wl, *h_wf;
+      if (ns_win == 0) win_n = 0;
       D.win_w0 = A.take<int>(ns_win, &h_w0);
       D.win_len = A.take<int>(ns_win, &h_wl);
       D.win_first = A.take<int>(nfp + 1, &h_wf);
       if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
-      win = true;
+      win = ns_win > 0;
       for (int sl = 0; sl < ns_win && win; ++sl) {
         const int a = sl * win_per, b = std::min(a + win_per, win_n);
         const int lo = wlo[h_word[a]];  // sorted by it
