@@ -522,6 +522,9 @@ def test_banded_windows_on_the_matrix_cores_agree_with_the_tile_kernel_and_the_o
             w["obs_pose"][w["obs_point"] == 7] = 0        # a free point seen from the fixed camera only (duplicates too)
             vs.tune_ba(schur_variant=0)
             a = vs.ba_solve(*_args(w), max_iterations=4)
+            a2 = vs.ba_solve(*_args(w), max_iterations=4)   # fixed summation orders everywhere: run to run the same bits
+            assert np.array_equal(a["poses"], a2["poses"]) and np.array_equal(a["points"], a2["points"])
+            assert np.array_equal(a["chi2_trace"], a2["chi2_trace"])
             vs.tune_ba(schur_variant=3)
             b = vs.ba_solve(*_args(w), max_iterations=4)
             o = oracle.ba_solve(*_args(w), max_iterations=4)
