@@ -134,22 +134,46 @@ __device__ __host__ inline void quat_from_pose(const double* m, double* q) {
     q[1] = (M(0, 2) - M(2, 0)) * s;
     q[2] = (M(1, 0) - M(0, 1)) * s;
   } else {
+    // largest diagonal element i, j = (i + 1) % 3, k = (j + 1) % 3 -- written out per i: with run-time indices the matrix
+    // and the quaternion live in scratch memory on the device (same expressions, same order of operations)
     int i = 0;
     if (M(1, 1) > M(0, 0)) i = 1;
-    if (M(2, 2) > M(i, i)) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    double s = sqrt(M(i, i) - M(j, j) - M(k, k) + 1.0);
-    q[i] = 0.5 * s;
-    s = 0.5 / s;
-    q[3] = (M(k, j) - M(j, k)) * s;
-    q[j] = (M(j, i) + M(i, j)) * s;
-    q[k] = (M(k, i) + M(i, k)) * s;
+    if ((i == 0 && M(2, 2) > M(0, 0)) || (i == 1 && M(2, 2) > M(1, 1))) i = 2;
+    if (i == 0) {
+      double s = sqrt(M(0, 0) - M(1, 1) - M(2, 2) + 1.0);
+      q[0] = 0.5 * s;
+      s = 0.5 / s;
+      q[3] = (M(2, 1) - M(1, 2)) * s;
+      q[1] = (M(1, 0) + M(0, 1)) * s;
+      q[2] = (M(2, 0) + M(0, 2)) * s;
+    } else if (i == 1) {
+      double s = sqrt(M(1, 1) - M(2, 2) - M(0, 0) + 1.0);
+      q[1] = 0.5 * s;
+      s = 0.5 / s;
+      q[3] = (M(0, 2) - M(2, 0)) * s;
+      q[2] = (M(2, 1) + M(1, 2)) * s;
+      q[0] = (M(0, 1) + M(1, 0)) * s;
+    } else {
+      double s = sqrt(M(2, 2) - M(0, 0) - M(1, 1) + 1.0);
+      q[2] = 0.5 * s;
+      s = 0.5 / s;
+      q[3] = (M(1, 0) - M(0, 1)) * s;
+      q[0] = (M(0, 2) + M(2, 0)) * s;
+      q[1] = (M(1, 2) + M(2, 1)) * s;
+    }
   }
 #undef M
-  if (q[3] < 0.0)
-    for (int a = 0; a < 4; ++a) q[a] = -q[a];
+  if (q[3] < 0.0) {
+    q[0] = -q[0];
+    q[1] = -q[1];
+    q[2] = -q[2];
+    q[3] = -q[3];
+  }
   const double nrm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  for (int a = 0; a < 4; ++a) q[a] /= nrm;
+  q[0] /= nrm;
+  q[1] /= nrm;
+  q[2] /= nrm;
+  q[3] /= nrm;
 }
 
 // arguments of the PnP-RANSAC kernels (vs_pnp.hip); also launched by the tracking session (vs_track.hip)

@@ -25,6 +25,16 @@ namespace {
 
 
 __device__ inline int pnp_count(const pnp_args& P) { return P.n_dev ? *P.n_dev : P.n; }
+// What a launch works out for itself (the count read on the device, the rows behind the period's offset, the guess in the
+// state buffer the previous solve ended on).  Kept apart from pnp_args ON PURPOSE: the argument struct is never written, so
+// it stays in the kernel-argument segment -- written to, it was copied to scratch memory at kernel entry (736 bytes per lane),
+// every field access became a scratch load, and a kernel with scratch cannot start on a queue before the runtime has
+// provided it, which on a fresh process happened to wait for the very kernels this one waits for in chained tracking.
+struct pnp_view {
+  int n, lm_cur;
+  const double *obj, *img;
+  const double* guess;  // the record to start from, or nullptr: pnp_args::cam0
+};
 // bounded, sleeping poll of a tagged word (nullptr: nothing to wait for); acquire: what the publisher wrote is visible after it
 __device__ inline bool pnp_wait_tag(const unsigned* word, unsigned tag) {
   if (!word) return true;
@@ -38,13 +48,13 @@ __device__ inline bool pnp_wait_tag(const unsigned* word, unsigned tag) {
   return false;
 }
 // chained tracking: the state-buffer index of the previous solve and with it the guess (valid once that solve has ended)
-__device__ inline void pnp_resolve_guess(pnp_args& P) {
+__device__ inline void pnp_resolve_guess(const pnp_args& P, pnp_view& V) {
   const int cur = P.cur_dev->cur & 1;
-  P.lm_cur = cur;
-  P.guess_dev[0] = P.guess_dev[cur];
+  V.lm_cur = cur;
+  V.guess = cur ? P.guess_dev[1] : P.guess_dev[0];  // (no run-time index into the argument struct: that would put it in scratch)
 }
 // (chained tracking: guess_dev[0] and lm_cur have been resolved from the device-side state by then)
-__device__ inline double pnp_guess(const pnp_args& P, int k) { return P.guess_dev[0] ? P.guess_dev[0][k] : P.cam0[k]; }
+__device__ inline double pnp_guess(const pnp_args& P, const pnp_view& V, int k) { return V.guess ? V.guess[k] : P.cam0[k]; }
 
 __device__ inline unsigned long long splitmix64(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -186,7 +196,7 @@ __device__ inline void pnp_reduce(double* v, double* s_red) {
 // memory each evaluation starts with two dependent round trips (index, then point and pixel) on an otherwise idle CU --
 // in-kernel stamps put the refinement at 5.7 us per iteration, mostly waiting for those.
 template <int STEPS, int NWAVES, int NREG>
-__device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int first, int stride, double* cam, double* s_red, int max_it) {
+__device__ inline void pnp_lm(const pnp_args& P, const pnp_view& V, const int* sel, int m, int first, int stride, double* cam, double* s_red, int max_it) {
   double trial[kCamStride];
   double lambda = 0.0, ni = 2.0;
   const bool in_regs = m <= NREG * stride;  // uniform
@@ -199,9 +209,9 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
       if (e < m) {
         const int i = sel ? sel[e] : e;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) rX[j][k] = P.obj[3 * (size_t)i + k];
-        rUV[j][0] = P.img[2 * (size_t)i];
-        rUV[j][1] = P.img[2 * (size_t)i + 1];
+        for (int k = 0; k < 3; ++k) rX[j][k] = V.obj[3 * (size_t)i + k];
+        rUV[j][0] = V.img[2 * (size_t)i];
+        rUV[j][1] = V.img[2 * (size_t)i + 1];
       }
     }
   }
@@ -216,8 +226,8 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
     } else {
       for (int e = first; e < m; e += stride) {
         const int i = sel ? sel[e] : e;
-        const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-        const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+        const double X[3] = {V.obj[3 * (size_t)i], V.obj[3 * (size_t)i + 1], V.obj[3 * (size_t)i + 2]};
+        const double uv[2] = {V.img[2 * (size_t)i], V.img[2 * (size_t)i + 1]};
         pnp_edge<true>(P, cam, X, uv, acc);
       }
     }
@@ -310,8 +320,8 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
         } else {
           for (int e = first; e < m; e += stride) {
             const int i = sel ? sel[e] : e;
-            const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-            const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+            const double X[3] = {V.obj[3 * (size_t)i], V.obj[3 * (size_t)i + 1], V.obj[3 * (size_t)i + 2]};
+            const double uv[2] = {V.img[2 * (size_t)i], V.img[2 * (size_t)i + 1]};
             pnp_edge<false>(P, trial, X, uv, tacc);
           }
         }
@@ -331,6 +341,7 @@ __device__ inline void pnp_lm(const pnp_args& P, const int* sel, int m, int firs
         lambda *= fmax(1.0 / 3.0, alpha);
         ni = 2.0;
         cur = temp;
+#pragma unroll
         for (int k = 0; k < kCamStride; ++k) cam[k] = trial[k];
       } else {
         lambda *= ni;
@@ -386,7 +397,7 @@ __device__ inline void pnp_stamp(const pnp_args& P, int row, int col) {  // diag
   if (P.stamps) P.stamps[(size_t)row * 8 + col] = wall_clock64();
 }
 
-__device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
+__device__ inline void pnp_hypothesis_role(const pnp_args& P, pnp_view& V, int nhw) {
   __shared__ int s_idx[kPnpWaves][8];
   __shared__ int s_cand[kPnpWaves][8];
   __shared__ double s_rec[kPnpWaves][kPnpModel];
@@ -395,12 +406,12 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
   if (h >= P.iterations) return;  // whole wave
   if (lane == 0) pnp_stamp(P, h, 0);
   const unsigned long long tag_hi = (unsigned long long)P.epoch << 32;
-  if (P.n < 5) {
+  if (V.n < 5) {
     if (lane == 0) __hip_atomic_store(&P.tag[h], tag_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   int* idx = s_idx[wv];
-  if (P.n == 5) {
+  if (V.n == 5) {
     if (lane < 5) idx[lane] = lane;
   } else {
     // the first five distinct values of the stream c_k = splitmix64(base ^ ((h << 20) + k)) % n, k = 0, 1, ...: eight
@@ -410,7 +421,7 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
     int got = 0;
     for (unsigned long long k0 = 0; got < 5; k0 += 8) {
       if (lane < 8)
-        cand[lane] = (int)(splitmix64(base ^ (((unsigned long long)h << 20) + k0 + (unsigned long long)lane)) % (unsigned long long)P.n);
+        cand[lane] = (int)(splitmix64(base ^ (((unsigned long long)h << 20) + k0 + (unsigned long long)lane)) % (unsigned long long)V.n);
       wave_lds_sync();
       if (lane == 0) {
         for (int k = 0; k < 8 && got < 5; ++k) {
@@ -434,15 +445,18 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
     if (threadIdx.x == 0) s_back = pnp_wait_tag(P.back_tag_dev, P.back_tag);
     __syncthreads();
     if (!s_back) return;  // the tags stay unpublished
-    pnp_resolve_guess(P);
+    pnp_resolve_guess(P, V);
   }
   double cam[kCamStride];
-  for (int k = 0; k < kCamStride; ++k) cam[k] = pnp_guess(P, k);
-  pnp_lm<3, 1, 1>(P, idx, 5, lane & 7, 8, cam, nullptr, min(P.iters_lm, kPnpHypIters));
+#pragma unroll
+  for (int k = 0; k < kCamStride; ++k) cam[k] = pnp_guess(P, V, k);
+  pnp_lm<3, 1, 1>(P, V, idx, 5, lane & 7, 8, cam, nullptr, min(P.iters_lm, kPnpHypIters));
   if (lane == 0) pnp_stamp(P, h, 2);
   // the model is handed on as a 4x4 pose (as the sequential algorithm does): re-derive the record from that matrix
   double m[16];
+#pragma unroll
   for (int r = 0; r < 3; ++r) {
+#pragma unroll
     for (int k = 0; k < 3; ++k) m[4 * r + k] = cam[7 + 4 * k + r];
     m[4 * r + 3] = cam[r];
   }
@@ -454,7 +468,9 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
   // round trip to wait for before the tag; 31 scalar write-through stores by one lane cost ~12 us here.
   double* rec = s_rec[wv];
   if (lane == 0) {
+#pragma unroll
     for (int k = 0; k < 12; ++k) rec[k] = m[k];
+#pragma unroll
     for (int k = 0; k < kCamStride; ++k) rec[12 + k] = cam[k];
     rec[31] = 0.0;
   }
@@ -462,12 +478,12 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
   if (lane < kPnpModel) st_wt(P.model_out + (size_t)h * kPnpModel + lane, rec[lane]);
   if (lane == 0) pnp_stamp(P, h, 5);
   int good = 0;
-  for (int i0 = 0; i0 < P.n; i0 += 64) {
+  for (int i0 = 0; i0 < V.n; i0 += 64) {
     const int i = i0 + lane;
     bool in = false;
-    if (i < P.n) {
-      const double X[3] = {P.obj[3 * (size_t)i], P.obj[3 * (size_t)i + 1], P.obj[3 * (size_t)i + 2]};
-      const double uv[2] = {P.img[2 * (size_t)i], P.img[2 * (size_t)i + 1]};
+    if (i < V.n) {
+      const double X[3] = {V.obj[3 * (size_t)i], V.obj[3 * (size_t)i + 1], V.obj[3 * (size_t)i + 2]};
+      const double uv[2] = {V.img[2 * (size_t)i], V.img[2 * (size_t)i + 1]};
       double eu, ev, pc[3];
       pnp_err(P, cam, X, uv, eu, ev, pc);
       in = eu * eu + ev * ev <= P.thr2;
@@ -482,7 +498,7 @@ __device__ inline void pnp_hypothesis_role(pnp_args& P, int nhw) {
   }
 }
 
-__device__ inline void pnp_finish_role(pnp_args& P) {
+__device__ inline void pnp_finish_role(const pnp_args& P, pnp_view& V) {
   __shared__ double s_red[kPnpRedDoubles];
   __shared__ int s_best[3], s_cnt[4], s_base, s_g[64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -496,18 +512,18 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
   for (int j = 0; j < kListPre; ++j) {
     const int i = kPnpFinish * j + tid;
     lX[j][0] = lX[j][1] = lX[j][2] = lU[j][0] = lU[j][1] = 0.0;
-    if (i < P.n) {
-      lX[j][0] = P.obj[3 * (size_t)i];
-      lX[j][1] = P.obj[3 * (size_t)i + 1];
-      lX[j][2] = P.obj[3 * (size_t)i + 2];
-      lU[j][0] = P.img[2 * (size_t)i];
-      lU[j][1] = P.img[2 * (size_t)i + 1];
+    if (i < V.n) {
+      lX[j][0] = V.obj[3 * (size_t)i];
+      lX[j][1] = V.obj[3 * (size_t)i + 1];
+      lX[j][2] = V.obj[3 * (size_t)i + 2];
+      lU[j][0] = V.img[2 * (size_t)i];
+      lU[j][1] = V.img[2 * (size_t)i + 1];
     }
   }
   if (P.lm_init && tid == 64) {  // the motion-only solve that follows starts from fresh LM records (no upload in between)
     mo_state z;
     memset(&z, 0, sizeof z);
-    z.cur = P.lm_cur;
+    z.cur = V.lm_cur;
     P.lm_init[0] = z;
     z.need_lin = 1;  // step 0 reads the record of parity 1
     z.ni = 2.0;
@@ -517,7 +533,7 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
     // replay of the sequential RANSAC loop (budget update after every improvement) over the per-hypothesis counts, as they
     // arrive: 64 tagged words per poll, the leading run that carries this call's epoch is consumed in order.  Every lane
     // of the wave runs the same replay on the same values.
-    int max_good = 0, niters = P.n >= 5 ? P.iterations : 0, best = -1, k = 0, timed_out = 0;
+    int max_good = 0, niters = V.n >= 5 ? P.iterations : 0, best = -1, k = 0, timed_out = 0;
     int rounds = 0;
     while (k < niters && k < P.iterations) {
       const int kk = min(k + lane, P.iterations - 1);
@@ -540,7 +556,7 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
         if (g > (max_good > 4 ? max_good : 4)) {
           max_good = g;
           best = k;
-          niters = ransac_update_iters_dev(P.confidence, (double)(P.n - g) / P.n, 5, niters);
+          niters = ransac_update_iters_dev(P.confidence, (double)(V.n - g) / V.n, 5, niters);
         }
       }
       wave_lds_sync();
@@ -572,18 +588,22 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
       }
     }
     if (P.rec_out[0] && tid < kCamStride) {
-      P.rec_out[0][tid] = pnp_guess(P, tid);
-      P.rec_out[1][tid] = pnp_guess(P, tid);
+      double g = 0.0;  // the guess's element `tid`, picked with compile-time indices (see pnp_view)
+#pragma unroll
+      for (int k = 0; k < kCamStride; ++k) g = tid == k ? pnp_guess(P, V, k) : g;
+      P.rec_out[0][tid] = g;
+      P.rec_out[1][tid] = g;
     }
     return;
   }
   double cam[kCamStride];
+#pragma unroll
   for (int k = 0; k < kCamStride; ++k) cam[k] = P.model_out[(size_t)best * kPnpModel + 12 + k];
   // ordered inlier list of the best model
-  for (int i0 = 0, j = 0; i0 < P.n; i0 += kPnpFinish, ++j) {
+  for (int i0 = 0, j = 0; i0 < V.n; i0 += kPnpFinish, ++j) {
     const int i = i0 + tid;
     bool in = false;
-    if (i < P.n) {
+    if (i < V.n) {
       double X[3], uv[2];
       if (j < kListPre) {
         // (static indices only: a register array indexed by the loop counter would go to scratch)
@@ -593,11 +613,11 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
         uv[0] = j == 0 ? lU[0][0] : lU[1][0];
         uv[1] = j == 0 ? lU[0][1] : lU[1][1];
       } else {
-        X[0] = P.obj[3 * (size_t)i];
-        X[1] = P.obj[3 * (size_t)i + 1];
-        X[2] = P.obj[3 * (size_t)i + 2];
-        uv[0] = P.img[2 * (size_t)i];
-        uv[1] = P.img[2 * (size_t)i + 1];
+        X[0] = V.obj[3 * (size_t)i];
+        X[1] = V.obj[3 * (size_t)i + 1];
+        X[2] = V.obj[3 * (size_t)i + 2];
+        uv[0] = V.img[2 * (size_t)i];
+        uv[1] = V.img[2 * (size_t)i + 1];
       }
       double eu, ev, pc[3];
       pnp_err(P, cam, X, uv, eu, ev, pc);
@@ -619,13 +639,16 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
   const int m = s_base;
   if (tid == 0) pnp_stamp(P, srow, 2);
   double pose[12];
+#pragma unroll
   for (int k = 0; k < 12; ++k) pose[k] = P.model_out[(size_t)best * kPnpModel + k];
   if (m >= 1 && P.iters_lm > 0) {
     // final refinement on the inliers (solvePnP(inliers, useExtrinsicGuess) in OpenCV)
     __threadfence_block();
-    pnp_lm<6, kPnpFinish / 64, 4>(P, P.inl_out, m, tid, kPnpFinish, cam, s_red, P.iters_lm);
+    pnp_lm<6, kPnpFinish / 64, 4>(P, V, P.inl_out, m, tid, kPnpFinish, cam, s_red, P.iters_lm);
     if (tid == 0) pnp_stamp(P, srow, 4);
+#pragma unroll
     for (int r = 0; r < 3; ++r) {
+#pragma unroll
       for (int k = 0; k < 3; ++k) pose[4 * r + k] = cam[7 + 4 * k + r];
       pose[4 * r + 3] = cam[r];
     }
@@ -633,18 +656,21 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
   if (P.rec_out[0] && tid == 0) {
     // the record is re-derived from the 4x4 result, as a caller that passes the pose matrix on would do
     double mat[16], rec[kCamStride];
+#pragma unroll
     for (int k = 0; k < 12; ++k) mat[k] = pose[k];
     rec[0] = mat[3];
     rec[1] = mat[7];
     rec[2] = mat[11];
     quat_from_pose(mat, rec + 3);
     quat_to_w2n(rec, rec + 3, rec + 7);
+#pragma unroll
     for (int k = 0; k < kCamStride; ++k) {
       P.rec_out[0][k] = rec[k];
       P.rec_out[1][k] = rec[k];
     }
   }
   if (tid == 0) {
+#pragma unroll
     for (int k = 0; k < 12; ++k) P.result[k] = pose[k];
     P.result[12] = P.result[13] = P.result[14] = 0.0;
     P.result[15] = 1.0;
@@ -653,6 +679,7 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
     P.result[18] = (double)best;
     P.result[19] = (double)s_best[1];
     if (P.host_result) {  // the class-API period reads the PnP outcome from pinned memory, without a copy launch
+#pragma unroll
       for (int k = 0; k < 12; ++k) P.host_result[k] = pose[k];
       P.host_result[12] = P.host_result[13] = P.host_result[14] = 0.0;
       P.host_result[15] = 1.0;
@@ -665,7 +692,7 @@ __device__ inline void pnp_finish_role(pnp_args& P) {
   }
 }
 
-__global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(pnp_args P) {
+__global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(const pnp_args P) {
   // chains of dependent FP64 instructions on single waves: when the next frame's detector shares the CUs (pipelined tracking),
   // the issue arbiter should serve these waves first
   __builtin_amdgcn_s_setprio(3);
@@ -695,15 +722,20 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(pnp_args P) {
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(P.pub_tag_word, P.pub_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  P.n = pnp_count(P);
+  pnp_view V;
+  V.n = pnp_count(P);
+  V.lm_cur = P.lm_cur;
+  V.obj = P.obj;
+  V.img = P.img;
+  V.guess = nullptr;
   if (P.off_dev) {
     const int off = *P.off_dev;
-    P.obj += 3 * (size_t)off;
-    P.img += 2 * (size_t)off;
-    if (fin) pnp_resolve_guess(P);  // (the hypothesis waves do it after their sampling, behind their own wait)
+    V.obj += 3 * (size_t)off;
+    V.img += 2 * (size_t)off;
+    if (fin) pnp_resolve_guess(P, V);  // (the hypothesis waves do it after their sampling, behind their own wait)
   }
-  if ((int)blockIdx.x < nhw) pnp_hypothesis_role(P, nhw);
-  else pnp_finish_role(P);
+  if ((int)blockIdx.x < nhw) pnp_hypothesis_role(P, V, nhw);
+  else pnp_finish_role(P, V);
 }
 
 // grid of pnp_ransac_kernel for `iterations` hypotheses

@@ -262,7 +262,9 @@ bool track_can_chain(vs_ctx* ctx, int set, int k) {
   const int lm = T.params[set].lm_iterations;
   static const bool off = getenv("VS_TRACK_NOCHAIN") != nullptr;  // developer aid: A/B against the host-paced form
   if (off) return false;
-  return T.mst_both && T.pnp_iters > 0 && lm > 0 && mo_persistent_ok(ctx, k, 1 + lm * 10);
+  // (n_points: only the register-resident instantiation of the one-launch solve -- the other one uses scratch memory, and a
+  // kernel that needs scratch may not be able to start while the kernel that waits for it in-kernel is running)
+  return T.mst_both && T.pnp_iters > 0 && lm > 0 && T.n_points <= kMoPersistObs && mo_persistent_ok(ctx, k, 1 + lm * 10);
 }
 
 // Back half, enqueue only (context stream): wait for the front half, PnP-RANSAC from the
