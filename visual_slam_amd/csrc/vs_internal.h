@@ -124,6 +124,7 @@ struct vs_ctx {
     unsigned front_seq = 0, front_tag[2] = {0, 0};  // tags of the front halves (track_append_kernel publishes them on the device)
     unsigned back_seq = 0, back_tag[2] = {0, 0};    // tags of the chained back halves' read-back blocks (track_publish_kernel)
     unsigned ba_seq = 0, ba_tag[2] = {0, 0};        // tags the chained back halves' motion-only solves publish on the device when they are through
+    int quiet = 1;     // no tracking work can be outstanding on any of the context's streams (set where results were handed out last)
     int mst_both = 0;  // both LM records on the device name the state buffer of the newest estimate (fresh period, or the last solve ran in one launch)
     int pending = -1;   // buffer set of the frame whose front half is done and whose back half is not, or -1
     int pending_step = -1;  // >= 0: that frame's back half is enqueued already, this many LM launches so far
