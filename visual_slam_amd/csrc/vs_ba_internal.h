@@ -189,6 +189,8 @@ struct pnp_args {
   unsigned epoch;      // this call's epoch (never 0; words of earlier calls never carry it)
   double* host_result;  // optional pinned mirror of `result` [20] (class-API period), or nullptr
   int* host_inl;        // ... and of inl_out
+  unsigned* host_tag_word;  // ... and the word (pinned) that receives host_tag once both are complete: the host polls it
+  unsigned host_tag;        //     instead of waiting for an event behind the launch
   unsigned long long* stamps;  // diagnostic (vs_pnp_profile): wall-clock stamps [H + 1][8] of the roles' phases, or nullptr
   double* result;      // [20]: pose 4x4, found, inliers, best hypothesis, hypotheses used
   int* inl_out;        // [n]

@@ -122,6 +122,8 @@ struct vs_ctx {
     int pending_published = 0;  // ... and its read-back block is on its way to the host (a kernel that publishes it has been enqueued)
     int pending_chained = 0;  // the pending back half was enqueued with its inputs read on the device (see vs_track_frame_pipelined)
     unsigned front_seq = 0, front_tag[2] = {0, 0};  // tags of the front halves (track_append_kernel publishes them on the device)
+    unsigned api_seq = 0;        // tags of the class-API entry points' pinned results (front half / PnP outcome)
+    unsigned back_tag_sync = 0;  // ... and of the host-paced back half's block (pinned block 0)
     unsigned back_seq = 0, back_tag[2] = {0, 0};    // tags of the chained back halves' read-back blocks (track_publish_kernel)
     unsigned ba_seq = 0, ba_tag[2] = {0, 0};        // tags the chained back halves' motion-only solves publish on the device when they are through
     int quiet = 1;     // no tracking work can be outstanding on any of the context's streams (set where results were handed out last)

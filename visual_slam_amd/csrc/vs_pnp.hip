@@ -53,6 +53,13 @@ __device__ inline void pnp_resolve_guess(const pnp_args& P, pnp_view& V) {
   V.lm_cur = cur;
   V.guess = cur ? P.guess_dev[1] : P.guess_dev[0];  // (no run-time index into the argument struct: that would put it in scratch)
 }
+// class-API period: "the outcome is in pinned memory" (every thread's stores first, then the tag with a system-scope release)
+__device__ inline void pnp_announce(const pnp_args& P) {
+  if (!P.host_tag_word) return;  // uniform
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(P.host_tag_word, P.host_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // (chained tracking: guess_dev[0] and lm_cur have been resolved from the device-side state by then)
 __device__ inline double pnp_guess(const pnp_args& P, const pnp_view& V, int k) { return V.guess ? V.guess[k] : P.cam0[k]; }
 
@@ -594,6 +601,7 @@ __device__ inline void pnp_finish_role(const pnp_args& P, pnp_view& V) {
       P.rec_out[0][tid] = g;
       P.rec_out[1][tid] = g;
     }
+    pnp_announce(P);
     return;
   }
   double cam[kCamStride];
@@ -690,6 +698,7 @@ __device__ inline void pnp_finish_role(const pnp_args& P, pnp_view& V) {
     }
     pnp_stamp(P, srow, 3);
   }
+  pnp_announce(P);
 }
 
 __global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(const pnp_args P) {
@@ -713,6 +722,7 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(const pnp_args P
         P.result[16] = -1.0;
         if (P.host_result) P.host_result[16] = -1.0;
       }
+      if (fin) pnp_announce(P);
       return;
     }
   }
