@@ -697,3 +697,26 @@ def test_pipelined_tracking_mixes_chained_and_host_paced_frames(vs):
     # and a second period right behind it on the same context (tags and tickets carry over)
     again = run(True, want_keypoints=False, want_matches=False)
     assert all(np.array_equal(a["poses"], b["poses"]) for a, b in zip(ref, again))
+
+
+def test_first_tracking_period_of_a_fresh_process_may_be_the_chained_one():
+    """In chained pipelined tracking a PnP launch waits in-kernel for kernels on other streams.  A kernel that needs scratch
+    memory cannot start on a queue before the runtime has provided it, and on a fresh process that provision waited for
+    the very kernels being waited for: the first chained period of a process timed out (pnp_ransac_kernel kept its argument
+    struct in scratch).  A child process whose very first tracking call is the chained form must simply work."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import numpy as np\n"
+        "from visual_slam_amd import Context, harness\n"
+        "ctx = Context(0)\n"
+        "frames, depth0 = harness.load_sequence(8)\n"
+        "a, _, _ = harness.track_sequence_resident(ctx, frames, depth0, pipelined=True)\n"
+        "b, _, _ = harness.track_sequence_resident(ctx, frames, depth0)\n"
+        "assert np.array_equal(a, b)\n"
+        "ctx.close()\n"
+        "print('fresh-process chained period ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fresh-process chained period ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
