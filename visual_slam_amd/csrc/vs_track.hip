@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256) void track_push_kernel(const double* xyz, cons
 // One key-frame period of the reference's tracking loop (src/v2/main.py:173-214) kept resident on the device: the key
 // frame's map points and descriptors are uploaded once (vs_track_begin); every vs_track_frame uploads only the image
 // and runs detect+describe -> match against the map -> PnP-RANSAC from the previous pose -> append the observations
-// -> motion-only BA over all poses of the period, with ONE host synchronisation, at the end (the matcher is launched for
-// max_kp train rows and reads the key-point count on the device).  Same kernels, same arithmetic as the separate entry points.
+// -> motion-only BA over all poses of the period, with ONE host wait, at the end (the matcher is launched for max_kp train
+// rows and reads the key-point count on the device; the wait is a poll of a tagged word in pinned memory that the last kernel
+// writes behind the results).  Same kernels, same arithmetic as the separate entry points.
 namespace {
 struct track_front {
   size_t fxy, fscore, fdesc, fn, mq, mt, md, M;
@@ -487,7 +488,7 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   auto& T = ctx->track;
   const track_layout L = layout_of(ctx);
   const track_front& F = L.f[set];
-  // chained: the context's stream holds the next back half already -- wait for this one's event, and fetch the optional
+  // chained: the streams hold the next back half already -- wait for this one's tag (below), and fetch the optional
   // per-frame arrays on another stream (this buffer set is not written again before the next call)
   hipStream_t s = chained ? ctx->aux_stream[0] : ctx->stream;
   uint8_t* d = (uint8_t*)ctx->d_track.p;
@@ -739,11 +740,11 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
   if (bgr) VS_TRY(track_check_frame(ctx, bgr, w, h_img, stride, lm_iterations, "vs_track_frame_pipelined"));
   VS_HIP(ctx, hipSetDevice(ctx->device));
   // The back half of the previous frame is on the GPU already.  Chained form (PnP on, LM on, the motion-only solve in one
-  // launch): the back half of THIS frame goes onto the context's stream right behind it, before the previous one's results
+  // launch): the back half of THIS frame is enqueued too (on the other of two streams), before the previous one's results
   // are known -- the PnP kernel reads the row offset of its correspondences, its guess and the state-buffer index on the
   // device -- so the GPU passes from one back half to the next without the host in between (the host round trip and the
   // dispatch of the next kernel onto an idle queue were ~20 us per frame on the chain of back halves, which is the critical
-  // path).  The previous frame's results are then awaited through the event behind ITS read-back copy.  Otherwise (a solve
+  // path).  The previous frame's results are then awaited through the tag behind ITS read-back block.  Otherwise (a solve
   // that may need further LM batches decided on the host): the back half is enqueued once the previous results are in.
   const int solve = T.pending;
   const bool solve_chained = solve >= 0 && T.pending_chained;
