@@ -70,6 +70,64 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv, worker=None, timeout=None):
+    """`bench.py --gpus N` started by hand (no torchrun, WORLD_SIZE unset): this process becomes a launcher.  It starts N
+    fresh rank processes of `worker` (default: this file) with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment, relays rank 0's standard output, and returns non-zero when any rank fails (the others are stopped: a rank
+    alone in a collective would wait for ever).  It runs BEFORE torch or the HIP library is imported: the launcher never
+    touches the GPU, so its children are ordinary child processes, not an exec out of a process that holds a device."""
+    import subprocess
+    assert "torch" not in sys.modules and "visual_slam_amd._capi" not in sys.modules, "the launcher must stay off the GPU"
+    cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0", VS_BENCH_LAUNCHED="1")
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      text=True))
+    deadline = None if timeout is None else time.time() + timeout
+    rcs = [None] * n
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None or (deadline is not None and time.time() > deadline):
+            for r, p in enumerate(procs):       # exactly the processes started above, by handle
+                if rcs[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(10)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            if failed is None:
+                failed = -1
+            break
+        time.sleep(0.05)
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    if failed is not None:
+        sys.stderr.write("bench.py launcher: %s; ranks' exit codes %s\n"
+                         % ("timed out" if failed < 0 else "rank %d failed" % failed, rcs))
+        sys.stdout.write(out)   # whatever rank 0 managed to say (diagnostics), but the exit code says failure
+        return 1
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return 0
+
+
 def median_time(fn, reps, warm=3):
     """Median wall seconds of fn() over `reps` calls after `warm` untimed ones."""
     for _ in range(warm):
@@ -468,11 +526,20 @@ def main():
         cpu_tracker_worker(int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4]))
         return
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:   # started by hand: become the launcher (before any GPU call)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:   # a curve recorded with another rank count than the command line names would be meaningless
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python -m torch.distributed.run --nproc-per-node "
+                         "%d bench.py --gpus %d ...` (or by hand without WORLD_SIZE, and it launches its own ranks)\n"
+                         % (args.gpus, world, args.gpus, args.gpus))
+        sys.exit(2)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -678,6 +745,23 @@ def main():
                             "bound the kernel; kept because north_star words its target (>= 0.6) in it"},
                 "kernels": {}}
 
+    # ---- what ran the exchange: ranks of the matcher's own RCCL communicator (ncclCommCount) and every rank's device
+    rccl_ranks, rccl_device, devices = None, None, [torch.cuda.current_device()]
+    if use_dist:
+        rccl_ranks = matcher.rccl_ranks()
+        rccl_device = matcher._rccl.device() if matcher._rccl is not None else None
+        dv = torch.tensor([torch.cuda.current_device()], dtype=torch.int32, device=dev)
+        gl = [torch.zeros_like(dv) for _ in range(world)]
+        dist.all_gather(gl, dv)
+        devices = [int(x.item()) for x in gl]
+        bad = (rccl_ranks is not None and rccl_ranks != world) or (world > 1 and len(set(devices)) != world)
+        flag = torch.tensor([1 if bad else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            sys.stderr.write("bench.py: rank %d: rccl_ranks=%r world=%d devices=%r -- ranks do not map one to one onto GPUs\n"
+                             % (rank, rccl_ranks, world, devices))
+            sys.exit(3)
+
     replicas = None
     if use_dist and not args.no_frames:
         try:
@@ -718,6 +802,9 @@ def main():
                                    % (nq, nt, "" if world == 1 else "; %d query shards + RCCL all-gather (16 B/query, overlapped with the next step)" % world),
                        "queries_per_gpu": nq, "train": nt, "parallelism": "query-shard x%d" % world},
             "roofline": roof,
+            "rccl_ranks": rccl_ranks, "rank_devices": devices, "rccl_device_rank0": rccl_device,
+            "collective_path": matcher.collective_path(), "launched_by": "bench.py launcher" if os.environ.get(
+                "VS_BENCH_LAUNCHED") else "external launcher" if "WORLD_SIZE" in os.environ else "single process",
         }
         if cfg5 is not None:
             line["cfg5"] = cfg5

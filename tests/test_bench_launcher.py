@@ -1,0 +1,101 @@
+"""bench.py --gpus N is authoritative (round-3 verdict weak #2): started by hand it launches its own N ranks BEFORE any GPU
+call, started by a launcher it refuses a WORLD_SIZE that differs from --gpus.  CPU only: the ranks are a stub worker."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+STUB = textwrap.dedent("""
+    import json, os, sys, time
+    rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                          "HSA_ENABLE_IPC_MODE_LEGACY")}
+    rec["argv"] = sys.argv[1:]
+    rec["pid"] = os.getpid()
+    open(os.path.join(os.environ["STUB_DIR"], "rank%s.json" % rec["RANK"]), "w").write(json.dumps(rec))
+    if os.environ.get("STUB_FAIL_RANK") == rec["RANK"]:
+        sys.exit(7)
+    if os.environ.get("STUB_FAIL_RANK") is not None:
+        time.sleep(30)   # a healthy rank would sit in a collective waiting for the failed one: the launcher must stop it
+    print(json.dumps({"from_rank": rec["RANK"]}))
+""")
+
+DRIVER = textwrap.dedent("""
+    import json, sys
+    sys.path.insert(0, %r)
+    import bench
+    rc = bench.launch_ranks(int(sys.argv[1]), ["--gpus", sys.argv[1], "--steps", "3"], worker=[sys.executable, sys.argv[2]],
+                            timeout=60)
+    gpu_mods = sorted(m for m in sys.modules if m == "torch" or m.startswith("torch.") or m.endswith("_capi"))
+    sys.stderr.write("LAUNCHER " + json.dumps({"rc": rc, "gpu_modules": gpu_mods}) + "\\n")
+    sys.exit(rc)
+""" % ROOT)
+
+
+def _run_launcher(tmp_path, n, fail_rank=None):
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    env = dict(os.environ, STUB_DIR=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
+    env.pop("MASTER_PORT", None)
+    if fail_rank is not None:
+        env["STUB_FAIL_RANK"] = str(fail_rank)
+    p = subprocess.run([sys.executable, "-c", DRIVER, str(n), str(stub)], env=env, capture_output=True, text=True, timeout=120)
+    info = [json.loads(ln[len("LAUNCHER "):]) for ln in p.stderr.splitlines() if ln.startswith("LAUNCHER ")]
+    recs = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(n) if (tmp_path / ("rank%d.json" % r)).exists()]
+    return p, info[0] if info else None, recs
+
+
+def test_launcher_starts_n_distinct_ranks_and_relays_rank_0(tmp_path):
+    p, info, recs = _run_launcher(tmp_path, 3)
+    assert p.returncode == 0, p.stderr
+    assert info == {"rc": 0, "gpu_modules": []}, "the launcher process must not import torch or the HIP binding"
+    assert len(recs) == 3
+    assert sorted(r["RANK"] for r in recs) == ["0", "1", "2"]
+    assert sorted(r["LOCAL_RANK"] for r in recs) == ["0", "1", "2"]
+    assert {r["WORLD_SIZE"] for r in recs} == {"3"}
+    assert {r["MASTER_ADDR"] for r in recs} == {"127.0.0.1"}
+    assert len({r["MASTER_PORT"] for r in recs}) == 1 and recs[0]["MASTER_PORT"].isdigit()
+    assert {r["HSA_ENABLE_IPC_MODE_LEGACY"] for r in recs} == {"0"}
+    assert len({r["pid"] for r in recs}) == 3
+    assert all(r["argv"] == ["--gpus", "3", "--steps", "3"] for r in recs)
+    # only rank 0's line comes back
+    assert [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")] == [{"from_rank": "0"}]
+
+
+def test_launcher_propagates_a_rank_failure_and_stops_the_others(tmp_path):
+    import time
+    t0 = time.time()
+    p, info, recs = _run_launcher(tmp_path, 3, fail_rank=1)
+    assert p.returncode != 0
+    assert info is not None and info["rc"] != 0
+    assert "rank 1 failed" in p.stderr
+    assert time.time() - t0 < 25, "the surviving ranks were not stopped"
+
+
+def test_bench_refuses_a_world_size_that_differs_from_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2
+    assert "--gpus 4 but WORLD_SIZE=2" in p.stderr
+    assert p.stdout.strip() == ""
+
+
+def test_bench_gpus_n_by_hand_becomes_the_launcher(tmp_path):
+    """`python bench.py --gpus 2` without WORLD_SIZE: two rank processes of bench.py itself.  There is no GPU here, so every
+    rank stops at `needs an MI355X` -- what is checked is that two ranks were started and the failure came back."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check of the launch path")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "bench.py launcher: rank" in p.stderr and "failed" in p.stderr
+    assert p.stderr.count("needs an MI355X") >= 1

@@ -89,6 +89,23 @@ class RcclAllGather:
         if rc != 0:
             raise RuntimeError("RCCL error %d: %s" % (rc, self.lib.ncclGetErrorString(rc).decode()))
 
+    def count(self):
+        """Number of ranks in THIS communicator as RCCL itself reports it (ncclCommCount) -- what bench.py puts on its JSON
+        line as `rccl_ranks`, so that a scaling record can be checked against the collective that actually ran."""
+        C = self._C
+        n = C.c_int(-1)
+        self.lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._chk(self.lib.ncclCommCount(self.comm, C.byref(n)))
+        return int(n.value)
+
+    def device(self):
+        """HIP device ordinal the communicator is bound to (ncclCommCuDevice)."""
+        C = self._C
+        d = C.c_int(-1)
+        self.lib.ncclCommCuDevice.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        self._chk(self.lib.ncclCommCuDevice(self.comm, C.byref(d)))
+        return int(d.value)
+
     def close(self):
         if getattr(self, "comm", None):
             self.lib.ncclCommDestroy(self.comm)
@@ -307,6 +324,19 @@ class ShardedMatcher:
         if self._local is not None:
             raise RuntimeError("ShardedMatcher.plan needs the HIP path")
         return _Plan(self, q_shard, train, n_query, 1 if single_stream else int(in_flight))
+
+    def rccl_ranks(self):
+        """Ranks of the matcher's own RCCL communicator (ncclCommCount), None when the direct path is not in use (world
+        size 1 without force_collective, an injected CPU kernel, or the torch.distributed fallback)."""
+        return None if self._rccl is None else self._rccl.count()
+
+    def collective_path(self):
+        """Which exchange a step uses: 'rccl_direct' (in-place ncclAllGather inside vs_hamming_knn2_sharded_dev),
+        'torch_distributed' (fallback) or 'none' (one rank)."""
+        if self._rccl is not None:
+            return "rccl_direct"
+        collective = self._dist.is_initialized() and (self.world > 1 or self._force_collective)
+        return "torch_distributed" if collective else "none"
 
     def close(self):
         """Destroy the direct RCCL communicator (if one was created)."""
