@@ -264,21 +264,28 @@ def cpu_baseline(nq, nt):
     except Exception:
         lib = oracle.load()
     q, t = match_workload(nq, nt)
-    cores = os.cpu_count() or 1
+    logical, quota = host_cpu_share()
     oracle.hamming_knn2(q[:512], t, threads=0, lib=lib)  # warm
-    times = []
-    t_end = time.time() + 12.0
-    while len(times) < 5 or (time.time() < t_end and len(times) < 40):
-        t0 = time.perf_counter()
-        oracle.hamming_knn2(q, t, threads=0, lib=lib)
-        times.append(time.perf_counter() - t0)
+    # the same thread sweep as the frames / local_ba legs (one machine, described once): the box reports its host's logical
+    # CPUs but the job runs on a cgroup share of them, so three thread counts are timed and the best is the figure
+    sweep = []
+    for th in sorted({min(logical, 32), min(logical, 96), logical}):
+        times = []
+        t_end = time.time() + 5.0
+        while len(times) < 3 or (time.time() < t_end and len(times) < 25):
+            t0 = time.perf_counter()
+            oracle.hamming_knn2(q, t, threads=th, lib=lib)
+            times.append(time.perf_counter() - t0)
+        sweep.append({"threads": th, "gmatches_per_s": nq * nt / statistics.median(times) / 1e9, "runs": len(times)})
+    best = max(sweep, key=lambda r: r["gmatches_per_s"])
     t0 = time.perf_counter()
     oracle.hamming_knn2(q, t, threads=1, lib=lib)
     t1 = time.perf_counter() - t0
-    med = statistics.median(times)
-    return {"value": nq * nt / med / 1e9, "unit": "Gmatches/s", "cores": cores, "kind": "port",
-            "sample": "full %dx%d cfg3 workload, CPU oracle (C, -O3 -march=native, OpenMP %d threads), median of %d runs"
-                      % (nq, nt, cores, len(times)),
+    return {"value": best["gmatches_per_s"], "unit": "Gmatches/s", "cores": best["threads"], "kind": "port",
+            "host_logical_cpus": logical, "cpu_quota_cores": quota, "sweep": sweep,
+            "sample": "full %dx%d cfg3 workload, CPU oracle (C, -O3 -march=native, OpenMP over queries), median of %d runs at "
+                      "%d threads (best of the thread counts in `sweep`; `cores` = threads used)"
+                      % (nq, nt, best["runs"], best["threads"]),
             "single_thread_value": nq * nt / t1 / 1e9}
 
 

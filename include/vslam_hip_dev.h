@@ -1,0 +1,40 @@
+/* vslam_hip_dev.h -- developer entry points of libvslam_hip.so: tuning knobs and profiling switches used by tests/, tools/
+ * and bench.py.  They are NOT part of the drop-in boundary (include/vslam_hip.h) -- nothing in the reference corresponds to
+ * them -- and may change between rounds without an ABI version bump.  All state they touch lives in the context (vs_tuning
+ * in csrc/vs_internal.h): two contexts never see each other's knobs.
+ *
+ * tests/test_abi.py fails on any exported vs_* symbol that neither header declares. */
+#ifndef VSLAM_HIP_DEV_H
+#define VSLAM_HIP_DEV_H
+
+#include "vslam_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Matcher (csrc/vs_match.hip).  target_blocks: workgroups per launch the chunk planner aims at (0 = automatic);
+ * tstage: 1 = train rows staged through LDS (default), 0 = wave-uniform scalar loads (sweep only -- that instantiation
+ * carries scratch memory and is refused on a device-chained tracking period).  A negative value leaves a knob as it is. */
+int vs_tune_match(vs_ctx* ctx, int target_blocks, int tstage);
+/* HIP-event pair around every launch of hamming_knn2_kernel on its launch stream while enabled. */
+int vs_match_profile(vs_ctx* ctx, int enable);
+/* Synchronises, stores the mean kernel duration [ms] of the profiled launches, clears them; returns their number. */
+int vs_match_profile_read(vs_ctx* ctx, float* kernel_ms);
+
+/* Bundle adjustment (csrc/vs_ba.hip).  schur_variant: 0 automatic, 1 tile kernel, 2 ba_schur_small with a linearisation
+ * launch per iteration, 3 banded windows on the tile kernel; points_per_workgroup (< 64: ba_schur_small, >= 64: slab size of
+ * ba_schur_window); max_slabs: cap on ba_schur_small's slabs; motion_variant: 0 one-launch motion-only solve where it
+ * applies, 1 one launch per LM step.  Values out of range leave a knob as it is. */
+int vs_tune_ba(vs_ctx* ctx, int schur_variant, int points_per_workgroup, int max_slabs, int motion_variant);
+
+/* Phase stamps of pnp_ransac_kernel (csrc/vs_pnp.hip).  vs_pnp_profile_read synchronises and returns the stamps of the
+ * newest profiled launch as microseconds since the launch's first stamp: rows 0..H-1 = hypotheses, row H = the finishing
+ * workgroup; 8 doubles per row, 0 = not reached.  Returns the number of rows (0 when nothing was profiled). */
+int vs_pnp_profile(vs_ctx* ctx, int enable);
+int vs_pnp_profile_read(vs_ctx* ctx, double* out, int cap_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSLAM_HIP_DEV_H */

@@ -9,8 +9,8 @@ import pytest
 from conftest import ROOT
 
 
-def _declared():
-    txt = open(os.path.join(ROOT, "include", "vslam_hip.h")).read()
+def _declared(header="vslam_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(vs_[a-z0-9_]+)\s*\(", txt)))
 
@@ -26,6 +26,22 @@ def test_library_exports_every_declared_symbol():
     assert set(names) <= exported, sorted(set(names) - exported)
     assert set(names) == set(_capi.SIGNATURES), sorted(set(names) ^ set(_capi.SIGNATURES))
     assert lib.vs_abi_version() == 3
+
+
+def test_no_exported_symbol_is_undeclared():
+    """Every vs_* symbol the library exports is declared in include/vslam_hip.h (the drop-in boundary) or in
+    include/vslam_hip_dev.h (tuning and profiling switches of tests, tools and bench.py) -- and the developer header declares
+    nothing the library lacks, with the binding's HOOKS table matching it name by name and parameter by parameter."""
+    from visual_slam_amd import _capi
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (vs_\w+)", out))
+    stable, dev = set(_declared()), set(_declared("vslam_hip_dev.h"))
+    assert not (stable & dev)
+    assert exported == stable | dev, sorted(exported ^ (stable | dev))
+    assert dev == set(_capi.HOOKS), sorted(dev ^ set(_capi.HOOKS))
+    protos = _header_prototypes("vslam_hip_dev.h")
+    for name, (_, argtypes) in _capi.HOOKS.items():
+        assert len(protos[name]) == len(argtypes), (name, protos[name], argtypes)
 
 
 def test_struct_layouts_match_the_header():
@@ -55,8 +71,8 @@ def test_product_never_imports_the_oracle():
                     "oracle/vs_oracle.c", ""), os.path.join(dirpath, f)
 
 
-def _header_prototypes():
-    txt = open(os.path.join(ROOT, "include", "vslam_hip.h")).read()
+def _header_prototypes(header="vslam_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     protos = {}
     for ret, name, params in re.findall(r"\b(int|void\s*\*|const char\s*\*)\s*(vs_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", txt):

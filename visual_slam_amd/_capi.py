@@ -111,7 +111,7 @@ SIGNATURES = {
                                               C.c_int, C.c_int, c_voidp, c_voidp, c_voidp, c_voidp, c_voidp]),
 }
 
-# test / sweep hooks (per context, not part of the stable ABI and not declared in the header)
+# test / sweep / profiling hooks (per context, not part of the stable ABI): declared in include/vslam_hip_dev.h
 HOOKS = {
     "vs_tune_match": (C.c_int, [c_ctxp, C.c_int, C.c_int]),                 # target workgroups, train staging (-1: keep)
     "vs_tune_ba": (C.c_int, [c_ctxp, C.c_int, C.c_int, C.c_int, C.c_int]),  # schur variant, points / workgroup, slab cap, motion variant

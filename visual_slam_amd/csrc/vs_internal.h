@@ -10,7 +10,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/vslam_hip.h"
+#include "../../include/vslam_hip_dev.h"  // includes vslam_hip.h; the compiler checks both sets of prototypes
 
 #define VS_API extern "C" __attribute__((visibility("default")))
 
