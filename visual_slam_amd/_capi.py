@@ -117,6 +117,9 @@ HOOKS = {
     "vs_tune_ba": (C.c_int, [c_ctxp, C.c_int, C.c_int, C.c_int, C.c_int]),  # schur variant, points / workgroup, slab cap, motion variant
     "vs_match_profile": (C.c_int, [c_ctxp, C.c_int]),
     "vs_match_profile_read": (C.c_int, [c_ctxp, C.POINTER(C.c_float)]),
+    "vs_match_stamps": (C.c_int, [c_ctxp, C.c_int]),
+    "vs_match_stamps_read": (C.c_int, [c_ctxp, c_f64p, C.c_int]),
+    "vs_track_debug": (C.c_int, [c_ctxp, C.c_int, c_intp]),
     "vs_pnp_profile": (C.c_int, [c_ctxp, C.c_int]),
     "vs_pnp_profile_read": (C.c_int, [c_ctxp, c_f64p, C.c_int]),
 }

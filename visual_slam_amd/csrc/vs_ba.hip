@@ -2682,7 +2682,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
 // loads on the other, no ticket).  Mailboxes are double buffered by step parity, as the partials of the multi-launch form:
 // a workgroup can be at most one step ahead of the slowest.  The arithmetic -- operands, order,
 // reductions, the decision (mo_decide) -- is that of ba_motion_step, the results are bit-identical (tested).
-// Every wait is bounded: a workgroup that does not see the others within ~2^22 polls ends the solve with terminated = 3.
+// Every wait is bounded: a workgroup that does not see the others within 2^16 polls (~0.1 s) ends the solve with terminated = 3.
 constexpr int kMoObsRegs = 2;      // observations a thread keeps in registers (kMoThreads * kMoObsRegs per camera)
 static_assert(kMoObsRegs * kMoThreads == kMoPersistObs, "register capacity of ba_motion_persistent");
 
@@ -2770,7 +2770,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
             s_box[g][jw] = (unsigned)(w >> 32);
           }
           if (__syncthreads_and(ready)) break;
-          if (++polls > (1 << 22)) {  // uniform: every thread counts the same rounds
+          if (++polls > (1 << 16)) {  // (~0.1 s; a rendezvous takes ~1 us) uniform: every thread counts the same rounds
             s_abort = 1;
             break;
           }

@@ -696,6 +696,19 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
 
 }  // namespace
 
+size_t vs_detect_chain_scratch_bytes() {
+  size_t worst = 0;
+  for (const void* fn : {(const void*)detect_band_kernel<true, true, false>, (const void*)select_describe_kernel<true>}) {
+    hipFuncAttributes a;
+    if (hipFuncGetAttributes(&a, fn) != hipSuccess) {
+      (void)hipGetLastError();
+      return (size_t)-1;
+    }
+    if (a.localSizeBytes > worst) worst = a.localSizeBytes;
+  }
+  return worst;
+}
+
 VS_API int vs_gray_mean3_u8(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* gray) {
   VS_TRY(check_image(ctx, bgr, w, h, stride, 3, "vs_gray_mean3_u8"));
   if (!gray) return vs_fail(ctx, VS_EINVAL, "%s: gray is NULL", "vs_gray_mean3_u8");

@@ -41,7 +41,9 @@ struct vs_match_scratch {
   hipStream_t stream = nullptr;
   bool used = false;
   uint64_t stamp = 0;  // last use (least recently used set is recycled for a new stream)
-  vs_buf partial, ticket;
+  vs_buf partial;      // [nchunks][qtiles][256] self-validating partial words (epoch | second key | best key)
+  vs_buf flag;         // pinned: set by a folding workgroup whose wait ran out (checked by the next launch on the stream)
+  int qtiles = 0, nchunks = 0, epoch = 0;  // geometry the slots were last used with; epoch of the newest launch (1 .. 63)
   vs_buf idx, dist;    // 2-NN rows between the match kernel and the ratio kernel (vs_match_ratio_dev)
 };
 constexpr int VS_MATCH_STREAMS = 4;
@@ -139,12 +141,24 @@ struct vs_ctx {
       unsigned long long seed;
       int lm_iterations;
     } params[2];
+    // recovery (vs_track.hip, track_redo): a back half whose in-kernel hand-offs did not complete is redone host-paced once
+    std::vector<uint8_t> good;  // read-back block [LM records | flags | PnP result | both camera buffers] of the newest frame handed out
+    double key_rec[19];         // the key frame's camera record (what both camera buffers start from)
+    double redo_rec[19];        // start record of a host-fed frame (vs_track_push_frame), kept for a redo
+    int recoveries = 0;         // back halves redone so far (vs_track_debug)
+    int recoverable = 0;        // set by track_back_finish next to an error a redo can cure
+    int in_redo = 0;            // a redo is running: the motion-only solve takes the launch-per-step form, nothing is chained
+    int inject = 0;             // developer aid (vs_track_debug): the next chained PnP launch waits for a tag nobody publishes
+    int dirty = 0;              // an entry point returned an error after enqueueing: vs_track_end / vs_track_begin synchronise fully
   } track;
   vs_buf d_bgr2;  // image buffer of the second set
   hipEvent_t ev_shard = nullptr;  // orders the all-gather stream behind the match kernel (vs_hamming_knn2_sharded_dev)
   hipEvent_t ev_after = nullptr;  // orders a compute stream behind the caller's stream (same entry point, after_stream)
   vs_tuning tune;
   std::vector<vs_prof_rec> match_prof;
+  vs_buf d_match_stamps;    // diagnostic phase stamps of the newest stamped match launch (vs_match_stamps)
+  bool match_stamps_on = false;
+  int match_stamps_rows = 0;
   vs_buf d_pnp_tag;         // tagged per-hypothesis words of pnp_ransac_kernel (zero when allocated)
   unsigned pnp_epoch = 0;   // epoch of the newest PnP call
   vs_buf d_pnp_stamps;      // diagnostic phase stamps of the newest PnP launch (vs_pnp_profile)
@@ -152,6 +166,7 @@ struct vs_ctx {
   int pnp_profile_h = 0;
   vs_pool pool;
   int mo_persist_cap = -1;  // camera workgroups of ba_motion_persistent the device keeps resident together (-1: not asked yet)
+  long long chain_scratch = -1;  // largest private segment among the kernels of a chained tracking period (-1: not asked yet; vs_track.hip)
 };
 
 // device copy of the n x 32-byte descriptor set at host pointer `h` (uploads unless the very same bytes are already
@@ -236,6 +251,11 @@ int vs_match_ratio_dev_n(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
 int vs_detect_describe_dev_mirror(vs_ctx* ctx, const void* d_bgr, int w, int h, int pitch, int thr, int max_kp, void* d_xy,
                                   void* d_score, void* d_desc, void* d_n_out, void* stream, uint8_t* h_block,
                                   unsigned h_off_score, unsigned h_off_xy, unsigned h_off_desc);
+
+// largest private segment (scratch bytes per lane) among the kernels this unit contributes to a tracking period's front half,
+// as the runtime reports it for the loaded code objects ((size_t)-1: could not be asked)
+size_t vs_match_chain_scratch_bytes(vs_ctx* ctx);
+size_t vs_detect_chain_scratch_bytes();
 
 // implemented in vs_match.hip / vs_detect.hip / vs_ba.hip
 void vs_ctx_free_buffers(vs_ctx* ctx);

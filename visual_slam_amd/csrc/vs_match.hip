@@ -7,19 +7,26 @@
 //   * lane = query.  Every lane keeps kQPL query descriptors (8 dwords each) in VGPRs for the whole kernel.
 //   * train descriptors are wave-uniform.  Default (TSTAGE): every wave stages 64 train rows at a time in its own 2 KB LDS
 //     slice (one coalesced 32-byte load per lane, prefetched one batch ahead, wave-synchronous: no barrier) and reads each
-//     row back as two broadcast ds_read_b128, so both v_xor_b32 operands are VGPRs (on gfx950 a VGPR-only v_xor issues at
-//     the 2-cycle wave64 rate, with an SGPR source at the 4-cycle rate: tools/valu_probe2.hip).  The older form -- scalar
-//     loads (s_load_dwordx8), the row as the SGPR operand of v_xor_b32 -- remains as the !TSTAGE instantiation (sweeps).
-//   * distance = 8 x (v_xor_b32 + v_bcnt_u32_b32 with accumulate), a dependent chain per query, kQPL chains in flight.
+//     row back as two broadcast ds_read_b128 -- the first half one step ahead of its use -- so both v_xor_b32 operands are
+//     VGPRs (on gfx950 a VGPR-only v_xor issues at the 2-cycle wave64 rate, with an SGPR source at the 4-cycle rate:
+//     tools/valu_probe2.hip).  The older form -- scalar loads (s_load_dwordx8), the row as the SGPR operand of v_xor_b32 --
+//     remains as the !TSTAGE instantiation (sweeps and tests).
+//   * distance = 8 x (v_xor_b32 + v_bcnt_u32_b32 with accumulate); a step is 2 rows x kQPL queries = 8 chains advanced word by
+//     word (8 xors, then 8 popcount-accumulates, held in that order by scheduling barriers).
 //   * top-2 bookkeeping on packed keys  key = dist << 20 | train index, two train rows per update:
 //       second = v_min_u32(second, v_med3_u32(best, ka, kb));  best = v_min3_u32(best, ka, kb)
 //     (the second smallest of {best, second, ka, kb} with best <= second is min(second, median(best, ka, kb))), so the
 //     tie rule "lower train index first" falls out of the packing.  16 + 1 + 1.5 = 18.5 VALU ops per distance.
-//   * the grid is (query tiles) x (train chunks) so that ~5 waves sit on every SIMD even at 10k x 10k.  Every
-//     (tile, chunk) workgroup publishes one 8-byte partial per query; the workgroup that arrives LAST at a tile (agent-
-//     scope ticket counter; write-through stores + acquire as MI355X_MICROARCH.md prescribes for inter-workgroup
-//     hand-offs) folds the tile's partials in chunk order and writes the final (idx, dist) rows: ONE launch, no merge kernel.
+//   * the grid is (query tiles) x (train chunks), ~5 workgroups per compute unit at 10k x 10k, the train rows cut evenly.  Every
+//     (tile, chunk) workgroup publishes one self-validating 8-byte partial per query (launch epoch | second key | best key, one
+//     write-through store); the workgroup of a tile's last chunk polls the tile's words and folds them in chunk order and writes
+//     the final (idx, dist) rows: ONE launch, no merge kernel, no ticket.
 //   * the ratio test + ordered compaction is one workgroup using wave ballots and popcounts for the prefix.
+// What the body can and cannot do (round 4, tools/valu_probe4.hip, tools/match_stamps.py): under this load the shader clock is
+// ~2.12 GHz, not 2.4; v_xor (VGPR, VGPR) issues in ~2.8 cycles, v_bcnt / v_lshl_or / v_min3 / v_med3 in 4; operand banks do not
+// matter; the 148 instructions of a step issue at 1.72 ns apiece with four or five waves per SIMD -- the kernel's 29 468
+// instructions per SIMD are 50.7 us of issue, the launch takes 53.5 - 57 us.  Waves of a SIMD are served oldest first: the five
+// workgroups of a compute unit finish one after the other (14, 25, 36, 47, 57 us), not together.
 #include "vs_internal.h"
 
 #include <dlfcn.h>
@@ -95,10 +102,22 @@ __device__ __forceinline__ void fold64(unsigned long long& B1, unsigned long lon
 // Workgroup (tile, chunk): kWaves waves hold the SAME kTileQ queries; wave w scans the w-th quarter of the chunk and the
 // four (best, second) pairs are merged through LDS, so one 8-byte partial per (chunk, query) is published:
 //   partial[(chunk * qtiles + tile) * kTileQ + local query]      (2 KB rows: no cache line is shared by two workgroups)
-// The last workgroup to arrive at a tile (ticket[tile], reset by that workgroup for the next launch) folds the chunks.
+// Chunks and quarters are cut evenly from the ACTUAL number of train rows (chunk c = rows [c nt / C, (c + 1) nt / C)): every
+// wave of the launch scans the same number of rows to within one (with chunk lengths rounded up to a multiple of 16 the last
+// chunk of a 10 000-row set was 80 rows against 320, and everybody else carried 2.4 % more than their share).
+//
+// Hand-off of the partials (round 4).  A partial is ONE self-validating 64-bit word
+//   [63:58] epoch of the launch (1 .. 63, from the host)   [57:29] second key   [28:0] best key     (key = dist << 20 | index)
+// stored write-through by one instruction.  The workgroup of the tile's LAST chunk -- dispatched last, so every other chunk
+// of the tile has been dispatched before it: no wait on a workgroup that cannot start -- folds the tile: thread = query polls
+// the tile's words until every one carries this launch's epoch.  One store and one (polled) load lie between the end of the
+// last body and the fold; the form before (store, drain, barrier, agent-scope ticket, barrier, acquire, loads) had three
+// dependent round trips to the coherence point there, and only then did the last arriver start loading.
+// A word of an earlier launch with the same geometry carries the previous epoch (every slot is rewritten by every launch);
+// when the geometry of a stream's launches changes, or after 63 launches... the host clears the slots (knn2_dev_impl).
 // PACKED: one 16-byte row (idx0, idx1, dist0, dist1) per query -- the layout the query-sharded matcher all-gathers.
 // TSTAGE (how the wave-uniform train rows reach the VALU):
-//   false: scalar loads (s_load_dwordx16), the row is the SGPR operand of v_xor_b32;
+//   false: scalar loads (s_load_dwordx16), the row is the SGPR operand of v_xor_b32 (sweeps only; carries scratch memory);
 //   true : every wave stages 64 rows at a time in its own LDS slice (one coalesced 32-B load per lane, prefetched one
 //          batch ahead) and reads each row back as two broadcast ds_read_b128 -- both v_xor_b32 operands are then VGPRs.
 //          tools/valu_probe2.hip: v_xor/v_and/v_or with VGPR sources issue at the 2-cycle wave64 rate on gfx950, with an
@@ -115,25 +134,85 @@ __device__ __forceinline__ u32x8 row_from(const uint4 a, const uint4 b) {
   return r;
 }
 
-template <bool PACKED, bool TSTAGE>
-__global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint4* __restrict__ q4, int nq,
-                                                                     const uint32_t* __restrict__ t, int nt,
-                                                                     int chunk_len, int sub_len, uint2* partial,
-                                                                     unsigned* ticket, int2* __restrict__ idx,
-                                                                     int2* __restrict__ dist, const int* __restrict__ nt_dev) {
+constexpr uint32_t kKey29 = (1u << 29) - 1u;  // a partial's keys: 9 bits of distance (0 .. 256), 20 bits of index; all ones = none
+constexpr int kEpochs = 63;                   // epochs 1 .. 63 (0: a cleared slot)
+
+// distances of 2 rows x kQPL queries as 2 * kQPL chains advanced word by word (all xors of a word, then all popcount-accumulates
+// of that word: no instruction depends on the one issued just before it in its wave); keys out
+__device__ __forceinline__ void keys2(const uint32_t (&qv)[kQPL][8], const u32x8& ta, const u32x8& tb, uint32_t j,
+                                      uint32_t (&ka)[kQPL], uint32_t (&kb)[kQPL]) {
+  uint32_t a[kQPL], b[kQPL];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    uint32_t xa[kQPL], xb[kQPL];
+#pragma unroll
+    for (int r = 0; r < kQPL; ++r) {
+      xa[r] = qv[r][k] ^ ta[k];
+      xb[r] = qv[r][k] ^ tb[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < kQPL; ++r) {
+      a[r] = bcnt_acc(xa[r], k ? a[r] : 0u);
+      b[r] = bcnt_acc(xb[r], k ? b[r] : 0u);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int r = 0; r < kQPL; ++r) {
+    ka[r] = (a[r] << kIdxBits) | j;
+    kb[r] = (b[r] << kIdxBits) | (j + 1);
+  }
+}
+// (best, second) of a query updated with the keys of two rows
+__device__ __forceinline__ void update2(const uint32_t (&ka)[kQPL], const uint32_t (&kb)[kQPL], uint32_t (&b1)[kQPL],
+                                        uint32_t (&b2)[kQPL]) {
+#pragma unroll
+  for (int r = 0; r < kQPL; ++r) {
+    b2[r] = min(b2[r], umed3(b1[r], ka[r], kb[r]));
+    b1[r] = umin3(b1[r], ka[r], kb[r]);
+  }
+}
+__device__ __forceinline__ void step2(const uint32_t (&qv)[kQPL][8], const u32x8& ta, const u32x8& tb, uint32_t j,
+                                      uint32_t (&b1)[kQPL], uint32_t (&b2)[kQPL]) {
+  uint32_t ka[kQPL], kb[kQPL];
+  keys2(qv, ta, tb, j, ka, kb);
+  update2(ka, kb, b1, b2);
+}
+
+template <bool TSTAGE>
+__global__ __launch_bounds__(64 * kWaves, TSTAGE ? 4 : 5) void hamming_knn2_kernel(const uint4* __restrict__ q4, int nq,
+                                                                     const uint32_t* __restrict__ t, int nt, int packed,
+                                                                     unsigned long long* partial, unsigned epoch,
+                                                                     unsigned* host_flag, int2* __restrict__ idx,
+                                                                     int2* __restrict__ dist, const int* __restrict__ nt_dev,
+                                                                     unsigned long long* __restrict__ stamps) {
   __shared__ uint2 lds[kWaves][kTileQ];
-  __shared__ int s_last;
+  // diagnostic (vs_match_stamps): wall-clock stamps of this workgroup's phases, thread 0 only
+  unsigned long long* st = stamps ? stamps + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+  long long cyc0 = 0;
+  if (st && threadIdx.x == 0) {
+    cyc0 = (long long)__builtin_readcyclecounter();
+    st[0] = wall_clock64();
+    st[7] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_ID
+            ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);  // XCC_ID
+  }
+  // keys carry the train index in their low kIdxBits bits: the global row index when all of them fit (the PLANNED nt <= 2^20
+  // -- keys of different chunks are then comparable as they are and the fold below is 32-bit min3 / med3), else the index within
+  // the workgroup's chunk (the fold rebuilds 64-bit keys from the chunk's first row)
+  const bool gkey = nt <= kMaxChunk;
   // nt_dev: the number of train rows lives on the device (a detector's key-point count the host has not read); the launch
-  // was planned for nt rows at most, chunks beyond the actual count are empty and still take their ticket
+  // was planned for nt rows at most, with fewer rows every chunk is shorter (or empty) and still publishes its partial
   if (nt_dev) nt = min(nt, *nt_dev);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
   const int tile = blockIdx.x, chunk = blockIdx.y, qtiles = gridDim.x, nchunks = gridDim.y;
   const int qbase = tile * kTileQ;
-  const int cbegin = chunk * chunk_len;
-  const int cend = min(cbegin + chunk_len, nt);
-  const int begin = min(cbegin + wave * sub_len, cend);
-  const int end = min(begin + sub_len, cend);
+  const int cbegin = (int)((long long)chunk * nt / nchunks);
+  const int cend = (int)((long long)(chunk + 1) * nt / nchunks);
+  const int clen = cend - cbegin;
+  const int begin = cbegin + (int)((long long)wave * clen / kWaves);
+  const int end = cbegin + (int)((long long)(wave + 1) * clen / kWaves);
 
   uint32_t qv[kQPL][8];
 #pragma unroll
@@ -148,10 +227,6 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
   for (int r = 0; r < kQPL; ++r) b1[r] = b2[r] = kEmpty;
 
   const uint32_t* tp = t + (size_t)begin * 8;  // wave-uniform -> scalar loads
-  // keys carry the train index in their low kIdxBits bits: the global row index when all of them fit (nt <= 2^20 -- keys of
-  // different chunks are then comparable as they are and the fold below is 32-bit min3 / med3), else the index within
-  // the workgroup's chunk (the fold rebuilds 64-bit keys from the chunk number)
-  const bool gkey = nt <= kMaxChunk;
   const uint32_t j0 = (uint32_t)(gkey ? begin : begin - cbegin);
   const int n = end - begin;
   if constexpr (TSTAGE) {
@@ -174,14 +249,34 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
         r1 = t4[2 * (size_t)row + 1];
       }
       wave_lds_order();
+      if (st && threadIdx.x == 0 && b == 0) st[1] = wall_clock64();  // queries and the first train batch have arrived
       const int cnt = min(64, n - 64 * b);
       const uint32_t jb = j0 + (uint32_t)(64 * b);
       int j = 0;
-      for (; j + 2 <= cnt; j += 2) {
-        const u32x8 ta = row_from(buf[2 * j], buf[2 * j + 1]), tb = row_from(buf[2 * j + 2], buf[2 * j + 3]);
-        accumulate2(qv, ta, tb, jb + (uint32_t)j, b1, b2);
+      // The FIRST halves (words 0..3) of the rows of step s + 1 are requested from LDS before the arithmetic of step s (two
+      // register sets in turn), the second halves at the top of their own step -- they are needed only four word groups later.
+      // No instruction of a step waits for a read issued just before it.  (Waves of a SIMD are served oldest first, so a wave
+      // that waits for its own reads at the top of every step hands the SIMD over and takes it back 39 times per scan:
+      // 57 -> 54.5 us per launch at 10k x 10k, 4.74 -> 4.53 ms at 100k x 100k, although the kernel now needs 108 VGPRs and
+      // holds four waves per SIMD instead of five.)
+      uint4 a0 = buf[0], c0 = buf[2];
+      for (; j + 4 <= cnt; j += 4) {
+        const uint4 a0h = buf[2 * j + 1], c0h = buf[2 * j + 3];
+        const uint4 a1 = buf[2 * j + 4], c1 = buf[2 * j + 6];
+        step2(qv, row_from(a0, a0h), row_from(c0, c0h), jb + (uint32_t)j, b1, b2);
+        const uint4 a1h = buf[2 * j + 5], c1h = buf[2 * j + 7];
+        const int jn = min(j + 4, 62);  // (the batch holds 64 rows; beyond a full batch's last step nothing uses these)
+        a0 = buf[2 * jn];
+        c0 = buf[2 * jn + 2];
+        step2(qv, row_from(a1, a1h), row_from(c1, c1h), jb + (uint32_t)(j + 2), b1, b2);
       }
-      if (j < cnt) accumulate1(qv, row_from(buf[2 * j], buf[2 * j + 1]), jb + (uint32_t)j, b1, b2);
+      if (j + 2 <= cnt) {
+        step2(qv, row_from(a0, buf[2 * j + 1]), row_from(c0, buf[2 * j + 3]), jb + (uint32_t)j, b1, b2);
+        j += 2;
+        if (j < cnt) accumulate1(qv, row_from(buf[2 * j], buf[2 * j + 1]), jb + (uint32_t)j, b1, b2);
+      } else if (j < cnt) {
+        accumulate1(qv, row_from(a0, buf[2 * j + 1]), jb + (uint32_t)j, b1, b2);
+      }
       wave_lds_order();
     }
   } else {
@@ -198,9 +293,14 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
       accumulate1(qv, tw, j0 + (uint32_t)j, b1, b2);
     }
   }
+  if (st && threadIdx.x == 0) {  // wave 0's scan is through
+    st[2] = wall_clock64();
+    st[chunk != nchunks - 1 ? 5 : 4] = (1ull << 63) | (unsigned long long)((long long)__builtin_readcyclecounter() - cyc0);  // (the slot this role leaves free)
+  }
 #pragma unroll
   for (int r = 0; r < kQPL; ++r) lds[wave][r * 64 + lane] = make_uint2(b1[r], b2[r]);
   __syncthreads();
+  if (st && threadIdx.x == 0) st[3] = wall_clock64();  // all four waves' scans are through
   // keys of different waves are distinct (disjoint index ranges), so min / max merge them exactly; thread = query
   const int lq = threadIdx.x, qi = qbase + lq;
   uint2 m = lds[0][lq];
@@ -213,66 +313,81 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
   }
   unsigned long long B1 = ~0ull, B2 = ~0ull;
   if (nchunks > 1) {
-    // ---- publish this chunk's partial row, then take a ticket.  Hand-off form (MI355X_MICROARCH.md, inter-workgroup
-    // visibility): every byte of the row is stored write-through (agent-scope relaxed atomic store = global_store ... sc1),
-    // every storing wave drains (vmcnt(0)), the barrier orders them before the ONE relaxed agent-scope ticket add;
-    // the workgroup whose add returns nchunks-1 is last: agent-scope ACQUIRE (this CU's L1 must not serve older lines
-    // of `partial`), drain, barrier, then plain loads.  No release fence is needed because nothing stays dirty in L2.
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(partial + ((size_t)chunk * qtiles + tile) * kTileQ + lq),
-                       ((unsigned long long)m.y << 32) | m.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned prev = __hip_atomic_fetch_add(&ticket[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = prev == (unsigned)(nchunks - 1);
-      if (last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&ticket[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-      }
-      s_last = last;
+    const unsigned long long tag = (unsigned long long)epoch << 58;
+    if (chunk != nchunks - 1) {
+      // ---- publish and leave: one write-through store (agent-scope relaxed atomic store = global_store_dwordx2 ... sc1)
+      __hip_atomic_store(partial + ((size_t)chunk * qtiles + tile) * kTileQ + lq,
+                         tag | ((unsigned long long)(m.y & kKey29) << 29) | (unsigned long long)(m.x & kKey29), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (st && threadIdx.x == 0) st[4] = wall_clock64();
+      return;
     }
-    __syncthreads();
-    if (!s_last) return;  // uniform
-    // ---- fold the tile's chunks in chunk order; the loads of up to 32 chunks are all in flight before the first use
-    constexpr int kFoldBatch = 32;
-    uint32_t g1 = kEmpty, g2 = kEmpty;
-    for (int c0 = 0; c0 < nchunks; c0 += kFoldBatch) {
-      uint2 p[kFoldBatch];
-#pragma unroll
-      for (int u = 0; u < kFoldBatch; ++u) {
-        const int c = min(c0 + u, nchunks - 1);
-        p[u] = partial[((size_t)c * qtiles + tile) * kTileQ + lq];
-      }
-      if (gkey) {  // uniform.  The fold sits in the kernel's tail (one workgroup per tile, the rest of the GPU idle): as a
-                   // chain of 64 dependent 64-bit merges it took 6 us of a 61 us launch, as 32 min3 / med3 pairs it does not show
+    // ---- the tile's last chunk folds: its own pair first, then the other chunks' words in chunk order, as they arrive
+    constexpr int kFoldBatch = 16;
+    uint32_t g1 = kKey29, g2 = kKey29;
+    bool lost = false;
+    for (int c0 = 0; c0 < nchunks - 1; c0 += kFoldBatch) {
+      unsigned long long w[kFoldBatch];
+      for (int spin = 0;; ++spin) {
+        bool ok = true;
 #pragma unroll
         for (int u = 0; u < kFoldBatch; ++u) {
-          const bool in = c0 + u < nchunks;  // beyond the last chunk the (clamped) load repeated a row: neutralise it
-          const uint32_t kx = in ? p[u].x : kEmpty, ky = in ? p[u].y : kEmpty;
+          const int c = min(c0 + u, nchunks - 2);
+          w[u] = __hip_atomic_load(partial + ((size_t)c * qtiles + tile) * kTileQ + lq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < kFoldBatch; ++u) ok &= (w[u] >> 58) == (unsigned long long)epoch;
+        if (ok) break;
+        if (spin > (1 << 18)) {  // bounded (~a second): a chunk's workgroup never ran.  Reported through the pinned flag.
+          lost = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (lost) break;
+      if (gkey) {  // uniform
+#pragma unroll
+        for (int u = 0; u < kFoldBatch; ++u) {
+          const bool in = c0 + u < nchunks - 1;  // beyond the last chunk the (clamped) load repeated a word: neutralise it
+          const uint32_t kx = in ? (uint32_t)(w[u] & kKey29) : kKey29, ky = in ? (uint32_t)((w[u] >> 29) & kKey29) : kKey29;
           g2 = min(g2, umed3(g1, kx, ky));
           g1 = umin3(g1, kx, ky);
         }
       } else {
 #pragma unroll
         for (int u = 0; u < kFoldBatch; ++u) {
-          if (c0 + u >= nchunks) break;
-          const unsigned long long base = (unsigned long long)(c0 + u) * (unsigned long long)chunk_len;
-          if (p[u].x != kEmpty) fold64(B1, B2, ((unsigned long long)(p[u].x >> kIdxBits) << 32) | (base + (p[u].x & kIdxMask)));
-          if (p[u].y != kEmpty) fold64(B1, B2, ((unsigned long long)(p[u].y >> kIdxBits) << 32) | (base + (p[u].y & kIdxMask)));
+          if (c0 + u >= nchunks - 1) break;
+          const unsigned long long base = (unsigned long long)((long long)(c0 + u) * nt / nchunks);
+          const uint32_t kx = (uint32_t)(w[u] & kKey29), ky = (uint32_t)((w[u] >> 29) & kKey29);
+          if (kx != kKey29) fold64(B1, B2, ((unsigned long long)(kx >> kIdxBits) << 32) | (base + (kx & kIdxMask)));
+          if (ky != kKey29) fold64(B1, B2, ((unsigned long long)(ky >> kIdxBits) << 32) | (base + (ky & kIdxMask)));
         }
       }
     }
+    if (st && threadIdx.x == 0) st[5] = wall_clock64();  // every chunk's word of thread 0's query has arrived
+    if (lost) {
+      if (host_flag) __hip_atomic_store(host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      g1 = g2 = kKey29;
+      B1 = B2 = ~0ull;
+      m.x = m.y = kEmpty;
+    }
     if (gkey) {
-      if (g1 != kEmpty) B1 = ((unsigned long long)(g1 >> kIdxBits) << 32) | (unsigned long long)(g1 & kIdxMask);
-      if (g2 != kEmpty) B2 = ((unsigned long long)(g2 >> kIdxBits) << 32) | (unsigned long long)(g2 & kIdxMask);
+      const uint32_t mx = m.x & kKey29, my = m.y & kKey29;
+      g2 = min(g2, umed3(g1, mx, my));
+      g1 = umin3(g1, mx, my);
+      if (g1 != kKey29) B1 = ((unsigned long long)(g1 >> kIdxBits) << 32) | (unsigned long long)(g1 & kIdxMask);
+      if (g2 != kKey29) B2 = ((unsigned long long)(g2 >> kIdxBits) << 32) | (unsigned long long)(g2 & kIdxMask);
+    } else {
+      const unsigned long long base = (unsigned long long)cbegin;
+      if (m.x != kEmpty) fold64(B1, B2, ((unsigned long long)(m.x >> kIdxBits) << 32) | (base + (m.x & kIdxMask)));
+      if (m.y != kEmpty) fold64(B1, B2, ((unsigned long long)(m.y >> kIdxBits) << 32) | (base + (m.y & kIdxMask)));
     }
   } else {
     if (m.x != kEmpty) fold64(B1, B2, ((unsigned long long)(m.x >> kIdxBits) << 32) | (unsigned long long)(m.x & kIdxMask));
     if (m.y != kEmpty) fold64(B1, B2, ((unsigned long long)(m.y >> kIdxBits) << 32) | (unsigned long long)(m.y & kIdxMask));
   }
   if (qi < nq) {
-    if (PACKED) {
+    if (packed) {
       reinterpret_cast<int4*>(idx)[qi] =
           make_int4((int)(B1 & 0xFFFFFFFFull), (int)(B2 & 0xFFFFFFFFull), (int)(B1 >> 32), (int)(B2 >> 32));
     } else {
@@ -280,6 +395,7 @@ __global__ __launch_bounds__(64 * kWaves, 5) void hamming_knn2_kernel(const uint
       dist[qi] = make_int2((int)(B1 >> 32), (int)(B2 >> 32));
     }
   }
+  if (st && threadIdx.x == 0) st[6] = wall_clock64();
 }
 
 // Lowe ratio test + ordered compaction: one workgroup, wave ballots + popcounts give the ranks.
@@ -340,14 +456,14 @@ __global__ __launch_bounds__(1024) void ratio_compact_kernel(const int2* __restr
   }
 }
 
-// chunk_len trains per workgroup (split into kWaves sub-ranges of sub_len), nchunks workgroups along y.
+// nchunks workgroups along y share the train rows evenly (the kernel cuts chunk c = rows [c nt / C, (c + 1) nt / C) itself).
 // Automatic plan (target_blocks == 0; > 0 is the sweep hook vs_tune_match): pick the number of train chunks that minimises
-//     ceil(workgroups / 256 CUs) * chunk_len  +  fold cost per chunk
+//     ceil(workgroups / 256 CUs) * chunk length  +  fold cost per chunk
 // over plans with 1000..4600 workgroups -- the first term is the busiest CU's share of train rows (workgroups are
-// spread round-robin, 4..16 resident per CU), the second the extra partial rows the last workgroup of a tile folds.  At
+// spread round-robin, 4..16 resident per CU), the second the extra partial words the folding workgroup of a tile reads.  At
 // 10k x 10k this gives 32 chunks x 40 query tiles = 1280 workgroups = 5 per CU, at 100k x 100k 11 x 391 = 4301 (98.8 %
 // balanced; a fixed 1024-workgroup plan loses 25 % there to 4-vs-3 workgroups per CU).
-void plan_chunks(int target_blocks, int nq, int nt, int* chunk_len, int* sub_len, int* nchunks) {
+void plan_chunks(int target_blocks, int nq, int nt, int* nchunks) {
   const int qtiles = (nq + kTileQ - 1) / kTileQ;
   const int q1 = qtiles > 0 ? qtiles : 1;
   long nch = 1;
@@ -366,19 +482,11 @@ void plan_chunks(int target_blocks, int nq, int nt, int* chunk_len, int* sub_len
       }
     }
   }
+  const long need = ((long)nt + kMaxChunk - 1) / kMaxChunk;  // a chunk's rows are indexed with kIdxBits bits
+  if (nch < need) nch = need;
+  if (nch > 65535) nch = 65535;  // gridDim.y
   if (nch < 1) nch = 1;
-  long len = (nt + nch - 1) / nch;
-  long sub = (len + kWaves - 1) / kWaves;
-  sub = (sub + kTU - 1) / kTU * kTU;
-  if (sub < 2 * kTU) sub = 2 * kTU;
-  len = sub * kWaves;
-  if (len > kMaxChunk) {
-    len = kMaxChunk;
-    sub = len / kWaves;
-  }
-  *chunk_len = (int)len;
-  *sub_len = (int)sub;
-  *nchunks = (int)((nt + len - 1) / len);
+  *nchunks = (int)nch;
 }
 
 int check_args(vs_ctx* ctx, const void* q, int nq, const void* t, int nt, const char* fn) {
@@ -394,7 +502,7 @@ int check_args(vs_ctx* ctx, const void* q, int nq, const void* t, int nt, const 
 VS_API int vs_tune_match(vs_ctx* ctx, int target_blocks, int tstage) {
   if (!ctx) return VS_EINVAL;
   if (target_blocks >= 0) ctx->tune.match_target_blocks = target_blocks;
-  if (tstage == 0 || tstage == 1) ctx->tune.match_tstage = tstage;
+  if (tstage == 0 || tstage == 1) ctx->tune.match_tstage = tstage, ctx->chain_scratch = -1;  // (another kernel: ask again)
   return VS_OK;
 }
 
@@ -430,19 +538,35 @@ static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
   if (nq == 0) return VS_OK;
   if (!d_idx || (!packed && !d_dist)) return vs_fail(ctx, VS_EINVAL, "%s: null output pointer", "vs_hamming_knn2_dev");
   hipStream_t s = vs_pick_stream(ctx, stream);
-  int chunk_len, sub_len, nchunks;
-  plan_chunks(ctx->tune.match_target_blocks, nq, nt, &chunk_len, &sub_len, &nchunks);
+  int nchunks;
+  plan_chunks(ctx->tune.match_target_blocks, nq, nt, &nchunks);
   if (((uintptr_t)d_q | (uintptr_t)d_t) & 31)
     return vs_fail(ctx, VS_EINVAL, "%s: descriptor arrays must be 32-byte aligned", "vs_hamming_knn2_dev");
   const int qtiles = (nq + kTileQ - 1) / kTileQ;
   vs_match_scratch* ms = nullptr;
   VS_TRY(match_scratch_for(ctx, s, &ms));
-  VS_TRY(vs_reserve(ctx, &ms->partial, sizeof(uint2) * (size_t)nchunks * qtiles * kTileQ));
-  // per-tile arrival tickets: zero when allocated; every launch leaves them zero again (its last workgroups reset them)
-  if (sizeof(unsigned) * (size_t)qtiles > ms->ticket.cap || !ms->ticket.p) {
-    VS_TRY(vs_reserve(ctx, &ms->ticket, sizeof(unsigned) * (size_t)qtiles));
-    VS_HIP(ctx, hipMemsetAsync(ms->ticket.p, 0, ms->ticket.cap, s));
+  if (!ms->flag.p) {  // one pinned word per scratch set: a folding workgroup that gave up waiting says so here
+    VS_TRY(vs_reserve_pinned(ctx, &ms->flag, 64));
+    *(volatile unsigned*)ms->flag.p = 0u;
   }
+  if (*(volatile unsigned*)ms->flag.p != 0u) {
+    *(volatile unsigned*)ms->flag.p = 0u;
+    ms->qtiles = ms->nchunks = 0;
+    return vs_fail(ctx, VS_EHIP, "%s: an earlier match launch on this stream did not see all its train chunks report", "vs_hamming_knn2_dev");
+  }
+  // the partial words validate themselves by the launch's epoch (1 .. 63, see the kernel).  Every launch of one geometry
+  // rewrites every slot, so a slot never carries the current epoch before its workgroup stores it -- unless the slots were
+  // laid out for another geometry, or the buffer is new: then they are cleared first (stream-ordered, in front of the launch)
+  const size_t pbytes = sizeof(unsigned long long) * (size_t)nchunks * qtiles * kTileQ;
+  const bool fresh = pbytes > ms->partial.cap || !ms->partial.p;
+  VS_TRY(vs_reserve(ctx, &ms->partial, pbytes));
+  if (fresh || ms->qtiles != qtiles || ms->nchunks != nchunks) {
+    if (nchunks > 1) VS_HIP(ctx, hipMemsetAsync(ms->partial.p, 0, pbytes, s));
+    ms->qtiles = qtiles;
+    ms->nchunks = nchunks;
+    ms->epoch = 0;
+  }
+  ms->epoch = ms->epoch % kEpochs + 1;
   dim3 grid(qtiles, nchunks);
   vs_prof_rec pr{};
   if (ctx->tune.match_profile) {
@@ -450,12 +574,21 @@ static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, 
     VS_HIP(ctx, hipEventCreate(&pr.e1));
     VS_HIP(ctx, hipEventRecord(pr.e0, s));
   }
-  typedef void (*knn2_fn)(const uint4*, int, const uint32_t*, int, int, int, uint2*, unsigned*, int2*, int2*, const int*);
-  static const knn2_fn kFn[2][2] = {{hamming_knn2_kernel<false, false>, hamming_knn2_kernel<false, true>},
-                                    {hamming_knn2_kernel<true, false>, hamming_knn2_kernel<true, true>}};
-  hipLaunchKernelGGL(kFn[packed ? 1 : 0][ctx->tune.match_tstage ? 1 : 0], grid, dim3(64 * kWaves), 0, s, (const uint4*)d_q, nq,
-                     (const uint32_t*)d_t, nt, chunk_len, sub_len, (uint2*)ms->partial.p, (unsigned*)ms->ticket.p,
-                     (int2*)d_idx, packed ? (int2*)nullptr : (int2*)d_dist, nt_dev);
+  typedef void (*knn2_fn)(const uint4*, int, const uint32_t*, int, int, unsigned long long*, unsigned, unsigned*, int2*, int2*, const int*,
+                          unsigned long long*);
+  static const knn2_fn kFn[2] = {hamming_knn2_kernel<false>, hamming_knn2_kernel<true>};
+  const int which = ctx->tune.match_tstage ? 1 : 0;
+  unsigned long long* d_stamps = nullptr;
+  if (ctx->match_stamps_on) {  // diagnostic: per-workgroup phase stamps of THIS launch (vs_match_stamps)
+    const size_t sb = sizeof(unsigned long long) * 8 * (size_t)qtiles * nchunks;
+    VS_TRY(vs_reserve(ctx, &ctx->d_match_stamps, sb));
+    VS_HIP(ctx, hipMemsetAsync(ctx->d_match_stamps.p, 0, sb, s));
+    ctx->match_stamps_rows = qtiles * nchunks;
+    d_stamps = (unsigned long long*)ctx->d_match_stamps.p;
+  }
+  hipLaunchKernelGGL(kFn[which], grid, dim3(64 * kWaves), 0, s, (const uint4*)d_q, nq, (const uint32_t*)d_t, nt, packed ? 1 : 0,
+                     (unsigned long long*)ms->partial.p, (unsigned)ms->epoch, (unsigned*)ms->flag.p, (int2*)d_idx,
+                     packed ? (int2*)nullptr : (int2*)d_dist, nt_dev, d_stamps);
   VS_LAUNCH_CHECK(ctx, "hamming_knn2_kernel");
   if (ctx->tune.match_profile) {
     VS_HIP(ctx, hipEventRecord(pr.e1, s));
@@ -567,6 +700,49 @@ VS_API int vs_match_profile_read(vs_ctx* ctx, float* kernel_ms) {
   ctx->match_prof.clear();
   if (kernel_ms) *kernel_ms = n ? (float)(a / n) : 0.f;
   return n;
+}
+
+static size_t func_scratch(const void* fn) {
+  hipFuncAttributes a;
+  if (hipFuncGetAttributes(&a, fn) != hipSuccess) {
+    (void)hipGetLastError();
+    return (size_t)-1;
+  }
+  return a.localSizeBytes;
+}
+size_t vs_match_chain_scratch_bytes(vs_ctx* ctx) {
+  const size_t a = ctx->tune.match_tstage ? func_scratch((const void*)hamming_knn2_kernel<true>) : func_scratch((const void*)hamming_knn2_kernel<false>);
+  const size_t b = func_scratch((const void*)ratio_compact_kernel);
+  return a > b ? a : b;
+}
+
+// diagnostic hooks (include/vslam_hip_dev.h): per-workgroup phase stamps of the match kernel.  vs_match_stamps_read synchronises and
+// returns the newest stamped launch as rows of 8 doubles, one per workgroup in (chunk, tile) order: microseconds since the
+// launch's first stamp of [0] start, [1] operands arrived, [2] wave 0 through its scan, [3] all waves through, [4] partial
+// stored (publishing workgroups), [5] all partials arrived (folding workgroups), [6] results written; [7] = XCC_ID * 2^16 +
+// HW_ID bits (where the workgroup ran).  0 = phase not reached.  Returns the number of rows.
+VS_API int vs_match_stamps(vs_ctx* ctx, int enable) {
+  if (!ctx) return VS_EINVAL;
+  ctx->match_stamps_on = enable != 0;
+  return VS_OK;
+}
+VS_API int vs_match_stamps_read(vs_ctx* ctx, double* out, int cap_rows) {
+  if (!ctx || !out) return VS_EINVAL;
+  const int rows = ctx->match_stamps_rows;
+  if (!ctx->d_match_stamps.p || rows <= 0 || cap_rows < rows) return 0;
+  std::vector<unsigned long long> h((size_t)rows * 8);
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(h.data(), ctx->d_match_stamps.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess)
+    return vs_fail(ctx, VS_EHIP, "%s: read-back failed", "vs_match_stamps_read");
+  unsigned long long t0 = ~0ull;
+  for (size_t i = 0; i < h.size(); ++i)
+    if ((i & 7) != 7 && h[i] && !(h[i] >> 63) && h[i] < t0) t0 = h[i];
+  for (size_t i = 0; i < h.size(); ++i) {
+    if ((i & 7) == 7) out[i] = (double)(((h[i] >> 32) & 0xFFFF) * 65536ull + (h[i] & 0xFFFF));
+    else if (h[i] >> 63) out[i] = -(double)(h[i] & ~(1ull << 63));  // a raw cycle count (negative: not a time)
+    else out[i] = h[i] ? (double)(h[i] - t0) * 0.01 : 0.0;  // wall_clock64: 100 MHz
+  }
+  return rows;
 }
 
 // nt_dev != nullptr: at most nt train rows, the actual count is read on the device (internal: vs_track.hip matches a frame

@@ -35,11 +35,16 @@ struct pnp_view {
   const double *obj, *img;
   const double* guess;  // the record to start from, or nullptr: pnp_args::cam0
 };
-// bounded, sleeping poll of a tagged word (nullptr: nothing to wait for); acquire: what the publisher wrote is visible after it
+// bounded, sleeping poll of a tagged word (nullptr: nothing to wait for); acquire: what the publisher wrote is visible after it.
+// The words carry sequence numbers that only grow (one word is shared by both buffer sets and every later front half / solve
+// overwrites it), so the wait is for "at least this tag", wrap-safe: a later publication can never hide an earlier one.
+// Bound: 2^15 polls of ~1.5 us (a sleep of 1024 cycles + the load) = ~50 ms -- what is waited for was enqueued BEFORE this launch
+// and takes ~0.1 ms; a workgroup that gives up leaves, the host then redoes the frame host-paced (vs_track.hip, track_recover).
+constexpr int kPnpWaitPolls = 1 << 15;
 __device__ inline bool pnp_wait_tag(const unsigned* word, unsigned tag) {
   if (!word) return true;
-  for (int it = 0; it < (1 << 22); ++it) {
-    if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) {
+  for (int it = 0; it < kPnpWaitPolls; ++it) {
+    if ((int)(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tag) >= 0) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // one cache invalidation, when the word has arrived -- not one per poll
       return true;
     }
@@ -549,7 +554,7 @@ __device__ inline void pnp_finish_role(const pnp_args& P, pnp_view& V) {
       const unsigned long long bal = __ballot(ready);
       const int run = bal == ~0ull ? 64 : __ffsll((long long)~bal) - 1;  // lanes 0 .. run-1 have arrived
       if (run == 0) {
-        if (++rounds > (1 << 21)) {  // bounded wait: hypothesis workgroups that never ran (a device without room for them)
+        if (++rounds > (1 << 16)) {  // bounded wait (~50 ms): hypothesis workgroups that never ran, or that gave up their own wait
           timed_out = 1;
           break;
         }

@@ -219,13 +219,13 @@ api_layout api_layout_of(int P, int max_kp) {
 }
 
 // Waits until a pinned word carries `want` (written last, with a system-scope release, by the kernel whose results precede
-// it): a poll of host memory instead of a stream / event synchronisation (~10 us less per wait).  Bounded: after 5 s the
-// streams are synchronised and the word is looked at once more.
+// it): a poll of host memory instead of a stream / event synchronisation (~10 us less per wait).  Bounded: after 1.5 s (every
+// in-kernel wait has given up long before: ~50 - 100 ms each) the streams are synchronised and the word is looked at once more.
 int track_poll(vs_ctx* ctx, const volatile unsigned* word, unsigned want, const char* who) {
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0; __atomic_load_n(word, __ATOMIC_ACQUIRE) != want; ++spins) {
     __builtin_ia32_pause();
-    if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+    if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1500)) {
       (void)hipStreamSynchronize(ctx->stream);
       (void)hipStreamSynchronize(ctx->aux_stream[1]);
       if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) break;
@@ -278,13 +278,42 @@ hipStream_t track_back_stream(vs_ctx* ctx, int set, bool chained) { return chain
 size_t rb_len(const track_layout& L) { return (L.rb_end - L.mst + 255) & ~(size_t)255; }
 size_t rb_stride(const track_layout& L) { return rb_len(L) + 256; }  // the block, then the word track_publish_kernel tags it with
 
+// 1 when none of the kernels a chained period puts on its streams has a private segment (asked once per context from the
+// runtime: hipFuncGetAttributes on the loaded code objects, i.e. on what actually runs, whatever the tuning knobs select)
+bool track_chain_scratch_free(vs_ctx* ctx) {
+  if (ctx->chain_scratch < 0) {
+    size_t worst = 0;
+    auto add = [&](const void* fn) {
+      hipFuncAttributes a;
+      if (hipFuncGetAttributes(&a, fn) != hipSuccess) {
+        (void)hipGetLastError();
+        worst = (size_t)-1;
+      } else if (a.localSizeBytes > worst) {
+        worst = a.localSizeBytes;
+      }
+    };
+    add((const void*)track_append_kernel);
+    add((const void*)track_publish_kernel);
+    add((const void*)pnp_ransac_kernel);
+    add((const void*)ba_motion_persistent<false>);
+    size_t front = vs_match_chain_scratch_bytes(ctx), det = vs_detect_chain_scratch_bytes();
+    worst = std::max(worst, std::max(front, det));
+    ctx->chain_scratch = (long long)worst;
+  }
+  return ctx->chain_scratch == 0;
+}
+
 // May the back half of pose k be enqueued before the previous one's results are known?  Only the form that needs no host
 // decision in between: PnP on, LM on, the motion-only solve in one launch.
 bool track_can_chain(vs_ctx* ctx, int set, int k) {
   const auto& T = ctx->track;
   const int lm = T.params[set].lm_iterations;
   static const bool off = getenv("VS_TRACK_NOCHAIN") != nullptr;  // developer aid: A/B against the host-paced form
-  if (off) return false;
+  if (off || T.in_redo) return false;
+  // build property the chain relies on, checked on the loaded code objects: no kernel a chained period launches may use
+  // scratch memory (a kernel that needs scratch may not be able to start while the kernel that waits for it in-kernel is
+  // resident -- the first chained period of a fresh process timed out on exactly that in round 3)
+  if (!track_chain_scratch_free(ctx)) return false;
   // (n_points: only the register-resident instantiation of the one-launch solve -- the other one uses scratch memory, and a
   // kernel that needs scratch may not be able to start while the kernel that waits for it in-kernel is running)
   return T.mst_both && T.pnp_iters > 0 && lm > 0 && T.n_points <= kMoPersistObs && mo_persistent_ok(ctx, k, 1 + lm * 10);
@@ -330,6 +359,10 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out, int k, bool chained
     A.cur_dev = reinterpret_cast<const mo_state*>(d + L.mst);  // a finished solve leaves its record in both slots
     A.front_tag_dev = (const unsigned*)(d + L.front_sync) + 64;
     A.front_tag = T.front_tag[set];
+    if (T.inject == 1) {  // developer aid (vs_track_debug): a tag nobody will publish -- every workgroup's wait runs out
+      A.front_tag += 0x40000000u;
+      T.inject = 0;
+    }
     if (publish_set >= 0) {  // a chained frame is in flight on the other stream: its solve announces its end on the device
       A.back_tag_dev = (const unsigned*)(d + L.back_sync) + 64;
       A.back_tag = T.ba_tag[publish_set];
@@ -434,7 +467,7 @@ int track_ba_batch(vs_ctx* ctx, int set, int* step, int k, bool chained = false)
     // Launches after the one that finds the solve finished are predicated no-ops of ~5 us each on the critical path of the
     // frame, and consecutive frames of a stream need about the same number of LM steps: the first batch is as long as the
     // previous solve was (+1); a solve that needs more gets further batches (the results do not depend on the split).
-    if (*step == 0 && mo_persistent_ok(ctx, k, max_steps)) {
+    if (*step == 0 && !T.in_redo && mo_persistent_ok(ctx, k, max_steps)) {
       // the whole solve in one launch (a frame has at most n_points matches); the final record lands in both state slots
       if (T.n_points <= kMoPersistObs) hipLaunchKernelGGL(ba_motion_persistent<false>, dim3(k), dim3(kMoThreads), 0, s, D, max_steps);
       else hipLaunchKernelGGL(ba_motion_persistent<true>, dim3(k), dim3(kMoThreads), 0, s, D, max_steps);
@@ -498,6 +531,10 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   mo_state fin;
   memset(&fin, 0, sizeof fin);
   fin.cur = T.cur;
+  // The four ways a back half's in-kernel hand-offs can fail (a tag that never came: the read-back, the PnP hypotheses, the
+  // solve's rendezvous, an unfinished one-launch solve) are marked recoverable: the caller redoes the frame host-paced
+  // (track_redo).  Nothing of the period's host-side state is touched before all of them have been ruled out.
+  T.recoverable = 1;
   for (;;) {
     // the tag behind the block, written last (system-scope release) by the kernel that copied the block to pinned memory
     VS_TRY(track_poll(ctx, (const volatile unsigned*)(rb + rb_len(L)), chained ? T.back_tag[set] : T.back_tag_sync, "vs_track_frame"));
@@ -511,6 +548,9 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   const int* rb_flags = (const int*)(rb + (L.flags - L.mst)) + 4 * set;
   const double* rb_res = (const double*)(rb + (L.pnp_res - L.mst));
   const int M = rb_flags[1], n_kp = rb_flags[2];
+  if (pnp_ran && T.pnp_iters > 0 && rb_res[16] < 0.0)
+    return vs_fail(ctx, VS_EHIP, "%s: the PnP hypothesis workgroups did not report", "vs_track_frame");
+  T.recoverable = 0;
   if (rb_flags[0]) return vs_fail(ctx, VS_ENOMEM, "%s: observation capacity of the period exceeded", "vs_track_frame");
   bool copies = false;
   if (xy_out && n_kp > 0) {
@@ -537,10 +577,66 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   *n_poses_out = k + 1;
   *n_matches = M;
   if (n_kp_out) *n_kp_out = n_kp;
-  if (pnp_ran && T.pnp_iters > 0 && rb_res[16] < 0.0)
-    return vs_fail(ctx, VS_EHIP, "%s: the PnP hypothesis workgroups did not report", "vs_track_frame");
+  T.good.assign(rb, rb + (L.rb_end - L.mst));  // what a redo of the next frame would start from
   if (pnp_found) *pnp_found = pnp_ran && T.pnp_iters > 0 && rb_res[16] != 0.0 ? (int)rb_res[17] : 0;  // inliers of the PnP model
   return VS_OK;
+}
+
+// A back half whose in-kernel hand-offs did not complete (track_back_finish set T.recoverable) is redone ONCE, host-paced:
+// drain every stream of the period, put the state the failed kernels may have written -- the LM records and both camera buffers
+// -- back to what the newest frame handed out left (or, for the period's first frame, to the key frame's record), and run the
+// frame's back half again in the form that needs no in-kernel wait: event-ordered behind the front half, the motion-only solve
+// one launch per LM step.  Same arithmetic: the poses equal the undisturbed run's bit for bit (tests).  The frame's front half
+// is not repeated -- its rows were appended by kernels that depend on no back half.
+int track_redo(vs_ctx* ctx, int set, double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found, float* xy_out,
+               uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t, bool pnp_ran) {
+  auto& T = ctx->track;
+  if (T.in_redo) return VS_EHIP;  // (the message of the failed redo stands)
+  T.recoverable = 0;
+  T.in_redo = 1;
+  ++T.recoveries;
+  struct leave {
+    int* p;
+    ~leave() { *p = 0; }
+  } guard{&T.in_redo};
+  for (hipStream_t st : {T.front_stream, ctx->stream, ctx->aux_stream[0], ctx->aux_stream[1]})
+    if (st) VS_HIP(ctx, hipStreamSynchronize(st));
+  const track_layout L = layout_of(ctx);
+  uint8_t* d = (uint8_t*)ctx->d_track.p;
+  const size_t blk = L.rb_end - L.mst;
+  if (T.good.size() == blk) {
+    // everything but the flag words (the front half of the frame being redone has written its counts there since)
+    VS_HIP(ctx, hipMemcpy(d + L.mst, T.good.data(), L.flags - L.mst, hipMemcpyHostToDevice));
+    VS_HIP(ctx, hipMemcpy(d + L.pnp_res, T.good.data() + (L.pnp_res - L.mst), L.rb_end - L.pnp_res, hipMemcpyHostToDevice));
+  } else {  // no frame of this period has been handed out yet: the control image of vs_track_begin
+    std::vector<uint8_t> img(blk, 0);
+    memcpy(img.data() + (L.cam0 - L.mst), T.key_rec, sizeof T.key_rec);
+    memcpy(img.data() + (L.cam1 - L.mst), T.key_rec, sizeof T.key_rec);
+    VS_HIP(ctx, hipMemcpy(d + L.mst, img.data(), L.flags - L.mst, hipMemcpyHostToDevice));
+    VS_HIP(ctx, hipMemcpy(d + L.pnp_res, img.data() + (L.pnp_res - L.mst), L.rb_end - L.pnp_res, hipMemcpyHostToDevice));
+  }
+  int step = 0;
+  const int k = T.n_frames + 1;
+  if (pnp_ran) {
+    VS_TRY(track_back_enqueue(ctx, set, &step, k));
+  } else {  // host-fed frame (vs_track_push_frame): its start record went up with the call and was overwritten by the restore
+    uint8_t* hp = (uint8_t*)ctx->h_track.p;
+    memcpy(hp + 2048, T.redo_rec, sizeof T.redo_rec);
+    VS_HIP(ctx, hipMemcpyAsync((double*)(d + L.cam0) + (size_t)k * kCamStride, hp + 2048, sizeof T.redo_rec, hipMemcpyHostToDevice, ctx->stream));
+    VS_HIP(ctx, hipMemcpyAsync((double*)(d + L.cam1) + (size_t)k * kCamStride, hp + 2048, sizeof T.redo_rec, hipMemcpyHostToDevice, ctx->stream));
+    if (T.params[set].lm_iterations > 0) {
+      mo_state* h_st = (mo_state*)(hp + 1024);
+      memset(h_st, 0, 256);
+      h_st[1].need_lin = 1;
+      h_st[1].ni = 2.0;
+      h_st[1].cur = T.cur;
+      h_st[0].cur = T.cur;
+      VS_HIP(ctx, hipMemcpyAsync(d + L.mst, h_st, 256, hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
+  VS_TRY(track_ba_batch(ctx, set, &step, k));
+  return track_back_finish(ctx, set, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out, match_q, match_t,
+                           pnp_ran, false);
 }
 
 int track_check_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int lm_iterations, const char* who) {
@@ -563,12 +659,16 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   // the one synchronisation of this call: the staging is free to be rewritten (or reallocated), the buffers are idle
   // (skipped when the previous period ended with all its results handed out: only tracking kernels touch these buffers, and
   // a synchronisation costs ~14 us per stream even when the stream is idle)
-  if (!T.quiet) {
+  if (!T.quiet || T.dirty) {
     VS_HIP(ctx, hipStreamSynchronize(T.front_stream));
     VS_HIP(ctx, hipStreamSynchronize(ctx->aux_stream[1]));
     VS_HIP(ctx, hipStreamSynchronize(s));
   }
   T.quiet = 0;
+  T.dirty = 0;
+  T.in_redo = 0;
+  T.recoverable = 0;
+  T.good.clear();
   const track_layout L = track_layout_of(n_points, max_frames, max_kp, pnp_iterations > 0 ? pnp_iterations : 1);
   VS_TRY(vs_reserve(ctx, &ctx->d_track, L.total));
   const size_t up = L.f[0].fxy;  // [xyz | mapdesc] are uploaded
@@ -622,6 +722,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   T.K[2] = cx;
   T.K[3] = cy;
   memcpy(T.last_rec, rec, sizeof rec);
+  memcpy(T.key_rec, rec, sizeof rec);
   return VS_OK;
 }
 
@@ -630,12 +731,13 @@ VS_API int vs_track_end(vs_ctx* ctx) {
   // Nothing is outstanding when the last frame's results have been handed out (every entry point that returns results has
   // waited for them, and the front half of a frame precedes its back half): then the three synchronisations (~14 us apiece
   // even on idle streams) are skipped.  vs_track_begin and vs_destroy synchronise before they touch the period's buffers.
-  if (ctx->track.pending >= 0 || ctx->track.api_stage != 0 || !ctx->track.active) {
+  if (ctx->track.pending >= 0 || ctx->track.api_stage != 0 || !ctx->track.active || ctx->track.dirty) {
     if (ctx->track.front_stream) (void)hipStreamSynchronize(ctx->track.front_stream);
     (void)hipStreamSynchronize(ctx->aux_stream[1]);
     (void)hipStreamSynchronize(ctx->stream);
   }
   ctx->track.quiet = 1;
+  ctx->track.dirty = 0;
   ctx->track.active = 0;
   ctx->track.pending = -1;
   ctx->track.pending_step = -1;
@@ -659,11 +761,17 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   VS_HIP(ctx, hipSetDevice(ctx->device));
   auto& T = ctx->track;
   T.params[0] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
+  T.api_stage = 0;  // a front half of the class-API entry points nobody followed up on: its rows are overwritten below
+  T.dirty = 1;      // (until this call has handed out its results: an error return leaves work in flight)
   VS_TRY(track_front_half(ctx, 0, T.n_frames, bgr, w, h_img, stride, thr, ratio, ctx->stream));
   int step = 0;
   VS_TRY(track_back_enqueue(ctx, 0, &step, T.n_frames + 1));
   VS_TRY(track_ba_batch(ctx, 0, &step, T.n_frames + 1));
-  return track_back_finish(ctx, 0, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out, match_q, match_t);
+  int rc = track_back_finish(ctx, 0, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out, match_q, match_t);
+  if (rc != VS_OK && T.recoverable)
+    rc = track_redo(ctx, 0, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out, match_q, match_t, true);
+  if (rc == VS_OK) T.dirty = 0;
+  return rc;
 }
 
 // Host-fed back half: the caller (the class API: FeatureMatcher.match_features + solvePnPRansac, src/v2/main.py:185-204)
@@ -707,6 +815,8 @@ VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const doub
   double rec[kCamStride];
   rec_from_pose(pose16, rec);
   memcpy(hp + 2048, rec, sizeof rec);
+  memcpy(T.redo_rec, rec, sizeof rec);
+  T.dirty = 1;
   double* cam0 = (double*)(d + L.cam0);
   double* cam1 = (double*)(d + L.cam1);
   VS_HIP(ctx, hipMemcpyAsync(cam0 + (size_t)k * kCamStride, hp + 2048, sizeof rec, hipMemcpyHostToDevice, s));
@@ -722,8 +832,12 @@ VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const doub
   }
   int step = 0, n_matches = 0;
   VS_TRY(track_ba_batch(ctx, 0, &step, k));
-  return track_back_finish(ctx, 0, &step, poses_out, n_poses_out, &n_matches, nullptr, nullptr, nullptr, nullptr, nullptr,
-                           nullptr, false);
+  int rc = track_back_finish(ctx, 0, &step, poses_out, n_poses_out, &n_matches, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             nullptr, false);
+  if (rc != VS_OK && T.recoverable)
+    rc = track_redo(ctx, 0, poses_out, n_poses_out, &n_matches, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false);
+  if (rc == VS_OK) T.dirty = 0;
+  return rc;
 }
 
 VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,
@@ -746,6 +860,8 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
   // dispatch of the next kernel onto an idle queue were ~20 us per frame on the chain of back halves, which is the critical
   // path).  The previous frame's results are then awaited through the tag behind ITS read-back block.  Otherwise (a solve
   // that may need further LM batches decided on the host): the back half is enqueued once the previous results are in.
+  T.api_stage = 0;
+  T.dirty = 1;  // (cleared where this call returns with nothing but the pending frame's own work outstanding)
   const int solve = T.pending;
   const bool solve_chained = solve >= 0 && T.pending_chained;
   int step = T.pending_step >= 0 ? T.pending_step : 0;
@@ -781,13 +897,18 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
   T.pending_step = -1;
   T.pending_chained = 0;
   if (solve >= 0) {
-    const int rc = track_back_finish(ctx, solve, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out,
-                                     match_q, match_t, true, solve_chained);
+    int rc = track_back_finish(ctx, solve, &step, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out,
+                               match_q, match_t, true, solve_chained);
+    if (rc != VS_OK && T.recoverable) {
+      // a hand-off inside the chain did not complete: redo this frame host-paced (everything is drained first).  The back
+      // half of the frame submitted by this call -- enqueued behind the failed one, on its results -- is void with it: that
+      // frame stays pending with only its front half done, and its back half is enqueued below, host-paced.
+      rc = track_redo(ctx, solve, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out, match_q, match_t, true);
+      chain = false;
+    }
     if (rc != VS_OK) {
-      if (chain) {  // the next back half is enqueued already: let it drain
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamSynchronize(ctx->aux_stream[1]);
-      }
+      for (hipStream_t st : {T.front_stream, ctx->stream, ctx->aux_stream[1]})  // whatever this call enqueued: let it drain
+        if (st) (void)hipStreamSynchronize(st);
       return rc;
     }
     *has_result = 1;
@@ -806,6 +927,7 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
     T.pending_step = next_step;
   }
   ++g_tt.n;
+  T.dirty = 0;
   return VS_OK;
 }
 
@@ -827,6 +949,7 @@ VS_API int vs_track_front(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   if (T.pending >= 0 || T.api_stage == 2) return vs_fail(ctx, VS_EINVAL, "%s: a back half is still running", "vs_track_front");
   VS_HIP(ctx, hipSetDevice(ctx->device));
   if (++T.api_seq == 0) ++T.api_seq;
+  T.dirty = 1;
   VS_TRY(track_front_half(ctx, 0, T.n_frames, bgr, w, h_img, stride, thr, ratio, ctx->stream, true));
   const api_layout AL = api_layout_of(T.n_points, T.max_kp);
   const uint8_t* hb = (const uint8_t*)ctx->h_api.p;
@@ -889,5 +1012,17 @@ VS_API int vs_track_back_end(vs_ctx* ctx, double* poses_out, int* n_poses_out) {
   VS_HIP(ctx, hipSetDevice(ctx->device));
   int step = T.api_step, n_matches = 0, pnp_found = 0;
   T.api_stage = 0;
-  return track_back_finish(ctx, 0, &step, poses_out, n_poses_out, &n_matches, &pnp_found, nullptr, nullptr, nullptr, nullptr, nullptr);
+  int rc = track_back_finish(ctx, 0, &step, poses_out, n_poses_out, &n_matches, &pnp_found, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (rc != VS_OK && T.recoverable)  // (the PnP outcome the caller already holds is reproduced: same inputs, same seed)
+    rc = track_redo(ctx, 0, poses_out, n_poses_out, &n_matches, &pnp_found, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+  if (rc == VS_OK) T.dirty = 0;
+  return rc;
+}
+
+// developer entry point (include/vslam_hip_dev.h): fault injection and the redo counter of the tracking period
+VS_API int vs_track_debug(vs_ctx* ctx, int inject_fault, int* recoveries_out) {
+  if (!ctx) return VS_EINVAL;
+  if (inject_fault == 1) ctx->track.inject = 1;
+  if (recoveries_out) *recoveries_out = ctx->track.recoveries;
+  return VS_OK;
 }
