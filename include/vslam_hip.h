@@ -38,7 +38,7 @@ typedef enum vs_status {
   VS_ENCCL = -6   /* RCCL is not loaded in the process, or the all-gather failed */
 } vs_status;
 
-#define VS_ABI_VERSION 3
+#define VS_ABI_VERSION 4
 #define VS_DESC_BYTES 32 /* BRIEF-256 */
 
 /* ---- context ---------------------------------------------------------------------------------------------- */
@@ -230,9 +230,14 @@ int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx /*[m]*/, const dou
  *                        match the map points (queries) against the frame (train), append the matches as the new frame's
  *                        observations; ONE synchronisation.  Returns key points, descriptors and the matches
  *                        (match_q = map point index, match_t = key point index, match_d = Hamming distance).
- *   vs_track_back_begin  cv2.solvePnPRansac (main.py:196-197): PnP-RANSAC from the period's previous pose on those matches
- *                        and, enqueued right behind it, the motion-only BA over all poses (LocalBA.py:195-229); returns when
- *                        the PnP outcome is in (pose16 = camera-to-world 4x4, the inlier indices into the match list).
+ *   vs_track_back_begin  cv2.solvePnPRansac (main.py:196-197): PnP-RANSAC on those matches and, enqueued right behind it, the
+ *                        motion-only BA over all poses (LocalBA.py:195-229); returns when the PnP outcome is in (pose16 =
+ *                        camera-to-world 4x4, the inlier indices into the match list).  The extrinsic guess is the period's
+ *                        previous pose, or guess_pose16 (camera-to-world 4x4) when the caller passes its own -- main.py:193-194
+ *                        builds rvec / tvec from W_T_prev itself, i.e. hands OpenCV the camera-to-world transform where a
+ *                        world-to-camera one is expected; a drop-in has to start from what the caller passed.  obj_as_f32 != 0:
+ *                        the object points are rounded to float32 when read, as main.py:196's objectPoints.astype(np.float32)
+ *                        does (the resident rows stay float64 for the bundle adjustment, as the reference's map does).
  *   vs_track_back_end    BundleAdjustment.motionOnlyBundleAdjustement (main.py:213-214): waits for that BA and returns all
  *                        poses of the period.
  * A front half that is not followed up (the caller went another way) costs nothing: the next frame overwrites its rows.
@@ -242,7 +247,8 @@ int vs_track_front(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, in
                    float* xy_out /*[max_kp][2]*/, uint8_t* desc_out /*[max_kp][32]*/, int* n_kp_out,
                    int32_t* match_q /*[n_points]*/, int32_t* match_t, int32_t* match_d, int* n_matches);
 int vs_track_back_begin(vs_ctx* ctx, double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations,
-                        double huber_delta, int* found, double* pose16, int32_t* inliers /*[n_matches]*/, int* n_inliers);
+                        double huber_delta, const double* guess_pose16 /*NULL: the period's previous pose*/, int obj_as_f32,
+                        int* found, double* pose16, int32_t* inliers /*[n_matches]*/, int* n_inliers);
 int vs_track_back_end(vs_ctx* ctx, double* poses_out /*[n_frames+1][16]*/, int* n_poses_out);
 int vs_track_end(vs_ctx* ctx);
 

@@ -42,6 +42,14 @@ int vs_tune_ba(vs_ctx* ctx, int schur_variant, int points_per_workgroup, int max
 int vs_pnp_profile(vs_ctx* ctx, int enable);
 int vs_pnp_profile_read(vs_ctx* ctx, double* out, int cap_rows);
 
+/* Per-step phase stamps of ba_motion_persistent inside a tracking period (camera 0's workgroup, thread 0).
+ * vs_mo_profile_read synchronises and returns the newest stamped solve as rows of 8 doubles, one per LM step: columns 0..6 in
+ * shader-clock cycles since the solve's first stamp ([0] step entered, [1] all cameras' partials arrived, [2] decision taken,
+ * [3] linearised + reduced, [4] 6x6 solved + trial record, [5] trial chi2 summed, [6] partials posted; 0 = phase skipped), column
+ * 7 the wall clock in microseconds since the first step.  Returns the number of steps (cap_rows must be >= 64). */
+int vs_mo_profile(vs_ctx* ctx, int enable);
+int vs_mo_profile_read(vs_ctx* ctx, double* out, int cap_rows);
+
 /* Tracking period (csrc/vs_track.hip).  inject_fault = 1: the next CHAINED back half's PnP launch waits for a front-half tag
  * nobody publishes -- every workgroup's bounded wait runs out, the frame is then redone host-paced (track_redo); 0: nothing.
  * *recoveries_out (may be NULL) = back halves redone so far on this context. */

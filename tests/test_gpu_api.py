@@ -789,3 +789,48 @@ def test_pipelined_tracking_with_the_other_train_staging_equals_frame_by_frame(v
             assert np.array_equal(ref, got), ts
     finally:
         vs.tune_match(tstage=1)
+
+
+def test_class_api_fast_path_engages_for_the_reference_call_as_written(vs):
+    """Round-3 advisor: the resident PnP + BA path was reached only by a caller that passed float64 object points and the
+    previous pose as the solver's guess.  main.py:187-204 as it stands passes objectPoints.astype(np.float32) and takes rvec /
+    tvec from W_T_prev itself (camera-to-world where OpenCV expects world-to-camera).  That call must (a) reach the resident
+    period too -- the device rounds its rows to float32 and starts from the caller's guess (vs_track_back_begin's
+    guess_pose16 / obj_as_f32) -- and (b) give what the same calls give when nothing is kept resident, to 1e-9."""
+    from visual_slam_amd import harness
+    from visual_slam_amd.map import Map
+    frames, depth0 = harness.load_sequence(12)
+    Map.use_device_mirror = False
+    try:
+        ref_poses, _ = harness.track_sequence_api(frames, depth0, context=vs, verbatim=True)
+    finally:
+        Map.use_device_mirror = True
+    calls = {"back_begin": [], "back_end": 0, "pnp": 0}
+    orig = {n: getattr(vs, n) for n in ("track_back_begin", "track_back_end", "pnp_ransac")}
+
+    def back_begin(*a, **k):
+        calls["back_begin"].append((k.get("guess") is not None, bool(k.get("obj_f32"))))
+        return orig["track_back_begin"](*a, **k)
+
+    def back_end(*a, **k):
+        calls["back_end"] += 1
+        return orig["track_back_end"](*a, **k)
+
+    def pnp(*a, **k):
+        calls["pnp"] += 1
+        return orig["pnp_ransac"](*a, **k)
+    vs.track_back_begin, vs.track_back_end, vs.pnp_ransac = back_begin, back_end, pnp
+    try:
+        poses, _ = harness.track_sequence_api(frames, depth0, context=vs, verbatim=True)
+    finally:
+        for n in orig:
+            delattr(vs, n)
+    # frame 1 is host-fed (the period does not exist before the first BA call): one plain PnP; every later frame's PnP ran in
+    # the period, on float32-rounded rows; the guess is the caller's own from the first frame whose previous pose is not the identity
+    assert calls["pnp"] == 1 and calls["back_end"] == len(calls["back_begin"]) == len(frames) - 2, calls
+    assert all(f32 for _, f32 in calls["back_begin"]) and any(g for g, _ in calls["back_begin"]), calls
+    rel = max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(poses, ref_poses))
+    assert rel <= 1e-9, rel
+    # and the verbatim call differs from the corrected one only as far as the other start point moves RANSAC + LM
+    fixed, _ = harness.track_sequence_api(frames, depth0, context=vs)
+    assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(poses, fixed)) < 1e-2

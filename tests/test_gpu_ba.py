@@ -570,3 +570,23 @@ def test_banded_cholesky_is_bitwise_the_dense_factorisation(vs):
         assert not vs.debug_cholesky(S, rhs)[0]
     finally:
         vs.tune_ba(schur_variant=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cams,n_points", [(13, 20000), (16, 30000)])
+def test_window_plan_fits_the_arena_of_a_fresh_context(oracle, n_cams, n_points):
+    """Round-3 advisor: the arena reservation covered the tile path's slabs (np * np + np doubles each) but not the banded-window
+    path's (9 312 doubles each whatever np is): with 11-20 free cameras np is small, a window plan of hundreds of slabs outgrew
+    it, and the solve ended in VS_ENOMEM 'internal arena sizing error' -- unless an earlier, larger solve on the same context
+    had grown the arena.  A FRESH context, few cameras, many points seen three times each: must solve and agree with the oracle."""
+    from visual_slam_amd import Context, _capi
+    if _capi.device_count() == 0:
+        pytest.skip("no GPU in this machine")
+    w = _sliding_window_scene(n_cams, n_points, 3, 21)
+    ctx = Context(0)  # nothing has grown this context's arena
+    try:
+        g = ctx.ba_solve(*_args(w), max_iterations=2)
+    finally:
+        ctx.close()
+    o = oracle.ba_solve(*_args(w), max_iterations=2)
+    _compare(g, o)

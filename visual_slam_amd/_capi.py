@@ -101,8 +101,8 @@ SIGNATURES = {
     "vs_track_push_frame": (C.c_int, [c_ctxp, c_i32p, c_f64p, C.c_int, c_f64p, C.c_int, C.c_double, c_f64p, c_intp]),
     "vs_track_front": (C.c_int, [c_ctxp, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, c_f32p, c_u8p, c_intp, c_i32p,
                                  c_i32p, c_i32p, c_intp]),
-    "vs_track_back_begin": (C.c_int, [c_ctxp, C.c_double, C.c_double, C.c_uint64, C.c_int, C.c_double, c_intp, c_f64p, c_i32p,
-                                      c_intp]),
+    "vs_track_back_begin": (C.c_int, [c_ctxp, C.c_double, C.c_double, C.c_uint64, C.c_int, C.c_double, c_f64p, C.c_int, c_intp,
+                                      c_f64p, c_i32p, c_intp]),
     "vs_track_back_end": (C.c_int, [c_ctxp, c_f64p, c_intp]),
     "vs_track_end": (C.c_int, [c_ctxp]),
     "vs_ba_solve": (C.c_int, [c_ctxp, C.POINTER(BAProblem), C.POINTER(BAResult)]),
@@ -119,6 +119,8 @@ HOOKS = {
     "vs_match_profile_read": (C.c_int, [c_ctxp, C.POINTER(C.c_float)]),
     "vs_match_stamps": (C.c_int, [c_ctxp, C.c_int]),
     "vs_match_stamps_read": (C.c_int, [c_ctxp, c_f64p, C.c_int]),
+    "vs_mo_profile": (C.c_int, [c_ctxp, C.c_int]),
+    "vs_mo_profile_read": (C.c_int, [c_ctxp, c_f64p, C.c_int]),
     "vs_track_debug": (C.c_int, [c_ctxp, C.c_int, c_intp]),
     "vs_pnp_profile": (C.c_int, [c_ctxp, C.c_int]),
     "vs_pnp_profile_read": (C.c_int, [c_ctxp, c_f64p, C.c_int]),

@@ -355,18 +355,21 @@ class Context:
         return dict(xy=xy[:n], desc=desc[:n], match_q=m[0, :M], match_t=m[1, :M], match_d=m[2, :M])
 
     def track_back_begin(self, seed=0, reproj_err=8.0, confidence=0.99, lm_iterations=10,
-                         huber_delta=float(np.sqrt(5.991))):
+                         huber_delta=float(np.sqrt(5.991)), guess=None, obj_f32=False):
         """PnP-RANSAC on the front half's matches + (enqueued behind it) the motion-only BA; returns the PnP outcome:
-        dict(found, pose [4,4] camera-to-world, inliers [m] int32 indices into the match list)."""
+        dict(found, pose [4,4] camera-to-world, inliers [m] int32 indices into the match list).  guess: the extrinsic guess as
+        a camera-to-world 4x4 (None: the period's previous pose); obj_f32: the object points are rounded to float32 first
+        (the reference passes objectPoints.astype(np.float32), main.py:196)."""
         t = self._track
         if t is None:
             raise VsError(-1, "track_back_begin: no tracking period (call track_begin)")
         pose = np.empty(16)
         inl = np.empty(max(t["P"], 1), np.int32)
         found, ni = C.c_int(0), C.c_int(0)
+        g = None if guess is None else np.ascontiguousarray(guess, np.float64).reshape(16)
         self._chk(self._lib.vs_track_back_begin(self._h, float(reproj_err), float(confidence), int(seed), int(lm_iterations),
-                                                float(huber_delta), C.byref(found), ptr(pose, c_f64p), ptr(inl, c_i32p),
-                                                C.byref(ni)))
+                                                float(huber_delta), None if g is None else ptr(g, c_f64p), 1 if obj_f32 else 0,
+                                                C.byref(found), ptr(pose, c_f64p), ptr(inl, c_i32p), C.byref(ni)))
         return dict(found=bool(found.value), pose=pose.reshape(4, 4), inliers=inl[:ni.value])
 
     def track_back_end(self):

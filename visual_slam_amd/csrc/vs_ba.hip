@@ -2704,6 +2704,11 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
   __shared__ unsigned s_box[kMoPersistCameras][8];  // payload halves of every camera's four partials
   __shared__ double s_pv[4];
   const int tid = threadIdx.x, c = blockIdx.x, nfp = D.nfp;
+  // diagnostic (vs_mo_profile): thread 0 of camera 0's workgroup stamps the phases of every step with the shader clock
+  // [0] step entered, [1] everybody's partials arrived, [2] decision taken, [3] linearised + reduced (0: linearisation kept),
+  // [4] 6x6 system solved + trial record written, [5] trial chi2 evaluated and summed, [6] partials posted, [7] wall clock
+  unsigned long long* const stamp_row = (D.mo_stamps && c == 0 && tid == 0) ? D.mo_stamps : nullptr;
+#define VS_MO_STAMP(col) do { if (stamp_row && step < 64) stamp_row[(size_t)step * 8 + (col)] = (col) == 7 ? wall_clock64() : (unsigned long long)__builtin_readcyclecounter(); } while (0)
   mo_state* g_state = reinterpret_cast<mo_state*>(D.st);
   const int pose = D.slot_pose[c];
   const int o0 = D.cam_start[c], o1 = D.cam_start[c + 1];
@@ -2751,6 +2756,8 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
   };
   int step = 0;
   for (;; ++step) {
+    VS_MO_STAMP(0);
+    VS_MO_STAMP(7);
     if (step > 0) {
       // ---- rendezvous: everybody's partials of step - 1, then the decision (every workgroup, identical inputs).
       // Eight lanes per camera poll the eight tagged words of its mailbox (see the end of the step) until every word of
@@ -2778,6 +2785,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
         }
       }
       __syncthreads();
+      VS_MO_STAMP(1);
       if (s_abort) {
         st.done = 1;
         st.terminated = 3;
@@ -2818,6 +2826,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
         if (tid < kCamStride) s_cam[tid] = s_trial[tid];
         __syncthreads();
       }
+      VS_MO_STAMP(2);
     }
     if (st.done || step > max_steps) break;
     const double* cam = s_cam;
@@ -2874,6 +2883,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
         }
       }
       block_reduce28(acc, s_all, s_grp, s_sum, tid);  // s_sum: upper triangle (21) + b (6) + chi2, kept across retries
+      VS_MO_STAMP(3);
       if (lin_only) {
         if (tid == 0) {
           double mx = 0.0;
@@ -2888,6 +2898,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
           s_pv[3] = mx;
         }
         post_partials(step);
+        VS_MO_STAMP(6);
         st.stage = 1;
         continue;
       }
@@ -2962,6 +2973,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
       s_x[0] = sc;
       s_ok = ok;
     }
+    VS_MO_STAMP(4);
     __syncthreads();
     // ---- robust chi2 of this camera's trial state
     double tcam[kCamStride];
@@ -2998,9 +3010,12 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
       s_pv[2] = ok ? 0.0 : 1.0;
       s_pv[3] = 0.0;
     }
+    VS_MO_STAMP(5);
     post_partials(step);
+    VS_MO_STAMP(6);
     st.stage = 2;
   }
+#undef VS_MO_STAMP
   if (c == 0 && tid == 0) {
     g_state[0] = st;
     g_state[1] = st;
@@ -3425,6 +3440,16 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   };
   const bool small_possible = tiled_possible && ntile == 1 && ctx->tune.schur_variant != 1;  // one tile: ba_schur_small
   const int ns_bound = std::max(slabs_for(false, false), slabs_for(tiled_possible, small_possible));
+  // ... and of the banded-window path (ba_schur_window), whose slabs are kWinSlabElems doubles whatever np is: with few free
+  // cameras np * np + np is much smaller than that, and a window plan with hundreds of slabs outgrew the reservation made for
+  // the tile path (round-3 advisor: 13 poses x 20 000 points needed 58 MB against 39 MB).  The plan below takes at most
+  // `target` slabs (win_per >= ceil(win_n / target)) unless vs_tune_ba fixes the slab size.
+  const bool win_possible = tiled_possible && ntile > 1 && ctx->tune.schur_variant != 3;
+  const int win_target = 2 * std::max(ctx->prop.multiProcessorCount, 64);
+  const int ns_win_bound = !win_possible ? 0
+                           : ctx->tune.win_per > 0 ? (nfl + std::min(kWinPerMax, ctx->tune.win_per) - 1) / std::min(kWinPerMax, ctx->tune.win_per)
+                                                   : std::max(std::min(win_target, (nfl + 31) / 32), (nfl + kWinPerMax - 1) / kWinPerMax);
+  const size_t slab_doubles = std::max((size_t)(ns_bound ? ns_bound : 1) * slab_elems, (size_t)ns_win_bound * kWinSlabElems);
   // workgroups per camera of the linearisation's camera role: about one observation per thread, at most 8
   int cam_split = 1;
   for (int c = 0; c < nfp; ++c) cam_split = std::max(cam_split, (cam_start[c + 1] - cam_start[c] + kCamThreads - 1) / kCamThreads);
@@ -3438,9 +3463,9 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
                                             2 * (size_t)n_cam_obs + 2 * (size_t)q.n_scale + nfl + 64) +
                 sizeof(double) * (5 * (size_t)n_obs + (size_t)q.n_scale + 2 * (size_t)F * kCamStride + 6 * (size_t)P +
                                   2 * (size_t)np * np + 8 * (size_t)np + 12 * (size_t)nfl + 18 * (size_t)n_obs +
-                                  9 * (size_t)nfl + (tiled_possible ? 5 * (size_t)nfl + nfp + 4096 : 0) + (size_t)(ns_bound ? ns_bound : 1) * slab_elems + 3 * (size_t)nb_pt + nfp +
+                                  9 * (size_t)nfl + (tiled_possible ? 5 * (size_t)nfl + nfp + 4096 : 0) + slab_doubles + 3 * (size_t)nb_pt + nfp +
                                   2 * (size_t)q.max_iterations + 64) +
-                256 * 64 + sizeof(int) * (3 * (size_t)n_obs + nfl + 16) + (sizeof(double) * 27 * 8 + 8) * (size_t)nfp + 1024 +
+                256 * 64 + sizeof(int) * (3 * (size_t)n_obs + nfl + 16 + 2 * (size_t)ns_win_bound + nfp + 64) + 4 * 256 + (sizeof(double) * 27 * 8 + 8) * (size_t)nfp + 1024 +
                 sizeof(double) * (64 + (size_t)F * kCamStride + 3 * (size_t)P + 2 * (size_t)q.max_iterations) + 512 +
                 (small_possible ? sizeof(double) * ((size_t)np * np + np + 12 * (size_t)nfl + 18 * (size_t)n_obs) + 5 * 256 : 0) + sizeof(double) * 8 * (size_t)(res->trial_trace ? std::max(res->trial_trace_cap, 0) : 0) + (motion_only ? sizeof(double) * (8 * (size_t)n_cam_obs + 50 * (size_t)nfp + 64) : 0);
   VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
@@ -3747,7 +3772,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       for (int l = 0; l < nfl; ++l)
         if (whi[l] >= 0) h_word[wcnt[wlo[l]]++] = l;  // stable: equal keys stay in point order
       // two workgroups per CU (registers), all resident at once; at least 32 points each
-      const int target = 2 * std::max(ctx->prop.multiProcessorCount, 64);
+      const int target = win_target;
       win_per = std::min(kWinPerMax, std::max(32, (win_n + target - 1) / target));
       if (ctx->tune.win_per > 0) win_per = std::min(kWinPerMax, ctx->tune.win_per);
       ns_win = (win_n + win_per - 1) / win_per;

@@ -65,6 +65,7 @@ struct ba_dev {
   double *mo_part, *mo_H;                // [2][nfp][4] per-camera partials by step parity; [nfp][42] H upper + b
   unsigned long long* mo_box;            // ba_motion_persistent: [2][kMoPersistCameras][8] tagged mailbox words
   unsigned mo_epoch;                     // ... tag of this solve (20 bits), so that words of an earlier solve never match
+  unsigned long long* mo_stamps;         // diagnostic (vs_mo_profile): [64 steps][8] shader-clock stamps of camera 0's workgroup, or nullptr
   unsigned* mo_done;                     // chained tracking: [0] arrival counter, [64] tag published when every camera workgroup is through (nullptr: none)
   unsigned mo_done_tag;
 };
@@ -180,7 +181,8 @@ __device__ __host__ inline void quat_from_pose(const double* m, double* q) {
 struct pnp_args {
   const double* obj;   // [n][3]
   const double* img;   // [n][2]
-  int n, iters_lm, iterations, pad;
+  int n, iters_lm, iterations;
+  int obj_f32;         // 1: object points are rounded to float32 when read (the reference passes objectPoints.astype(np.float32))
   double fx, fy, cx, cy, thr2, confidence;
   unsigned long long seed;
   double cam0[kCamStride];

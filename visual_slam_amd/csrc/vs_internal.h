@@ -135,6 +135,9 @@ struct vs_ctx {
     int next_set = 0;
     // class-API feeding (vs_track_front / vs_track_back_begin / vs_track_back_end): 0 idle, 1 front half done, 2 back half running
     int api_stage = 0, api_step = 0, api_matches = 0;
+    int api_back = 0;  // the back half being enqueued (or redone) is vs_track_back_begin's
+    int api_obj_f32 = 0, api_guess_set = 0;  // vs_track_back_begin: object points as float32 / an explicit PnP guess (else the previous pose)
+    double api_guess_rec[19];
     hipEvent_t ev_api = nullptr;  // recorded behind the PnP kernel of vs_track_back_begin
     struct {
       double reproj_err, confidence, huber;
@@ -156,6 +159,8 @@ struct vs_ctx {
   hipEvent_t ev_after = nullptr;  // orders a compute stream behind the caller's stream (same entry point, after_stream)
   vs_tuning tune;
   std::vector<vs_prof_rec> match_prof;
+  vs_buf d_mo_stamps;       // diagnostic step stamps of the newest one-launch motion-only solve of a tracking period (vs_mo_profile)
+  bool mo_profile = false;
   vs_buf d_match_stamps;    // diagnostic phase stamps of the newest stamped match launch (vs_match_stamps)
   bool match_stamps_on = false;
   int match_stamps_rows = 0;

@@ -25,6 +25,12 @@ namespace {
 
 
 __device__ inline int pnp_count(const pnp_args& P) { return P.n_dev ? *P.n_dev : P.n; }
+// Coordinate k of object point i.  obj_f32: rounded to float32 first -- what the solver sees when the caller hands it
+// objectPoints.astype(np.float32) as the reference does (src/v2/main.py:196) while the period's resident rows are float64.
+__device__ __forceinline__ double pnp_obj(const pnp_args& P, const double* obj, size_t i, int k) {
+  const double v = obj[3 * i + k];
+  return P.obj_f32 ? (double)(float)v : v;
+}
 // What a launch works out for itself (the count read on the device, the rows behind the period's offset, the guess in the
 // state buffer the previous solve ended on).  Kept apart from pnp_args ON PURPOSE: the argument struct is never written, so
 // it stays in the kernel-argument segment -- written to, it was copied to scratch memory at kernel entry (736 bytes per lane),
@@ -221,7 +227,7 @@ __device__ inline void pnp_lm(const pnp_args& P, const pnp_view& V, const int* s
       if (e < m) {
         const int i = sel ? sel[e] : e;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) rX[j][k] = V.obj[3 * (size_t)i + k];
+        for (int k = 0; k < 3; ++k) rX[j][k] = pnp_obj(P, V.obj, (size_t)i, k);
         rUV[j][0] = V.img[2 * (size_t)i];
         rUV[j][1] = V.img[2 * (size_t)i + 1];
       }
@@ -238,7 +244,7 @@ __device__ inline void pnp_lm(const pnp_args& P, const pnp_view& V, const int* s
     } else {
       for (int e = first; e < m; e += stride) {
         const int i = sel ? sel[e] : e;
-        const double X[3] = {V.obj[3 * (size_t)i], V.obj[3 * (size_t)i + 1], V.obj[3 * (size_t)i + 2]};
+        const double X[3] = {pnp_obj(P, V.obj, (size_t)i, 0), pnp_obj(P, V.obj, (size_t)i, 1), pnp_obj(P, V.obj, (size_t)i, 2)};
         const double uv[2] = {V.img[2 * (size_t)i], V.img[2 * (size_t)i + 1]};
         pnp_edge<true>(P, cam, X, uv, acc);
       }
@@ -332,7 +338,7 @@ __device__ inline void pnp_lm(const pnp_args& P, const pnp_view& V, const int* s
         } else {
           for (int e = first; e < m; e += stride) {
             const int i = sel ? sel[e] : e;
-            const double X[3] = {V.obj[3 * (size_t)i], V.obj[3 * (size_t)i + 1], V.obj[3 * (size_t)i + 2]};
+            const double X[3] = {pnp_obj(P, V.obj, (size_t)i, 0), pnp_obj(P, V.obj, (size_t)i, 1), pnp_obj(P, V.obj, (size_t)i, 2)};
             const double uv[2] = {V.img[2 * (size_t)i], V.img[2 * (size_t)i + 1]};
             pnp_edge<false>(P, trial, X, uv, tacc);
           }
@@ -494,7 +500,7 @@ __device__ inline void pnp_hypothesis_role(const pnp_args& P, pnp_view& V, int n
     const int i = i0 + lane;
     bool in = false;
     if (i < V.n) {
-      const double X[3] = {V.obj[3 * (size_t)i], V.obj[3 * (size_t)i + 1], V.obj[3 * (size_t)i + 2]};
+      const double X[3] = {pnp_obj(P, V.obj, (size_t)i, 0), pnp_obj(P, V.obj, (size_t)i, 1), pnp_obj(P, V.obj, (size_t)i, 2)};
       const double uv[2] = {V.img[2 * (size_t)i], V.img[2 * (size_t)i + 1]};
       double eu, ev, pc[3];
       pnp_err(P, cam, X, uv, eu, ev, pc);
@@ -525,9 +531,9 @@ __device__ inline void pnp_finish_role(const pnp_args& P, pnp_view& V) {
     const int i = kPnpFinish * j + tid;
     lX[j][0] = lX[j][1] = lX[j][2] = lU[j][0] = lU[j][1] = 0.0;
     if (i < V.n) {
-      lX[j][0] = V.obj[3 * (size_t)i];
-      lX[j][1] = V.obj[3 * (size_t)i + 1];
-      lX[j][2] = V.obj[3 * (size_t)i + 2];
+      lX[j][0] = pnp_obj(P, V.obj, (size_t)i, 0);
+      lX[j][1] = pnp_obj(P, V.obj, (size_t)i, 1);
+      lX[j][2] = pnp_obj(P, V.obj, (size_t)i, 2);
       lU[j][0] = V.img[2 * (size_t)i];
       lU[j][1] = V.img[2 * (size_t)i + 1];
     }
@@ -626,9 +632,9 @@ __device__ inline void pnp_finish_role(const pnp_args& P, pnp_view& V) {
         uv[0] = j == 0 ? lU[0][0] : lU[1][0];
         uv[1] = j == 0 ? lU[0][1] : lU[1][1];
       } else {
-        X[0] = V.obj[3 * (size_t)i];
-        X[1] = V.obj[3 * (size_t)i + 1];
-        X[2] = V.obj[3 * (size_t)i + 2];
+        X[0] = pnp_obj(P, V.obj, (size_t)i, 0);
+        X[1] = pnp_obj(P, V.obj, (size_t)i, 1);
+        X[2] = pnp_obj(P, V.obj, (size_t)i, 2);
         uv[0] = V.img[2 * (size_t)i];
         uv[1] = V.img[2 * (size_t)i + 1];
       }

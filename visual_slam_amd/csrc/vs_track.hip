@@ -352,6 +352,10 @@ int track_back_enqueue(vs_ctx* ctx, int set, int* steps_out, int k, bool chained
   A.confidence = Q.confidence;
   A.seed = Q.seed;
   memcpy(A.cam0, T.last_rec, sizeof A.cam0);
+  if (T.api_back) {  // class-API back half (vs_track_back_begin / its redo): the caller's own guess and object-point precision
+    if (T.api_guess_set) memcpy(A.cam0, T.api_guess_rec, sizeof A.cam0);
+    A.obj_f32 = T.api_obj_f32;
+  }
   if (chained) {
     A.off_dev = (const int*)(d + L.cam_start) + (k - 1);  // written by the previous frames' appends
     A.guess_dev[0] = cam0 + (size_t)(k - 1) * kCamStride;
@@ -468,9 +472,15 @@ int track_ba_batch(vs_ctx* ctx, int set, int* step, int k, bool chained = false)
     // frame, and consecutive frames of a stream need about the same number of LM steps: the first batch is as long as the
     // previous solve was (+1); a solve that needs more gets further batches (the results do not depend on the split).
     if (*step == 0 && !T.in_redo && mo_persistent_ok(ctx, k, max_steps)) {
+      ba_dev Dp = D;
+      if (ctx->mo_profile) {  // diagnostic: step stamps of camera 0's workgroup (vs_mo_profile)
+        VS_TRY(vs_reserve(ctx, &ctx->d_mo_stamps, sizeof(unsigned long long) * 64 * 8));
+        VS_HIP(ctx, hipMemsetAsync(ctx->d_mo_stamps.p, 0, sizeof(unsigned long long) * 64 * 8, s));
+        Dp.mo_stamps = (unsigned long long*)ctx->d_mo_stamps.p;
+      }
       // the whole solve in one launch (a frame has at most n_points matches); the final record lands in both state slots
-      if (T.n_points <= kMoPersistObs) hipLaunchKernelGGL(ba_motion_persistent<false>, dim3(k), dim3(kMoThreads), 0, s, D, max_steps);
-      else hipLaunchKernelGGL(ba_motion_persistent<true>, dim3(k), dim3(kMoThreads), 0, s, D, max_steps);
+      if (T.n_points <= kMoPersistObs) hipLaunchKernelGGL(ba_motion_persistent<false>, dim3(k), dim3(kMoThreads), 0, s, Dp, max_steps);
+      else hipLaunchKernelGGL(ba_motion_persistent<true>, dim3(k), dim3(kMoThreads), 0, s, Dp, max_steps);
       VS_LAUNCH_CHECK(ctx, "ba_motion_persistent");
       *step = max_steps + 2;  // nothing left to enqueue
       T.mst_both = 1;
@@ -717,6 +727,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   T.mst_both = 1;
   T.next_set = 0;
   T.api_stage = 0;
+  T.api_back = 0;
   T.K[0] = fx;
   T.K[1] = fy;
   T.K[2] = cx;
@@ -762,6 +773,7 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
   auto& T = ctx->track;
   T.params[0] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
   T.api_stage = 0;  // a front half of the class-API entry points nobody followed up on: its rows are overwritten below
+  T.api_back = 0;
   T.dirty = 1;      // (until this call has handed out its results: an error return leaves work in flight)
   VS_TRY(track_front_half(ctx, 0, T.n_frames, bgr, w, h_img, stride, thr, ratio, ctx->stream));
   int step = 0;
@@ -788,6 +800,7 @@ VS_API int vs_track_push_frame(vs_ctx* ctx, const int32_t* point_idx, const doub
   if (T.pending >= 0) return vs_fail(ctx, VS_EINVAL, "%s: a pipelined frame is pending (flush it first)", "vs_track_push_frame");
   if (T.api_stage == 2) return vs_fail(ctx, VS_EINVAL, "%s: a back half is running (vs_track_back_end first)", "vs_track_push_frame");
   T.api_stage = 0;  // a front half nobody followed up on: its rows are overwritten below
+  T.api_back = 0;
   if (T.n_frames >= T.cap_frames) return vs_fail(ctx, VS_ENOMEM, "%s: the period holds max_frames frames already", "vs_track_push_frame");
   if (m > T.n_points) return vs_fail(ctx, VS_EINVAL, "%s: more observations than map points", "vs_track_push_frame");
   for (int i = 0; i < m; ++i)
@@ -861,6 +874,7 @@ VS_API int vs_track_frame_pipelined(vs_ctx* ctx, const uint8_t* bgr, int w, int 
   // path).  The previous frame's results are then awaited through the tag behind ITS read-back block.  Otherwise (a solve
   // that may need further LM batches decided on the host): the back half is enqueued once the previous results are in.
   T.api_stage = 0;
+  T.api_back = 0;
   T.dirty = 1;  // (cleared where this call returns with nothing but the pending frame's own work outstanding)
   const int solve = T.pending;
   const bool solve_chained = solve >= 0 && T.pending_chained;
@@ -972,7 +986,8 @@ VS_API int vs_track_front(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
 }
 
 VS_API int vs_track_back_begin(vs_ctx* ctx, double pnp_reproj_err, double pnp_confidence, uint64_t seed, int lm_iterations,
-                               double huber_delta, int* found, double* pose16, int32_t* inliers, int* n_inliers) {
+                               double huber_delta, const double* guess_pose16, int obj_as_f32, int* found, double* pose16,
+                               int32_t* inliers, int* n_inliers) {
   if (!ctx) return VS_EINVAL;
   auto& T = ctx->track;
   if (!T.active || T.api_stage != 1) return vs_fail(ctx, VS_EINVAL, "%s: no front half to continue (vs_track_front)", "vs_track_back_begin");
@@ -980,6 +995,10 @@ VS_API int vs_track_back_begin(vs_ctx* ctx, double pnp_reproj_err, double pnp_co
     return vs_fail(ctx, VS_EINVAL, "%s: bad arguments", "vs_track_back_begin");
   VS_HIP(ctx, hipSetDevice(ctx->device));
   T.params[0] = {pnp_reproj_err, pnp_confidence, huber_delta, seed, lm_iterations};
+  T.api_obj_f32 = obj_as_f32 != 0;
+  T.api_guess_set = guess_pose16 != nullptr;
+  if (guess_pose16) rec_from_pose(guess_pose16, T.api_guess_rec);
+  T.api_back = 1;
   int step = 0;
   if (++T.api_seq == 0) ++T.api_seq;
   VS_TRY(track_back_enqueue(ctx, 0, &step, T.n_frames + 1));  // PnP-RANSAC; its outcome also goes to pinned memory, tagged
@@ -999,7 +1018,7 @@ VS_API int vs_track_back_begin(vs_ctx* ctx, double pnp_reproj_err, double pnp_co
     memcpy(inliers, (const uint8_t*)ctx->h_api.p + AL.pnp_inl, sizeof(int32_t) * (size_t)m);
     *n_inliers = m;
   } else {
-    pose_from_rec(T.last_rec, pose16);  // nothing found: the guess, as cv2 leaves rvec / tvec untouched
+    pose_from_rec(T.api_guess_set ? T.api_guess_rec : T.last_rec, pose16);  // nothing found: the guess, as cv2 leaves rvec / tvec untouched
   }
   return VS_OK;
 }
@@ -1013,10 +1032,37 @@ VS_API int vs_track_back_end(vs_ctx* ctx, double* poses_out, int* n_poses_out) {
   int step = T.api_step, n_matches = 0, pnp_found = 0;
   T.api_stage = 0;
   int rc = track_back_finish(ctx, 0, &step, poses_out, n_poses_out, &n_matches, &pnp_found, nullptr, nullptr, nullptr, nullptr, nullptr);
-  if (rc != VS_OK && T.recoverable)  // (the PnP outcome the caller already holds is reproduced: same inputs, same seed)
+  if (rc != VS_OK && T.recoverable)  // (the PnP outcome the caller already holds is reproduced: same inputs, same seed, same guess)
     rc = track_redo(ctx, 0, poses_out, n_poses_out, &n_matches, &pnp_found, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+  T.api_back = 0;
   if (rc == VS_OK) T.dirty = 0;
   return rc;
+}
+
+// diagnostic hooks (include/vslam_hip_dev.h): per-step phase stamps of ba_motion_persistent inside a tracking period (camera 0's
+// workgroup, thread 0).  vs_mo_profile_read synchronises and returns the newest stamped solve as rows of 8 doubles, one per LM
+// step: columns 0..6 in shader-clock cycles since the solve's first stamp ([0] step entered, [1] partials of all cameras arrived,
+// [2] decision taken, [3] linearised + reduced, [4] 6x6 solved + trial record, [5] trial chi2 summed, [6] partials posted; 0 = phase
+// skipped), column 7 the wall clock in microseconds since the first step.  Returns the number of steps stamped.
+VS_API int vs_mo_profile(vs_ctx* ctx, int enable) {
+  if (!ctx) return VS_EINVAL;
+  ctx->mo_profile = enable != 0;
+  return VS_OK;
+}
+VS_API int vs_mo_profile_read(vs_ctx* ctx, double* out, int cap_rows) {
+  if (!ctx || !out) return VS_EINVAL;
+  if (!ctx->d_mo_stamps.p || cap_rows < 64) return 0;
+  unsigned long long h[64 * 8];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, ctx->d_mo_stamps.p, sizeof h, hipMemcpyDeviceToHost) != hipSuccess)
+    return vs_fail(ctx, VS_EHIP, "%s: read-back failed", "vs_mo_profile_read");
+  int rows = 0;
+  while (rows < 64 && h[rows * 8]) ++rows;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < 8; ++c) {
+      const unsigned long long v = h[r * 8 + c], base = c == 7 ? h[7] : h[0];
+      out[r * 8 + c] = !v ? 0.0 : c == 7 ? (double)(v - base) * 0.01 : (double)(v - base);
+    }
+  return rows;
 }
 
 // developer entry point (include/vslam_hip_dev.h): fault injection and the redo counter of the tracking period

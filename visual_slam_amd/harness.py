@@ -133,12 +133,15 @@ def track_sequence_resident(ctx, frames, depth0, pnp=True, pipelined=False):
     return poses, dt, n_matches
 
 
-def track_sequence_api(frames, depth0, context=None, ba_solver=None, pnp=True, pnp_solver=None):
-    """The same tracking period written against the reference's class API exactly as src/v2/main.py:173-214 uses it:
-    Frame.process_frame -> Map.GetImagePointsWithFrameID -> FeatureMatcher.match_features ->
+def track_sequence_api(frames, depth0, context=None, ba_solver=None, pnp=True, pnp_solver=None, verbatim=False):
+    """The same tracking period written against the reference's class API as src/v2/main.py:173-214 uses it:
+    Frame.process_frame -> Map.GetImagePointsWithFrameID -> FeatureMatcher.match_features -> solvePnPRansac ->
     Map.AddParentAndPose / AddPointToFrameCorrespondences -> BundleAdjustment.motionOnlyBundleAdjustement.
-    Returns (poses [n,4,4], seconds)."""
-    from .LocalBA import BundleAdjustment, Camera
+    verbatim=False: the PnP call is handed float64 object points and the previous pose as its (world-to-camera) guess, per frame
+    seed k -- the period is then the array path's, pose for pose.  verbatim=True: the statements of main.py:187-204 as they
+    stand -- the object points as .astype(np.float32), rvec / tvec guesses taken from W_T_prev itself (camera-to-world where
+    OpenCV expects world-to-camera), no check of retval, the default seed.  Returns (poses [n,4,4], seconds)."""
+    from .LocalBA import BundleAdjustment, Camera, Isometry3d
     from .frame import FeatureExtractor, FeatureMatcher, Frame
     from .map import Map
     from .point import Point
@@ -164,7 +167,20 @@ def track_sequence_api(frames, depth0, context=None, ba_solver=None, pnp=True, p
         kp_prev, ft_prev, known_3d, point_ids = local_map.GetImagePointsWithFrameID(0)
         matches, _, _, cur_pts, cur_fts = matcher.match_features(kp_prev, ft_prev, kp_cur, ft_cur)
         prev_pose = np.asarray(local_map.GetFrame(k - 1).GetPose(), np.float64)
-        if pnp and len(matches) >= 5:  # main.py:189-204
+        if verbatim:  # main.py:187-204
+            known_3d_matched = np.array([known_3d[m[0].queryIdx] for m in matches])
+            W_T_prev = local_map.GetFrame(k - 1).GetPose()
+            rvec_guess = hf.Rtorvec(W_T_prev[0:3, 0:3])
+            tvec_guess = W_T_prev[0:3, 3]
+            retval, rvec, tvec, inliers = hf.solvePnPRansac(
+                objectPoints=known_3d_matched[:, np.newaxis, :].astype(np.float32),
+                imagePoints=cur_pts[:, np.newaxis, :].astype(np.float32), cameraMatrix=K, distCoeffs=np.array([]),
+                rvec=rvec_guess.copy(), tvec=tvec_guess.copy(), useExtrinsicGuess=True, context=context, solver=pnp_solver)
+            tvec = tvec[:, np.newaxis]
+            T = hf.transformMatrix(rvec, tvec)
+            r, t = T[:3, :3], np.asarray(T[:3, -1]).squeeze()
+            prev_pose = Isometry3d(R=np.asarray(r), t=t).inverse().matrix()  # W_T_curr
+        elif pnp and len(matches) >= 5:  # main.py:189-204
             known = known_3d[matches.query_idx]
             c_T_w = np.linalg.inv(prev_pose)
             ok, rvec, tvec, _ = hf.solvePnPRansac(known, cur_pts, K, None, hf.Rtorvec(c_T_w[:3, :3]), c_T_w[:3, 3],
@@ -226,6 +242,15 @@ def bench_frames(ctx, repeats=5):
     # the same period through the reference's class API (Frame / Map / FeatureMatcher / BundleAdjustment objects)
     track_sequence_api(frames[:3], depth0, context=ctx)
     api_dt, api_min, (api_poses, _) = timed(lambda: track_sequence_api(frames, depth0, context=ctx), repeats)
+    # ... and with main.py:187-204 as it stands (float32 object points, the camera-to-world pose as the solver's guess)
+    track_sequence_api(frames[:3], depth0, context=ctx, verbatim=True)
+    vb_dt, vb_min, (vb_poses, _) = timed(lambda: track_sequence_api(frames, depth0, context=ctx, verbatim=True), repeats)
+    from .map import Map
+    Map.use_device_mirror = False  # the same calls with nothing resident: every step uploads its own arrays
+    try:
+        vb_plain, _ = track_sequence_api(frames, depth0, context=ctx, verbatim=True)
+    finally:
+        Map.use_device_mirror = True
     # the same period with the map resident on the device (one image upload per frame)
     track_sequence_resident(ctx, frames[:4], depth0)
     res_dt, res_min, (res_poses, _, _) = timed(lambda: track_sequence_resident(ctx, frames, depth0), repeats)
@@ -239,6 +264,12 @@ def bench_frames(ctx, repeats=5):
            "resident_vs_array_path": float(max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(res_poses, poses))),
            "class_api_frames_per_s": n / api_dt, "class_api_frames_per_s_max": n / api_min,
            "class_api_vs_array_path": float(max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(api_poses, poses))),
+           "class_api_verbatim_frames_per_s": n / vb_dt, "class_api_verbatim_frames_per_s_max": n / vb_min,
+           "class_api_verbatim_vs_nothing_resident": float(max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(vb_poses, vb_plain))),
+           "class_api_note": "class_api_*: the reference's call sequence with float64 object points and the previous pose as the "
+                             "solver's guess (equals the array path); class_api_verbatim_*: main.py:187-204 as it stands "
+                             "(objectPoints.astype(float32), rvec / tvec taken from the camera-to-world pose), compared with the "
+                             "same calls when nothing is kept resident",
            "stage_ms_per_frame": {k: v / n * 1e3 for k, v in stages.items()},
            "mean_matches": float(np.mean(nm)), "resolution": "640x480",
            "data": "ICL-NUIM living-room traj3 frames 0-19 (fixtures)",

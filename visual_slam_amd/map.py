@@ -201,18 +201,38 @@ class _PeriodMirror:
         sp["img_expect"] = sp["xy"][sp["match_t"]]
         return sp["match_q"], sp["match_t"], sp["match_d"]
 
+    kLmIterations, kHuber = 10, float(np.sqrt(5.991))  # the motion-only BA speculate_back enqueues behind the PnP (LocalBA's constants)
+
     def speculate_back(self, obj, img, K4, pose0, iterations, reproj_err, confidence, seed):
-        """PnP-RANSAC inside the period if the call is the one main.py:196-197 makes on the matches in flight, else None."""
+        """PnP-RANSAC inside the period if the call is the one main.py:196-197 makes on the matches in flight, else None.
+
+        Two spellings of that call are recognised.  The object points may be the map's float64 rows or -- as the reference
+        writes it, objectPoints=known_3d_matched[...].astype(np.float32) -- those rows rounded to float32 (the device then
+        rounds its resident rows the same way: same values into the same arithmetic as the plain path).  The extrinsic guess
+        may be the previous pose, or ANY other pose: main.py:193-194 builds rvec / tvec from W_T_prev itself (camera-to-world
+        where OpenCV expects world-to-camera), so what reaches the solver is the inverse of the previous pose; whatever the
+        caller passed is what the device starts from."""
         sp = self.spec
         if (sp is None or sp["stage"] != 1 or not sp["matched"] or not self._alive() or iterations != 100
                 or tuple(float(v) for v in K4) != self.K4):
             return None
         mq = sp["match_q"]
-        if (obj.shape != (len(mq), 3) or img.shape != (len(mq), 2) or len(mq) < 5 or not np.array_equal(obj, sp["obj_expect"])
-                or not np.array_equal(img, sp["img_expect"]) or float(np.abs(pose0 - self.last_pose).max()) > 1e-9):
+        if obj.shape != (len(mq), 3) or img.shape != (len(mq), 2) or len(mq) < 5 or not np.array_equal(img, sp["img_expect"]):
             return None
-        r = self.ctx.track_back_begin(seed=seed, reproj_err=reproj_err, confidence=confidence)
-        sp["stage"], sp["pnp"] = 2, r
+        want = sp["obj_expect"]
+        if np.array_equal(obj, want):
+            f32 = False
+        elif np.array_equal(obj, want.astype(np.float32)):  # (exact: float32 -> float64 is lossless)
+            f32 = True
+        else:
+            return None
+        pose0 = np.asarray(pose0, np.float64)
+        if pose0.shape != (4, 4) or not np.all(np.isfinite(pose0)):
+            return None
+        guess = None if float(np.abs(pose0 - self.last_pose).max()) <= 1e-9 else pose0
+        r = self.ctx.track_back_begin(seed=seed, reproj_err=reproj_err, confidence=confidence, lm_iterations=self.kLmIterations,
+                                      huber_delta=self.kHuber, guess=guess, obj_f32=f32)
+        sp["stage"], sp["pnp"], sp["lm"] = 2, r, (self.kLmIterations, self.kHuber)
         return r
 
     def solve(self, map_, huber_delta, max_iterations):
@@ -279,7 +299,9 @@ class _PeriodMirror:
                 b = rows.get(fid)
                 if b is not None and b[0] >= self.consumed and b[2] == len(sp["match_q"]):
                     sl, obs = soa.batch_data[b[0]]
+                    # (... and the solve the device ran is the one asked for: same iteration cap, same kernel width)
                     if (np.array_equal(sl, sp["match_q"]) and np.array_equal(obs, sp["img_expect"])
+                            and sp.get("lm") == (int(max_iterations), float(huber_delta))
                             and float(np.abs(np.asarray(f.GetPose(), np.float64) - sp["pnp"]["pose"]).max()) <= 1e-9):
                         poses = ctx.track_back_end()
                         self.pushed.append(fid)
