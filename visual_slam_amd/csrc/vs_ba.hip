@@ -2313,10 +2313,33 @@ __global__ __launch_bounds__(256) void ba_export(ba_dev D, double* out) {
 // (mo_X / mo_uv / mo_info) so every load is coalesced and index-free.
 
 
-// The LM bookkeeping of the motion-only path, run on identical inputs by one thread of every camera's workgroup: st is
+// Wave-wide sum (or maximum of non-negative values) in a fixed order, result in every lane: four row_shr steps inside each row
+// of 16 lanes, row_bcast:15 / row_bcast:31 across the rows (data-parallel-primitive moves: ~20 cycles per step; the same
+// reduction as an xor-butterfly of __shfl_xor is twelve ds_bpermute round trips, ~0.3 us on a lone wave), readlane 63.
+template <int CTRL, int ROW_MASK, bool MAX>
+__device__ __forceinline__ double mo_dpp_acc(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true);  // lanes without a source add 0.0
+  const int ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+  const double o = __hiloint2double(ohi, olo);
+  return MAX ? fmax(v, o) : v + o;
+}
+template <bool MAX>
+__device__ __forceinline__ double mo_wave_reduce(double v) {
+  v = mo_dpp_acc<0x111, 0xF, MAX>(v);  // row_shr:1
+  v = mo_dpp_acc<0x112, 0xF, MAX>(v);  // row_shr:2
+  v = mo_dpp_acc<0x114, 0xF, MAX>(v);  // row_shr:4
+  v = mo_dpp_acc<0x118, 0xF, MAX>(v);  // row_shr:8   -> lane 15 of every row holds the row's value
+  v = mo_dpp_acc<0x142, 0xA, MAX>(v);  // row_bcast:15 into rows 1 and 3
+  v = mo_dpp_acc<0x143, 0xC, MAX>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's value
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// The LM bookkeeping of the motion-only path, run on identical inputs by EVERY thread of every camera's workgroup (in registers:
+// no broadcast of the outcome, no barrier): st is
 // the state after the launch / step that produced the sums (chi2; max diagonal or gain denominator; cameras whose 6x6
 // system was not positive definite).  Camera 0's workgroup records the traces.
-__device__ inline void mo_decide(const ba_dev& D, mo_state& st, double chi, double second, double bad, int c) {
+__device__ inline void mo_decide(const ba_dev& D, mo_state& st, double chi, double second, double bad, bool writer) {
   if (st.stage == 1) {  // iteration 0 has just been linearised: computeLambdaInit + the first chi2
     st.lambda = 1e-5 * second;
     st.ni = 2.0;
@@ -2333,7 +2356,7 @@ __device__ inline void mo_decide(const ba_dev& D, mo_state& st, double chi, doub
     double rho = st.current_chi - temp;
     scale += 1e-3;
     rho /= scale;
-    if (c == 0 && D.trial_trace && st.trials <= D.trial_cap) {
+    if (writer && D.trial_trace && st.trials <= D.trial_cap) {
       double* row = D.trial_trace + 4 * (size_t)(st.trials - 1);
       row[0] = st.lambda;
       row[1] = temp;
@@ -2358,7 +2381,7 @@ __device__ inline void mo_decide(const ba_dev& D, mo_state& st, double chi, doub
     if (!stop && rho < 0 && st.qmax < 10) {
       st.need_lin = 0;  // retry with the same linearisation
     } else {
-      if (c == 0) {
+      if (writer) {
         if (D.chi_trace) D.chi_trace[st.it] = st.current_chi;
         if (D.lambda_trace) D.lambda_trace[st.it] = st.lambda;
       }
@@ -2423,7 +2446,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
   __shared__ double s_all[kMoRows][29];
   __shared__ double s_grp[kRedGroups][28];
   __shared__ double s_sum[28];
-  __shared__ double s_part[3][kMoThreads];  // chi, scale / maxd, ok of up to 256 cameras (strided beyond)
+  __shared__ double s_part[1][kMoThreads / 64];  // the waves' chi2 totals
   __shared__ mo_state s_st;
   __shared__ double s_x[6];
   __shared__ int s_ok;
@@ -2455,46 +2478,36 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
   const double pre_gh = tid < 27 ? gH[tid] : 0.0;
   const double pre_cam0 = tid < kCamStride ? D.cam[0][(size_t)pose * kCamStride + tid] : 0.0;
   const double pre_cam1 = tid < kCamStride ? D.cam[1][(size_t)pose * kCamStride + tid] : 0.0;
-  // ... and the previous launch's per-camera partials (thread t: camera t), which the decision below sums
+  // ... and the previous launch's per-camera partials (lane l of every wave: camera l), which the decision below sums
+  const int lane = tid & 63;
   double pre_part[4] = {0.0, 0.0, 0.0, 0.0};
-  if (tid < nfp) {
+  if (lane < nfp) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pre_part[k] = prev_part[4 * (size_t)tid + k];
+    for (int k = 0; k < 4; ++k) pre_part[k] = prev_part[4 * (size_t)lane + k];
   }
 
-  // ---- prologue: every workgroup derives the current LM state from the previous launch's state + partials
+  // ---- prologue: every THREAD derives the current LM state from the previous launch's state + partials: lane l of every
+  // wave sums cameras l, l + 64, ... in that order, the wave reduces in a fixed order (mo_wave_reduce), every lane runs the
+  // decision on the same sums.  (One thread summing all cameras and taking the decision for the others cost two barriers
+  // and, in the one-launch form where this block sits on the critical path of every step, 0.9 - 1.7 us.)
   if (tid == 0) s_st = g_state[(step + 1) & 1];
   __syncthreads();
-  const int done_on_entry = s_st.done;
-  if (s_st.stage != 0 && !s_st.done) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;  // fixed order: thread t sums cameras t, t+256, ... then thread 0 sums threads
-    for (int k = tid; k < nfp; k += kMoThreads) {
-      const bool pre = k == tid;  // the first pass was requested at the top of the launch
+  mo_state st = s_st;
+  const int done_on_entry = st.done;
+  if (st.stage != 0 && !st.done) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int k = lane; k < nfp; k += 64) {
+      const bool pre = k == lane;  // the first pass was requested at the top of the launch
       a0 += pre ? pre_part[0] : prev_part[4 * k];
-      if (s_st.stage == 1) a1 = fmax(a1, pre ? pre_part[3] : prev_part[4 * k + 3]);
+      if (st.stage == 1) a1 = fmax(a1, pre ? pre_part[3] : prev_part[4 * k + 3]);
       else a1 += pre ? pre_part[1] : prev_part[4 * k + 1];
       a2 += pre ? pre_part[2] : prev_part[4 * k + 2];  // number of cameras whose 6x6 system was not positive definite
     }
-    s_part[0][tid] = a0;
-    s_part[1][tid] = a1;
-    s_part[2][tid] = a2;
-    __syncthreads();
-    if (tid == 0) {
-      mo_state st = s_st;
-      const int n = min(nfp, kMoThreads);
-      double chi = 0.0, second = 0.0, bad = 0.0;
-      for (int k = 0; k < n; ++k) {
-        chi += s_part[0][k];
-        if (st.stage == 1) second = fmax(second, s_part[1][k]);
-        else second += s_part[1][k];
-        bad += s_part[2][k];
-      }
-      mo_decide(D, st, chi, second, bad, c);
-      s_st = st;
-    }
-    __syncthreads();
+    const double chi = mo_wave_reduce<false>(a0);
+    const double second = st.stage == 1 ? mo_wave_reduce<true>(a1) : mo_wave_reduce<false>(a1);
+    const double bad = mo_wave_reduce<false>(a2);
+    mo_decide(D, st, chi, second, bad, c == 0 && tid == 0);
   }
-  mo_state st = s_st;
   if (!done_on_entry) st.seq = step;  // ends as the index of the launch whose prologue found the solve finished
   if (st.done) {
     if (c == 0 && tid == 0) g_state[step & 1] = st;
@@ -2653,9 +2666,8 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_step(ba_dev D, int step)
     }
     chi += E.rho0;
   }
-  // workgroup sum of chi: xor-butterfly inside each wave, then the wave totals in wave order
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) chi += __shfl_xor(chi, d);
+  // workgroup sum of chi: fixed-order reduction inside each wave (mo_wave_reduce), then the wave totals in wave order
+  chi = mo_wave_reduce<false>(chi);
   if ((tid & 63) == 0) s_part[0][tid >> 6] = chi;
   __syncthreads();
   if (tid == 0) {
@@ -2696,7 +2708,7 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
   __shared__ double s_all[kMoRows][29];
   __shared__ double s_grp[kRedGroups][28];
   __shared__ double s_sum[28];
-  __shared__ double s_part[3][kMoThreads];
+  __shared__ double s_part[1][kMoThreads / 64];  // the waves' chi2 totals
   __shared__ mo_state s_st;
   __shared__ double s_x[6];
   __shared__ double s_cam[kCamStride], s_trial[kCamStride];
@@ -2794,34 +2806,21 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
       auto part_at = [&](int cam_k, int which) {
         return __longlong_as_double((long long)(((unsigned long long)s_box[cam_k][2 * which] << 32) | (unsigned long long)s_box[cam_k][2 * which + 1]));
       };
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0;  // fixed order: thread t sums cameras t, t+512, ... then thread 0 sums threads
-      for (int kk = tid; kk < nfp; kk += kMoThreads) {
-        a0 += part_at(kk, 0);
-        if (st.stage == 1) a1 = fmax(a1, part_at(kk, 3));
-        else a1 += part_at(kk, 1);
-        a2 += part_at(kk, 2);
+      // the decision, by every thread on the same sums (lane l of every wave: camera l; at most 64 cameras in this form): the
+      // same order of operations as ba_motion_step's prologue
+      const int lane = tid & 63;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      if (lane < nfp) {
+        a0 = part_at(lane, 0);
+        a1 = st.stage == 1 ? fmax(0.0, part_at(lane, 3)) : part_at(lane, 1);
+        a2 = part_at(lane, 2);
       }
-      s_part[0][tid] = a0;
-      s_part[1][tid] = a1;
-      s_part[2][tid] = a2;
-      __syncthreads();
+      const double chi = mo_wave_reduce<false>(a0);
+      const double second = st.stage == 1 ? mo_wave_reduce<true>(a1) : mo_wave_reduce<false>(a1);
+      const double bad = mo_wave_reduce<false>(a2);
       const int cur_before = st.cur;
-      if (tid == 0) {
-        mo_state nst = st;
-        const int n = min(nfp, kMoThreads);
-        double chi = 0.0, second = 0.0, bad = 0.0;
-        for (int k = 0; k < n; ++k) {
-          chi += s_part[0][k];
-          if (nst.stage == 1) second = fmax(second, s_part[1][k]);
-          else second += s_part[1][k];
-          bad += s_part[2][k];
-        }
-        mo_decide(D, nst, chi, second, bad, c);
-        nst.seq = step;
-        s_st = nst;
-      }
-      __syncthreads();
-      st = s_st;
+      mo_decide(D, st, chi, second, bad, c == 0 && tid == 0);
+      st.seq = step;
       if (st.cur != cur_before) {  // accepted: the trial record is the estimate now
         if (tid < kCamStride) s_cam[tid] = s_trial[tid];
         __syncthreads();
@@ -2997,9 +2996,8 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
         chi += E.rho0;
       }
     }
-    // workgroup sum of chi: xor-butterfly inside each wave, then the wave totals in wave order
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) chi += __shfl_xor(chi, d);
+    // workgroup sum of chi: fixed-order reduction inside each wave (mo_wave_reduce), then the wave totals in wave order
+    chi = mo_wave_reduce<false>(chi);
     if ((tid & 63) == 0) s_part[0][tid >> 6] = chi;
     __syncthreads();
     if (tid == 0) {

@@ -31,6 +31,8 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+
 #include <vector>
 
 namespace {
@@ -482,6 +484,10 @@ void plan_chunks(int target_blocks, int nq, int nt, int* nchunks) {
       }
     }
   }
+  // at least 32 rows per chunk (8 per wave): below that a workgroup is all prologue and hand-off -- the 600 x 3000 match of a
+  // tracked frame takes 94 chunks (10 us); 334 chunks of 9 rows, which the cost model alone would pick, took 27 us
+  const long most = std::max(1L, (long)nt / 32);
+  if (nch > most) nch = most;
   const long need = ((long)nt + kMaxChunk - 1) / kMaxChunk;  // a chunk's rows are indexed with kIdxBits bits
   if (nch < need) nch = need;
   if (nch > 65535) nch = 65535;  // gridDim.y
