@@ -2766,6 +2766,67 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
       }
     }
   };
+  // the normal equations of this camera at the record `camp`: upper triangle (21) + b (6) + chi2 into out[28]
+  auto linearise = [&](const double* camp, double* out) {
+    double acc[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < kMoObsRegs; ++j) {
+      if (o0 + tid + j * kMoThreads >= o1) continue;
+      edge_t E;
+      eval_edge<true>(D, camp, oX[j], oUV[j], D.has_info ? oW[j] : nullptr, E);
+      const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+      const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
+      const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
+      double WJ[2][6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        WJ[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
+        WJ[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
+      }
+      int n = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+#pragma unroll
+        for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJ[0][l] + E.Jj[1][k] * WJ[1][l];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
+      acc[27] += E.rho0;
+    }
+    if constexpr (OVF) {
+      for (int i = o0 + tid + kMoObsRegs * kMoThreads; i < o1; i += kMoThreads) {
+        const double X[3] = {D.mo_X[3 * (size_t)i], D.mo_X[3 * (size_t)i + 1], D.mo_X[3 * (size_t)i + 2]};
+        edge_t E;
+        eval_edge<true>(D, camp, X, D.mo_uv + 2 * (size_t)i, D.has_info ? D.mo_info + 3 * (size_t)i : nullptr, E);
+        const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
+        const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
+        const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
+        double WJ[2][6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          WJ[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
+          WJ[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
+        }
+        int n = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+          for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJ[0][l] + E.Jj[1][k] * WJ[1][l];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
+        acc[27] += E.rho0;
+      }
+    }
+    block_reduce28(acc, s_all, s_grp, out, tid);
+  };
+  // Speculation (round 4): while the other cameras' partials of a trial are on their way (the rendezvous at the top of the
+  // next step: ~1.2 us of waiting), this workgroup already linearises at its TRIAL record.  If the trial is accepted that IS the
+  // next linearisation (same record, same code: same bits) and the step goes straight to the 6x6 solve; if it is rejected the
+  // sums are dropped.  Done only while trials are being accepted (the first trial, and any trial after an accepted one): the
+  // rejected trials at the end of a solve -- LM retries up to ten times before it gives up -- cost nothing extra.
+  __shared__ double s_spec[28];
+  bool speculate = true, have_spec = false, used_spec = false;
   int step = 0;
   for (;; ++step) {
     VS_MO_STAMP(0);
@@ -2821,67 +2882,23 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
       const int cur_before = st.cur;
       mo_decide(D, st, chi, second, bad, c == 0 && tid == 0);
       st.seq = step;
-      if (st.cur != cur_before) {  // accepted: the trial record is the estimate now
+      const bool accepted = st.cur != cur_before;
+      used_spec = accepted && have_spec && st.need_lin;
+      if (accepted) {  // the trial record is the estimate now -- and, if it was linearised ahead, its sums the normal equations
         if (tid < kCamStride) s_cam[tid] = s_trial[tid];
+        if (used_spec && tid < 28) s_sum[tid] = s_spec[tid];
         __syncthreads();
       }
+      speculate = accepted || st.stage == 1;  // (stage 1: the decision behind the first linearisation -- the first trial follows)
+      have_spec = false;
       VS_MO_STAMP(2);
     }
+    if (step == 0) used_spec = false;
     if (st.done || step > max_steps) break;
     const double* cam = s_cam;
     const bool lin_only = st.need_lin && st.it == 0 && st.stage == 0;
-    if (st.need_lin) {
-      double acc[28];
-#pragma unroll
-      for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-#pragma unroll
-      for (int j = 0; j < kMoObsRegs; ++j) {
-        if (o0 + tid + j * kMoThreads >= o1) continue;
-        edge_t E;
-        eval_edge<true>(D, cam, oX[j], oUV[j], D.has_info ? oW[j] : nullptr, E);
-        const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
-        const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
-        const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
-        double WJ[2][6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          WJ[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
-          WJ[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
-        }
-        int n = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-          for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJ[0][l] + E.Jj[1][k] * WJ[1][l];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
-        acc[27] += E.rho0;
-      }
-      if constexpr (OVF) {
-        for (int i = o0 + tid + kMoObsRegs * kMoThreads; i < o1; i += kMoThreads) {
-          const double X[3] = {D.mo_X[3 * (size_t)i], D.mo_X[3 * (size_t)i + 1], D.mo_X[3 * (size_t)i + 2]};
-          edge_t E;
-          eval_edge<true>(D, cam, X, D.mo_uv + 2 * (size_t)i, D.has_info ? D.mo_info + 3 * (size_t)i : nullptr, E);
-          const double We0 = E.W[0] * E.e[0] + E.W[1] * E.e[1], We1 = E.W[1] * E.e[0] + E.W[2] * E.e[1];
-          const double r0 = -We0 * E.rho1, r1 = -We1 * E.rho1;
-          const double w0 = E.rho1 * E.W[0], w1 = E.rho1 * E.W[1], w2 = E.rho1 * E.W[2];
-          double WJ[2][6];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            WJ[0][k] = w0 * E.Jj[0][k] + w1 * E.Jj[1][k];
-            WJ[1][k] = w1 * E.Jj[0][k] + w2 * E.Jj[1][k];
-          }
-          int n = 0;
-#pragma unroll
-          for (int k = 0; k < 6; ++k)
-#pragma unroll
-            for (int l = k; l < 6; ++l) acc[n++] += E.Jj[0][k] * WJ[0][l] + E.Jj[1][k] * WJ[1][l];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) acc[21 + k] += E.Jj[0][k] * r0 + E.Jj[1][k] * r1;
-          acc[27] += E.rho0;
-        }
-      }
-      block_reduce28(acc, s_all, s_grp, s_sum, tid);  // s_sum: upper triangle (21) + b (6) + chi2, kept across retries
+    if (st.need_lin && !used_spec) {
+      linearise(s_cam, s_sum);  // s_sum is kept across retries
       VS_MO_STAMP(3);
       if (lin_only) {
         if (tid == 0) {
@@ -3012,6 +3029,10 @@ __global__ __launch_bounds__(kMoThreads) void ba_motion_persistent(ba_dev D, int
     post_partials(step);
     VS_MO_STAMP(6);
     st.stage = 2;
+    if (speculate && st.it + 1 < D.max_it && step < max_steps) {  // (an accepted trial that ends the solve needs no linearisation)
+      linearise(s_trial, s_spec);
+      have_spec = true;
+    }
   }
 #undef VS_MO_STAMP
   if (c == 0 && tid == 0) {

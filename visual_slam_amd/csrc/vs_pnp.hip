@@ -1,6 +1,8 @@
 // vs_pnp.hip -- PnP-RANSAC (gfx950).
 #include "vs_ba_internal.h"
 
+#include <type_traits>
+
 using namespace vsba;
 
 // The LM of the PnP kernels is a long dependent FP64 chain executed by one wave: fused multiply-adds halve it.  The
@@ -182,11 +184,35 @@ __device__ inline void pnp_reduce(double* v, double* s_red) {
     for (int k = 0; k < NV; ++k) v[k] = tot[k];
     return;
   }
+  // xor-butterfly over aligned groups of 2^STEPS lanes with data-parallel-primitive moves instead of ds_bpermute round trips
+  // (__shfl_xor): partner lane^1 and lane^2 by quad permutes; for lane^4 the half-row mirror (lane 7 - i of the group of 8, which
+  // holds the same bits as lane i^4 once the quads are uniform), for lane^8 the row mirror likewise; across the rows of 16 the
+  // four row values are read out (readlane) and added as the butterfly would -- (r0 + r1) + (r2 + r3), addition commutes --
+  // so every lane ends with exactly the bits the __shfl_xor form gave it.
+  auto dpp_add = [](double x, auto ctrl) {
+    constexpr int kCtrl = decltype(ctrl)::value;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), kCtrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), kCtrl, 0xF, 0xF, false);
+    return x + __hiloint2double(hi, lo);
+  };
 #pragma unroll
-  for (int d = 1; d < (1 << STEPS); d <<= 1) {
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] += __shfl_xor(v[k], d);
+  for (int k = 0; k < NV; ++k) {
+    double x = v[k];
+    if (STEPS >= 1) x = dpp_add(x, std::integral_constant<int, 0xB1>());   // quad_perm [1,0,3,2]
+    if (STEPS >= 2) x = dpp_add(x, std::integral_constant<int, 0x4E>());   // quad_perm [2,3,0,1]
+    if (STEPS >= 3) x = dpp_add(x, std::integral_constant<int, 0x141>());  // row_half_mirror
+    if (STEPS >= 4) x = dpp_add(x, std::integral_constant<int, 0x140>());  // row_mirror
+    if (STEPS == 6) {
+      const int lo = __double2loint(x), hi = __double2hiint(x);
+      const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+      const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+      const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+      const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+      x = (r0 + r1) + (r2 + r3);
+    }
+    v[k] = x;
   }
+  static_assert(STEPS == 3 || STEPS == 6, "groups of 8 lanes (hypotheses) or whole waves (finishing workgroup)");
   if (NWAVES > 1) {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads();  // previous readers of s_red are done
