@@ -691,6 +691,25 @@ def main():
         e1.record(stream)
         torch.cuda.synchronize()
         busy_ms = e0.elapsed_time(e1) / args.steps
+        # the shader clock DURING the kernel: in-kernel stamps of one launch (vs_match_stamps: every workgroup's thread 0 reads the
+        # shader-clock counter and the 100 MHz wall clock at its start and at the end of its scan)
+        clock_ghz = None
+        try:
+            lib.vs_match_stamps(ctx.handle, 1)
+            matcher.knn2_local_shard(q, t)
+            lib.vs_match_stamps(ctx.handle, 0)
+            torch.cuda.synchronize()
+            st = np.zeros((8192, 8))
+            rows = lib.vs_match_stamps_read(ctx.handle, st.ctypes.data, len(st))
+            if rows > 0:
+                st = st[:rows]
+                cyc = -np.where(st[:, 4] > 0, st[:, 5], st[:, 4])
+                dt_us = np.maximum(st[:, 2], 0) - np.maximum(st[:, 0], 0)
+                ok = (dt_us > 5) & (cyc > 0)
+                if ok.any():
+                    clock_ghz = float(np.median(cyc[ok] / dt_us[ok])) / 1e3
+        except Exception:
+            clock_ghz = None
         kernel_ms_isolated = float(km.value)
         kernel_ms = region_ms if not use_dist else kernel_ms_isolated
         pairs = float(nq) * nt
@@ -699,7 +718,7 @@ def main():
         alg_bytes = BYTES_PER_MATCH * pairs
         traffic = None
         pmc_src = None
-        for name in ("r03_pmc_match.json", "r02_pmc_match.json", "r01_pmc_match.json"):
+        for name in ("r04_pmc_match.json", "r03_pmc_match.json", "r02_pmc_match.json", "r01_pmc_match.json"):
             try:  # HBM bytes per launch from the committed PMC passes (profiles/), only for the workload they were taken on
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if (nq, nt) == (10000, 10000):
@@ -734,6 +753,12 @@ def main():
                     "frac_two_in_flight": frac_of(ms_per_step, VALU_PEAK_UNIFORM_4CYCLE) if world == 1 else None,
                     "note": "round 2's yard-stick: every op priced at one wave64 op per 4 cycles per SIMD (understates the "
                             "roof by 1.28x for this mix: the xor operands are staged into VGPRs precisely to issue faster)"},
+                "shader_clock_ghz_measured": clock_ghz,
+                "against_measured_clock": None if not clock_ghz else {
+                    "peak": VALU_PEAK_LANE_OPS * clock_ghz / 2.4 / 1e12, "frac": achieved / (VALU_PEAK_LANE_OPS * clock_ghz / 2.4),
+                    "note": "the same mix-specific ceiling at the shader clock measured inside this kernel (in-kernel cycle counter "
+                            "against the 100 MHz wall clock, median over the workgroups of one stamped launch) instead of the nominal "
+                            "2.4 GHz: under this integer load the clock settles near 2.1 GHz"},
                 "against_measured_mix_rate": {
                     "peak": VALU_PROBE_MIX_LANE_OPS / 1e12, "frac": achieved / VALU_PROBE_MIX_LANE_OPS,
                     "note": "what a dependent xor -> bcnt stream was measured to issue at on this chip with 5 waves per SIMD "
@@ -743,7 +768,7 @@ def main():
                     "frac_of_8TBps": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "compulsory_bytes": 32 * (nq + nt) + 16 * nq, "source": pmc_src,
                     "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 "
-                            "correction (upper bound); the excess over compulsory is the per-chunk partial rows"},
+                            "correction (upper bound); the excess over compulsory is the per-chunk partial words"},
                 "hbm_model_secondary": {
                     "bound": "hbm", "model": "SURVEY.md 8d streamed-operand: 32 B per distance evaluation",
                     "algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": alg_bytes / (kernel_ms * 1e-3) / 1e9,

@@ -1,6 +1,6 @@
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/pmc
+O=$R/gpurun_out/pmc_r04
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-frames --no-cpu-baseline --no-cfg5 --single-stream --steps 20 --warmup 5"

@@ -43,7 +43,7 @@ out = {
                 "this kernel mixes 16-B/lane query loads with coalesced 32-B/lane train-row loads that are staged through "
                 "LDS (64 rows per wave at a time), an uncalibrated pattern, so both the raw value and the 2x upper bound are "
                 "given.  WRITE_SIZE = the per-chunk partial rows "
-                "(32 chunks x 40 tiles x 256 x 8 B, write-through) + the 160 KB of results.",
+                "(31 publishing chunks x 40 tiles x 256 x 8 B, write-through) + the 160 KB of results; the folding workgroups poll those words (their loads bypass the caches).",
     },
 }
 if "SQ_INSTS_VALU" in p:
