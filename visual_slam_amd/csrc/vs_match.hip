@@ -538,6 +538,18 @@ static int match_scratch_for(vs_ctx* ctx, hipStream_t s, vs_match_scratch** out)
   return VS_OK;
 }
 
+// after a synchronisation of stream `s`: did a folding workgroup of a launch on it give up its bounded wait?  (the device entry
+// points cannot know -- they only enqueue -- and find out on the stream's next launch; the host entry points ask right away)
+static int match_check_flag(vs_ctx* ctx, hipStream_t s, const char* who) {
+  for (vs_match_scratch& m : ctx->match_scratch)
+    if (m.used && m.stream == s && m.flag.p && *(volatile unsigned*)m.flag.p != 0u) {
+      *(volatile unsigned*)m.flag.p = 0u;
+      m.qtiles = m.nchunks = 0;  // the slots are cleared before the next launch
+      return vs_fail(ctx, VS_EHIP, "%s: a train chunk of the match launch did not report within the bounded wait", who);
+    }
+  return VS_OK;
+}
+
 static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_idx, void* d_dist,
                          bool packed, void* stream, const int* nt_dev = nullptr) {
   VS_TRY(check_args(ctx, d_q, nq, d_t, nt, "vs_hamming_knn2_dev"));
@@ -796,7 +808,7 @@ VS_API int vs_hamming_knn2(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t*
   VS_HIP(ctx, hipMemcpyAsync(idx, ctx->d_mq.p, sizeof(int2) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
   VS_HIP(ctx, hipMemcpyAsync(dist, ctx->d_mt.p, sizeof(int2) * (size_t)nq, hipMemcpyDeviceToHost, ctx->stream));
   VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return VS_OK;
+  return match_check_flag(ctx, ctx->stream, "vs_hamming_knn2");
 }
 
 VS_API int vs_match_ratio(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, double ratio,
@@ -819,6 +831,7 @@ VS_API int vs_match_ratio(vs_ctx* ctx, const uint8_t* q, int nq, const uint8_t* 
   VS_TRY(vs_match_ratio_dev(ctx, dq, nq, dt, nt, ratio, blk + 16, blk + 16 + row, blk + 16 + 2 * row, blk, ctx->stream));
   VS_HIP(ctx, hipMemcpyAsync(ctx->h_pin.p, blk, bytes, hipMemcpyDeviceToHost, ctx->stream));
   VS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  VS_TRY(match_check_flag(ctx, ctx->stream, "vs_match_ratio"));
   const uint8_t* hp = (const uint8_t*)ctx->h_pin.p;
   const int n = *(const int32_t*)hp;
   if (n < 0 || n > nq) return vs_fail(ctx, VS_EHIP, "%s: device returned an impossible match count", "vs_match_ratio");
