@@ -23,10 +23,11 @@
 //     the final (idx, dist) rows: ONE launch, no merge kernel, no ticket.
 //   * the ratio test + ordered compaction is one workgroup using wave ballots and popcounts for the prefix.
 // What the body can and cannot do (round 4, tools/valu_probe4.hip, tools/match_stamps.py): under this load the shader clock is
-// ~2.12 GHz, not 2.4; v_xor (VGPR, VGPR) issues in ~2.8 cycles, v_bcnt / v_lshl_or / v_min3 / v_med3 in 4; operand banks do not
-// matter; the 148 instructions of a step issue at 1.72 ns apiece with four or five waves per SIMD -- the kernel's 29 468
-// instructions per SIMD are 50.7 us of issue, the launch takes 53.5 - 57 us.  Waves of a SIMD are served oldest first: the five
-// workgroups of a compute unit finish one after the other (14, 25, 36, 47, 57 us), not together.
+// 2.1 - 2.4 GHz depending on the box (bench.py measures it per run); on a 2.12 GHz box v_xor (VGPR, VGPR) issues in ~2.8 cycles,
+// v_bcnt / v_lshl_or / v_min3 / v_med3 in ~4.1; operand banks do not matter; the 148 instructions of a step issue at 1.72 ns
+// apiece with four or five waves per SIMD -- the kernel's 29 440 instructions per SIMD are 50.7 us of issue there, the launch
+// takes 57 - 58 us (53 us on a 2.38 GHz box).  Waves of a SIMD are served oldest first: the workgroups of a compute unit finish
+// one after the other (14, 25, 36, 47, 57 us), not together.
 #include "vs_internal.h"
 
 #include <dlfcn.h>
