@@ -129,3 +129,30 @@ def test_saturated_and_extreme_images(vs, oracle):
             _eq_detect(vs.fast9_detect(img, 20, 3, cap), oracle.fast9_detect(img, 20, 3, cap))
         bgr = np.ascontiguousarray(np.repeat(img[:, :, None], 3, 2))
         _eq_detect(vs.detect_describe_bgr(bgr, 20, 3000), oracle.detect_describe_bgr(bgr, 20, 3000))
+
+
+def test_frames_alternating_through_one_pinned_buffer(vs, oracle):
+    """Different frames alternate through ONE pinned buffer (same addresses, new contents every call, DMA-ed from where they lie)
+    for several hundred calls: no cache and no resident copy may ever serve rows of an earlier frame.  Plus assorted shapes, a
+    pageable frame (staged) -- every result compared with the oracle's.  (Written for round 4's chunked upload, which was
+    measured and dropped -- profiles/tried_and_dropped.md -- and kept for the plain path.)"""
+    from visual_slam_amd.workloads import synthetic_frame
+    frames = [icl_frame(i) for i in (0, 5, 10, 150)] + [synthetic_frame(640, 480, s) for s in (2, 7)]
+    want = [oracle.detect_describe_bgr(f, 20, 3000) for f in frames]
+    buf = vs.pin(np.zeros_like(frames[0]))
+    for it in range(360):
+        k = (it * 5 + it // 7) % len(frames)
+        buf[...] = frames[k]
+        xy, sc, desc = vs.detect_describe_bgr(buf, 20, 3000)
+        oxy, osc, odesc = want[k]
+        assert np.array_equal(xy, oxy) and np.array_equal(sc, osc) and np.array_equal(desc, odesc), (it, k)
+    for w, h in ((640, 480), (321, 243), (100, 64), (1280, 720)):   # pinned, assorted shapes (some take the plain upload)
+        f = vs.pin(synthetic_frame(w, h, w + h))
+        for _ in range(3):
+            xy, sc, desc = vs.detect_describe_bgr(f, 20, 3000)
+            oxy, osc, odesc = oracle.detect_describe_bgr(np.asarray(f), 20, 3000)
+            assert np.array_equal(xy, oxy) and np.array_equal(sc, osc) and np.array_equal(desc, odesc), (w, h)
+    f = synthetic_frame(640, 480, 11)                                 # pageable: staged, plain upload
+    xy, sc, desc = vs.detect_describe_bgr(f, 20, 3000)
+    oxy, osc, odesc = oracle.detect_describe_bgr(f, 20, 3000)
+    assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
