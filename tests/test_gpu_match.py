@@ -128,11 +128,11 @@ def test_random_shapes_property(vs, oracle):
 
 
 def test_fused_fold_under_back_to_back_launches(vs, oracle):
-    """The match is ONE launch: every (tile, chunk) workgroup publishes an 8-byte partial per query and the workgroup that
-    arrives last at a tile folds them (agent-scope ticket + release/acquire).  Stale partial rows from the previous
-    launch would go unnoticed with repeated identical inputs, so two different workloads alternate through the same
-    scratch buffers, back to back without host synchronisation in between, and every result is checked -- in both
-    train-row staging modes and over several launch geometries (1 chunk = no fold, few, many)."""
+    """The match is ONE launch: every (tile, chunk) workgroup publishes an 8-byte partial per query and the workgroup of the
+    tile's last chunk folds them (self-validating words: launch epoch | second key | best key; round 3: a ticket).  Stale
+    partial words from the previous launch would go unnoticed with repeated identical inputs, so different workloads alternate
+    through the same scratch buffers, back to back without host synchronisation in between, and every result is checked -- in
+    both train-row staging modes and over several launch geometries (1 chunk = no fold, few, many)."""
     import torch
     stream = torch.cuda.ExternalStream(vs.stream)
     sets = []
@@ -172,3 +172,31 @@ def test_both_train_staging_modes_bit_exact(vs, oracle, tstage):
             assert np.array_equal(idx, oidx) and np.array_equal(dist, odist), (tstage, nq, nt)
     finally:
         vs.tune_match(tstage=1)
+
+
+def test_partial_word_epochs_wrap_and_geometries_alternate(vs, oracle):
+    """Round 4: the fold trusts a partial word iff it carries the launch's epoch (1 .. 63, cycling).  Every launch of one
+    geometry rewrites every slot; a change of geometry (other tile / chunk counts on the same stream's scratch) clears the slots
+    first.  200 launches back to back on one stream -- runs of one geometry long enough to wrap the epoch more than once,
+    geometries alternating in between, a different workload almost every launch -- and every result checked."""
+    import torch
+    stream = torch.cuda.ExternalStream(vs.stream)
+    shapes = [(1500, 2600), (1500, 2600), (700, 4100), (2600, 900), (1500, 2601)]
+    sets = []
+    for seed, (nq, nt) in enumerate(shapes):
+        q, t = match_workload(nq, nt, n_dup=8, seed=170 + seed)
+        sets.append((q, t) + oracle.hamming_knn2(q, t, threads=0))
+    # 140 launches of geometry A / A' (same tile and chunk counts, different data), then switches every few launches
+    order = [k % 2 for k in range(140)] + [2, 2, 0, 3, 3, 3, 1, 4, 4, 2] * 6
+    with torch.cuda.stream(stream):
+        dev = [(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()) for q, t, _, _ in sets]
+        outs = [(torch.empty((2600, 2), dtype=torch.int32, device="cuda"), torch.empty((2600, 2), dtype=torch.int32, device="cuda"))
+                for _ in order]
+        for k, (oi, od) in zip(order, outs):
+            dq, dt = dev[k]
+            vs.hamming_knn2_dev(dq.data_ptr(), dq.shape[0], dt.data_ptr(), dt.shape[0], oi.data_ptr(), od.data_ptr())
+        stream.synchronize()
+    for n_launch, (k, (oi, od)) in enumerate(zip(order, outs)):
+        _, _, ridx, rdist = sets[k]
+        n = ridx.shape[0]
+        assert np.array_equal(oi.cpu().numpy()[:n], ridx) and np.array_equal(od.cpu().numpy()[:n], rdist), (n_launch, k)
