@@ -25,7 +25,10 @@ namespace {
 #endif
 constexpr int kBand = VS_DET_BAND;  // image rows per workgroup (2: 240 workgroups at 640x480; 3 and 4 measured slower, see profiles/tried_and_dropped.md)
 constexpr int kHalo = 4;         // 3 (circle radius) + 1 (NMS neighbour)
-constexpr int kDetThreads = 1024; // 16 waves: 4 per SIMD hide the LDS latency of the box / score phases
+#ifndef VS_DET_THREADS
+#define VS_DET_THREADS 1024
+#endif
+constexpr int kDetThreads = VS_DET_THREADS; // 16 waves: 4 per SIMD hide the LDS latency of the box / score phases (512 and 256 measured in round 4, see profiles/tried_and_dropped.md)
 constexpr int kStageUnroll = 2; // staging groups per thread with their loads in flight together
 constexpr int kSelThreads = 256;
 constexpr int kMaxDim = 4096;    // x, y packed in 12 bits each
