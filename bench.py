@@ -87,12 +87,13 @@ def launch_ranks(n, argv, worker=None, timeout=None):
     assert "torch" not in sys.modules and "visual_slam_amd._capi" not in sys.modules, "the launcher must stay off the GPU"
     cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
     port = os.environ.get("MASTER_PORT") or str(_free_port())
+    import tempfile
+    out0 = tempfile.TemporaryFile(mode="w+")  # rank 0's standard output (a pipe nobody drains could fill up and block the rank)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0", VS_BENCH_LAUNCHED="1")
-        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
-                                      text=True))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
     deadline = None if timeout is None else time.time() + timeout
     rcs = [None] * n
     failed = None
@@ -117,7 +118,9 @@ def launch_ranks(n, argv, worker=None, timeout=None):
                 failed = -1
             break
         time.sleep(0.05)
-    out = procs[0].stdout.read() if procs[0].stdout else ""
+    out0.seek(0)
+    out = out0.read()
+    out0.close()
     if failed is not None:
         sys.stderr.write("bench.py launcher: %s; ranks' exit codes %s\n"
                          % ("timed out" if failed < 0 else "rank %d failed" % failed, rcs))
