@@ -1,7 +1,7 @@
 # dev tool: SQ counters of the match kernel in both train-staging modes (separate rocprofv3 --pmc passes, counters only)
 set -e
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/pmc_sq_r2
+O=$R/gpurun_out/pmc_sq_r4
 rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for TS in 0 1; do
@@ -11,7 +11,7 @@ for TS in 0 1; do
 done
 cd $R && python3 - <<'PY'
 import csv, glob, os, collections
-root = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "pmc_sq_r2")
+root = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "pmc_sq_r4")
 for d in sorted(glob.glob(os.path.join(root, "ts*"))):
     if not os.path.isdir(d): continue
     acc = collections.defaultdict(list)
