@@ -751,10 +751,21 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(const pnp_args P
   // and has sampled by the time the previous solve ends.
   const bool fin = (int)blockIdx.x == nhw;
   if (P.front_tag_dev || (fin && P.back_tag_dev)) {
-    __shared__ int s_front;
-    if (threadIdx.x == 0) s_front = pnp_wait_tag(P.front_tag_dev, P.front_tag) && (!fin || pnp_wait_tag(P.back_tag_dev, P.back_tag));
+    __shared__ int s_front, s_back;
+    if (threadIdx.x == 0) {
+      s_front = pnp_wait_tag(P.front_tag_dev, P.front_tag);
+      s_back = !fin || pnp_wait_tag(P.back_tag_dev, P.back_tag);
+    }
     __syncthreads();
-    if (!s_front) {
+    // the previous frame's results to the host, before anything here overwrites them -- they depend on the previous solve only,
+    // so they go out even when THIS frame's front half never reported (the host then redoes this frame, not the previous one)
+    if (fin && P.pub_src && s_back) {
+      for (int i = threadIdx.x; i < P.pub_n16; i += kPnpFinish) P.pub_dst[i] = P.pub_src[i];
+      __threadfence_system();
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(P.pub_tag_word, P.pub_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (!s_front || !s_back) {
       if (fin && threadIdx.x == 0) {
         P.result[16] = -1.0;
         if (P.host_result) P.host_result[16] = -1.0;
@@ -762,8 +773,7 @@ __global__ __launch_bounds__(kPnpFinish) void pnp_ransac_kernel(const pnp_args P
       if (fin) pnp_announce(P);
       return;
     }
-  }
-  if (fin && P.pub_src) {  // the previous frame's results to the host, before anything here overwrites them
+  } else if (fin && P.pub_src) {
     for (int i = threadIdx.x; i < P.pub_n16; i += kPnpFinish) P.pub_dst[i] = P.pub_src[i];
     __threadfence_system();
     __syncthreads();
