@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--no-frames", action="store_true", help="skip the cfg2 / local BA / frames legs")
     ap.add_argument("--no-cfg5", action="store_true")
     ap.add_argument("--in-flight", type=int, default=2, help="steps in flight on as many streams (1..4)")
+    ap.add_argument("--buffers", type=int, default=0, help="rotating result buffer sets of a step (0: 2, or 4 with a collective)")
     ap.add_argument("--single-stream", action="store_true",
                     help="one step at a time on one stream (default: two steps in flight on two streams); the rocprofv3 "
                          "kernel summaries under profiles/ are taken this way so that kernel durations do not overlap")
@@ -591,7 +592,11 @@ def main():
         all-gather of step k is started asynchronously and collected after the kernels of step k+1 are enqueued (two
         rotating buffer sets), so the exchange overlaps the next step's compute; drain() collects the last one inside
         the timed region."""
-        plan = matcher.plan(qq, tt, n_total, single_stream=args.single_stream or single, in_flight=args.in_flight)
+        # the bench's inputs are resident long before the first step and results are only read after collect(): the steps'
+        # kernels need no ordering behind the library's stream (static_inputs); with a collective, four buffer sets on the two
+        # compute streams keep the in-place all-gather of a set off the chain of launches (sharded.py, _Plan)
+        plan = matcher.plan(qq, tt, n_total, single_stream=args.single_stream or single, in_flight=args.in_flight,
+                            buffers=args.buffers or (4 if use_dist else None), static_inputs=True)
         plans.append(plan)
 
         def step():

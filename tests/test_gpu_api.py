@@ -244,6 +244,58 @@ def test_plan_keeps_steps_in_flight_without_racing_its_own_buffers(vs, oracle, i
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("collective", [True, False])
+def test_static_input_plan_runs_the_exchange_on_the_librarys_stream(vs, oracle, collective):
+    """Round 4: plan(static_inputs=True, buffers=4) is what bench.py drives with a collective -- the step's kernel is not
+    ordered behind the library's stream, more buffer sets rotate than streams run, and the in-place all-gather runs on the
+    library's own stream (a stream made later may share a hardware queue with a compute stream).  The inputs never change,
+    so every slot's buffer is poisoned after its results were read: a step that returned before its kernel and exchange had
+    rewritten the slot would show the poison."""
+    import torch
+    import visual_slam_amd.context as vctx
+    from visual_slam_amd.sharded import ShardedMatcher
+    vctx._DEFAULT = vs
+    dist = _one_rank_group(vs) if collective else None
+    try:
+        m = ShardedMatcher(force_collective=collective)
+        stream = m.torch_stream()
+        nq, nt, steps = 5000, 4000, 13
+        q, t = match_workload(nq, nt, n_dup=8, seed=411)
+        oi, od = oracle.hamming_knn2(q, t, threads=0)
+        with torch.cuda.stream(stream):
+            dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+            stream.synchronize()
+            plan = m.plan(dq, dt, nq, in_flight=2, buffers=4, static_inputs=True)
+            assert plan.nslots == 4 and len({s.cuda_stream for s in plan.streams}) == 2
+            if collective:
+                assert plan.direct and plan.args[0][11] == stream.cuda_stream
+            with pytest.raises(ValueError):
+                plan.submit(q=dq)
+            pending, results = [], []
+
+            def consume(slot):
+                i, d = plan.collect(slot)
+                results.append((i.clone(), d.clone()))
+                for buf in plan.bufs[slot]:
+                    if buf is not None:
+                        buf.fill_(-1)
+                stream.synchronize()   # the contract of static_inputs: done with a slot's results before its next submit
+
+            for k in range(steps):
+                pending.append(plan.submit())
+                while len(pending) > 3:
+                    consume(pending.pop(0))
+            while pending:
+                consume(pending.pop(0))
+        torch.cuda.synchronize()
+        assert len(results) == steps
+        for k, (i, d) in enumerate(results):
+            assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(d.cpu().numpy(), od), k
+        m.close()
+    finally:
+        if dist is not None:
+            dist.destroy_process_group()
+
 
 def test_descriptor_cache_never_serves_stale_data(vs, oracle):
     """The host matcher keeps device copies keyed by (address, n) and verified byte-for-byte against a host shadow of the

@@ -312,18 +312,22 @@ class ShardedMatcher:
             self._order_caller_after()
         return out[:n_query, 0:2], out[:n_query, 2:4]
 
-    def plan(self, q_shard, train, n_query, single_stream=False, in_flight=2):
+    def plan(self, q_shard, train, n_query, single_stream=False, in_flight=2, buffers=None, static_inputs=False):
         """A pre-bound step for a fixed shape (bench.py, streaming callers): every ctypes argument of the rotating buffer
         sets is built once, so `submit()` is one C call (stream waits + kernel [+ event + in-place ncclAllGather] + done
         event) and `collect(slot)` one stream-side wait.  The caller works on `torch_stream()` (checked here); other
-        callers use submit / collect / knn2, which order against torch's current stream themselves."""
+        callers use submit / collect / knn2, which order against torch's current stream themselves.
+        buffers: rotating buffer sets (default: one per stream in flight, at least two).  static_inputs=True: the inputs are
+        complete before the first submit() and never change, and the caller is done with a slot's results (synchronised, or
+        waited for on every stream it uses) before the submit() that reuses the slot, `buffers` steps later -- the step's kernel
+        is then not ordered behind the library's stream at all, and the exchange runs on that stream."""
         import torch
         mine = self.torch_stream()
         if torch.cuda.current_stream(mine.device).cuda_stream != mine.cuda_stream:
             raise RuntimeError("ShardedMatcher.plan: make torch_stream() the current stream first")
         if self._local is not None:
             raise RuntimeError("ShardedMatcher.plan needs the HIP path")
-        return _Plan(self, q_shard, train, n_query, 1 if single_stream else int(in_flight))
+        return _Plan(self, q_shard, train, n_query, 1 if single_stream else int(in_flight), buffers, bool(static_inputs))
 
     def rccl_ranks(self):
         """Ranks of the matcher's own RCCL communicator (ncclCommCount), None when the direct path is not in use (world
@@ -372,7 +376,7 @@ class _Plan:
     least `in_flight` input buffers and names them per step, submit(q=..., t=...).  in_flight == 1: everything on the
     library's stream."""
 
-    def __init__(self, m, q, t, n_query, in_flight=2):
+    def __init__(self, m, q, t, n_query, in_flight=2, buffers=None, static_inputs=False):
         import torch
         from . import _capi
         b, e, per = shard_bounds(n_query, m.world, m.rank)
@@ -383,17 +387,33 @@ class _Plan:
         self.direct = collective and m._direct_ready(q)
         self.fallback = collective and not self.direct
         assert 1 <= in_flight <= 4
-        self.nslots = max(2, in_flight)  # two rotating buffer sets even on one stream
+        # `in_flight` compute streams, `buffers` rotating buffer sets (at least as many; default: one per stream, two on one
+        # stream).  More buffer sets than streams take the exchange off the chain of launches: a step's kernel has to wait for
+        # the all-gather that last used ITS buffer set -- with two sets that is the step before the previous one, whose in-place
+        # all-gather has only just been enqueued behind its kernel; with four sets it finished two steps ago.
+        self.nslots = max(2, in_flight, int(buffers) if buffers else 0)
+        assert self.nslots <= 8
+        # static_inputs (contract in ShardedMatcher.plan): the step's kernel is NOT ordered behind the library's stream, which
+        # carries the waits of earlier collect()s -- ordering every kernel behind them makes step k + 1 wait for the all-gather
+        # of step k - 1
+        self.static_inputs = static_inputs
         self.shape = (tuple(q.shape), tuple(t.shape))
         main = m._stream
+        # where the in-place all-gather runs.  A stream made after the context (the communicator's own) may share a hardware
+        # queue with one of the compute streams: the all-gather of step k, waiting there for kernel k, then holds back kernel
+        # k + 1 behind it (measured at one rank, 10k x 10k: 65 us / step against 47 without the collective).  With static
+        # inputs nothing else is enqueued on the library's stream between collect()s, and it owns a queue: 49 us / step.
+        # With per-step inputs the library's stream carries their producers, which must not queue behind an all-gather.
+        comm = main if static_inputs else (m._rccl.stream if self.direct else None)
         # compute streams of the slots: the context's own auxiliary streams first (created with the context, each on a
         # hardware queue of its own -- streams made later may share a queue with the library's and then never overlap it),
         # torch streams only beyond those
-        self.streams = []
-        for slot in range(self.nslots):
-            aux = m._ctx.aux_stream(slot) if in_flight > 1 else None
-            self.streams.append(main if in_flight == 1 else torch.cuda.ExternalStream(aux, device=q.device) if aux
-                                else torch.cuda.Stream(device=q.device))
+        pool = []
+        for i in range(max(in_flight, 1)):
+            aux = m._ctx.aux_stream(i) if in_flight > 1 else None
+            pool.append(main if in_flight == 1 else torch.cuda.ExternalStream(aux, device=q.device) if aux
+                        else torch.cuda.Stream(device=q.device))
+        self.streams = [pool[slot % len(pool)] for slot in range(self.nslots)]
         self.args, self.outs, self.done, self.bufs, self.keep = [], [], [], [], []
         nq, nt = q.shape[0], t.shape[0]
         for slot in range(self.nslots):
@@ -401,10 +421,10 @@ class _Plan:
             cs = self.streams[slot]
             ev = torch.cuda.Event()
             ev.record(cs)  # creates the hipEvent_t; complete by the time anything waits for it
-            after = main.cuda_stream if cs is not main else None
+            after = main.cuda_stream if cs is not main and not static_inputs else None
             if self.direct:   # this rank's rows go straight into its slot of the gather buffer, then the in-place all-gather
                 args = [self.h, q.data_ptr(), nq, t.data_ptr(), nt, gathered.data_ptr(), per, m.rank, m.world,
-                        m._rccl.comm.value, cs.cuda_stream, m._rccl.stream.cuda_stream, ev.cuda_event, after]
+                        m._rccl.comm.value, cs.cuda_stream, comm.cuda_stream, ev.cuda_event, after]
                 out = gathered
             else:             # no collective inside the call (world 1, or torch's collective afterwards): packed rows only
                 # everything on the library's own stream is ordered by the stream itself: no event between two launches
@@ -426,6 +446,8 @@ class _Plan:
         self.slot = (slot + 1) % self.nslots
         args = self.args[slot]
         if q is not None or t is not None:
+            if self.static_inputs:
+                raise ValueError("ShardedMatcher.plan(static_inputs=True): per-step inputs need the ordering this plan gave up")
             kq, kt = self.keep[slot]
             q = kq if q is None else q
             t = kt if t is None else t
