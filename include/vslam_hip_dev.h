@@ -35,6 +35,10 @@ int vs_match_stamps_read(vs_ctx* ctx, double* out, int cap_rows);
  * ba_schur_window); max_slabs: cap on ba_schur_small's slabs; motion_variant: 0 one-launch motion-only solve where it
  * applies, 1 one launch per LM step.  Values out of range leave a knob as it is. */
 int vs_tune_ba(vs_ctx* ctx, int schur_variant, int points_per_workgroup, int max_slabs, int motion_variant);
+/* Large problems (>= 400 000 observations, observation arrays in pinned memory, grouped by point) build their sparsity
+ * structure on the device (csrc/vs_ba_build.hip); on_host = 1 keeps it on the host passes (tests compare the two). */
+int vs_tune_ba_structure(vs_ctx* ctx, int on_host);
+int vs_ba_structure_on_device(vs_ctx* ctx); /* 1: the newest vs_ba_solve of this context built its structure on the device */
 
 /* Phase stamps of pnp_ransac_kernel (csrc/vs_pnp.hip).  vs_pnp_profile_read synchronises and returns the stamps of the
  * newest profiled launch as microseconds since the launch's first stamp: rows 0..H-1 = hypotheses, row H = the finishing

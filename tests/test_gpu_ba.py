@@ -508,6 +508,88 @@ def _sliding_window_scene(n_cams, n_points, window, seed):
                 obs_pose=cam, obs_point=pt, obs_uv=uv, K=ICL_NUIM_K, poses_gt=poses)
 
 
+def _solve_both_ways(vs, w, iters=2):
+    """the same large problem with its structure built on the device and by the host passes; (device result, host result)"""
+    args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], vs.pin(w["obs_pose"]), vs.pin(w["obs_point"]), vs.pin(w["obs_uv"]), w["K"])
+    try:
+        vs.tune_ba_structure(on_host=False)
+        d = vs.ba_solve(*args, max_iterations=iters)
+        on_device = vs.ba_structure_on_device()
+        vs.tune_ba_structure(on_host=True)
+        h = vs.ba_solve(*args, max_iterations=iters)
+        assert not vs.ba_structure_on_device()
+    finally:
+        vs.tune_ba_structure(on_host=False)
+    return d, h, on_device
+
+
+def _same_solve(a, b):
+    return (a["trials"] == b["trials"] and np.array_equal(a["chi2_trace"], b["chi2_trace"]) and np.array_equal(a["poses"], b["poses"])
+            and np.array_equal(a["points"], b["points"]))
+
+
+@pytest.mark.parametrize("case", ["banded", "fixed_points", "unobserved_points", "dense", "single_tile", "one_point_per_camera_run"])
+def test_large_problem_structure_built_on_the_device_equals_the_host_passes(vs, case):
+    """Round 4: problems with >= 400 000 observations in pinned arrays build their sparsity structure (observation ranges, Hpl
+    blocks, per-camera lists, tile masks, the banded-window plan) on the device, from the device copy of the observation list
+    (csrc/vs_ba_build.hip).  Integer work only, so the arrays -- and with them the whole solve -- must be BIT-identical to what
+    the host passes give, over every Schur path the structure feeds."""
+    n_cams, n_points, window = 40, 45000, 10
+    if case == "dense":
+        n_cams, n_points, window = 30, 16000, 30     # every camera sees every point: no banded window, the tile kernel
+    elif case == "single_tile":
+        n_cams, n_points, window = 10, 45000, 10     # nine free cameras: ba_schur_small
+    w = _sliding_window_scene(n_cams, n_points, window, seed=21)
+    if case == "fixed_points":      # fixed points seen from free cameras only: active observations without an Hpl block
+        seen_by_0 = np.zeros(n_points, bool)
+        seen_by_0[w["obs_point"][w["obs_pose"] == 0]] = True
+        w["point_fixed"][(np.arange(n_points) % 7 == 3) & ~seen_by_0] = 1
+    elif case == "unobserved_points":  # free points nobody observes (damping only), in the middle and at both ends of the list
+        drop = (w["obs_point"] % 1000 == 5) | (w["obs_point"] < 3) | (w["obs_point"] >= n_points - 4)
+        for k in ("obs_pose", "obs_point", "obs_uv"):
+            w[k] = np.ascontiguousarray(w[k][~drop])
+    elif case == "one_point_per_camera_run":  # observations of a point not in camera order
+        r = np.random.default_rng(5)
+        o = np.arange(len(w["obs_pose"])).reshape(n_points, window)
+        o = np.take_along_axis(o, r.permuted(np.tile(np.arange(window), (n_points, 1)), axis=1), 1).ravel()
+        for k in ("obs_pose", "obs_point", "obs_uv"):
+            w[k] = np.ascontiguousarray(w[k][o])
+    assert len(w["obs_pose"]) >= 400000
+    d, h, on_device = _solve_both_ways(vs, w)
+    assert on_device, "the device-side structure was not taken"
+    assert d["trials"] >= 2 and d["chi2_final"] < d["chi2_initial"]
+    assert _same_solve(d, h)
+
+
+def test_large_problems_the_device_structure_does_not_cover_fall_back_to_the_host_passes(vs):
+    """... a list that is not grouped by point, inactive observations (fixed point seen from the fixed camera), the same camera
+    twice in one point: the device reports it in one word and the host passes run after all; an index out of range is still an
+    error."""
+    w = _sliding_window_scene(40, 45000, 10, seed=22)
+    r = np.random.default_rng(8)
+    perm = r.permutation(len(w["obs_pose"]))
+    shuffled = dict(w, obs_pose=w["obs_pose"][perm], obs_point=w["obs_point"][perm], obs_uv=w["obs_uv"][perm])
+    d, h, on_device = _solve_both_ways(vs, shuffled)
+    assert not on_device and _same_solve(d, h)
+    inactive = dict(w, point_fixed=w["point_fixed"].copy())
+    inactive["point_fixed"][::97] = 1
+    d, h, on_device = _solve_both_ways(vs, inactive)
+    assert not on_device and _same_solve(d, h)
+    twice = dict(w, obs_pose=w["obs_pose"].copy())
+    twice["obs_pose"][10 * 20000 + 3] = twice["obs_pose"][10 * 20000 + 2]   # point 20000 seen twice from one camera
+    d, h, on_device = _solve_both_ways(vs, twice)
+    assert not on_device and _same_solve(d, h)
+    for where in (0, len(w["obs_pose"]) // 2, len(w["obs_pose"]) - 1):
+        bad = dict(w, obs_point=w["obs_point"].copy())
+        bad["obs_point"][where] = 45000
+        with pytest.raises(Exception):
+            _solve_both_ways(vs, bad, iters=1)
+    bad = dict(w, obs_pose=w["obs_pose"].copy())
+    bad["obs_pose"][12345] = -1
+    with pytest.raises(Exception):
+        _solve_both_ways(vs, bad, iters=1)
+
+
 def test_banded_windows_on_the_matrix_cores_agree_with_the_tile_kernel_and_the_oracle(vs, oracle):
     """Windows of more than ten free cameras whose points are seen from neighbouring cameras only: the points are ordered
     by their lowest camera, every slab's contribution is one dense window of S accumulated with FP64 MFMA

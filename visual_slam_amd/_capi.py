@@ -114,6 +114,8 @@ SIGNATURES = {
 # test / sweep / profiling hooks (per context, not part of the stable ABI): declared in include/vslam_hip_dev.h
 HOOKS = {
     "vs_tune_match": (C.c_int, [c_ctxp, C.c_int, C.c_int]),                 # target workgroups, train staging (-1: keep)
+    "vs_tune_ba_structure": (C.c_int, [c_ctxp, C.c_int]),
+    "vs_ba_structure_on_device": (C.c_int, [c_ctxp]),
     "vs_tune_ba": (C.c_int, [c_ctxp, C.c_int, C.c_int, C.c_int, C.c_int]),  # schur variant, points / workgroup, slab cap, motion variant
     "vs_match_profile": (C.c_int, [c_ctxp, C.c_int]),
     "vs_match_profile_read": (C.c_int, [c_ctxp, C.POINTER(C.c_float)]),

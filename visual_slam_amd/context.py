@@ -92,6 +92,14 @@ class Context:
         self._chk(self._lib.vs_tune_ba(self._h, int(schur_variant), int(points_per_workgroup), int(max_slabs),
                                        int(motion_variant)))
 
+    def tune_ba_structure(self, on_host):
+        """Where a large problem's sparsity structure is built: on the device (default) or by the host passes."""
+        self._chk(self._lib.vs_tune_ba_structure(self._h, int(bool(on_host))))
+
+    def ba_structure_on_device(self):
+        """True when the newest ba_solve of this context built its structure on the device."""
+        return bool(self._lib.vs_ba_structure_on_device(self._h))
+
     # ------------------------------------------------------------------ detection / description (A2-A4)
     def gray_mean3(self, bgr):
         bgr = np.ascontiguousarray(bgr, np.uint8)

@@ -3154,6 +3154,15 @@ VS_API int vs_tune_ba(vs_ctx* ctx, int schur_variant, int points_per_workgroup, 
   return VS_OK;
 }
 
+// developer hook (include/vslam_hip_dev.h): where the structure of a large problem is built (tests compare both)
+VS_API int vs_tune_ba_structure(vs_ctx* ctx, int on_host) {
+  if (!ctx) return VS_EINVAL;
+  ctx->tune.ba_host_structure = on_host != 0;
+  return VS_OK;
+}
+
+VS_API int vs_ba_structure_on_device(vs_ctx* ctx) { return ctx ? ctx->ba_structure_dev : 0; }
+
 namespace vsba {
 // The one-launch motion-only solve needs all its camera workgroups resident at the same time (they rendezvous through
 // mailboxes).  The bound is what THIS device can hold -- compute units x workgroups of this kernel per unit, as the runtime
@@ -3275,7 +3284,15 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   for (int i = 0; i < F; ++i) pose_slot[i] = p->pose_fixed[i] ? -1 : nfp++;
   for (int j = 0; j < P; ++j) pt_slot[j] = p->point_fixed[j] ? -1 : nfl++;
   const int np = 6 * nfp;
-  W.cnt.assign((size_t)P + 1, 0);
+  // Large problems whose observation arrays lie in pinned memory: the arrays are DMA-ed from where they lie and the structure
+  // below is built ON THE DEVICE from that copy (vs_ba_build.hip) -- no host pass reads the observations at all.  Whatever that
+  // path does not cover (an index out of range, a list not grouped by point, inactive observations or points, a camera twice
+  // in one point) comes back as a flag, and the host passes run after all (`goto host_passes`, once).
+  static const bool kHostStructure = getenv("VS_BA_HOST_STRUCTURE") != nullptr;  // developer aid: never build on the device
+  bool dev = !kHostStructure && !ctx->tune.ba_host_structure && p->n_obs >= 400000 && !p->obs_info && nfp > 0 && nfl > 0 && nfp + 1 <= kBuildMaxKeys &&
+             p->max_iterations > 0 && vs_is_pinned(p->obs_uv) && vs_is_pinned(p->obs_pose) && vs_is_pinned(p->obs_point);
+host_passes:
+  W.cnt.assign(dev ? 1 : (size_t)P + 1, 0);
   W.cam_start.assign((size_t)nfp + 1, 0);
   int* cnt = W.cnt.data();
   int* cam_start = W.cam_start.data();
@@ -3289,7 +3306,9 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     ctx->pool.run(nt, [](void* a, int t, int n) { (*static_cast<B*>(a))(t, n); }, (void*)&body);
   };
   // (the loops are written out, not shared through a lambda: the closure's indirections cost 10 us at 20 000 observations)
-  if (T == 1) {
+  if (dev) {
+    n_obs = n_hpl = p->n_obs;  // bounds until the device reports (every observation active is a condition of that path)
+  } else if (T == 1) {
     // locals whose address is never taken: the threaded variant below captures the function's own variables by reference,
     // which would make every store here a possible alias of them
     int* const cnt_ = cnt;
@@ -3414,15 +3433,16 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   // active points = free points (even without observations: they still receive the lambda damping) + fixed points
   // that are observed by a free camera.  Skipped points own no active observation, so the sorted observation ranges
   // of consecutive active points are adjacent: pt_start[a] = cnt[act_pt[a]], pt_start[n_act] = n_obs.
-  int n_act = 0;
-  for (int j = 0; j < P; ++j) {
-    n_act += cnt[j + 1] > 0 || pt_slot[j] >= 0;
-    cnt[j + 1] += cnt[j];
-  }
+  int n_act = dev ? P : 0;  // (device path: every point active is a condition, too)
+  if (!dev)
+    for (int j = 0; j < P; ++j) {
+      n_act += cnt[j + 1] > 0 || pt_slot[j] >= 0;
+      cnt[j + 1] += cnt[j];
+    }
   for (int c = 0; c < nfp; ++c) cam_start[c + 1] += cam_start[c];
-  const int n_cam_obs = cam_start[nfp];
+  const int n_cam_obs = dev ? n_obs : cam_start[nfp];
   // stable order of the active observations by point; the identity when they arrive grouped and all are active
-  const bool identity = grouped && n_obs == p->n_obs;
+  const bool identity = dev || (grouped && n_obs == p->n_obs);
   const int* order = nullptr;
   if (!identity) {
     W.order.resize(n_obs ? n_obs : 1);
@@ -3472,7 +3492,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   // workgroups per camera of the linearisation's camera role: about one observation per thread, at most 8
   int cam_split = 1;
   for (int c = 0; c < nfp; ++c) cam_split = std::max(cam_split, (cam_start[c + 1] - cam_start[c] + kCamThreads - 1) / kCamThreads);
-  cam_split = std::min(cam_split, 8);
+  cam_split = dev ? 8 : std::min(cam_split, 8);  // (device path: the bound, for the arena; the count comes back with the structure)
 
   const auto t_struct = now();
   t_lap = t_struct;
@@ -3487,6 +3507,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
                 256 * 64 + sizeof(int) * (3 * (size_t)n_obs + nfl + 16 + 2 * (size_t)ns_win_bound + nfp + 64) + 4 * 256 + (sizeof(double) * 27 * 8 + 8) * (size_t)nfp + 1024 +
                 sizeof(double) * (64 + (size_t)F * kCamStride + 3 * (size_t)P + 2 * (size_t)q.max_iterations) + 512 +
                 (small_possible ? sizeof(double) * ((size_t)np * np + np + 12 * (size_t)nfl + 18 * (size_t)n_obs) + 5 * 256 : 0) + sizeof(double) * 8 * (size_t)(res->trial_trace ? std::max(res->trial_trace_cap, 0) : 0) + (motion_only ? sizeof(double) * (8 * (size_t)n_cam_obs + 50 * (size_t)nfp + 64) : 0);
+  if (dev) need += sizeof(int) * (ba_build_temp_ints(n_obs, nfp, nfl) + (size_t)nfl + 2 * (size_t)ns_win_bound + nfp + 64) + 4096;
   VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, need));
   VS_HIP(ctx, hipStreamSynchronize(s));
@@ -3498,7 +3519,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   // Observation arrays that the caller keeps in pinned memory (Context.pinned_empty / vs_host_alloc) and that need no
   // reordering are DMA-ed from where they lie, started NOW so that the transfer runs beside the host passes below; they
   // sit in front of the uploaded part of the arena.  (Large problems only: the three pointer queries cost microseconds.)
-  const bool direct_obs = identity && T > 1 && !q.obs_info && vs_is_pinned(q.obs_uv) && vs_is_pinned(q.obs_pose) && vs_is_pinned(q.obs_point);
+  const bool direct_obs = dev || (identity && T > 1 && !q.obs_info && vs_is_pinned(q.obs_uv) && vs_is_pinned(q.obs_pose) && vs_is_pinned(q.obs_point));
   size_t upload_begin = 0;
   if (direct_obs) {
     D.o_cam = A.take<int>(n_obs);
@@ -3528,32 +3549,39 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   D.cy = q.cy;
   D.huber = q.huber_delta;
   D.dcs = q.dcs_phi;
-  int *h_pose_slot, *h_pt_slot, *h_act, *h_ptstart, *h_ocam = nullptr, *h_opt = nullptr, *h_cstart, *h_cobs, *h_scp, *h_scc;
+  int *h_pose_slot, *h_pt_slot, *h_act = nullptr, *h_ptstart = nullptr, *h_ocam = nullptr, *h_opt = nullptr, *h_cstart = nullptr, *h_cobs = nullptr, *h_scp, *h_scc;
   double *h_uv = nullptr, *h_info = nullptr, *h_scm, *h_cam0, *h_pts0;
   D.pose_slot = A.take<int>(F, &h_pose_slot);
   D.pt_slot = A.take<int>(P, &h_pt_slot);
-  D.act_pt = A.take<int>(n_act, &h_act);
-  D.pt_start = A.take<int>(n_act + 1, &h_ptstart);
+  // (device path: the structure arrays are carved behind the uploaded part, see below)
+  if (!dev) {
+    D.act_pt = A.take<int>(n_act, &h_act);
+    D.pt_start = A.take<int>(n_act + 1, &h_ptstart);
+  }
   if (!direct_obs) {
     D.o_cam = A.take<int>(n_obs, &h_ocam);
     D.o_pt = A.take<int>(n_obs, &h_opt);
   }
-  D.cam_start = A.take<int>(nfp + 1, &h_cstart);
-  D.cam_obs = A.take<int>(n_cam_obs, &h_cobs);
-  int* h_cpt;
-  D.cam_pt = A.take<int>(n_cam_obs, &h_cpt);  // point index of the same entry (saves the camera role one dependent load)
+  int* h_cpt = nullptr;
+  if (!dev) {
+    D.cam_start = A.take<int>(nfp + 1, &h_cstart);
+    D.cam_obs = A.take<int>(n_cam_obs, &h_cobs);
+    D.cam_pt = A.take<int>(n_cam_obs, &h_cpt);  // point index of the same entry (saves the camera role one dependent load)
+  }
   D.sc_parent = A.take<int>(q.n_scale, &h_scp);
   D.sc_child = A.take<int>(q.n_scale, &h_scc);
   int* h_sp;
   D.slot_pose = A.take<int>(nfp, &h_sp);
   for (int i = 0; i < F; ++i)
     if (pose_slot[i] >= 0) h_sp[pose_slot[i]] = i;
-  int *h_ohpl, *h_fps, *h_fpl;
-  D.o_hpl = A.take<int>(n_obs, &h_ohpl);
-  D.fp_start = A.take<int>(nfl + 1, &h_fps);
-  D.fp_slot = A.take<int>(n_hpl, &h_fpl);
+  int *h_ohpl = nullptr, *h_fps = nullptr, *h_fpl = nullptr;
   unsigned long long* h_mask = nullptr;
-  if (tiled_possible) D.fp_mask = A.take<unsigned long long>(nfl, &h_mask);
+  if (!dev) {
+    D.o_hpl = A.take<int>(n_obs, &h_ohpl);
+    D.fp_start = A.take<int>(nfl + 1, &h_fps);
+    D.fp_slot = A.take<int>(n_hpl, &h_fpl);
+    if (tiled_possible) D.fp_mask = A.take<unsigned long long>(nfl, &h_mask);
+  }
   if (!direct_obs) D.o_uv = A.take<double>(2 * (size_t)n_obs, &h_uv);
   if (D.has_info) D.o_info = A.take<double>(3 * (size_t)n_obs, &h_info);
   D.sc_meas = A.take<double>(q.n_scale, &h_scm);
@@ -3587,12 +3615,33 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
 
   lap(0);  // reserve + carve
+  // scale edges, start state (both state buffers), LM record
+  auto fill_states = [&]() {
+    for (int k = 0; k < q.n_scale; ++k) {
+      h_scp[k] = q.scale_parent[k];
+      h_scc[k] = q.scale_child[k];
+      h_scm[k] = q.scale_meas[k];
+    }
+    for (int i = 0; i < F; ++i) {
+      const double* m = q.poses + 16 * (size_t)i;
+      double* c = h_cam0 + (size_t)i * kCamStride;
+      c[0] = m[3];
+      c[1] = m[7];
+      c[2] = m[11];
+      quat_from_pose(m, c + 3);
+      quat_to_w2n(c, c + 3, c + 7);
+    }
+    memcpy(h_pts0, q.points, sizeof(double) * 3 * (size_t)P);
+    memset(h_st, 0, sizeof(lm_state));
+    h_st->need_lin = 1;
+    h_st->ni = 2.0;
+  };
   // ---- pass 2 over the observations in point order, straight into the pinned arena: the active points, the sorted
   // observation records, the Hpl blocks (observations whose point AND camera are free, stored contiguously per free
   // point), the per-camera lists, the camera-tile mask of every free point (tiled Schur) and duplicate cameras per point
   memcpy(h_pose_slot, pose_slot, sizeof(int) * F);
   memcpy(h_pt_slot, pt_slot, sizeof(int) * P);
-  memcpy(h_cstart, cam_start, sizeof(int) * ((size_t)nfp + 1));
+  if (!dev) memcpy(h_cstart, cam_start, sizeof(int) * ((size_t)nfp + 1));
   // the observation records of the identity case are plain copies (48 MB at 2 000 000 observations): split over the threads
   // ... unless the caller keeps them in pinned memory (Context.pinned_empty / vs_host_alloc): then they are DMA-ed from
   // where they lie, behind the arena upload (large problems only: the three pointer queries cost a few microseconds)
@@ -3606,7 +3655,96 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     });
   }
   lap(1);  // slot tables, observation records
-  int mmax = 1, dups = 0, a_idx = 0, k_hpl = 0;
+  int mmax = 1, dups = 0, a_idx = 0, k_hpl = 0, max_rank = 0;
+  auto t_win0 = now();
+  bool win = false;
+  int win_n = 0, win_per = 0, ns_win = 0, win_cams = 0;
+  size_t upload_bytes = 0;
+  if (dev) {
+    // ---- the structure on the device: the small tables and the start state go up now, the structure arrays are carved behind
+    // them and produced from the device copy of the observation list (vs_ba_build.hip); one 64-byte read-back tells what came out
+    fill_states();
+    upload_bytes = A.off;
+    VS_HIP(ctx, hipMemcpyAsync(A.base + upload_begin, A.host + upload_begin, upload_bytes - upload_begin, hipMemcpyHostToDevice, s));
+    ba_build B;
+    memset(&B, 0, sizeof B);
+    B.o_cam = D.o_cam;
+    B.o_pt = D.o_pt;
+    B.pose_slot = D.pose_slot;
+    B.pt_slot = D.pt_slot;
+    B.n_obs = n_obs;
+    B.F = F;
+    B.P = P;
+    B.nfp = nfp;
+    B.nfl = nfl;
+    B.tile_cams = kTileCams;
+    B.win_target = win_target;
+    B.win_per_tune = ctx->tune.win_per;
+    B.win_per_max = kWinPerMax;
+    B.ns_cap = ns_win_bound;
+    B.act_pt = A.take<int>(P);
+    B.pt_start = A.take<int>((size_t)P + 1);
+    B.cam_start = A.take<int>((size_t)nfp + 1);
+    B.cam_obs = A.take<int>(n_obs);
+    B.cam_pt = A.take<int>(n_obs);
+    B.o_hpl = A.take<int>(n_obs);
+    B.fp_start = A.take<int>((size_t)nfl + 1);
+    B.fp_slot = A.take<int>(n_obs);
+    if (tiled_possible) B.fp_mask = A.take<unsigned long long>(nfl);
+    if (win_possible && ns_win_bound > 0) {
+      B.win_order = A.take<int>(nfl);
+      B.win_w0 = A.take<int>(ns_win_bound);
+      B.win_len = A.take<int>(ns_win_bound);
+      B.win_first = A.take<int>((size_t)nfp + 1);
+    }
+    int* h_binfo;
+    B.info = A.take<int>(kBuildInfoInts, &h_binfo);
+    const size_t nblk_o = ((size_t)n_obs + 1023) / 1024, nblk_p = ((size_t)nfl + 1023) / 1024, ncols = (size_t)nfp + 2;
+    B.ckey = A.take<int>(n_obs);
+    B.wkey = A.take<int>(nfl);
+    B.wlo = A.take<int>(nfl);
+    B.whi = A.take<int>(nfl);
+    B.hist_o = A.take<int>(nblk_o * ncols);
+    B.tot_o = A.take<int>(ncols);
+    B.hist_p = A.take<int>(nblk_p * ncols);
+    B.tot_p = A.take<int>(ncols);
+    B.win_start = A.take<int>(ncols);
+    if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
+    VS_TRY(ba_build_enqueue(ctx, s, B));
+    VS_HIP(ctx, hipMemcpyAsync(h_binfo, B.info, sizeof(int) * kBuildInfoInts, hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipStreamSynchronize(s));
+    lap(2);
+    if (h_binfo[kBuildBad] | h_binfo[kBuildUngrouped] | h_binfo[kBuildInactive] | h_binfo[kBuildDups]) {
+      dev = false;  // not this path's case: the host passes take it (and report what is wrong with it, if anything)
+      goto host_passes;
+    }
+    D.act_pt = B.act_pt;
+    D.pt_start = B.pt_start;
+    D.cam_start = B.cam_start;
+    D.cam_obs = B.cam_obs;
+    D.cam_pt = B.cam_pt;
+    D.o_hpl = B.o_hpl;
+    D.fp_start = B.fp_start;
+    D.fp_slot = B.fp_slot;
+    D.fp_mask = B.fp_mask;
+    n_hpl = h_binfo[kBuildHpl];
+    mmax = std::max(1, h_binfo[kBuildMmax]);
+    cam_split = std::min(8, std::max(1, (h_binfo[kBuildCamMax] + kCamThreads - 1) / kCamThreads));
+    D.cam_split = cam_split;
+    if (B.win_order) {
+      win_n = h_binfo[kBuildWinN];
+      win_per = h_binfo[kBuildWinPer];
+      ns_win = h_binfo[kBuildWinSlabs];
+      win_cams = h_binfo[kBuildWinCams];
+      if (ns_win > ns_win_bound || sizeof(int) * 2 * (size_t)ns_win > 48 * 1024) ns_win = 0;  // as below
+      win = win_n > 0 && ns_win > 0 && win_cams <= kWinCams;
+      D.win_order = B.win_order;
+      D.win_w0 = B.win_w0;
+      D.win_len = B.win_len;
+      D.win_first = B.win_first;
+    }
+  }
+  if (!dev) {
   // one point: its active-point record, its sorted observation records, its Hpl blocks and the per-camera lists.  The
   // running positions (active index, Hpl block index, per-camera fill positions) are the caller's: sequential for small
   // problems; for large ones every thread takes a range of points whose starting positions a counting pass fixed.
@@ -3753,7 +3891,6 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   lap(2);  // per-point pass
   h_ptstart[n_act] = n_obs;
   h_fps[nfl] = k_hpl;
-  int max_rank = 0;
   if (dups) {  // rare: per Hpl block, how many earlier blocks of the same point belong to the same camera
     int* h_fpr;
     D.fp_rank = A.take<int>(n_hpl, &h_fpr);
@@ -3775,9 +3912,7 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
   // ---- banded window?  (several tiles, no duplicates): the contributing free points ordered by their lowest camera slot
   // and cut into slabs; taken when the cameras of every slab span at most kWinCams slots (ba_schur_window)
   lap(3);
-  const auto t_win0 = now();
-  bool win = false;
-  int win_n = 0, win_per = 0, ns_win = 0, win_cams = 0;
+  t_win0 = now();
   if (tiled_possible && !dups && ntile > 1 && ctx->tune.schur_variant != 3) {
     W.wcnt.assign((size_t)nfp + 1, 0);
     int* const wcnt = W.wcnt.data();
@@ -3820,8 +3955,10 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
     }
   }
   lap(4);  // window plan
-  const double win_plan_us = us(t_win0, now());
-  const size_t upload_bytes = A.off;
+  upload_bytes = A.off;
+  }  // host passes
+  const double win_plan_us = dev ? 0.0 : us(t_win0, now());
+  ctx->ba_structure_dev = dev;
   const bool tiled = tiled_possible && !dups;
   const bool small = tiled && small_possible;
   const bool spec = small && ctx->tune.schur_variant != 2;  // two linearisations: the trial kernel linearises the trial state
@@ -3908,28 +4045,11 @@ VS_API int vs_ba_solve(vs_ctx* ctx, const vs_ba_problem* p, vs_ba_result* res) {
       }
     }
   }
-  for (int k = 0; k < q.n_scale; ++k) {
-    h_scp[k] = q.scale_parent[k];
-    h_scc[k] = q.scale_child[k];
-    h_scm[k] = q.scale_meas[k];
-  }
-  for (int i = 0; i < F; ++i) {
-    const double* m = q.poses + 16 * (size_t)i;
-    double* c = h_cam0 + (size_t)i * kCamStride;
-    c[0] = m[3];
-    c[1] = m[7];
-    c[2] = m[11];
-    quat_from_pose(m, c + 3);
-    quat_to_w2n(c, c + 3, c + 7);
-  }
-  memcpy(h_pts0, q.points, sizeof(double) * 3 * (size_t)P);
-  memset(h_st, 0, sizeof(lm_state));
-  h_st->need_lin = 1;
-  h_st->ni = 2.0;
+  if (!dev) fill_states();
   const bool nothing = (np + 3 * nfl == 0) || q.max_iterations == 0;
   lap(5);  // states
   const auto t_filled = now();
-  VS_HIP(ctx, hipMemcpyAsync(A.base + upload_begin, A.host + upload_begin, upload_bytes - upload_begin, hipMemcpyHostToDevice, s));
+  if (!dev) VS_HIP(ctx, hipMemcpyAsync(A.base + upload_begin, A.host + upload_begin, upload_bytes - upload_begin, hipMemcpyHostToDevice, s));
   // both state buffers start identical (fixed cameras / points are never rewritten in the trial buffer's points)
   VS_HIP(ctx, hipMemcpyAsync(D.cam[1], D.cam[0], sizeof(double) * (size_t)F * kCamStride, hipMemcpyDeviceToDevice, s));
   VS_HIP(ctx, hipMemcpyAsync(D.pts[1], D.pts[0], sizeof(double) * 3 * (size_t)P, hipMemcpyDeviceToDevice, s));

@@ -229,4 +229,27 @@ int pnp_grid(int iterations);  // workgroups of pnp_ransac_kernel: four hypothes
 int pnp_tags(vs_ctx* ctx, int iterations, hipStream_t s, unsigned long long** tag, unsigned* epoch);  // vs_pnp.hip
 int pnp_stamps(vs_ctx* ctx, int iterations, hipStream_t s, unsigned long long** stamps);
 
+// ---- vs_ba_build.hip: the structure arrays of a large problem produced on the device from the device copy of the caller's
+// observation list (what vs_ba_solve's host passes produce otherwise; same arrays, bit for bit)
+constexpr int kBuildMaxKeys = 1022;      // free cameras + 1 that the stable counting sort takes (its histogram lives in LDS)
+constexpr int kBuildMaxPerPoint = 512;   // observations per point up to which the duplicate-camera scan runs on the device
+// words of ba_build::info (zeroed by ba_build_enqueue)
+enum { kBuildBad = 0, kBuildUngrouped, kBuildInactive, kBuildDups, kBuildHpl, kBuildMmax, kBuildCamMax, kBuildWinN, kBuildWinPer, kBuildWinSlabs,
+       kBuildWinCams, kBuildInfoInts = 16 };
+struct ba_build {
+  // in (device)
+  const int *o_cam, *o_pt, *pose_slot, *pt_slot;
+  int n_obs, F, P, nfp, nfl, tile_cams;
+  int win_target, win_per_tune, win_per_max, ns_cap;  // window plan: slabs wanted, vs_tune_ba's slab size (0: none), kWinPerMax, capacity of win_w0 / win_len
+  // out (device)
+  int *pt_start, *act_pt, *o_hpl, *fp_start, *fp_slot, *cam_start, *cam_obs, *cam_pt;
+  unsigned long long* fp_mask;                         // or nullptr
+  int *win_order, *win_w0, *win_len, *win_first;       // win_order == nullptr: no window plan
+  int* info;                                           // [kBuildInfoInts]
+  // temporaries (device)
+  int *ckey, *wkey, *wlo, *whi, *hist_o, *tot_o, *hist_p, *tot_p, *win_start;
+};
+size_t ba_build_temp_ints(int n_obs, int nfp, int nfl);
+int ba_build_enqueue(vs_ctx* ctx, hipStream_t s, const ba_build& B);
+
 }  // namespace vsba

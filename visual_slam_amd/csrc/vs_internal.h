@@ -54,6 +54,7 @@ struct vs_tuning {
   int match_target_blocks = 0;  // 0: automatic plan (plan_chunks); > 0: fixed number of workgroups
   int match_tstage = 1;         // train rows staged through LDS into VGPRs (1) or fed from SGPRs (0)
   bool match_profile = false;   // HIP events around every match launch (bench.py)
+  int ba_host_structure = 0;    // 1: large problems build their structure with the host passes, never on the device (vs_tune_ba_structure)
   int schur_variant = 0;        // single-tile windows: 0 ba_schur_small + speculative linearisation, 1 tile kernel, 2 ba_schur_small + linearise launch; 3: as 0, and banded windows of several tiles on ba_schur_tile instead of ba_schur_window
   int small_per = 0;            // points per ba_schur_small workgroup (0: kSmallPts)
   int small_ns_cap = 512;       // cap on its slab count
@@ -161,6 +162,7 @@ struct vs_ctx {
   std::vector<vs_prof_rec> match_prof;
   vs_buf d_mo_stamps;       // diagnostic step stamps of the newest one-launch motion-only solve of a tracking period (vs_mo_profile)
   bool mo_profile = false;
+  int ba_structure_dev = 0;  // 1: the newest vs_ba_solve built its structure on the device (vs_ba_structure_on_device)
   vs_buf d_match_stamps;    // diagnostic phase stamps of the newest stamped match launch (vs_match_stamps)
   bool match_stamps_on = false;
   int match_stamps_rows = 0;
