@@ -1828,207 +1828,229 @@ __global__ __launch_bounds__(256) void ba_chol_update(ba_dev D, int j0, int nbw)
     }
 }
 
-// Banded systems (ba_schur_window's windows: S[r][c] = 0 for r - c >= band): the whole factorisation in ONE launch.  A
-// window of W = nbw + band rows and columns of the lower triangle (plus the rhs as its last row) lives in LDS and slides
-// down the diagonal: factorise the window's first nbw columns exactly as ba_chol_panel does, update the rest of the
-// window exactly as ba_chol_update does (per element the same subtractions in the same order, so L is bit-identical to
-// the dense path's; what lies outside the band is an exact zero there and is simply not visited here), write the panel to
-// HBM, move the window up-left by nbw and read the next nbw rows, which no earlier column has touched.  That replaces
-// 2 n / nbw launches whose dependent hand-overs were the cost (25 x (22 + 7) us at 594 unknowns) by one.
-constexpr int kBandMax = 6 * kWinCams, kBandNbw = 24, kBandW = kBandNbw + kBandMax;
-constexpr int kBandShift = ((kBandW - kBandNbw + 1) * (kBandW - kBandNbw) + kPanelThreads - 1) / kPanelThreads;
-constexpr int kBandFetch = (kBandNbw * kBandW + kBandNbw + kPanelThreads - 1) / kPanelThreads;
-constexpr size_t kBandLds = sizeof(double) * ((size_t)(kBandW + 1) * ((kBandW + 1) | 1) + kBandNbw) + 64;
+// Banded systems (ba_schur_window's windows: S[r][c] = 0 for r - c >= band): the whole factorisation in ONE launch, one
+// 6 x 6 block column per step.  The rows the current block column reaches (band + 5 of them) live in LDS as a RING in both
+// directions -- element (i, c) at [i mod WR][c mod WR], WR = band + 12 -- so nothing is ever moved: the six rows that enter
+// the window for the next step are written into slots no current row uses, straight from the registers they were fetched
+// into a step earlier.  A step is
+//     diagonal 6 x 6 block (one lane; a chain of six dependent reciprocal square roots, ~0.5 us: THE critical path)
+//  X  column solve of the rows below and of the right-hand side (thread = row; result to LDS and to HBM from registers)
+//  Y  rank-6 update of the trailing lower triangle (2 x 2 register tiles) -- wave 0 takes the NEXT diagonal block's 21
+//     elements first and factorises it at once, while the other waves update the rest and bring the new rows in
+// so the diagonal chain of step b + 1 runs beside the update of step b (look-ahead) and a step costs two barriers.  Per
+// element the subtractions are those of ba_chol_panel / ba_chol_update in their order (ascending column, one product at a
+// time), so L is bit-identical to the dense path's; what lies outside the band is an exact zero there.
+// Round 3's form (24-column panels, the window slid through registers after each) spent 27 % of its 420 us at 594 unknowns
+// with 511 threads waiting for the diagonal lane, 30 % moving the window and writing panels, 22 % in the trailing update.
+constexpr int kBandMax = 6 * kWinCams, kBandRing = kBandMax + 12, kBandLd = kBandRing | 1;
+constexpr size_t kBandLds = sizeof(double) * ((size_t)kBandRing * kBandLd + kBandRing + 64) + 64;
+constexpr int kBandLoaders = kPanelThreads - 64;  // threads of the waves that do not factorise
+constexpr int kBandNew = (6 * (kBandMax + 6) + kBandLoaders - 1) / kBandLoaders;
 
 __global__ __launch_bounds__(kPanelThreads) void ba_chol_band(ba_dev D, int band) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   if (D.st->done) return;
-  const int n = D.np, tid = threadIdx.x;
-  constexpr int nbw = kBandNbw;
-  const int W = nbw + band, ld = (kBandW + 1) | 1;
-  double* A = s_mem;                                  // [W + 1][ld]: window rows, then the rhs row at index W
-  double* rinv = s_mem + (size_t)(kBandW + 1) * ld;   // [nbw]
-  int* s_flag = reinterpret_cast<int*>(rinv + nbw);
+  const int n = D.np, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int WR = band + 12;
+  constexpr int ld = kBandLd;
+  double* A = s_mem;                     // [WR][ld] ring
+  double* Y = A + kBandRing * ld;        // [WR] right-hand side entries by column slot
+  double* blk = Y + kBandRing;           // [21] the next diagonal block before its factorisation
+  double* rv = blk + 24;                 // [6] reciprocal pivots of the current block column
+  int* s_flag = reinterpret_cast<int*>(rv + 8);
   {
-    const int R0 = min(W, n);
-    for (int e = tid; e < (R0 + 1) * R0; e += kPanelThreads) {
+    const int R0 = min(n, band + 5);
+    for (int e = tid; e < R0 * R0; e += kPanelThreads) {
       const int r = e / R0, c = e - r * R0;
-      A[(r < R0 ? r : W) * ld + c] = (c <= r || r == R0) ? chol_row(D, r < R0 ? r : n)[c] : 0.0;
+      if (c <= r) A[r * ld + c] = D.S[(size_t)r * n + c];
     }
+    for (int c = tid; c < R0; c += kPanelThreads) Y[c] = D.bs[c];
   }
   if (tid == 0) {
     *s_flag = 0;
     *D.chol_fail = 0;
   }
   __syncthreads();
-  for (int j0 = 0; j0 < n; j0 += nbw) {
-    const int w = min(nbw, n - j0), R = min(W, n - j0);  // panel columns, window rows (local row R stands for the rhs)
-    // the rows that enter the window after this step, requested now: global rows j0 + R .. j0 + w + R' - 1
-    const int Rn = min(W, n - j0 - w), fresh = max(Rn - (R - w), 0);  // next window's rows; how many of them are new
-    double fv[kBandFetch];
+  // the diagonal block whose first column is global column g0 (ring slot sg): lanes e < 21 of wave 0 bring its elements --
+  // after the rank-6 update by block column [g0 - 6, g0) when `upd` -- to `blk`, lane 0 factorises (ba_chol_panel's
+  // arithmetic), stores L in the ring and in HBM and the reciprocal pivots in rv / D.rinv
+  auto diag = [&](int g0, int sg, bool upd) {
+    const int sp = sg >= 6 ? sg - 6 : sg - 6 + WR;  // slot of column g0 - 6
+    if (lane < 21) {
+      int r = 0, e = lane;
+      while (e > r) e -= ++r;  // (r, c): lane = r (r + 1) / 2 + c
+      const int c = e;
+      const int sr = sg + r >= WR ? sg + r - WR : sg + r, sc = sg + c >= WR ? sg + c - WR : sg + c;
+      double acc = A[sr * ld + sc];
+      if (upd) {
 #pragma unroll
-    for (int k = 0; k < kBandFetch; ++k) {
-      const int e = tid + kPanelThreads * k;
-      fv[k] = 0.0;
-      if (e < fresh * W) {
-        const int fr = e / W, c = e - fr * W, lr = R - w + fr;  // row / column in the NEXT window
-        if (c <= lr) fv[k] = D.S[(size_t)(j0 + w + lr) * n + j0 + w + c];
-      } else if (e < fresh * W + fresh) {
-        fv[k] = D.bs[j0 + w + (R - w) + (e - fresh * W)];
+        for (int k = 0; k < 6; ++k) {
+          const int sk = sp + k >= WR ? sp + k - WR : sp + k;
+          acc -= A[sr * ld + sk] * A[sc * ld + sk];
+        }
+      }
+      blk[lane] = acc;
+    }
+    wave_lds_sync();
+    if (lane == 0) {
+      double L[6][6], ri[6];
+      int good = 1;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c <= r; ++c) L[r][c] = blk[r * (r + 1) / 2 + c];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double d = L[c][c];
+        if (!(d > 0.0)) good = 0;
+        double r = __builtin_amdgcn_rsq(d);
+        r = r * (1.5 - 0.5 * d * r * r);
+        r = r * (1.5 - 0.5 * d * r * r);
+        double l = d * r;
+        l = l + 0.5 * r * (d - l * l);
+        L[c][c] = l;
+        ri[c] = r;
+#pragma unroll
+        for (int i = c + 1; i < 6; ++i) L[i][c] = L[i][c] * r;
+#pragma unroll
+        for (int i = c + 1; i < 6; ++i)
+#pragma unroll
+          for (int k = c + 1; k <= i; ++k) L[i][k] -= L[i][c] * L[k][c];
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int sr = sg + r >= WR ? sg + r - WR : sg + r;
+#pragma unroll
+        for (int c = 0; c <= r; ++c) {
+          const int sc = sg + c >= WR ? sg + c - WR : sg + c;
+          A[sr * ld + sc] = L[r][c];
+          D.S[(size_t)(g0 + r) * n + g0 + c] = L[r][c];
+        }
+        rv[r] = ri[r];
+        D.rinv[g0 + r] = ri[r];
+      }
+      if (!good) *s_flag = 1;
+    }
+  };
+  if (wv == 0) diag(0, 0, false);
+  int s0 = 0;  // ring slot of column c0
+#ifdef VS_BAND_STAMPS
+  long long tb[6] = {0, 0, 0, 0, 0, 0}, tb0 = __builtin_readcyclecounter(), tbS = tb0;
+#define VS_BAND_LAP(k) { const long long t_ = __builtin_readcyclecounter(); tb[k] += t_ - tb0; tb0 = t_; }
+#else
+#define VS_BAND_LAP(k)
+#endif
+  for (int c0 = 0; c0 < n; c0 += 6) {
+    const int m = min(band + 5, n - c0) - 6;  // trailing rows of this block column: c0 + 6 .. c0 + 6 + m - 1
+    auto slot = [&](int d) { return s0 + d >= WR ? s0 + d - WR : s0 + d; };  // of global index c0 + d, 0 <= d < WR
+    // the rows that enter the window for the next step, requested now: g = c0 + band + 5 + rr, columns c0 + 6 .. g
+    const int g_first = c0 + band + 5;
+    double nv[kBandNew];
+    if (wv > 0) {
+#pragma unroll
+      for (int q = 0; q < kBandNew; ++q) {
+        const int e = tid - 64 + kBandLoaders * q, rr = e / (band + 6), cc = e - rr * (band + 6), g = g_first + rr;
+        nv[q] = 0.0;
+        if (rr < 6 && g < n) {
+          if (cc < band + rr) nv[q] = D.S[(size_t)g * n + c0 + 6 + cc];
+          else if (cc == band + 5) nv[q] = D.bs[g];
+        }
       }
     }
-    for (int b0 = 0; b0 < w; b0 += 6) {
-      if (tid == 0) {
-        double L[6][6], ri[6];
-        int good = 1;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-          for (int c = 0; c <= r; ++c) L[r][c] = A[(b0 + r) * ld + b0 + c];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const double d = L[c][c];
-          if (!(d > 0.0)) good = 0;
-          double r = __builtin_amdgcn_rsq(d);
-          r = r * (1.5 - 0.5 * d * r * r);
-          r = r * (1.5 - 0.5 * d * r * r);
-          double l = d * r;
-          l = l + 0.5 * r * (d - l * l);
-          L[c][c] = l;
-          ri[c] = r;
-#pragma unroll
-          for (int i = c + 1; i < 6; ++i) L[i][c] = L[i][c] * r;
-#pragma unroll
-          for (int i = c + 1; i < 6; ++i)
-#pragma unroll
-            for (int k = c + 1; k <= i; ++k) L[i][k] -= L[i][c] * L[k][c];
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-#pragma unroll
-          for (int c = 0; c <= r; ++c) A[(b0 + r) * ld + b0 + c] = L[r][c];
-          rinv[b0 + r] = ri[r];
-        }
-        if (!good) *s_flag = 1;
-      }
-      __syncthreads();
-      if (*s_flag) break;  // uniform
-      for (int i = b0 + 6 + tid; i <= R; i += kPanelThreads) {
-        double* row = A + (i < R ? i : W) * ld;
-        double a[6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) a[c] = row[b0 + c];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          double v = a[c];
-#pragma unroll
-          for (int k = 0; k < c; ++k) v -= a[k] * A[(b0 + c) * ld + b0 + k];
-          a[c] = v * rinv[b0 + c];
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) row[b0 + c] = a[c];
-      }
-      __syncthreads();
-      const int wc = w - b0 - 6;
-      if (wc > 0) {
-        for (int e = tid; e < (R + 1 - b0 - 6) * wc; e += kPanelThreads) {
-          const int i = b0 + 6 + e / wc, c = b0 + 6 + e % wc;
-          if (c > i && i < R) continue;  // strictly upper part (the rhs row keeps all columns)
-          double* row = A + (i < R ? i : W) * ld;
-          double acc = row[c];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) acc -= row[b0 + k] * A[c * ld + b0 + k];
-          row[c] = acc;
-        }
-        __syncthreads();
-      }
-    }
+    VS_BAND_LAP(0)  // prefetch issue
+    lds_barrier();  // X: the diagonal block of this column is factorised; the previous step's update is complete
+    VS_BAND_LAP(1)  // wait at X
     if (*s_flag) {
       if (tid == 0) *D.chol_fail = 1;
       return;
     }
-    // the rest of the window: 4 x 4 register tiles over rows w .. R (R = rhs) and columns w .. R - 1, lower triangle
-    {
-      const int tr_n = (R - w + 1 + 3) >> 2, tc_n = (R - w + 3) >> 2;
-      for (int t = tid; t < tr_n * tc_n; t += kPanelThreads) {
-        const int tr = t / tc_n, tc = t - tr * tc_n;
-        const int r0 = w + 4 * tr, c0 = w + 4 * tc;
-        if (c0 > r0 + 3 && r0 + 3 < R) continue;  // wholly above the diagonal and without the rhs row
-        const double* rp[4];
-        const double* cp[4];
+    // ---- column solve: thread t < m takes row c0 + 6 + t, thread m the right-hand side
+    if (tid <= m) {
+      double* row = tid < m ? A + slot(6 + tid) * ld : Y;
+      int sk[6];
+      double a[6];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int i = min(r0 + a, R);
-          rp[a] = A + (i < R ? i : W) * ld;
-          cp[a] = A + min(c0 + a, R - 1) * ld;
+      for (int c = 0; c < 6; ++c) {
+        sk[c] = slot(c);
+        a[c] = row[sk[c]];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double v = a[c];
+#pragma unroll
+        for (int k = 0; k < c; ++k) v -= a[k] * A[sk[c] * ld + sk[k]];
+        a[c] = v * rv[c];
+      }
+      double* out = tid < m ? D.S + (size_t)(c0 + 6 + tid) * n + c0 : D.bs + c0;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        row[sk[c]] = a[c];
+        out[c] = a[c];
+      }
+    }
+    VS_BAND_LAP(2)  // solve
+    lds_barrier();  // Y
+    VS_BAND_LAP(3)  // wait at Y
+    if (m <= 0) break;
+    if (wv == 0) {
+      diag(c0 + 6, slot(6), true);
+    } else {
+      int sk[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sk[k] = slot(k);
+      const int t = tid - 64;
+      // 2 x 2 tiles of the trailing lower triangle, rows / columns 6 + 2 tr + {0, 1}, without the next diagonal block (tr < 3)
+      const int nt = (m + 1) >> 1, total = nt * (nt + 1) / 2;
+      for (int e = t + 6; e < total; e += kBandLoaders) {
+        int tr = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (tr * (tr + 1) / 2 > e) --tr;
+        while ((tr + 1) * (tr + 2) / 2 <= e) ++tr;
+        const int tc = e - tr * (tr + 1) / 2;
+        const int i0 = 2 * tr, j0 = 2 * tc;  // relative to c0 + 6
+        const int i1 = min(i0 + 1, m - 1);
+        const int si0 = slot(6 + i0), si1 = slot(6 + i1), sj0 = slot(6 + j0), sj1 = slot(6 + j0 + 1);  // j0 + 1 <= i0 + 1 <= m: a slot in the ring even when unused
+        double acc00 = A[si0 * ld + sj0], acc01 = A[si0 * ld + sj1], acc10 = A[si1 * ld + sj0], acc11 = A[si1 * ld + sj1];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const double r0 = A[si0 * ld + sk[k]], r1 = A[si1 * ld + sk[k]], q0 = A[sj0 * ld + sk[k]], q1 = A[sj1 * ld + sk[k]];
+          acc00 -= r0 * q0;
+          acc01 -= r0 * q1;
+          acc10 -= r1 * q0;
+          acc11 -= r1 * q1;
         }
-        double acc[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) acc[a][b] = rp[a][min(c0 + b, R - 1)];
-        for (int k = 0; k < w; ++k) {
-          double rv[4], cv[4];
-#pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            rv[a] = rp[a][k];
-            cv[a] = cp[a][k];
-          }
-#pragma unroll
-          for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] -= rv[a] * cv[b];
+        A[si0 * ld + sj0] = acc00;
+        if (j0 + 1 <= i0) A[si0 * ld + sj1] = acc01;
+        if (i0 + 1 < m) {
+          A[si1 * ld + sj0] = acc10;
+          A[si1 * ld + sj1] = acc11;  // j0 + 1 <= i0 + 1
         }
+      }
+      // the right-hand side entries of the trailing columns
+      for (int j = t; j < m; j += kBandLoaders) {
+        const int sj = slot(6 + j);
+        double acc = Y[sj];
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int k = 0; k < 6; ++k) acc -= Y[sk[k]] * A[sj * ld + sk[k]];
+        Y[sj] = acc;
+      }
+      // the new rows
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            const int i = r0 + a, c = c0 + b;
-            if (i > R || c >= R || (c > i && i < R)) continue;
-            const_cast<double*>(rp[a])[c] = acc[a][b];
-          }
+      for (int q = 0; q < kBandNew; ++q) {
+        const int e = t + kBandLoaders * q, rr = e / (band + 6), cc = e - rr * (band + 6), g = g_first + rr;
+        if (rr < 6 && g < n) {
+          if (cc < band + rr) A[slot(band + 5 + rr) * ld + slot(6 + cc)] = nv[q];
+          else if (cc == band + 5) Y[slot(band + 5 + rr)] = nv[q];
+        }
       }
     }
-    // the finished panel (and its part of the forward-substituted rhs) to HBM
-    for (int e = tid; e < (R + 1) * w; e += kPanelThreads) {
-      const int i = e / w, c = e - i * w;
-      if (c <= i || i == R) chol_row(D, i < R ? j0 + i : n)[j0 + c] = A[(i < R ? i : W) * ld + c];
-    }
-    for (int c = tid; c < w; c += kPanelThreads) D.rinv[j0 + c] = rinv[c];
-    __syncthreads();
-    if (j0 + w >= n) break;
-    // slide: (i, c) -> (i - w, c - w) through registers, then the fresh rows
-    double mv[kBandShift];
-    const int keep_r = R - w + 1, keep_c = R - w;  // rows w .. R (rhs last), columns w .. R - 1
-#pragma unroll
-    for (int k = 0; k < kBandShift; ++k) {
-      const int e = tid + kPanelThreads * k;
-      if (e < keep_r * keep_c) {
-        const int i = w + e / keep_c, c = w + e % keep_c;
-        mv[k] = A[(i < R ? i : W) * ld + c];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < kBandShift; ++k) {
-      const int e = tid + kPanelThreads * k;
-      if (e < keep_r * keep_c) {
-        const int i = w + e / keep_c, c = w + e % keep_c;
-        A[(i < R ? i - w : W) * ld + c - w] = mv[k];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < kBandFetch; ++k) {
-      const int e = tid + kPanelThreads * k;
-      if (e < fresh * W) {
-        const int fr = e / W, c = e - fr * W, lr = R - w + fr;
-        if (c <= lr) A[lr * ld + c] = fv[k];
-      } else if (e < fresh * W + fresh) {
-        A[W * ld + (R - w) + (e - fresh * W)] = fv[k];
-      }
-    }
-    __syncthreads();
+    s0 = s0 + 6 >= WR ? s0 + 6 - WR : s0 + 6;
+    VS_BAND_LAP(4)  // diagonal block (wave 0) / update + new rows (the others)
   }
+#ifdef VS_BAND_STAMPS
+  if (lane == 0 && wv < 2)
+    printf("ba_chol_band n %d band %d wave %d: cycles prefetch issue %lld, wait X %lld, solve %lld, wait Y %lld, %s %lld, total %lld\n", n, band, wv, tb[0], tb[1], tb[2],
+           tb[3], wv ? "update" : "diagonal", tb[4], (long long)__builtin_readcyclecounter() - tbS);
+#endif
 }
 
 __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nbw) {
@@ -2041,6 +2063,70 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
   if (ok) {
     for (int i = tid; i < n; i += kPanelThreads) x[i] = D.bs[i];
     __syncthreads();
+    if (D.band > 0 && D.band <= 128) {
+      // Banded L: one wave, x in registers.  Lane l holds x[64 m + l] of the chunk being finished (xa) and of the two chunks
+      // below it (xb, xc: a band of at most 128 reaches no further); step k -- from the last unknown down -- broadcasts
+      // x_k = x[k] / L[k][k] out of its lane and subtracts L[k][i] x_k from every x_i the band reaches: each x_i receives
+      // its subtractions in descending k, one product at a time, exactly as the blocked form below orders them (same
+      // bits).  Row k of L is three coalesced loads that do not depend on x: eight rows are requested ahead.  A step is a
+      // lane read, a multiplication and three multiply / subtract pairs: ~50 cycles, against two LDS round trips and two
+      // barriers per unknown in the blocked form (210 -> 25 us at 594 unknowns).
+      if (tid < 64) {
+        const int band = D.band, nch = (n + 63) >> 6;
+        auto ld_y = [&](int ch) { const int i = 64 * ch + tid; return ch >= 0 && i < n ? x[i] : 0.0; };
+        double xa = ld_y(nch - 1), xb = ld_y(nch - 2), xc = ld_y(nch - 3);
+        constexpr int G = 8;
+        double la0[G], lb0[G], lc0[G], la1[G], lb1[G], lc1[G];  // two buffers, named apart: a run-time buffer index would put them in scratch
+        // rows k_hi, k_hi - 1, ... of chunk m, columns 64 (m - j) + lane.  The loads are unconditional (addresses clamped into
+        // the matrix) so that the compiler can count them: a conditional load makes every later wait a wait for all of them.
+        // What lies on or above the diagonal, beyond the band or outside the matrix is masked when the value is used.
+        auto fetch = [&](double* la, double* lb, double* lc, int m, int k_hi) {
+          const int ca = 64 * m + tid, a_ = min(ca, n - 1), b_ = max(ca - 64, 0), c_ = max(ca - 128, 0);
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const double* row = D.S + (size_t)max(k_hi - g, 64 * m) * n;
+            la[g] = row[a_];
+            lb[g] = row[b_];
+            lc[g] = row[c_];
+          }
+        };
+        auto lane_read = [](double v, int l) {  // v of lane l (uniform): two v_readlane_b32, not a trip through the LDS crossbar
+          const long long b = __double_as_longlong(v);
+          const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+          return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        };
+        for (int m = nch - 1; m >= 0; --m) {
+          const int k_top = min(n, 64 * m + 64) - 1;
+          const double ri = 64 * m + tid < n ? D.rinv[64 * m + tid] : 0.0;
+          const int ca = 64 * m + tid, cb = ca - 64, cc = ca - 128;
+          auto steps = [&](const double* la, const double* lb, const double* lc, int k_hi) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              const int k = k_hi - g;
+              if (k < 64 * m) break;  // uniform
+              const int kl = __builtin_amdgcn_readfirstlane(k & 63);
+              const double xk = lane_read(xa, kl) * lane_read(ri, kl);
+              if (tid == kl) xa = xk;
+              xa -= (ca < k && k - ca < band ? la[g] : 0.0) * xk;
+              xb -= (cb >= 0 && k - cb < band ? lb[g] : 0.0) * xk;
+              xc -= (cc >= 0 && k - cc < band ? lc[g] : 0.0) * xk;
+            }
+          };
+          fetch(la0, lb0, lc0, m, k_top);
+          for (int k_hi = k_top; k_hi >= 64 * m; k_hi -= 2 * G) {
+            fetch(la1, lb1, lc1, m, k_hi - G);
+            steps(la0, lb0, lc0, k_hi);
+            fetch(la0, lb0, lc0, m, k_hi - 2 * G);
+            steps(la1, lb1, lc1, k_hi - G);
+          }
+          if (64 * m + tid < n) x[64 * m + tid] = xa;
+          xa = xb;
+          xb = xc;
+          xc = ld_y(m - 3);
+        }
+      }
+      __syncthreads();
+    } else {
     // blocks of nbw rows from the bottom: triangular solve inside the block (wave 0), then one matvec for the rows above
     // (the block's triangle and pivots are brought into LDS first: read from global memory inside the serial loop, every
     // one of its steps waited for a round trip.  A banded system -- D.band -- has nothing but zeros above row k0 - band.)
@@ -2072,6 +2158,7 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
       }
       __syncthreads();
       k1 = k0;
+    }
     }
     for (int i = tid; i < n; i += kPanelThreads) D.xp[i] = x[i];
   }
@@ -3115,8 +3202,8 @@ int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& 
   if (P.lds) {
     hipLaunchKernelGGL(ba_solve_block, dim3(1), dim3(kSolveBlock), P.lds_bytes, s, D);
   } else if (P.band_ok && D.band > 0 && D.band <= kBandMax) {
-    hipLaunchKernelGGL(ba_chol_band, dim3(1), dim3(kPanelThreads), kBandLds, s, D, D.band);
-    hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64, s, D, kBandNbw);
+    hipLaunchKernelGGL(ba_chol_band, dim3(1), dim3(kPanelThreads), kBandLds, s, D, std::max(D.band, 12));  // (the look-ahead wants the next diagonal block inside the window)
+    hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64, s, D, 24);
   } else if (P.nbw > 0) {
     for (int j0 = 0; j0 < np; j0 += P.nbw) {
       const int w = std::min(P.nbw, np - j0);

@@ -94,6 +94,11 @@ __device__ __forceinline__ double vs_fast_rsq(double x) {
   return r;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the fence also waits
+// for every global load and store the wave has in flight (s_waitcnt vmcnt(0)): a kernel that streams results to HBM and
+// requests rows ahead while its waves meet through LDS would pay a memory round trip at every barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
