@@ -1842,40 +1842,51 @@ __global__ __launch_bounds__(256) void ba_chol_update(ba_dev D, int j0, int nbw)
 // time), so L is bit-identical to the dense path's; what lies outside the band is an exact zero there.
 // Round 3's form (24-column panels, the window slid through registers after each) spent 27 % of its 420 us at 594 unknowns
 // with 511 threads waiting for the diagonal lane, 30 % moving the window and writing panels, 22 % in the trailing update.
-constexpr int kBandMax = 6 * kWinCams, kBandRing = kBandMax + 12, kBandLd = kBandRing | 1;
-constexpr size_t kBandLds = sizeof(double) * ((size_t)kBandRing * kBandLd + kBandRing + 64) + 64;
-constexpr int kBandLoaders = kPanelThreads - 64;  // threads of the waves that do not factorise
+constexpr int kBandMax = 6 * kWinCams, kBandRing = kBandMax + 12, kBandLd = kBandRing | 1, kBandPld = kBandMax + 8;
+constexpr size_t kBandLds = sizeof(double) * ((size_t)kBandRing * kBandLd + kBandRing + 6 * kBandPld + 128) + 64;
+constexpr int kBandThreads = 1024, kBandLoaders = kBandThreads - 64;  // sixteen waves; fifteen of them update while wave 0 factorises the next diagonal block
 constexpr int kBandNew = (6 * (kBandMax + 6) + kBandLoaders - 1) / kBandLoaders;
 
-__global__ __launch_bounds__(kPanelThreads) void ba_chol_band(ba_dev D, int band) {
+__global__ __launch_bounds__(kBandThreads) void ba_chol_band(ba_dev D, int band) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   if (D.st->done) return;
   const int n = D.np, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int WR = band + 12;
-  constexpr int ld = kBandLd;
+  constexpr int ld = kBandLd, pld = kBandPld;
   double* A = s_mem;                     // [WR][ld] ring
   double* Y = A + kBandRing * ld;        // [WR] right-hand side entries by column slot
-  double* blk = Y + kBandRing;           // [21] the next diagonal block before its factorisation
+  double* P = Y + kBandRing;             // [6][pld] the solved block column, transposed: P[k][t] = L[c0 + 6 + t][c0 + k]
+  double* Ld = P + 6 * pld;              // [6][6] the factorised diagonal block
+  double* blk = Ld + 36;                 // [21] the next diagonal block before its factorisation
   double* rv = blk + 24;                 // [6] reciprocal pivots of the current block column
-  int* s_flag = reinterpret_cast<int*>(rv + 8);
+  double* yb = rv + 8;                   // [6] solved right-hand side entries of the current block column
+  int* s_flag = reinterpret_cast<int*>(yb + 8);
   {
     const int R0 = min(n, band + 5);
-    for (int e = tid; e < R0 * R0; e += kPanelThreads) {
+    for (int e = tid; e < R0 * R0; e += kBandThreads) {
       const int r = e / R0, c = e - r * R0;
       if (c <= r) A[r * ld + c] = D.S[(size_t)r * n + c];
     }
-    for (int c = tid; c < R0; c += kPanelThreads) Y[c] = D.bs[c];
+    for (int c = tid; c < R0; c += kBandThreads) Y[c] = D.bs[c];
   }
   if (tid == 0) {
     *s_flag = 0;
     *D.chol_fail = 0;
   }
   __syncthreads();
+#ifdef VS_BAND_STAMPS
+  long long td[5] = {0, 0, 0, 0, 0};
+#define VS_DIAG_LAP(k) { const long long t_ = __builtin_readcyclecounter(); td[k] += t_ - td0; td0 = t_; }
+#else
+#define VS_DIAG_LAP(k)
+#endif
   // the diagonal block whose first column is global column g0 (ring slot sg): lanes e < 21 of wave 0 bring its elements --
-  // after the rank-6 update by block column [g0 - 6, g0) when `upd` -- to `blk`, lane 0 factorises (ba_chol_panel's
-  // arithmetic), stores L in the ring and in HBM and the reciprocal pivots in rv / D.rinv
+  // after the rank-6 update by the block column in P when `upd` -- to `blk`, lane 0 factorises (ba_chol_panel's
+  // arithmetic), stores L in Ld and in HBM and the reciprocal pivots in rv / D.rinv
   auto diag = [&](int g0, int sg, bool upd) {
-    const int sp = sg >= 6 ? sg - 6 : sg - 6 + WR;  // slot of column g0 - 6
+#ifdef VS_BAND_STAMPS
+    long long td0 = __builtin_readcyclecounter();
+#endif
     if (lane < 21) {
       int r = 0, e = lane;
       while (e > r) e -= ++r;  // (r, c): lane = r (r + 1) / 2 + c
@@ -1884,14 +1895,12 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_band(ba_dev D, int band
       double acc = A[sr * ld + sc];
       if (upd) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          const int sk = sp + k >= WR ? sp + k - WR : sp + k;
-          acc -= A[sr * ld + sk] * A[sc * ld + sk];
-        }
+        for (int k = 0; k < 6; ++k) acc -= P[k * pld + r] * P[k * pld + c];
       }
       blk[lane] = acc;
     }
     wave_lds_sync();
+    VS_DIAG_LAP(0)
     if (lane == 0) {
       double L[6][6], ri[6];
       int good = 1;
@@ -1899,6 +1908,10 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_band(ba_dev D, int band
       for (int r = 0; r < 6; ++r)
 #pragma unroll
         for (int c = 0; c <= r; ++c) L[r][c] = blk[r * (r + 1) / 2 + c];
+#ifdef VS_BAND_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      VS_DIAG_LAP(1)
+#endif
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         const double d = L[c][c];
@@ -1919,23 +1932,22 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_band(ba_dev D, int band
       }
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        const int sr = sg + r >= WR ? sg + r - WR : sg + r;
 #pragma unroll
         for (int c = 0; c <= r; ++c) {
-          const int sc = sg + c >= WR ? sg + c - WR : sg + c;
-          A[sr * ld + sc] = L[r][c];
+          Ld[6 * r + c] = L[r][c];
           D.S[(size_t)(g0 + r) * n + g0 + c] = L[r][c];
         }
         rv[r] = ri[r];
         D.rinv[g0 + r] = ri[r];
       }
       if (!good) *s_flag = 1;
+      VS_DIAG_LAP(2)
     }
   };
   if (wv == 0) diag(0, 0, false);
   int s0 = 0;  // ring slot of column c0
 #ifdef VS_BAND_STAMPS
-  long long tb[6] = {0, 0, 0, 0, 0, 0}, tb0 = __builtin_readcyclecounter(), tbS = tb0;
+  long long tb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tb0 = __builtin_readcyclecounter(), tbS = tb0;
 #define VS_BAND_LAP(k) { const long long t_ = __builtin_readcyclecounter(); tb[k] += t_ - tb0; tb0 = t_; }
 #else
 #define VS_BAND_LAP(k)
@@ -1966,25 +1978,22 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_band(ba_dev D, int band
     }
     // ---- column solve: thread t < m takes row c0 + 6 + t, thread m the right-hand side
     if (tid <= m) {
-      double* row = tid < m ? A + slot(6 + tid) * ld : Y;
-      int sk[6];
+      const double* row = tid < m ? A + slot(6 + tid) * ld : Y;
       double a[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        sk[c] = slot(c);
-        a[c] = row[sk[c]];
-      }
+      for (int c = 0; c < 6; ++c) a[c] = row[slot(c)];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         double v = a[c];
 #pragma unroll
-        for (int k = 0; k < c; ++k) v -= a[k] * A[sk[c] * ld + sk[k]];
+        for (int k = 0; k < c; ++k) v -= a[k] * Ld[6 * c + k];
         a[c] = v * rv[c];
       }
       double* out = tid < m ? D.S + (size_t)(c0 + 6 + tid) * n + c0 : D.bs + c0;
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
-        row[sk[c]] = a[c];
+        if (tid < m) P[c * pld + tid] = a[c];
+        else yb[c] = a[c];
         out[c] = a[c];
       }
     }
@@ -1995,44 +2004,45 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_band(ba_dev D, int band
     if (wv == 0) {
       diag(c0 + 6, slot(6), true);
     } else {
-      int sk[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) sk[k] = slot(k);
       const int t = tid - 64;
-      // 2 x 2 tiles of the trailing lower triangle, rows / columns 6 + 2 tr + {0, 1}, without the next diagonal block (tr < 3)
+      // 2 x 2 tiles of the trailing lower triangle, rows 2 tr, 2 tr + 1 and columns 2 tc, 2 tc + 1 relative to c0 + 6, without
+      // the next diagonal block (tr < 3), which wave 0 owns.  One tile per thread and many waves per SIMD: a lone wave issues
+      // an FP64 multiply or add only every ~16 cycles (stamps: a 4 x 4 tile per thread on three waves took 4 000 cycles).
       const int nt = (m + 1) >> 1, total = nt * (nt + 1) / 2;
       for (int e = t + 6; e < total; e += kBandLoaders) {
         int tr = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while (tr * (tr + 1) / 2 > e) --tr;
         while ((tr + 1) * (tr + 2) / 2 <= e) ++tr;
         const int tc = e - tr * (tr + 1) / 2;
-        const int i0 = 2 * tr, j0 = 2 * tc;  // relative to c0 + 6
-        const int i1 = min(i0 + 1, m - 1);
-        const int si0 = slot(6 + i0), si1 = slot(6 + i1), sj0 = slot(6 + j0), sj1 = slot(6 + j0 + 1);  // j0 + 1 <= i0 + 1 <= m: a slot in the ring even when unused
-        double acc00 = A[si0 * ld + sj0], acc01 = A[si0 * ld + sj1], acc10 = A[si1 * ld + sj0], acc11 = A[si1 * ld + sj1];
+        const int i0 = 2 * tr, j0 = 2 * tc;
+        // (the ring length and every block start are even: a column pair never straddles the wrap)
+        const int sj = slot(6 + j0), si0 = slot(6 + i0) * ld, si1 = slot(6 + min(i0 + 1, m - 1)) * ld;
+        double acc00 = A[si0 + sj], acc01 = A[si0 + sj + 1], acc10 = A[si1 + sj], acc11 = A[si1 + sj + 1];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
-          const double r0 = A[si0 * ld + sk[k]], r1 = A[si1 * ld + sk[k]], q0 = A[sj0 * ld + sk[k]], q1 = A[sj1 * ld + sk[k]];
+          const double r0 = P[k * pld + i0], r1 = P[k * pld + i0 + 1], q0 = P[k * pld + j0], q1 = P[k * pld + j0 + 1];  // (beyond m: padding, never stored)
           acc00 -= r0 * q0;
           acc01 -= r0 * q1;
           acc10 -= r1 * q0;
           acc11 -= r1 * q1;
         }
-        A[si0 * ld + sj0] = acc00;
-        if (j0 + 1 <= i0) A[si0 * ld + sj1] = acc01;
+        A[si0 + sj] = acc00;
+        if (j0 + 1 <= i0) A[si0 + sj + 1] = acc01;
         if (i0 + 1 < m) {
-          A[si1 * ld + sj0] = acc10;
-          A[si1 * ld + sj1] = acc11;  // j0 + 1 <= i0 + 1
+          A[si1 + sj] = acc10;
+          A[si1 + sj + 1] = acc11;  // j0 + 1 <= i0 + 1
         }
       }
+      VS_BAND_LAP(5)
       // the right-hand side entries of the trailing columns
       for (int j = t; j < m; j += kBandLoaders) {
         const int sj = slot(6 + j);
         double acc = Y[sj];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc -= Y[sk[k]] * A[sj * ld + sk[k]];
+        for (int k = 0; k < 6; ++k) acc -= yb[k] * P[k * pld + j];
         Y[sj] = acc;
       }
+      VS_BAND_LAP(6)
       // the new rows
 #pragma unroll
       for (int q = 0; q < kBandNew; ++q) {
@@ -2047,9 +2057,10 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_band(ba_dev D, int band
     VS_BAND_LAP(4)  // diagonal block (wave 0) / update + new rows (the others)
   }
 #ifdef VS_BAND_STAMPS
-  if (lane == 0 && wv < 2)
-    printf("ba_chol_band n %d band %d wave %d: cycles prefetch issue %lld, wait X %lld, solve %lld, wait Y %lld, %s %lld, total %lld\n", n, band, wv, tb[0], tb[1], tb[2],
-           tb[3], wv ? "update" : "diagonal", tb[4], (long long)__builtin_readcyclecounter() - tbS);
+  if (tid == 0) printf("  diagonal block: update + sync %lld, load %lld, chain + stores %lld\n", td[0], td[1], td[2]);
+  if (lane == 0 && (wv < 2 || wv == 9 || wv == 15))
+    printf("ba_chol_band n %d band %d wave %d: cycles prefetch issue %lld, wait X %lld, solve %lld, wait Y %lld, %s %lld (tiles %lld, rhs %lld), total %lld\n", n, band, wv, tb[0], tb[1], tb[2],
+           tb[3], wv ? "new rows" : "diagonal", tb[4], tb[5], tb[6], (long long)__builtin_readcyclecounter() - tbS);
 #endif
 }
 
@@ -2069,10 +2080,10 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
       // x_k = x[k] / L[k][k] out of its lane and subtracts L[k][i] x_k from every x_i the band reaches: each x_i receives
       // its subtractions in descending k, one product at a time, exactly as the blocked form below orders them (same
       // bits).  Row k of L is three coalesced loads that do not depend on x: eight rows are requested ahead.  A step is a
-      // lane read, a multiplication and three multiply / subtract pairs: ~50 cycles, against two LDS round trips and two
-      // barriers per unknown in the blocked form (210 -> 25 us at 594 unknowns).
+      // dozen instructions of one wave (~110 cycles), against two LDS round trips and two barriers per unknown in the
+      // blocked form.
       if (tid < 64) {
-        const int band = D.band, nch = (n + 63) >> 6;
+        const int nch = (n + 63) >> 6;
         auto ld_y = [&](int ch) { const int i = 64 * ch + tid; return ch >= 0 && i < n ? x[i] : 0.0; };
         double xa = ld_y(nch - 1), xb = ld_y(nch - 2), xc = ld_y(nch - 3);
         constexpr int G = 8;
@@ -2098,18 +2109,22 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
         for (int m = nch - 1; m >= 0; --m) {
           const int k_top = min(n, 64 * m + 64) - 1;
           const double ri = 64 * m + tid < n ? D.rinv[64 * m + tid] : 0.0;
-          const int ca = 64 * m + tid, cb = ca - 64, cc = ca - 128;
+          const int ca = 64 * m + tid;
+          // A lone wave issues one instruction every ~9 cycles whatever it is (tools/f64_probe.hip), so a step is priced by its
+          // instruction count: the whole chunk is scaled by the reciprocal pivots in one instruction (lane k's product is
+          // x_k: its value no longer changes once step k is through, because the mask below keeps columns >= k out), x_k goes
+          // to scalar registers and is the scalar operand of the three multiplications.  Only the chunk on the diagonal needs a
+          // mask (above the diagonal S holds other data); outside the band L is an exact zero in memory, and lanes in front of
+          // column 0 (chunks m - 1, m - 2 of the first chunks) carry values that are never stored.
           auto steps = [&](const double* la, const double* lb, const double* lc, int k_hi) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
               const int k = k_hi - g;
               if (k < 64 * m) break;  // uniform
-              const int kl = __builtin_amdgcn_readfirstlane(k & 63);
-              const double xk = lane_read(xa, kl) * lane_read(ri, kl);
-              if (tid == kl) xa = xk;
-              xa -= (ca < k && k - ca < band ? la[g] : 0.0) * xk;
-              xb -= (cb >= 0 && k - cb < band ? lb[g] : 0.0) * xk;
-              xc -= (cc >= 0 && k - cc < band ? lc[g] : 0.0) * xk;
+              const double xk = lane_read(xa * ri, __builtin_amdgcn_readfirstlane(k & 63));
+              xa -= (ca < k ? la[g] : 0.0) * xk;
+              xb -= lb[g] * xk;
+              xc -= lc[g] * xk;
             }
           };
           fetch(la0, lb0, lc0, m, k_top);
@@ -2119,7 +2134,7 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
             fetch(la0, lb0, lc0, m, k_hi - 2 * G);
             steps(la1, lb1, lc1, k_hi - G);
           }
-          if (64 * m + tid < n) x[64 * m + tid] = xa;
+          if (64 * m + tid < n) x[64 * m + tid] = xa * ri;
           xa = xb;
           xb = xc;
           xc = ld_y(m - 3);
@@ -2189,14 +2204,21 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
       quat_to_w2n(t, q, dst + 7);
     }
   }
-  if (tid == 0) {
+  // gain denominator x^T (lambda x + b): one wave sums it (lane l takes the terms l, l + 64, ...; butterfly over the wave), as
+  // ba_solve_block does -- on one lane the 594 terms of the scaled run were 13 us of dependent instructions
+  if (tid < 64) {
+    const double lambda = st->lambda;
     double sc = 0.0;
     if (ok)
-      for (int j = 0; j < n; ++j) sc += x[j] * (st->lambda * x[j] + D.bp[j]);
-    st->scale_pose = sc;
-    st->solve_ok = ok;
-    st->trials += 1;
-    if (!ok) st->not_pd += 1;
+      for (int j = tid; j < n; j += 64) sc += x[j] * (lambda * x[j] + D.bp[j]);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) sc += __shfl_xor(sc, d);
+    if (tid == 0) {
+      st->scale_pose = sc;
+      st->solve_ok = ok;
+      st->trials += 1;
+      if (!ok) st->not_pd += 1;
+    }
   }
 }
 
@@ -3202,7 +3224,7 @@ int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& 
   if (P.lds) {
     hipLaunchKernelGGL(ba_solve_block, dim3(1), dim3(kSolveBlock), P.lds_bytes, s, D);
   } else if (P.band_ok && D.band > 0 && D.band <= kBandMax) {
-    hipLaunchKernelGGL(ba_chol_band, dim3(1), dim3(kPanelThreads), kBandLds, s, D, std::max(D.band, 12));  // (the look-ahead wants the next diagonal block inside the window)
+    hipLaunchKernelGGL(ba_chol_band, dim3(1), dim3(kBandThreads), kBandLds, s, D, std::max(D.band, 12));  // (the look-ahead wants the next diagonal block inside the window)
     hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64, s, D, 24);
   } else if (P.nbw > 0) {
     for (int j0 = 0; j0 < np; j0 += P.nbw) {
