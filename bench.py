@@ -407,9 +407,11 @@ def ba_scaled_leg(ctx):
             "lm_trials": trials, "mresiduals_per_s": n_res * trials / med / 1e6,
             "hbm_GBps_at_178B_per_residual": 178.0 * n_res * trials / med / 1e9,
             "chi2": [float(g["chi2_initial"]), float(g["chi2_final"])],
-            "note": "whole vs_ba_solve call: host structure passes (worker pool) + upload + kernels (banded Schur complement "
-                    "on the FP64 matrix cores, banded Cholesky in one launch) + read-back; checked against the CPU oracle by "
-                    "tools/ba_scaled.py --check (profiles/r03_ba_scaled.log)"}
+            "structure_built_on_device": bool(ctx.ba_structure_on_device()),
+            "note": "whole vs_ba_solve call: DMA of the pinned observation arrays + sparsity structure built on the device "
+                    "(csrc/vs_ba_build.hip) + kernels (banded Schur complement on the FP64 matrix cores, banded Cholesky with "
+                    "look-ahead in one launch) + read-back; checked against the CPU oracle by tools/ba_scaled.py --check "
+                    "(profiles/r04_ba_scaled.log); counter traffic in profiles/r04_ba_scaled_pmc.txt"}
 
 
 def frames_leg(ctx, cpu=True):

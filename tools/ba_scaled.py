@@ -24,20 +24,26 @@ def main():
     ap.add_argument("--window", type=int, default=10)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--win-per", type=int, default=0, help="points per slab of ba_schur_window (vs_tune_ba; 0: the plan's own)")
+    ap.add_argument("--reps", type=int, default=1)
     a = ap.parse_args()
     w = scene(a.cams, a.points, a.window)
     n_obs = len(w["obs_pose"])
     from visual_slam_amd.context import Context
     ctx = Context()
+    if a.win_per:
+        ctx.tune_ba(points_per_workgroup=a.win_per)
     kw = dict(huber_delta=np.sqrt(5.991), max_iterations=a.iters)
     if os.environ.get("PINNED", "1") == "1":  # the observation arrays in pinned memory: DMA-ed from where they lie
         for k in ("obs_pose", "obs_point", "obs_uv"):
             w[k] = ctx.pin(np.ascontiguousarray(w[k]))
     args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
     g = ctx.ba_solve(*args, **kw)
-    t0 = time.perf_counter()
-    g = ctx.ba_solve(*args, **kw)
-    dt = time.perf_counter() - t0
+    dt = 1e9
+    for _ in range(max(a.reps, 1)):
+        t0 = time.perf_counter()
+        g = ctx.ba_solve(*args, **kw)
+        dt = min(dt, time.perf_counter() - t0)
     trials = max(int(g["trials"]), 1)
     print("scene: %d cameras, %d points, %d residuals; reduced system %d x %d" % (a.cams, a.points, n_obs, 6 * (a.cams - 1), 6 * (a.cams - 1)))
     print("GPU: %.1f ms per solve (%d iterations, %d trials) = %.2f ms/trial, %.1f Mresiduals/s, %.1f GB/s at 178 B/residual; chi2 %.6g -> %.6g"

@@ -4330,7 +4330,10 @@ host_passes:
   if (timing)
     fprintf(stderr, "vs_ba_solve: structure %.1f us, arena fill %.1f us, upload + kernels %.1f us, read-back %.1f us (upload %zu B; window plan %.1f us inside the fill, %d slabs)\n",
             us(t_begin, t_struct), us(t_struct, t_filled), us(t_filled, t_solved), us(t_solved, now()), upload_bytes, win_plan_us, win ? ns : 0);
-  if (timing)
+  if (timing && dev)
+    fprintf(stderr, "  structure on the device: reserve + carve %.1f, slot tables %.1f, start state + DMA of the observation arrays + build kernels + read-back %.1f us\n", lap_us[0],
+            lap_us[1], lap_us[2]);
+  else if (timing)
     fprintf(stderr, "  fill: reserve + carve %.1f, tables + records %.1f, per-point pass %.1f, ranks %.1f, window plan %.1f, states %.1f us (%d threads)\n", lap_us[0],
             lap_us[1], lap_us[2], lap_us[3], lap_us[4], lap_us[5], T);
   res->iterations = hst->it;
