@@ -162,12 +162,8 @@ __device__ inline double scale_err(const double* t1, const double* t2, double me
 template <int T, bool SECOND_IS_MAX>
 __device__ inline void block_reduce2(double& a, double& b, double* s_red) {
   constexpr int kW = T / 64;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    a += __shfl_xor(a, d);
-    const double o = __shfl_xor(b, d);
-    b = SECOND_IS_MAX ? fmax(b, o) : b + o;
-  }
+  a = vs_group_reduce<6>(a);
+  b = vs_group_reduce<6, SECOND_IS_MAX>(b);
   const int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
     s_red[wv] = a;
@@ -187,16 +183,12 @@ __device__ inline void block_reduce2(double& a, double& b, double* s_red) {
 __device__ inline double wave_sum_partials(const double* v, int n) {
   double a = 0.0;
   for (int i = threadIdx.x; i < n; i += 64) a += v[i];
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) a += __shfl_xor(a, d);
-  return a;
+  return vs_group_reduce<6>(a);
 }
 __device__ inline double wave_max_partials(const double* v, int n) {
   double a = 0.0;
   for (int i = threadIdx.x; i < n; i += 64) a = fmax(a, v[i]);
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) a = fmax(a, __shfl_xor(a, d));
-  return a;
+  return vs_group_reduce<6, true>(a);
 }
 
 // ------------------------------------------------------------------------------------------------ linearize
@@ -256,13 +248,11 @@ __device__ inline double linearize_point(const ba_dev& D, const lin_view& L, con
     }
   }
   if (ls >= 0) {  // uniform inside the lane group
+    static_assert(kPtLanes == 8, "vs_group_reduce<3>");
 #pragma unroll
-    for (int d = 1; d < kPtLanes; d <<= 1) {
+    for (int k = 0; k < 9; ++k) H[k] = vs_group_reduce<3>(H[k]);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) H[k] += __shfl_xor(H[k], d);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) b[k] += __shfl_xor(b[k], d);
-    }
+    for (int k = 0; k < 3; ++k) b[k] = vs_group_reduce<3>(b[k]);
     if (sub == 0) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) L.Hll[9 * (size_t)ls + k] = H[k];
@@ -1683,8 +1673,7 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
     double sc = 0.0;
     if (ok)
       for (int j = lane; j < n; j += 64) sc += x[j] * (lambda * x[j] + s_bp[j]);
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) sc += __shfl_xor(sc, d);
+    sc = vs_group_reduce<6>(sc);
     if (lane == 0) {
       st->scale_pose = sc;
       st->solve_ok = ok;
@@ -2211,8 +2200,7 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
     double sc = 0.0;
     if (ok)
       for (int j = tid; j < n; j += 64) sc += x[j] * (lambda * x[j] + D.bp[j]);
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) sc += __shfl_xor(sc, d);
+    sc = vs_group_reduce<6>(sc);
     if (tid == 0) {
       st->scale_pose = sc;
       st->solve_ok = ok;
@@ -2324,9 +2312,7 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
           for (int k = 0; k < 6; ++k) part[b] += B[3 * k + b] * xc[k];
       }
 #pragma unroll
-      for (int d = 1; d < kPtLanes; d <<= 1)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) part[b] += __shfl_xor(part[b], d);
+      for (int b = 0; b < 3; ++b) part[b] = vs_group_reduce<3>(part[b]);
       const double cl[3] = {L.bl[3 * (size_t)ls] - part[0], L.bl[3 * (size_t)ls + 1] - part[1], L.bl[3 * (size_t)ls + 2] - part[2]};
       const double* Di = D.Dinv + 9 * (size_t)ls;
 #pragma unroll

@@ -99,6 +99,36 @@ __device__ __forceinline__ double vs_fast_rsq(double x) {
 // requests rows ahead while its waves meet through LDS would pay a memory round trip at every barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Xor-butterfly sum (or maximum) over aligned groups of 2^STEPS lanes, every lane of a group ending with the same bits -- the
+// bits `for (d = 1; d < 2^STEPS; d <<= 1) v += __shfl_xor(v, d)` gives, without its two ds_bpermute round trips per step:
+// partners lane^1 and lane^2 by quad permutes, lane^4 by the half-row mirror and lane^8 by the row mirror (lane 7 - i / 15 - i
+// of the group holds what lane i^4 / i^8 holds once the smaller groups are uniform); across the four rows of 16 the row values
+// are read out and combined as the butterfly combines them, (r0 + r1) + (r2 + r3) -- addition and fmax commute.
+template <int STEPS, bool MAX = false>
+__device__ __forceinline__ double vs_group_reduce(double x) {
+  static_assert(STEPS >= 1 && STEPS <= 6 && STEPS != 5, "groups of 2, 4, 8, 16 lanes or the whole wave");
+#define VS_DPP_STEP(ctrl)                                                                                      \
+  {                                                                                                            \
+    const double o_ = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, false), \
+                                       __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, false)); \
+    x = MAX ? fmax(x, o_) : x + o_;                                                                            \
+  }
+  if (STEPS >= 1) VS_DPP_STEP(0xB1)   // quad_perm [1,0,3,2]
+  if (STEPS >= 2) VS_DPP_STEP(0x4E)   // quad_perm [2,3,0,1]
+  if (STEPS >= 3) VS_DPP_STEP(0x141)  // row_half_mirror
+  if (STEPS >= 4) VS_DPP_STEP(0x140)  // row_mirror
+#undef VS_DPP_STEP
+  if (STEPS == 6) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    x = MAX ? fmax(fmax(r0, r1), fmax(r2, r3)) : (r0 + r1) + (r2 + r3);
+  }
+  return x;
+}
+
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
