@@ -504,6 +504,40 @@ __global__ __launch_bounds__(kCamThreads) void ba_linearize(ba_dev D) {
   }
 }
 
+// The two roles as launches of their own, for large problems.  In the combined kernel a point block is a 512-thread workgroup
+// of which 256 threads work, with the camera role's register count (204): one workgroup per CU, ONE working wave per SIMD -- and
+// a lone wave issues an instruction only every ~9 cycles (tools/f64_probe.hip).  At 6 250 point blocks (the scaled run) that
+// was 24 rounds of 11 us; as 256-thread workgroups four of them share a CU.  (Small problems keep the single launch: there
+// the launch boundary is what counts.)
+__global__ __launch_bounds__(kPtThreads, 3) void ba_linearize_points(ba_dev D) {
+  __shared__ double s_red[2 * kPtThreads / 64];
+  const int tid = threadIdx.x;
+  const int a = blockIdx.x * kPtPerBlock + tid / kPtLanes, sub = tid % kPtLanes;
+  const bool mine = a < D.n_act;
+  const int p = mine ? D.act_pt[a] : 0;
+  const lm_state st = *D.st;
+  if (st.done || !st.need_lin) return;
+  const double* cams = D.cam[st.cur];
+  const double* pts = D.pts[st.cur];
+  const lin_view L = lin_of(D, st.cur);
+  double chi = 0.0, maxd = 0.0;
+  if (mine) {
+    const double X[3] = {pts[3 * (size_t)p], pts[3 * (size_t)p + 1], pts[3 * (size_t)p + 2]};
+    chi = linearize_point(D, L, cams, X, a, D.pt_slot[p], sub, maxd);
+  }
+  double csum = chi, cmax = maxd;
+  block_reduce2<kPtThreads, true>(csum, cmax, s_red);  // (four wave values instead of eight: added in wave order either way)
+  if (tid == 0) {
+    D.part_chi[blockIdx.x] = csum;
+    D.part_maxd[blockIdx.x] = cmax;
+  }
+}
+__global__ __launch_bounds__(kCamThreads) void ba_linearize_cameras(ba_dev D) {
+  __shared__ double s_all[kCamThreads / 2][27];
+  __shared__ double s_grp[kCamThreads / 64][27];
+  linearize_camera(D, blockIdx.x / D.cam_split, blockIdx.x % D.cam_split, s_all, s_grp);
+}
+
 // chi2 of the scale edges for state buffer `buf` (few edges: one thread)
 __device__ inline double scale_edges_chi(const ba_dev& D, const double* cams) {
   double chi = 0.0;
@@ -885,7 +919,7 @@ constexpr int kWinCams = 16, kWinN = 6 * kWinCams, kWinBatch = 8, kWinK = 3 * kW
 constexpr int kWinSlabElems = kWinN * kWinN + kWinN, kWinPerMax = 512, kWinTilesPerWave = 6;
 typedef double win_d4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void ba_schur_window(ba_dev D) {
+__global__ __launch_bounds__(256, 2) void ba_schur_window(ba_dev D) {
   __shared__ __attribute__((aligned(16))) double sY[kWinK * kWinStride];
   __shared__ __attribute__((aligned(16))) double sH[kWinK * kWinStride];
   __shared__ double sD[kWinBatch][12];
@@ -4179,8 +4213,15 @@ host_passes:
   };
   auto launch_slot = [&](bool first) -> int {
     if (first || !spec) {  // spec: later states are linearised inside ba_point_trial (points) and ba_schur_small (cameras)
-      hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp * cam_split), dim3(kCamThreads), 0, s, D);
-      VS_LAUNCH_CHECK(ctx, "ba_linearize");
+      if (nb_pt >= 1024) {  // large problems: the two roles as launches of their own (see ba_linearize_points)
+        hipLaunchKernelGGL(ba_linearize_points, dim3(nb_pt), dim3(kPtThreads), 0, s, D);
+        VS_LAUNCH_CHECK(ctx, "ba_linearize_points");
+        if (nfp > 0) hipLaunchKernelGGL(ba_linearize_cameras, dim3(nfp * cam_split), dim3(kCamThreads), 0, s, D);
+        VS_LAUNCH_CHECK(ctx, "ba_linearize_cameras");
+      } else {
+        hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp * cam_split), dim3(kCamThreads), 0, s, D);
+        VS_LAUNCH_CHECK(ctx, "ba_linearize");
+      }
     }
     if (first) {
       hipLaunchKernelGGL(ba_lambda_init, dim3(1), dim3(64), 0, s, D);
