@@ -528,7 +528,30 @@ def _same_solve(a, b):
             and np.array_equal(a["points"], b["points"]))
 
 
-@pytest.mark.parametrize("case", ["banded", "fixed_points", "unobserved_points", "dense", "single_tile", "one_point_per_camera_run"])
+def _ragged_scene(seed=31, n_cams=300, n_points=70000):
+    """300 cameras on a track, three of them fixed (one in the middle of the window), every point seen from 2 .. 12 cameras out of a
+    neighbourhood of 14, in random camera order: ragged observation ranges, Hpl-less observations of free points everywhere."""
+    r = np.random.default_rng(seed)
+    fx, fy, cx, cy = ICL_NUIM_K
+    poses = np.tile(np.eye(4), (n_cams, 1, 1))
+    poses[:, 0, 3] = 0.1 * np.arange(n_cams)
+    start = r.integers(0, n_cams - 14, n_points)
+    cnt = r.integers(2, 13, n_points)
+    pts = np.stack([0.1 * (start + 7) + r.uniform(-1, 1, n_points), r.uniform(-1.2, 1.2, n_points), r.uniform(2.5, 5.5, n_points)], 1)
+    cam = np.concatenate([start[j] + r.permutation(14)[:cnt[j]] for j in range(n_points)]).astype(np.int32)
+    pt = np.repeat(np.arange(n_points, dtype=np.int32), cnt)
+    pc = pts[pt] - poses[cam, :3, 3]
+    uv = np.stack([fx * pc[:, 0] / pc[:, 2] + cx, fy * pc[:, 1] / pc[:, 2] + cy], 1) + r.normal(0, 0.5, (len(cam), 2))
+    poses0 = poses.copy()
+    poses0[:, :3, 3] += r.normal(0, 0.01, (n_cams, 3))
+    fixed = np.zeros(n_cams, np.uint8)
+    fixed[[0, n_cams // 2, n_cams - 1]] = 1
+    poses0[fixed == 1] = poses[fixed == 1]
+    return dict(poses=poses0, pose_fixed=fixed, points=pts + r.normal(0, 0.03, pts.shape), point_fixed=np.zeros(n_points, np.uint8),
+                obs_pose=cam, obs_point=pt, obs_uv=uv, K=ICL_NUIM_K, poses_gt=poses)
+
+
+@pytest.mark.parametrize("case", ["banded", "fixed_points", "unobserved_points", "dense", "single_tile", "one_point_per_camera_run", "ragged"])
 def test_large_problem_structure_built_on_the_device_equals_the_host_passes(vs, case):
     """Round 4: problems with >= 400 000 observations in pinned arrays build their sparsity structure (observation ranges, Hpl
     blocks, per-camera lists, tile masks, the banded-window plan) on the device, from the device copy of the observation list
@@ -539,7 +562,7 @@ def test_large_problem_structure_built_on_the_device_equals_the_host_passes(vs, 
         n_cams, n_points, window = 30, 16000, 30     # every camera sees every point: no banded window, the tile kernel
     elif case == "single_tile":
         n_cams, n_points, window = 10, 45000, 10     # nine free cameras: ba_schur_small
-    w = _sliding_window_scene(n_cams, n_points, window, seed=21)
+    w = _ragged_scene() if case == "ragged" else _sliding_window_scene(n_cams, n_points, window, seed=21)
     if case == "fixed_points":      # fixed points seen from free cameras only: active observations without an Hpl block
         seen_by_0 = np.zeros(n_points, bool)
         seen_by_0[w["obs_point"][w["obs_pose"] == 0]] = True
@@ -559,6 +582,22 @@ def test_large_problem_structure_built_on_the_device_equals_the_host_passes(vs, 
     assert on_device, "the device-side structure was not taken"
     assert d["trials"] >= 2 and d["chi2_final"] < d["chi2_initial"]
     assert _same_solve(d, h)
+
+
+def test_device_structure_over_repeated_calls_of_changing_size(vs):
+    """the arena and the flag words are reused from call to call: scenes of different sizes, a fall-back in between, the first scene
+    again -- every device-built solve equals the host-built one, and the first result comes back bit for bit"""
+    scenes = [_sliding_window_scene(40, 45000, 10, seed=41), _ragged_scene(seed=42, n_cams=120, n_points=60000), _sliding_window_scene(25, 50000, 9, seed=43)]
+    first = None
+    for k in (0, 1, 2, 0):
+        d, h, on_device = _solve_both_ways(vs, scenes[k])
+        assert on_device and _same_solve(d, h), k
+        if k == 0 and first is None:
+            first = d
+            bad = dict(scenes[0], obs_point=scenes[0]["obs_point"][::-1].copy(), obs_pose=scenes[0]["obs_pose"][::-1].copy(), obs_uv=scenes[0]["obs_uv"][::-1].copy())
+            d2, h2, dev2 = _solve_both_ways(vs, bad)   # descending points: not grouped in ascending order -> host passes
+            assert not dev2 and _same_solve(d2, h2)
+    assert _same_solve(d, first)
 
 
 def test_large_problems_the_device_structure_does_not_cover_fall_back_to_the_host_passes(vs):
