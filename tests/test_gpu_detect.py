@@ -134,8 +134,11 @@ def test_saturated_and_extreme_images(vs, oracle):
 def test_frames_alternating_through_one_pinned_buffer(vs, oracle):
     """Different frames alternate through ONE pinned buffer (same addresses, new contents every call, DMA-ed from where they lie)
     for several hundred calls: no cache and no resident copy may ever serve rows of an earlier frame.  Plus assorted shapes, a
-    pageable frame (staged) -- every result compared with the oracle's.  (Written for round 4's chunked upload, which was
-    measured and dropped -- profiles/tried_and_dropped.md -- and kept for the plain path.)"""
+    pageable frame (staged) -- every result compared with the oracle's.  Since round 4 a pinned frame whose width is a multiple
+    of 4 and whose bands all fit on the device at once is not copied at all: detect_band_kernel reads its own rows from the
+    pinned memory, publishes them as gray rows behind a per-band flag (this frame's sequence number) and takes its halo from
+    the neighbours' -- stale rows of the previous frame in the gray image, or a flag of an earlier frame, would show up here.
+    Shapes that do not qualify (width not a multiple of 4, more bands than compute units) take the copy."""
     from visual_slam_amd.workloads import synthetic_frame
     frames = [icl_frame(i) for i in (0, 5, 10, 150)] + [synthetic_frame(640, 480, s) for s in (2, 7)]
     want = [oracle.detect_describe_bgr(f, 20, 3000) for f in frames]
@@ -146,7 +149,7 @@ def test_frames_alternating_through_one_pinned_buffer(vs, oracle):
         xy, sc, desc = vs.detect_describe_bgr(buf, 20, 3000)
         oxy, osc, odesc = want[k]
         assert np.array_equal(xy, oxy) and np.array_equal(sc, osc) and np.array_equal(desc, odesc), (it, k)
-    for w, h in ((640, 480), (321, 243), (100, 64), (1280, 720)):   # pinned, assorted shapes (some take the plain upload)
+    for w, h in ((640, 480), (321, 243), (100, 64), (1280, 720), (644, 480), (64, 16), (320, 600), (8, 8)):   # pinned, assorted shapes
         f = vs.pin(synthetic_frame(w, h, w + h))
         for _ in range(3):
             xy, sc, desc = vs.detect_describe_bgr(f, 20, 3000)

@@ -16,6 +16,8 @@
 //                        row-major output slot; one wave per keypoint evaluates the 256 BRIEF tests, 64 per ballot.
 // Everything is integer work and bit-exact against oracle/vs_oracle.c.
 #include "vs_internal.h"
+
+#include <chrono>
 #include "../../include/vs_brief_pattern.h"
 
 namespace {
@@ -91,7 +93,7 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 __device__ __forceinline__ int fast_div(int i, uint32_t magic) { return (int)__umulhi((uint32_t)i, magic); }
 __host__ inline uint32_t div_magic(int d) { return (uint32_t)((0x100000000ull + (uint64_t)d - 1) / (uint64_t)d); }
 
-template <bool FROM_BGR, bool DO_BOX, bool WRITE_GRAY>
+template <bool FROM_BGR, bool DO_BOX, bool WRITE_GRAY, bool HOSTSRC = false>
 __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t* __restrict__ img, int pitch, int w,
                                                                    int h, int thr, int border,
                                                                    uint8_t* __restrict__ gray_out,
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
                                                                    uint32_t* __restrict__ raw, int band_cap,
                                                                    int* __restrict__ bandcnt, int* __restrict__ bandhist,
                                                                    uint32_t magic_w, uint32_t magic_w4, uint32_t magic_gpr,
-                                                                   int* __restrict__ framehist) {
+                                                                   int* __restrict__ framehist, unsigned* band_flag, unsigned seq,
+                                                                   int* host_err) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   __shared__ int s_bhist[256];  // scores of this band's survivors (the cap of select_describe_kernel needs their histogram)
   if (threadIdx.x < 256) s_bhist[threadIdx.x] = 0;
@@ -120,7 +123,58 @@ __global__ __launch_bounds__(kDetThreads) void detect_band_kernel(const uint8_t*
   // kStageUnroll groups per thread are all issued before the first use (the frame is read once, at HBM latency).
   const int groups_per_row = w4 >> 2;
   const int ngroups = (kBand + 2 * kHalo) * groups_per_row;
-  for (int g0 = 0; g0 < ngroups; g0 += kDetThreads * kStageUnroll) {
+  if (HOSTSRC) {
+    // The frame is read WHERE IT LIES, in the caller's pinned host memory, and every workgroup fetches only its own kBand rows
+    // over the bus (with the halo each row would cross it five times): it converts them, keeps them in LDS and publishes them as
+    // gray words in HBM -- write-through stores, drained, then the band's flag = this frame's sequence number.  The halo rows
+    // are its neighbours' bands: it waits for their flags (all bands are resident at once -- the host checks that there are
+    // at least as many compute units -- so everybody's rows are on their way) and reads them from HBM past the L1.  The
+    // transfer and the detection overlap: a band starts as soon as its ten rows have arrived, not when the whole frame has.
+    uint32_t* gray_words = reinterpret_cast<uint32_t*>(gray_out);  // pitch w4
+    const int band = blockIdx.x, nbands_ = gridDim.x, own = kBand * groups_per_row;
+    // (16-byte pieces parked in LDS and converted from there were tried: 36 us per launch against 34 with the three dword loads
+    // per pixel group below -- a kernel reads the uncached host memory at ~27 GB/s either way, the copy engine at 51)
+    for (int g = tid; g < own; g += kDetThreads) {
+      const int r = fast_div(g, magic_gpr), x = (g - r * groups_per_row) << 2, y = y0 + r;
+      uint32_t packed = 0;
+      if (y < h) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(img + (size_t)y * pitch + 3 * x);
+        const uint32_t d0 = __builtin_nontemporal_load(p), d1 = __builtin_nontemporal_load(p + 1), d2 = __builtin_nontemporal_load(p + 2);
+        const uint32_t g0_ = ((d0 & 255) + ((d0 >> 8) & 255) + ((d0 >> 16) & 255)) / 3u;
+        const uint32_t g1_ = ((d0 >> 24) + (d1 & 255) + ((d1 >> 8) & 255)) / 3u;
+        const uint32_t g2_ = (((d1 >> 16) & 255) + (d1 >> 24) + (d2 & 255)) / 3u;
+        const uint32_t g3_ = (((d2 >> 8) & 255) + ((d2 >> 16) & 255) + (d2 >> 24)) / 3u;
+        packed = g0_ | (g1_ << 8) | (g2_ << 16) | (g3_ << 24);
+        __hip_atomic_store(gray_words + (size_t)y * groups_per_row + (x >> 2), packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      *reinterpret_cast<uint32_t*>(s_gray + (kHalo + r) * P + x) = packed;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(band_flag + band, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 4) {  // the two bands above and the two below (kHalo = 2 kBand)
+      const int nb = band + (tid < 2 ? tid - 2 : tid - 1);
+      if (nb >= 0 && nb < nbands_) {
+        int it = 0;
+        while ((int)(__hip_atomic_load(band_flag + nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) < 0) {
+          if (++it > (1 << 20)) {  // ~0.1 s: cannot happen with every band resident; reported, never silent
+            *host_err = 1;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+    }
+    __syncthreads();
+    for (int g = tid; g < 2 * kHalo * groups_per_row; g += kDetThreads) {
+      const int rr = fast_div(g, magic_gpr), x = (g - rr * groups_per_row) << 2;
+      const int r = rr < kHalo ? rr : rr + kBand, y = y0 - kHalo + r;
+      uint32_t packed = 0;
+      if (y >= 0 && y < h) packed = __hip_atomic_load(gray_words + (size_t)y * groups_per_row + (x >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *reinterpret_cast<uint32_t*>(s_gray + r * P + x) = packed;
+    }
+  }
+  for (int g0 = 0; !HOSTSRC && g0 < ngroups; g0 += kDetThreads * kStageUnroll) {
     uint32_t d[kStageUnroll][3];
     int lds_off[kStageUnroll];
 #pragma unroll
@@ -597,18 +651,18 @@ int frame_tables(vs_ctx* ctx, hipStream_t s, int** cur, int** next) {
   return VS_OK;
 }
 
-template <bool FROM_BGR, bool DO_BOX, bool WRITE_GRAY>
+template <bool FROM_BGR, bool DO_BOX, bool WRITE_GRAY, bool HOSTSRC = false>
 int launch_detect(vs_ctx* ctx, hipStream_t s, const uint8_t* d_img, int pitch, int w, int h, int thr, int border,
                   uint8_t* d_gray, uint16_t* d_box, uint32_t* d_raw, int band_cap, int* d_bandcnt, int* d_bandhist,
-                  int* d_framehist) {
+                  int* d_framehist, unsigned* d_bandflag = nullptr, unsigned seq = 0, int* host_err = nullptr) {
   const int nbands = (h + kBand - 1) / kBand;
   const size_t lds = detect_lds_bytes(w, DO_BOX);
-  auto fn = detect_band_kernel<FROM_BGR, DO_BOX, WRITE_GRAY>;
+  auto fn = detect_band_kernel<FROM_BGR, DO_BOX, WRITE_GRAY, HOSTSRC>;
   if (lds > 64 * 1024)
     VS_HIP(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int w4 = (w + 3) & ~3;
   hipLaunchKernelGGL(fn, dim3(nbands), dim3(kDetThreads), lds, s, d_img, pitch, w, h, thr, border, d_gray, d_box, d_raw,
-                     band_cap, d_bandcnt, d_bandhist, div_magic(w), div_magic(w4), div_magic(w4 >> 2), d_framehist);
+                     band_cap, d_bandcnt, d_bandhist, div_magic(w), div_magic(w4), div_magic(w4 >> 2), d_framehist, d_bandflag, seq, host_err);
   VS_LAUNCH_CHECK(ctx, "detect_band_kernel");
   return VS_OK;
 }
@@ -639,7 +693,29 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   const int cap = max_kp > 0 ? max_kp : 1;
   const result_layout L = make_layout(cap);
   int pitch = 0;
-  VS_TRY(upload_image(ctx, from_bgr ? &ctx->d_bgr : &ctx->d_gray, host_img, (from_bgr ? 3 : 1) * w, h, stride, &pitch));
+  static const bool kTiming = getenv("VS_DET_TIMING") != nullptr;  // developer aid: host phases on stderr
+  const auto t_begin = std::chrono::steady_clock::now();
+  // A pinned BGR frame (vs_host_alloc) is read where it lies by the detection kernel itself (detect_band_kernel<.., HOSTSRC>):
+  // no copy in front of the kernels, and the transfer overlaps the detection.  Needs every band resident at the same time.
+  static const bool kNoZeroCopy = getenv("VS_DET_NO_ZEROCOPY") != nullptr;  // developer aid (A/B)
+  bool zero_copy = false;
+  void* dev_view = nullptr;
+  if (from_bgr && !kNoZeroCopy && describe && (w & 3) == 0 && stride == 3 * w && ((uintptr_t)host_img & 3) == 0 && nbands <= ctx->prop.multiProcessorCount &&
+      kHalo == 2 * kBand && vs_is_pinned(host_img)) {
+    if (hipHostGetDevicePointer(&dev_view, const_cast<uint8_t*>(host_img), 0) == hipSuccess && dev_view) {
+      VS_TRY(vs_reserve(ctx, &ctx->d_gray, (size_t)w * h + 16));
+      if (ctx->d_bandflag.cap < sizeof(unsigned) * (size_t)nbands) {
+        VS_TRY(vs_reserve(ctx, &ctx->d_bandflag, sizeof(unsigned) * (size_t)nbands));
+        VS_HIP(ctx, hipMemsetAsync(ctx->d_bandflag.p, 0, sizeof(unsigned) * (size_t)nbands, ctx->stream));
+        ctx->det_seq = 0;
+      }
+      zero_copy = true;
+      pitch = 3 * w;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  if (!zero_copy) VS_TRY(upload_image(ctx, from_bgr ? &ctx->d_bgr : &ctx->d_gray, host_img, (from_bgr ? 3 : 1) * w, h, stride, &pitch));
   VS_TRY(vs_reserve(ctx, &ctx->d_box, sizeof(uint16_t) * (size_t)w * h));
   VS_TRY(vs_reserve(ctx, &ctx->d_raw, sizeof(uint32_t) * (size_t)nbands * band_cap));
   VS_TRY(vs_reserve(ctx, &ctx->d_bandcnt, sizeof(int) * (size_t)nbands));
@@ -658,7 +734,17 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
     VS_TRY(vs_desc_slot_for_output(ctx, (size_t)cap * VS_DESC_BYTES, &slot));
     if (slot) d_desc_out = (uint8_t*)slot->dev.p;
   }
-  if (from_bgr) {
+  if (zero_copy) {
+    if (++ctx->det_seq == 0x7FFFFFFFu) {  // the flags only ever grow: start over long before the comparison could wrap
+      VS_HIP(ctx, hipMemsetAsync(ctx->d_bandflag.p, 0, sizeof(unsigned) * (size_t)nbands, s));
+      ctx->det_seq = 1;
+    }
+    int* host_err = reinterpret_cast<int*>(ctx->h_pin.p) + 1;  // second word of the pinned result block's header
+    *host_err = 0;
+    VS_TRY((launch_detect<true, true, false, true>(ctx, s, (const uint8_t*)dev_view, pitch, w, h, thr, border, (uint8_t*)ctx->d_gray.p, (uint16_t*)ctx->d_box.p,
+                                                   (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p, fh,
+                                                   (unsigned*)ctx->d_bandflag.p, ctx->det_seq, host_err)));
+  } else if (from_bgr) {
     VS_TRY((launch_detect<true, true, false>(ctx, s, d_img, pitch, w, h, thr, border, nullptr, (uint16_t*)ctx->d_box.p,
                                              (uint32_t*)ctx->d_raw.p, band_cap, (int*)ctx->d_bandcnt.p, (int*)ctx->d_hist.p, fh)));
   } else if (describe) {
@@ -681,9 +767,12 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
                        (unsigned)L.off_desc);
   }
   VS_LAUNCH_CHECK(ctx, "select_describe_kernel");
+  const auto t_enq = std::chrono::steady_clock::now();
   VS_HIP(ctx, hipStreamSynchronize(s));  // the results are in the pinned block already (written by the kernel itself)
+  const auto t_sync = std::chrono::steady_clock::now();
   const uint8_t* hp = (const uint8_t*)ctx->h_pin.p;
   const int n = *(const int*)hp;
+  if (zero_copy && reinterpret_cast<const int*>(hp)[1] != 0) return vs_fail(ctx, VS_EHIP, "%s: a band never saw its neighbours' rows (frame read from pinned memory)", fn);
   if (n < 0 || n > cap) return vs_fail(ctx, VS_EHIP, "%s: device returned an impossible keypoint count", fn);
   memcpy(xy, hp + L.off_xy, (size_t)n * 8);
   if (score) memcpy(score, hp + L.off_score, (size_t)n);
@@ -694,6 +783,11 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
     if (slot) vs_desc_adopt_slot(ctx, slot, desc, n, hp + L.off_desc);
   }
   *n_out = n;
+  if (kTiming) {
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "%s: enqueue %.1f us (%s), wait %.1f us, copy out %.1f us\n", fn, us(t_begin, t_enq), zero_copy ? "frame read where it lies" : "frame copied first",
+            us(t_enq, t_sync), us(t_sync, std::chrono::steady_clock::now()));
+  }
   return VS_OK;
 }
 

@@ -101,6 +101,8 @@ struct vs_ctx {
   vs_buf d_bgr, d_gray, d_box, d_raw, d_bandcnt, d_hist, d_xy, d_score, d_desc, d_n, d_xy_in, d_keep;
   vs_buf d_framehist;  // two 256-entry suffix-sum score tables of whole frames, used alternately (vs_detect.hip)
   int det_parity = 0;
+  vs_buf d_bandflag;       // per band: sequence number of the newest frame whose gray rows of that band are in d_gray (frames read where they lie)
+  unsigned det_seq = 0;
   // bundle adjustment
   vs_buf d_ba;      // one arena, carved per solve
   vs_buf h_pin;     // pinned staging (small read-backs)
