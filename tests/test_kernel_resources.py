@@ -21,7 +21,7 @@ def meta():
     return kernel_meta()
 
 
-CHAIN = ["detect_band_kernel<true, true, false>(", "select_describe_kernel<true>(", "hamming_knn2_kernel<true>(",
+CHAIN = ["detect_band_kernel<true, true, false, false>(", "select_describe_kernel<true>(", "hamming_knn2_kernel<true>(",
          "hamming_knn2_kernel<false>(", "ratio_compact_kernel(", "track_append_kernel(", "track_publish_kernel(",
          "vsba::pnp_ransac_kernel(", "vsba::ba_motion_persistent<false>("]
 
