@@ -700,7 +700,7 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   static const bool kNoZeroCopy = getenv("VS_DET_NO_ZEROCOPY") != nullptr;  // developer aid (A/B)
   bool zero_copy = false;
   void* dev_view = nullptr;
-  if (from_bgr && !kNoZeroCopy && describe && (w & 3) == 0 && stride == 3 * w && ((uintptr_t)host_img & 3) == 0 && nbands <= ctx->prop.multiProcessorCount &&
+  if (from_bgr && !kNoZeroCopy && !ctx->det_copy_only && describe && (w & 3) == 0 && stride == 3 * w && ((uintptr_t)host_img & 3) == 0 && nbands <= ctx->prop.multiProcessorCount &&
       kHalo == 2 * kBand && vs_is_pinned(host_img)) {
     if (hipHostGetDevicePointer(&dev_view, const_cast<uint8_t*>(host_img), 0) == hipSuccess && dev_view) {
       VS_TRY(vs_reserve(ctx, &ctx->d_gray, (size_t)w * h + 16));
@@ -772,7 +772,12 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   const auto t_sync = std::chrono::steady_clock::now();
   const uint8_t* hp = (const uint8_t*)ctx->h_pin.p;
   const int n = *(const int*)hp;
-  if (zero_copy && reinterpret_cast<const int*>(hp)[1] != 0) return vs_fail(ctx, VS_EHIP, "%s: a band never saw its neighbours' rows (frame read from pinned memory)", fn);
+  if (zero_copy && reinterpret_cast<const int*>(hp)[1] != 0) {
+    // a band gave up waiting for its neighbours' rows (bounded wait; the device must have been shared with long-running foreign
+    // work): this frame is done again through the copy, and so is every later one of this context
+    ctx->det_copy_only = true;
+    return detect_common(ctx, true, host_img, w, h, stride, thr, border, max_kp, describe, xy, score, desc, n_out, fn);
+  }
   if (n < 0 || n > cap) return vs_fail(ctx, VS_EHIP, "%s: device returned an impossible keypoint count", fn);
   memcpy(xy, hp + L.off_xy, (size_t)n * 8);
   if (score) memcpy(score, hp + L.off_score, (size_t)n);

@@ -103,6 +103,7 @@ struct vs_ctx {
   int det_parity = 0;
   vs_buf d_bandflag;       // per band: sequence number of the newest frame whose gray rows of that band are in d_gray (frames read where they lie)
   unsigned det_seq = 0;
+  bool det_copy_only = false;  // a band once gave up waiting for its neighbours' rows: this context copies its frames from then on
   // bundle adjustment
   vs_buf d_ba;      // one arena, carved per solve
   vs_buf h_pin;     // pinned staging (small read-backs)
