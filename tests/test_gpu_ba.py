@@ -711,3 +711,28 @@ def test_window_plan_fits_the_arena_of_a_fresh_context(oracle, n_cams, n_points)
         ctx.close()
     o = oracle.ba_solve(*_args(w), max_iterations=2)
     _compare(g, o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cams,n_points,window", [(14, 140000, 3), (60, 50000, 9), (10, 42000, 10)])
+def test_device_built_structure_fits_the_arena_of_a_fresh_context(n_cams, n_points, window):
+    """the device-side structure carves its arrays and its temporaries (keys, block histograms, window order) out of the same
+    arena: on a FRESH context, first solve, with few cameras and many points (the case the round-3 reservation missed), a banded
+    and a single-tile window -- and the result equals the host passes' on another fresh context"""
+    from visual_slam_amd import Context, _capi
+    if _capi.device_count() == 0:
+        pytest.skip("no GPU in this machine")
+    w = _sliding_window_scene(n_cams, n_points, window, 77)
+    assert len(w["obs_pose"]) >= 400000
+    out = []
+    for on_host in (False, True):
+        ctx = Context(0)
+        try:
+            ctx.tune_ba_structure(on_host=on_host)
+            args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], ctx.pin(w["obs_pose"]), ctx.pin(w["obs_point"]), ctx.pin(w["obs_uv"]), w["K"])
+            out.append(ctx.ba_solve(*args, max_iterations=2))
+            assert ctx.ba_structure_on_device() == (not on_host)
+        finally:
+            ctx.close()
+    assert _same_solve(out[0], out[1])
+
