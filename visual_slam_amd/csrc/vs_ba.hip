@@ -3638,7 +3638,16 @@ host_passes:
                 (small_possible ? sizeof(double) * ((size_t)np * np + np + 12 * (size_t)nfl + 18 * (size_t)n_obs) + 5 * 256 : 0) + sizeof(double) * 8 * (size_t)(res->trial_trace ? std::max(res->trial_trace_cap, 0) : 0) + (motion_only ? sizeof(double) * (8 * (size_t)n_cam_obs + 50 * (size_t)nfp + 64) : 0);
   if (dev) need += sizeof(int) * (ba_build_temp_ints(n_obs, nfp, nfl) + (size_t)nfl + 2 * (size_t)ns_win_bound + nfp + 64) + 4096;
   VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
-  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, need));
+  // the pinned mirror covers what is uploaded from it or read back into it.  Host passes: the structure arrays, i.e. nearly
+  // everything; device-built structure: the slot tables, the start state, the read-back block and a few flag words -- a few MB behind
+  // the (device-only) observation arrays at the front of the arena, not the whole gigabyte (pinning it cost 0.23 s on a context's
+  // first large solve)
+  const int trial_cap_early = res->trial_trace && res->trial_trace_cap > 0 ? res->trial_trace_cap : 0;
+  const size_t out_elems_early = 32 + (size_t)F * kCamStride + 3 * (size_t)P + 2 * (size_t)p->max_iterations + 4 * (size_t)trial_cap_early;
+  const size_t pin_need = !dev ? need
+                               : (size_t)24 * n_obs + sizeof(int) * ((size_t)F + P + 3 * (size_t)nfp + 2 * (size_t)p->n_scale + 256) +
+                                     sizeof(double) * ((size_t)p->n_scale + (size_t)F * kCamStride + 3 * (size_t)P + out_elems_early + 256) + 256 * 40 + (1u << 16);
+  VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, pin_need));
   VS_HIP(ctx, hipStreamSynchronize(s));
   arena A;
   A.base = (uint8_t*)ctx->d_ba.p;
@@ -3785,6 +3794,7 @@ host_passes:
   }
   lap(1);  // slot tables, observation records
   int mmax = 1, dups = 0, a_idx = 0, k_hpl = 0, max_rank = 0;
+  double *d_out_pre = nullptr, *h_out_pre = nullptr;  // device-built structure: the read-back block, carved early (see there)
   auto t_win0 = now();
   bool win = false;
   int win_n = 0, win_per = 0, ns_win = 0, win_cams = 0;
@@ -3797,6 +3807,11 @@ host_passes:
     VS_HIP(ctx, hipMemcpyAsync(A.base + upload_begin, A.host + upload_begin, upload_bytes - upload_begin, hipMemcpyHostToDevice, s));
     ba_build B;
     memset(&B, 0, sizeof B);
+    // what comes BACK into the pinned mirror sits right behind the uploaded part: the read-back block of ba_export and the flag words
+    d_out_pre = A.take<double>(out_elems_early, &h_out_pre);
+    int* h_binfo;
+    B.info = A.take<int>(kBuildInfoInts, &h_binfo);
+    if (A.off > ctx->h_pin_big.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error (pinned mirror)", "vs_ba_solve");
     B.o_cam = D.o_cam;
     B.o_pt = D.o_pt;
     B.pose_slot = D.pose_slot;
@@ -3826,8 +3841,6 @@ host_passes:
       B.win_len = A.take<int>(ns_win_bound);
       B.win_first = A.take<int>((size_t)nfp + 1);
     }
-    int* h_binfo;
-    B.info = A.take<int>(kBuildInfoInts, &h_binfo);
     const size_t nblk_o = ((size_t)n_obs + 1023) / 1024, nblk_p = ((size_t)nfl + 1023) / 1024, ncols = (size_t)nfp + 2;
     B.ckey = A.take<int>(n_obs);
     B.wkey = A.take<int>(nfl);
@@ -4151,8 +4164,8 @@ host_passes:
     D.mo_H = A.take<double>(42 * (size_t)nfp);
   }
   const size_t out_elems = 32 + (size_t)F * kCamStride + 3 * (size_t)P + 2 * (size_t)q.max_iterations + 4 * (size_t)trial_cap;
-  double* h_out = nullptr;
-  double* d_out = A.take<double>(out_elems, &h_out);  // ba_export's block and its pinned landing place
+  double* h_out = h_out_pre;
+  double* d_out = d_out_pre ? d_out_pre : A.take<double>(out_elems, &h_out);  // ba_export's block and its pinned landing place
   if (A.off > ctx->d_ba.cap) return vs_fail(ctx, VS_ENOMEM, "%s: internal arena sizing error", "vs_ba_solve");
 
   if (motion_only) {
