@@ -3649,6 +3649,10 @@ host_passes:
                                      sizeof(double) * ((size_t)p->n_scale + (size_t)F * kCamStride + 3 * (size_t)P + out_elems_early + 256) + 256 * 40 + (1u << 16);
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin_big, pin_need));
   VS_HIP(ctx, hipStreamSynchronize(s));
+  if (ctx->ba_aux_copy_pending) {  // an earlier call failed between its copy on the auxiliary stream and the wait for it
+    VS_HIP(ctx, hipStreamSynchronize(ctx->aux_stream[0]));
+    ctx->ba_aux_copy_pending = false;
+  }
   arena A;
   A.base = (uint8_t*)ctx->d_ba.p;
   A.host = (uint8_t*)ctx->h_pin_big.p;
@@ -3667,7 +3671,9 @@ host_passes:
     upload_begin = A.off;
     VS_HIP(ctx, hipMemcpyAsync((void*)D.o_cam, q.obs_pose, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, s));
     VS_HIP(ctx, hipMemcpyAsync((void*)D.o_pt, q.obs_point, sizeof(int) * (size_t)n_obs, hipMemcpyHostToDevice, s));
-    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_uv, q.obs_uv, sizeof(double) * 2 * (size_t)n_obs, hipMemcpyHostToDevice, s));
+    // (device-built structure: the image points -- two thirds of the bytes, and nothing the structure kernels read -- go up later,
+    // on an auxiliary stream, BEHIND the small tables, so that the structure is built while they are on the bus)
+    if (!dev) VS_HIP(ctx, hipMemcpyAsync((void*)D.o_uv, q.obs_uv, sizeof(double) * 2 * (size_t)n_obs, hipMemcpyHostToDevice, s));
   }
   D.n_poses = F;
   D.n_points = P;
@@ -3805,6 +3811,10 @@ host_passes:
     fill_states();
     upload_bytes = A.off;
     VS_HIP(ctx, hipMemcpyAsync(A.base + upload_begin, A.host + upload_begin, upload_bytes - upload_begin, hipMemcpyHostToDevice, s));
+    if (!ctx->ev_after) VS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_after, hipEventDisableTiming));
+    VS_HIP(ctx, hipMemcpyAsync((void*)D.o_uv, q.obs_uv, sizeof(double) * 2 * (size_t)n_obs, hipMemcpyHostToDevice, ctx->aux_stream[0]));
+    VS_HIP(ctx, hipEventRecord(ctx->ev_after, ctx->aux_stream[0]));
+    ctx->ba_aux_copy_pending = true;
     ba_build B;
     memset(&B, 0, sizeof B);
     // what comes BACK into the pinned mirror sits right behind the uploaded part: the read-back block of ba_export and the flag words
@@ -3855,6 +3865,8 @@ host_passes:
     VS_TRY(ba_build_enqueue(ctx, s, B));
     VS_HIP(ctx, hipMemcpyAsync(h_binfo, B.info, sizeof(int) * kBuildInfoInts, hipMemcpyDeviceToHost, s));
     VS_HIP(ctx, hipStreamSynchronize(s));
+    VS_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_after, 0));  // everything enqueued behind this point may read the image points
+    ctx->ba_aux_copy_pending = false;
     lap(2);
     if (h_binfo[kBuildBad] | h_binfo[kBuildUngrouped] | h_binfo[kBuildInactive] | h_binfo[kBuildDups]) {
       dev = false;  // not this path's case: the host passes take it (and report what is wrong with it, if anything)

@@ -165,6 +165,7 @@ struct vs_ctx {
   std::vector<vs_prof_rec> match_prof;
   vs_buf d_mo_stamps;       // diagnostic step stamps of the newest one-launch motion-only solve of a tracking period (vs_mo_profile)
   bool mo_profile = false;
+  bool ba_aux_copy_pending = false;  // a copy into the BA arena is in flight on aux_stream[0] and the main stream has not been ordered behind it yet
   int ba_structure_dev = 0;  // 1: the newest vs_ba_solve built its structure on the device (vs_ba_structure_on_device)
   vs_buf d_match_stamps;    // diagnostic phase stamps of the newest stamped match launch (vs_match_stamps)
   bool match_stamps_on = false;
