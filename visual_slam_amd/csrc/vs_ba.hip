@@ -180,14 +180,32 @@ __device__ inline void block_reduce2(double& a, double& b, double* s_red) {
 }
 
 // sum / max of the per-block partials by one wave: lane l takes entries l, l + 64, ... in order, then an xor-butterfly
+// (the loads of eight entries are issued together, the additions keep their order: with thousands of point blocks -- the scaled
+// run has 6 250 -- one load per round trip made this the tail of every trial)
 __device__ inline double wave_sum_partials(const double* v, int n) {
   double a = 0.0;
-  for (int i = threadIdx.x; i < n; i += 64) a += v[i];
+  int i = threadIdx.x;
+  for (; i + 7 * 64 < n; i += 8 * 64) {
+    double x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = v[i + 64 * k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += x[k];
+  }
+  for (; i < n; i += 64) a += v[i];
   return vs_group_reduce<6>(a);
 }
 __device__ inline double wave_max_partials(const double* v, int n) {
   double a = 0.0;
-  for (int i = threadIdx.x; i < n; i += 64) a = fmax(a, v[i]);
+  int i = threadIdx.x;
+  for (; i + 7 * 64 < n; i += 8 * 64) {
+    double x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = v[i + 64 * k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a = fmax(a, x[k]);
+  }
+  for (; i < n; i += 64) a = fmax(a, v[i]);
   return vs_group_reduce<6, true>(a);
 }
 
