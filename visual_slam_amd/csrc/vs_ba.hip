@@ -55,7 +55,12 @@ using namespace vsba;
 namespace {
 
 constexpr int kPtThreads = 256; // threads per point block
-constexpr int kPtLanes = 8;  // lanes that share one point's observations (linearisation and trial)
+#ifndef VS_PT_LANES
+#define VS_PT_LANES 8
+#endif
+constexpr int kPtLanes = VS_PT_LANES;  // lanes that share one point's observations (linearisation and trial)
+constexpr int kPtLaneSteps = kPtLanes == 16 ? 4 : 3;
+static_assert(kPtLanes == 8 || kPtLanes == 16, "vs_group_reduce over the lanes of a point");
 constexpr int kPtPerBlock = kPtThreads / kPtLanes;
 constexpr int kCamThreads = 512;  // ba_linearize: a camera's observations are spread over this many threads
 constexpr int kSchurThreads = 256;
@@ -266,11 +271,10 @@ __device__ inline double linearize_point(const ba_dev& D, const lin_view& L, con
     }
   }
   if (ls >= 0) {  // uniform inside the lane group
-    static_assert(kPtLanes == 8, "vs_group_reduce<3>");
 #pragma unroll
-    for (int k = 0; k < 9; ++k) H[k] = vs_group_reduce<3>(H[k]);
+    for (int k = 0; k < 9; ++k) H[k] = vs_group_reduce<kPtLaneSteps>(H[k]);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) b[k] = vs_group_reduce<3>(b[k]);
+    for (int k = 0; k < 3; ++k) b[k] = vs_group_reduce<kPtLaneSteps>(b[k]);
     if (sub == 0) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) L.Hll[9 * (size_t)ls + k] = H[k];
@@ -2364,7 +2368,7 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
           for (int k = 0; k < 6; ++k) part[b] += B[3 * k + b] * xc[k];
       }
 #pragma unroll
-      for (int b = 0; b < 3; ++b) part[b] = vs_group_reduce<3>(part[b]);
+      for (int b = 0; b < 3; ++b) part[b] = vs_group_reduce<kPtLaneSteps>(part[b]);
       const double cl[3] = {L.bl[3 * (size_t)ls] - part[0], L.bl[3 * (size_t)ls + 1] - part[1], L.bl[3 * (size_t)ls + 2] - part[2]};
       const double* Di = D.Dinv + 9 * (size_t)ls;
 #pragma unroll
