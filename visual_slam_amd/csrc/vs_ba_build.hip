@@ -210,7 +210,9 @@ __global__ __launch_bounds__(256) void build_points(ba_build B) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   int mf = 0, dup = 0, inact = 0;
   if (j < B.P) {
-    const int i0 = B.pt_start[j], i1 = B.pt_start[j + 1], ls = B.pt_slot[j];
+    // (a list with an index out of range or not grouped by point leaves entries of pt_start unwritten or out of order: the host
+    // passes will take the problem over, but this kernel still runs -- keep every range inside the observation list)
+    const int i0 = min(max(B.pt_start[j], 0), B.n_obs), i1 = min(max(B.pt_start[j + 1], i0), B.n_obs), ls = B.pt_slot[j];
     B.act_pt[j] = j;
     inact = i0 >= i1 && ls < 0;
     if (ls >= 0) {
