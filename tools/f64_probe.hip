@@ -33,18 +33,21 @@ KERNEL(mulsub_4acc, 8, "v_mul_f64 v[16:17], v[24:25], v[26:27]\nv_mul_f64 v[18:1
 KERNEL(rsq_indep, 4, "v_rsq_f64 v[8:9], v[24:25]\nv_rsq_f64 v[10:11], v[24:25]\nv_rsq_f64 v[12:13], v[24:25]\nv_rsq_f64 v[14:15], v[24:25]")
 KERNEL(rsq_chain, 4, "v_rsq_f64 v[24:25], v[24:25]\nv_rsq_f64 v[24:25], v[24:25]\nv_rsq_f64 v[24:25], v[24:25]\nv_rsq_f64 v[24:25], v[24:25]")
 KERNEL(add_f32_indep, 8, "v_add_f32 v8, v24, v26\nv_add_f32 v10, v24, v26\nv_add_f32 v12, v24, v26\nv_add_f32 v14, v24, v26\nv_add_f32 v16, v24, v26\nv_add_f32 v18, v24, v26\nv_add_f32 v20, v24, v26\nv_add_f32 v22, v24, v26")
+KERNEL(xor_indep, 8, "v_xor_b32 v8, v24, v26\nv_xor_b32 v10, v24, v26\nv_xor_b32 v12, v24, v26\nv_xor_b32 v14, v24, v26\nv_xor_b32 v16, v24, v26\nv_xor_b32 v18, v24, v26\nv_xor_b32 v20, v24, v26\nv_xor_b32 v22, v24, v26")
+KERNEL(bcnt_indep, 8, "v_bcnt_u32_b32 v8, v24, v8\nv_bcnt_u32_b32 v10, v24, v10\nv_bcnt_u32_b32 v12, v24, v12\nv_bcnt_u32_b32 v14, v24, v14\nv_bcnt_u32_b32 v16, v24, v16\nv_bcnt_u32_b32 v18, v24, v18\nv_bcnt_u32_b32 v20, v24, v20\nv_bcnt_u32_b32 v22, v24, v22")
+KERNEL(xor_bcnt_mix, 8, "v_xor_b32 v9, v24, v26\nv_bcnt_u32_b32 v8, v9, v8\nv_xor_b32 v11, v25, v27\nv_bcnt_u32_b32 v10, v11, v10\nv_xor_b32 v13, v24, v27\nv_bcnt_u32_b32 v12, v13, v12\nv_xor_b32 v15, v25, v26\nv_bcnt_u32_b32 v14, v15, v14")
 KERNEL(readlane_mul, 2, "v_readlane_b32 s4, v8, 3\nv_readlane_b32 s5, v9, 3\nv_mul_f64 v[8:9], s[4:5], v[26:27]")
 
 template <class K>
 static void run(const char* name, K k, int per_iter, double* d_out, long long* d_cyc) {
   const int iters = 20000;
-  for (int threads : {64, 256, 512, 1024}) {
+  for (int threads : {64, 256, 512, 768, 1024}) {
     hipLaunchKernelGGL(k, dim3(1), dim3(threads), 0, 0, d_out, iters, d_cyc);
     hipDeviceSynchronize();
     long long cyc = 0;
     hipMemcpy(&cyc, d_cyc, sizeof cyc, hipMemcpyDeviceToHost);
     const double per = (double)cyc / ((double)iters * per_iter);
-    const int waves_per_simd = threads <= 256 ? 1 : threads / 256;
+    const int waves_per_simd = threads <= 256 ? 1 : threads / 256;  // 768 threads: 3
     printf("%-14s %4d threads (%d wave%s/SIMD%s): %6.2f cycles per instruction of one wave, %6.2f per SIMD issue slot\n", name, threads, waves_per_simd, waves_per_simd > 1 ? "s" : "",
            threads == 64 ? ", one SIMD" : "", per, per / waves_per_simd);
   }
@@ -67,5 +70,8 @@ int main() {
   RUN(rsq_chain);
   RUN(add_f32_indep);
   RUN(readlane_mul);
+  RUN(xor_indep);
+  RUN(bcnt_indep);
+  RUN(xor_bcnt_mix);
   return 0;
 }
