@@ -53,10 +53,36 @@ static void run(const char* name, K k, int per_iter, double* d_out, long long* d
   }
 }
 
+// the same streams with every CU busy: `blocks` workgroups of 1024 threads (2 per CU = eight waves per SIMD at this register count)
+template <class K>
+static void run_chip(const char* name, K k, int per_iter, double* d_out, long long* d_cyc) {
+  const int iters = 20000;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int blocks : {1, 256, 512, 1024}) {
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(1024), 0, 0, d_out, iters, d_cyc);  // warm
+    hipDeviceSynchronize();
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(1024), 0, 0, d_out, iters, d_cyc);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    long long cyc = 0;
+    hipMemcpy(&cyc, d_cyc, sizeof cyc, hipMemcpyDeviceToHost);
+    const double per_wave = (double)cyc / ((double)iters * per_iter);
+    // chip-wide: wave-instructions per second and SIMD, against the clock workgroup 0 saw (its cycles over the kernel's time if it ran the whole time)
+    const double winstr = (double)blocks * 16 * iters * per_iter, ns_per_simd_instr = ms * 1e6 / (winstr / 1024.0);
+    printf("%-14s %4d workgroups of 1024 threads: %6.2f cycles per instruction of one wave (workgroup 0); kernel %.3f ms = %.3f ns per instruction and SIMD\n", name, blocks,
+           per_wave, ms, ns_per_simd_instr);
+  }
+}
+
 int main() {
   double* d_out;
   long long* d_cyc;
-  hipMalloc(&d_out, 1024 * sizeof(double));
+  hipMalloc(&d_out, (size_t)1024 * 1024 * sizeof(double));  // the largest launch: 1024 workgroups of 1024 threads, one double each
   hipMalloc(&d_cyc, sizeof(long long));
 #define RUN(name) run(#name, name, name##_n, d_out, d_cyc)
   RUN(mul_indep);
@@ -73,5 +99,9 @@ int main() {
   RUN(xor_indep);
   RUN(bcnt_indep);
   RUN(xor_bcnt_mix);
+  run_chip("xor_indep", xor_indep, xor_indep_n, d_out, d_cyc);
+  run_chip("bcnt_indep", bcnt_indep, bcnt_indep_n, d_out, d_cyc);
+  run_chip("xor_bcnt_mix", xor_bcnt_mix, xor_bcnt_mix_n, d_out, d_cyc);
+  run_chip("fma_indep", fma_indep, fma_indep_n, d_out, d_cyc);
   return 0;
 }
