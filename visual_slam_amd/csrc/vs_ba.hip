@@ -1897,6 +1897,7 @@ __global__ __launch_bounds__(kBandThreads) void ba_chol_band(ba_dev D, int band)
   if (D.st->done) return;
   const int n = D.np, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int WR = band + 12;
+  if (wv == 0) __builtin_amdgcn_s_setprio(3);  // the wave that factorises the diagonal blocks is the critical path: it goes first on its SIMD
   constexpr int ld = kBandLd, pld = kBandPld;
   double* A = s_mem;                     // [WR][ld] ring
   double* Y = A + kBandRing * ld;        // [WR] right-hand side entries by column slot
@@ -2054,7 +2055,9 @@ __global__ __launch_bounds__(kBandThreads) void ba_chol_band(ba_dev D, int band)
       // the next diagonal block (tr < 3), which wave 0 owns.  One tile per thread and many waves per SIMD: a lone wave issues
       // an FP64 multiply or add only every ~16 cycles (stamps: a 4 x 4 tile per thread on three waves took 4 000 cycles).
       const int nt = (m + 1) >> 1, total = nt * (nt + 1) / 2;
-      for (int e = t + 6; e < total; e += kBandLoaders) {
+      // (the waves that share wave 0's SIMD -- 4, 8, 12 -- take no tiles: they would take issue slots from the factorisation)
+      const int tw = (wv & 3) ? (wv - 1 - (wv >> 2)) * 64 + lane : total;
+      for (int e = tw + 6; e < total; e += 12 * 64) {
         int tr = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while (tr * (tr + 1) / 2 > e) --tr;
         while ((tr + 1) * (tr + 2) / 2 <= e) ++tr;
