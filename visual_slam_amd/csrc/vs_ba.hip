@@ -1545,6 +1545,9 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   const int done = st->done, cur = st->cur;
   const double lambda = st->lambda;
   const int n = D.np, tid = threadIdx.x, tx = tid % kSolveTile, ty = tid / kSolveTile;
+#ifndef VS_SOLVE_NO_PRIO
+  if (tid < 64) __builtin_amdgcn_s_setprio(3);  // wave 0 factorises the diagonal blocks: the critical path of every step
+#endif
   const int ld = (n + 1) | 1;
   double* A = s_mem;                        // (n + 1) rows of ld: rows 0..n-1 matrix, row n = rhs
   double* rinv = s_mem + (size_t)(n + 1) * ld;  // [n]
@@ -1645,9 +1648,10 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
         wave_lds_sync();
         if (tid == 0) factor_diag(j0 + 6);
       }
-    } else {
-      const int t2 = tid - 64, ux = t2 % kSolveTile, uy = t2 / kSolveTile;  // (kSolveBlock - 64) / kSolveTile rows of threads
-      constexpr int kRowsPer = (kSolveBlock - 64) / kSolveTile;
+    } else if ((tid >> 6) & 3) {
+      // (waves 4, 8, 12 share wave 0's SIMD: they stay out of the update, the factorisation has the SIMD's issue slots to itself)
+      const int wv_ = tid >> 6, t2 = (wv_ - 1 - (wv_ >> 2)) * 64 + (tid & 63), ux = t2 % kSolveTile, uy = t2 / kSolveTile;
+      constexpr int kRowsPer = (kSolveBlock / 64 - kSolveBlock / 256) * 64 / kSolveTile;  // twelve waves' threads as rows of kSolveTile
       for (int r = j0 + (next_diag ? 12 : 6) + uy; r <= n; r += kRowsPer) {  // rows j0+6..j0+11 lie inside wave 0's block
         double ar[6];
 #pragma unroll
