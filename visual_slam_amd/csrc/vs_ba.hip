@@ -713,14 +713,15 @@ __global__ __launch_bounds__(256) void ba_dinv(ba_dev D) {
   if (st.done) return;
   const int l = blockIdx.x * 256 + threadIdx.x;
   if (l >= D.nfl) return;
+  const lin_view L = lin_of(D, st.cur);
   double Dm[9], inv[9];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) Dm[k] = D.Hll[9 * (size_t)l + k];
+  for (int k = 0; k < 9; ++k) Dm[k] = L.Hll[9 * (size_t)l + k];
   Dm[0] += st.lambda;
   Dm[4] += st.lambda;
   Dm[8] += st.lambda;
   inv3(Dm, inv);
-  const double b0 = D.bl[3 * (size_t)l], b1 = D.bl[3 * (size_t)l + 1], b2 = D.bl[3 * (size_t)l + 2];
+  const double b0 = L.bl[3 * (size_t)l], b1 = L.bl[3 * (size_t)l + 1], b2 = L.bl[3 * (size_t)l + 2];
 #pragma unroll
   for (int k = 0; k < 9; ++k) D.Dinv[9 * (size_t)l + k] = inv[k];
 #pragma unroll
@@ -948,6 +949,7 @@ __global__ __launch_bounds__(256, 2) void ba_schur_window(ba_dev D) {
   __shared__ int sRec[kWinPerMax][3];  // point slot, first Hpl block, blocks
   __shared__ unsigned sMask[kWinBatch];  // window cameras that see the point
   if (D.st->done) return;
+  const double* const Hpl = lin_of(D, D.st->cur).Hpl;  // (large problems keep two linearisations, too: see `spec` in vs_ba_solve)
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: the tile tests below are branches, not masks
   const int s = blockIdx.x, i0 = s * D.win_per, n = min(D.win_per, D.win_n - i0);
   const int w0 = D.win_w0[s], wlen = D.win_len[s], ncol = 6 * wlen, ntr = (ncol + 15) >> 4;
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(256, 2) void ba_schur_window(ba_dev D) {
       pvalid &= ~(1u << k);
       if (pb < nb && i < sRec[b0 + pb][2]) {
         const int blk = sRec[b0 + pb][1] + i;
-        const double* B = D.Hpl + 18 * (size_t)blk + 3 * ar;
+        const double* B = Hpl + 18 * (size_t)blk + 3 * ar;
         pvalid |= 1u << k;
         pslot[k] = D.fp_slot[blk];
         ph[k][0] = B[0];
@@ -1516,7 +1518,7 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve(ba_dev D) {
   if (tid == 0) {
     double sc = 0.0;
     if (ok)
-      for (int j = 0; j < n; ++j) sc += x[j] * (st->lambda * x[j] + D.bp[j]);
+      for (int j = 0; j < n; ++j) sc += x[j] * (st->lambda * x[j] + lin_of(D, st->cur).bp[j]);
     st->scale_pose = sc;
     st->solve_ok = ok;
     st->trials += 1;
@@ -2260,9 +2262,10 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
   // ba_solve_block does -- on one lane the 594 terms of the scaled run were 13 us of dependent instructions
   if (tid < 64) {
     const double lambda = st->lambda;
+    const double* const bp = lin_of(D, cur).bp;
     double sc = 0.0;
     if (ok)
-      for (int j = tid; j < n; j += 64) sc += x[j] * (lambda * x[j] + D.bp[j]);
+      for (int j = tid; j < n; j += 64) sc += x[j] * (lambda * x[j] + bp[j]);
     sc = vs_group_reduce<6>(sc);
     if (tid == 0) {
       st->scale_pose = sc;
@@ -2389,9 +2392,10 @@ __global__ __launch_bounds__(kPtThreads) void ba_point_trial(ba_dev D) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) pts1[3 * (size_t)p + k] = X[k];
     }
-    if (D.spec) {
+    if (D.spec && st.it + 1 < D.max_it) {
       // the trial state's point role of the linearisation comes with its chi2 (same code, lanes and operands as
-      // ba_linearize would use after an accepted step): written to the other linearisation, dropped if the step is rejected
+      // ba_linearize would use after an accepted step): written to the other linearisation, dropped if the step is rejected.
+      // Not in the last outer iteration: accepted or not, nothing is linearised after it (the chi2 below is the same sum).
       double maxd = 0.0;
       chi = linearize_point(D, lin_of(D, st.cur ^ 1), cams1, X, a, ls, sub, maxd);
     } else {
@@ -3664,7 +3668,7 @@ host_passes:
                                   2 * (size_t)q.max_iterations + 64) +
                 256 * 64 + sizeof(int) * (3 * (size_t)n_obs + nfl + 16 + 2 * (size_t)ns_win_bound + nfp + 64) + 4 * 256 + (sizeof(double) * 27 * 8 + 8) * (size_t)nfp + 1024 +
                 sizeof(double) * (64 + (size_t)F * kCamStride + 3 * (size_t)P + 2 * (size_t)q.max_iterations) + 512 +
-                (small_possible ? sizeof(double) * ((size_t)np * np + np + 12 * (size_t)nfl + 18 * (size_t)n_obs) + 5 * 256 : 0) + sizeof(double) * 8 * (size_t)(res->trial_trace ? std::max(res->trial_trace_cap, 0) : 0) + (motion_only ? sizeof(double) * (8 * (size_t)n_cam_obs + 50 * (size_t)nfp + 64) : 0);
+                (small_possible || (win_possible && nb_pt >= 1024) ? sizeof(double) * ((size_t)np * np + np + 12 * (size_t)nfl + 18 * (size_t)n_obs) + 5 * 256 : 0) + sizeof(double) * 8 * (size_t)(res->trial_trace ? std::max(res->trial_trace_cap, 0) : 0) + (motion_only ? sizeof(double) * (8 * (size_t)n_cam_obs + 50 * (size_t)nfp + 64) : 0);
   if (dev) need += sizeof(int) * (ba_build_temp_ints(n_obs, nfp, nfl) + (size_t)nfl + 2 * (size_t)ns_win_bound + nfp + 64) + 4096;
   VS_TRY(vs_reserve(ctx, &ctx->d_ba, need));
   // the pinned mirror covers what is uploaded from it or read back into it.  Host passes: the structure arrays, i.e. nearly
@@ -4144,12 +4148,16 @@ host_passes:
   ctx->ba_structure_dev = dev;
   const bool tiled = tiled_possible && !dups;
   const bool small = tiled && small_possible;
-  const bool spec = small && ctx->tune.schur_variant != 2;  // two linearisations: the trial kernel linearises the trial state
+  // two linearisations, indexed like the state buffers: the trial kernel linearises the trial state's points, so an accepted step
+  // needs no point linearisation of its own.  Single-tile windows (cfg4), and since round 4 large banded windows as well -- there
+  // the point linearisation is a launch of 0.15 ms per accepted step (the scaled run), the second set of blocks is 300 MB of 288 GB
+  const bool spec_win = win && nb_pt >= 1024 && ctx->tune.schur_variant == 0;
+  const bool spec = (small && ctx->tune.schur_variant != 2) || spec_win;
   int ns = slabs_for(tiled, small);
   // ba_schur_small with camera workgroups beside it: keep the whole grid within one workgroup per CU.  Two Schur
   // workgroups on one CU take turns at its LDS in the product phase (measured 14-15 us per launch at 286 workgroups on
   // 256 CUs against 10 us alone); a workgroup with a few more points costs less than that.
-  if (spec) ns = std::max(1, std::min(ns, std::max(ctx->prop.multiProcessorCount, 64) - nfp * cam_split));
+  if (spec && !spec_win) ns = std::max(1, std::min(ns, std::max(ctx->prop.multiProcessorCount, 64) - nfp * cam_split));
   if (win) {
     ns = ns_win;
     D.win = 1;
@@ -4276,6 +4284,9 @@ host_passes:
         hipLaunchKernelGGL(ba_linearize, dim3(nb_pt + nfp * cam_split), dim3(kCamThreads), 0, s, D);
         VS_LAUNCH_CHECK(ctx, "ba_linearize");
       }
+    } else if (spec_win && nfp > 0) {  // the points of an accepted state were linearised by ba_point_trial: the camera role is all that is left
+      hipLaunchKernelGGL(ba_linearize_cameras, dim3(nfp * cam_split), dim3(kCamThreads), 0, s, D);
+      VS_LAUNCH_CHECK(ctx, "ba_linearize_cameras");
     }
     if (first) {
       hipLaunchKernelGGL(ba_lambda_init, dim3(1), dim3(64), 0, s, D);
