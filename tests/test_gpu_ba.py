@@ -736,3 +736,26 @@ def test_device_built_structure_fits_the_arena_of_a_fresh_context(n_cams, n_poin
             ctx.close()
     assert _same_solve(out[0], out[1])
 
+
+def test_large_windows_with_two_linearisations_equal_one_linearisation_per_step(vs):
+    """Round 4: large banded windows keep two sets of linearisation blocks like cfg4 -- ba_point_trial linearises the trial state's
+    points, an accepted step launches only the camera role, a failed or rejected one drops the blocks.  vs_tune_ba(schur_variant=2)
+    takes the same kernels with a linearisation launch per step: same bits -- on a plain scene, and on one whose first trials fail
+    (negative-definite information on a third of the edges makes the reduced system indefinite until lambda has grown: the
+    reference's one real edge case, see test_not_positive_definite_trials_in_lock_step)."""
+    w = _sliding_window_scene(40, 45000, 10, seed=33)
+    n = len(w["obs_pose"])
+    info = np.tile([1.0, 0.0, 1.0], (n, 1))
+    info[np.random.default_rng(3).random(n) < 0.3] = [-1.0, 0.0, -1.0]
+    args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
+    for kw in (dict(max_iterations=4), dict(max_iterations=3, obs_info=info)):
+        try:
+            vs.tune_ba(schur_variant=0)
+            a = vs.ba_solve(*args, **kw)
+            vs.tune_ba(schur_variant=2)
+            b = vs.ba_solve(*args, **kw)
+        finally:
+            vs.tune_ba(schur_variant=0)
+        if "obs_info" in kw:
+            assert a["not_pd"] >= 2 and a["trials"] > a["not_pd"], "the scene was meant to fail its first trials and then recover"
+        assert a["not_pd"] == b["not_pd"] and _same_solve(a, b)
