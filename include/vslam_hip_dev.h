@@ -59,6 +59,11 @@ int vs_mo_profile_read(vs_ctx* ctx, double* out, int cap_rows);
  * *recoveries_out (may be NULL) = back halves redone so far on this context. */
 int vs_track_debug(vs_ctx* ctx, int inject_fault, int* recoveries_out);
 
+/* Allocation poisoning (tests).  byte in 0..255: every device buffer the context allocates FROM NOW ON (vs_reserve) is filled
+ * with that byte before first use; -1: off (default).  A kernel or protocol that relies on what hipMalloc happens to return --
+ * flags assumed zero, tags assumed stale -- fails its parity test under a poison byte instead of once in a blue moon. */
+int vs_debug_poison_alloc(vs_ctx* ctx, int byte);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,17 +9,18 @@ import numpy as np
 
 
 def triangulate(pose1, pose2, pts1, pts2):
-    """reference src/v2/helper_functions.py:281-291 -- one 4x4 DLT system per match, X = last right singular vector."""
-    ret = np.zeros((pts1.shape[0], 4))
-    for i, p in enumerate(zip(pts1, pts2)):
-        A = np.zeros((4, 4))
-        A[0] = p[0][0] * pose1[2] - pose1[0]
-        A[1] = p[0][1] * pose1[2] - pose1[1]
-        A[2] = p[1][0] * pose2[2] - pose2[0]
-        A[3] = p[1][1] * pose2[2] - pose2[1]
-        _, _, vt = np.linalg.svd(A)
-        ret[i] = vt[3]
-    return ret
+    """What reference src/v2/helper_functions.py:281-291 computes -- per match the right singular vector of the smallest singular
+    value of the 4x4 DLT system [u1*P1[2]-P1[0]; v1*P1[2]-P1[1]; u2*P2[2]-P2[0]; v2*P2[2]-P2[1]] -- as ONE batched
+    decomposition.  Checked against the stored outputs of the reference's own function (tests/test_ref_fixtures.py); the GPU
+    tests compare the kernel with those stored outputs, this function serves the CPU driver (tests/test_slam_driver.py)."""
+    pts1, pts2 = np.asarray(pts1, np.float64), np.asarray(pts2, np.float64)
+    if len(pts1) == 0:
+        return np.zeros((0, 4))
+    uv = np.concatenate([pts1[:, :2], pts2[:, :2]], axis=1)                    # [n, 4] = u1 v1 u2 v2
+    last = np.stack([pose1[2], pose1[2], pose2[2], pose2[2]])                   # row multiplied by the image coordinate
+    first = np.stack([pose1[0], pose1[1], pose2[0], pose2[1]])                  # row subtracted
+    systems = uv[:, :, None] * last[None] - first[None]                         # [n, 4, 4]
+    return np.linalg.svd(systems)[2][:, 3, :]
 
 
 def cheirality_filter(p1, p2, X4):

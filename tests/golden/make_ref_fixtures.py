@@ -114,6 +114,19 @@ def main():
     out.update(tri_syn_K=K, tri_syn_w2c1=w2c1, tri_syn_w2c2=w2c2, tri_syn_P1=P1s, tri_syn_P2=P2s, tri_syn_Xh=Xh,
                tri_syn_pts1=x1s, tri_syn_pts2=x2s, tri_syn_X=triangulate(P1s, P2s, x1s, x2s),
                cpm_R=R, cpm_t=t, cpm_out=cpm(R, t, K))
+    # (c) the two-view scenes of tests/test_triangulate.py (sizes 1 .. 3 000, with and without pixel noise): the GPU tests
+    #     compare vs_triangulate_dlt with THESE outputs of the reference's function, not with a restatement of it
+    from visual_slam_amd.workloads import ba_workload
+    for case, (n, noise, seed) in enumerate(sc.TWO_VIEW_CASES):
+        w = ba_workload(n_cams=2, n_points=n, seed=seed, noise_px=noise, outlier_frac=0, pose_sigma_t=0, pose_sigma_deg=0,
+                        point_sigma=0)
+        p1, p2 = np.linalg.inv(w["poses_gt"][0]), np.linalg.inv(w["poses_gt"][1])
+        uv = w["obs_uv"].reshape(n, 2, 2)
+        Pa, Pb = cpm2(p1, K), cpm2(p2, K)
+        xa, xb = make_h(uv[:, 0]), make_h(uv[:, 1])
+        pre = "tri_tv%d_" % case
+        out.update({pre + "w2c1": p1, pre + "w2c2": p2, pre + "P1": Pa, pre + "P2": Pb, pre + "x1": xa, pre + "x2": xb,
+                    pre + "gt": w["points_gt"], pre + "X": triangulate(Pa, Pb, xa, xb)})
     # ---- Map / Point / Frame (host API mirror) -----------------------------------------------------------------------------
     Point = extract("src/v2/point.py", "Point")
     Map = extract("src/v2/map.py", "Map")

@@ -191,3 +191,7 @@ def graph_case_name(i):
 def map_state(m):
     return {"poses_after": np.stack([np.asarray(f.GetPose(), np.float64) for f in m.frames.values()]),
             "points_after": np.asarray(m.GetAll3DPoints(), np.float64)}
+
+# (n, pixel noise, seed) of the two-view scenes whose triangulation by the reference's own function is stored in
+# tests/golden/ref_fixtures.npz (tri_tv<i>_*) and compared with vs_triangulate_dlt by tests/test_triangulate.py
+TWO_VIEW_CASES = ((1, 0.0, 1), (500, 0.0, 2), (3000, 0.7, 3), (257, 2.0, 4), (800, 0.3, 7))

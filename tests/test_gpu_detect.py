@@ -159,3 +159,36 @@ def test_frames_alternating_through_one_pinned_buffer(vs, oracle):
     xy, sc, desc = vs.detect_describe_bgr(f, 20, 3000)
     oxy, osc, odesc = oracle.detect_describe_bgr(f, 20, 3000)
     assert np.array_equal(xy, oxy) and np.array_equal(desc, odesc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("poison", [0x01, 0xFF, 0x7F])
+def test_band_count_growing_inside_the_flag_buffer(oracle, poison):
+    """Zero-copy detection keeps one flag word per band (the newest frame whose gray rows of the band are published).  The flag
+    buffer is over-allocated: 240 bands (640 x 480) reserve room for 300.  A pinned frame with 250 bands (320 x 500) fits without
+    a reallocation, so its last ten flags are whatever the ALLOCATION left there -- they must have been cleared then, or a word
+    that happens to compare >= the frame's sequence number lets a neighbouring band read halo rows nobody has written.  Every
+    device buffer of this context is poisoned on allocation (vs_debug_poison_alloc): 0x01010101 and 0x7F7F7F7F pass such a
+    comparison, 0xFFFFFFFF never does (a band waiting on it runs out of its bounded wait).  The whole fused path runs under the
+    same poison, so any other table assumed zero shows up here too."""
+    from visual_slam_amd import Context
+    from visual_slam_amd.workloads import synthetic_frame
+    ctx = Context(0)
+    ctx.debug_poison_alloc(poison)
+    shapes = [(640, 480), (640, 480), (320, 500), (320, 500), (640, 512), (320, 500), (640, 480), (320, 598), (640, 480)]
+    for k, (w, h) in enumerate(shapes):
+        f = ctx.pin(synthetic_frame(w, h, 40 + k))
+        for _ in range(2):
+            xy, sc, desc = ctx.detect_describe_bgr(f, 20, 3000)
+            oxy, osc, odesc = oracle.detect_describe_bgr(np.asarray(f), 20, 3000)
+            assert np.array_equal(xy, oxy) and np.array_equal(sc, osc) and np.array_equal(desc, odesc), (poison, k, w, h)
+    # the rest of the path on poisoned buffers: a match and a small BA
+    from visual_slam_amd.workloads import ba_workload, match_workload
+    q, t = match_workload(700, 900, n_dup=8, seed=5)
+    idx, dist = ctx.hamming_knn2(q, t)
+    oidx, odist = oracle.hamming_knn2(q, t)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    wk = ba_workload(n_cams=4, n_points=60, seed=2)
+    args = (wk["poses"], wk["pose_fixed"], wk["points"], wk["point_fixed"], wk["obs_pose"], wk["obs_point"], wk["obs_uv"], wk["K"])
+    g, o = ctx.ba_solve(*args, max_iterations=5), oracle.ba_solve(*args, max_iterations=5)
+    assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(g["poses"], o["poses"])) < 1e-9

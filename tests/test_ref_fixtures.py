@@ -36,6 +36,11 @@ def test_numpy_restatements_equal_the_executed_reference(fx):
     assert np.array_equal(ref.make_homogeneous(fx["tri_syn_Xh"][:, :3]), fx["tri_syn_Xh"])
     got = ref.triangulate(fx["tri_syn_P1"], fx["tri_syn_P2"], fx["tri_syn_pts1"], fx["tri_syn_pts2"])
     assert np.allclose(_flip(got), _flip(fx["tri_syn_X"]), rtol=0, atol=1e-13)
+    for case in range(len(sc.TWO_VIEW_CASES)):
+        pre = "tri_tv%d_" % case
+        got = ref.triangulate(fx[pre + "P1"], fx[pre + "P2"], fx[pre + "x1"], fx[pre + "x2"])
+        assert np.allclose(_flip(got), _flip(fx[pre + "X"]), rtol=0, atol=1e-13)
+    assert ref.triangulate(fx["tri_syn_P1"], fx["tri_syn_P2"], fx["tri_syn_pts1"][:0], fx["tri_syn_pts2"][:0]).shape == (0, 4)
 
 
 def test_product_helpers_equal_the_executed_reference(fx):
@@ -53,6 +58,35 @@ def test_the_v1_held_points_triangulate_consistently(fx):
     assert np.linalg.norm(X[0] - X[1]) < 0.02 * np.linalg.norm(X[0]) and np.linalg.norm(X[0] - X[2]) < 0.02 * np.linalg.norm(X[0])
 
 
+def tri_case_bounds(tol):
+    """(absolute bound on the unit 4-vectors, relative bound on the dehomogenised points) for a case whose systems have
+    entries of unit scale (tol 1e-11) or of pixel scale (the v1 matrices reach 5e3: tol 1e-9)."""
+    return tol, (1e-7 if tol > 1e-10 else 1e-9)
+
+
+def tri_check(X4, want, tol):
+    """X4: triangulated unit 4-vectors (sign-normalised), want: what the reference's triangulate returned."""
+    atol, rel = tri_case_bounds(tol)
+    if not np.allclose(X4, _flip(want), rtol=0, atol=atol):
+        return False
+    Xg, Xw = X4[:, :3] / X4[:, 3:], want[:, :3] / want[:, 3:]
+    return bool(np.max(np.linalg.norm(Xg - Xw, axis=1) / np.linalg.norm(Xw, axis=1)) < rel)
+
+
+def test_the_triangulation_check_rejects_a_relative_error_of_1e_8(fx):
+    """The check the GPU test applies must bite: the reference's own output passes, the same output with its points moved by
+    1e-8 relative does not (round 4's form of the assertion parsed as `assert (x < 1e-7) if .. else 1e-9` and asserted a
+    constant for the unit-scale case)."""
+    want = fx["tri_syn_X"]
+    assert tri_check(_flip(want), want, 1e-11)
+    X = want[:, :3] / want[:, 3:]
+    moved = np.c_[X * (1 + 1e-8), np.ones(len(X))]
+    moved = _flip(moved / np.linalg.norm(moved, axis=1, keepdims=True))
+    assert not tri_check(moved, want, 1e-11)
+    rel = np.max(np.linalg.norm(moved[:, :3] / moved[:, 3:] - X, axis=1) / np.linalg.norm(X, axis=1))
+    assert 0.9e-8 < rel < 1.1e-8 and tri_case_bounds(1e-11)[1] < rel < tri_case_bounds(1e-9)[1]
+
+
 @pytest.mark.gpu
 def test_hip_triangulation_equals_the_executed_reference(vs, fx):
     """vs_triangulate_dlt (one-sided Jacobi SVD in registers) against what the reference's triangulate returned.
@@ -65,9 +99,10 @@ def test_hip_triangulation_equals_the_executed_reference(vs, fx):
     eye = np.eye(4)
     for P1, P2, x1, x2, want, tol in cases:
         X4, _ = vs.triangulate_dlt(P1, P2, ref.make_homogeneous(x1), ref.make_homogeneous(x2), eye, eye)
-        assert np.allclose(X4, _flip(want), rtol=0, atol=tol)
-        Xg, Xw = X4[:, :3] / X4[:, 3:], want[:, :3] / want[:, 3:]
-        assert np.max(np.linalg.norm(Xg - Xw, axis=1) / np.linalg.norm(Xw, axis=1)) < 1e-7 if tol > 1e-10 else 1e-9
+        assert tri_check(X4, want, tol)
+        X = X4[:, :3] / X4[:, 3:]
+        moved = np.c_[X * (1 + 1e-8), np.ones(len(X))]
+        assert not tri_check(_flip(moved / np.linalg.norm(moved, axis=1, keepdims=True)), want, 1e-11)
 
 
 # ------------------------------------------------------------------------------------------------------------- Map / Point / Frame

@@ -1,12 +1,31 @@
 """Two-view DLT triangulation.  The reference implements it in pure NumPy
-(src/v2/helper_functions.py:281-291), so the oracle here IS the reference's arithmetic (np.linalg.svd): parity pinned.
+(src/v2/helper_functions.py:281-291): the GPU tests compare vs_triangulate_dlt with what the reference's OWN function returned
+for these scenes (tests/golden/ref_fixtures.npz, tri_tv<i>_*, written by tests/golden/make_ref_fixtures.py) -- parity pinned.
 Tolerance: 1e-9 relative on the dehomogenised points (two different SVD algorithms in FP64; the DLT systems of a
 sane two-view geometry have singular-value gaps of 1e-3..1e-1)."""
+import os
+
 import numpy as np
 import pytest
 
+from conftest import GOLDEN
 from oracle import np_reference as ref
+from ref_scenarios import TWO_VIEW_CASES
 from visual_slam_amd.workloads import ICL_NUIM_K, ba_workload
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(GOLDEN, "ref_fixtures.npz"))
+
+
+def _stored(fx, n, noise, seed):
+    """The stored scene (n, noise, seed) -- its inputs are regenerated here and must equal the stored ones bit for bit -- and
+    the reference's output for it."""
+    pre = "tri_tv%d_" % TWO_VIEW_CASES.index((n, noise, seed))
+    K, p1, p2, x1, x2, gt = _two_view(n, seed, noise)
+    assert np.array_equal(x1, fx[pre + "x1"]) and np.array_equal(x2, fx[pre + "x2"]) and np.array_equal(p2, fx[pre + "w2c2"])
+    return K, p1, p2, x1, x2, gt, fx[pre + "P1"], fx[pre + "P2"], fx[pre + "X"]
 
 
 def _two_view(n=500, seed=0, noise=0.0):
@@ -42,35 +61,40 @@ def test_host_helpers_match_the_reference_definitions():
     assert np.allclose(np.asarray(T), p2, atol=1e-12) and hf.Rtorvec(R).shape == (3, 1)
 
 
+def test_stored_scenes_are_the_scenes_generated_here(fx):
+    for n, noise, seed in TWO_VIEW_CASES:
+        K, p1, p2, x1, x2, gt, P1, P2, want = _stored(fx, n, noise, seed)
+        assert np.array_equal(ref.camera_projection_matrix2(p1, K), P1) and np.array_equal(ref.camera_projection_matrix2(p2, K), P2)
+        assert want.shape == (n, 4) and np.allclose(np.linalg.norm(want, axis=1), 1.0)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,noise,seed", [(1, 0.0, 1), (500, 0.0, 2), (3000, 0.7, 3), (257, 2.0, 4)])
-def test_hip_triangulation_equals_numpy_svd(vs, n, noise, seed):
-    K, p1, p2, x1, x2, gt = _two_view(n, seed, noise)
-    P1, P2 = ref.camera_projection_matrix2(p1, K), ref.camera_projection_matrix2(p2, K)
-    want = ref.triangulate(P1, P2, x1, x2)
+@pytest.mark.parametrize("n,noise,seed", TWO_VIEW_CASES[:4])
+def test_hip_triangulation_equals_the_reference_output(vs, fx, n, noise, seed):
+    K, p1, p2, x1, x2, gt, P1, P2, want = _stored(fx, n, noise, seed)
     X4, depth = vs.triangulate_dlt(P1, P2, x1, x2, p1, p2)
     assert np.allclose(np.linalg.norm(X4, axis=1), 1.0, atol=1e-14) and np.all(X4[:, 3] >= 0)
     want_s = want * np.where(want[:, 3:] < 0, -1.0, 1.0)  # LAPACK's sign is arbitrary
     assert np.allclose(X4, want_s, rtol=0, atol=1e-11)
     Xg, Xw = X4[:, :3] / X4[:, 3:], want[:, :3] / want[:, 3:]
     assert np.max(np.linalg.norm(Xg - Xw, axis=1) / np.linalg.norm(Xw, axis=1)) < 1e-9
-    _, _, wdepth = ref.cheirality_filter(p1, p2, want)
+    _, _, wdepth = ref.cheirality_filter(p1, p2, want)  # main.py:286-309 applied to the reference's points
     assert np.allclose(depth, wdepth, rtol=1e-9, atol=1e-9)
     if noise == 0.0:
         assert np.allclose(Xg, gt, atol=1e-8)
 
 
 @pytest.mark.gpu
-def test_helper_functions_triangulate_drop_in(vs):
+def test_helper_functions_triangulate_drop_in(vs, fx):
     from visual_slam_amd import helper_functions as hf
-    K, p1, p2, x1, x2, gt = _two_view(800, 7, 0.3)
+    K, p1, p2, x1, x2, gt, _, _, want = _stored(fx, 800, 0.3, 7)
     P1, P2 = hf.CameraProjectionMatrix2(p1, K), hf.CameraProjectionMatrix2(p2, K)
     pts = hf.triangulate(pose1=P1, pose2=P2, pts1=x1, pts2=x2, context=vs)   # main.py:284
     pts /= pts[:, 3:]                                                       # main.py:286
-    want = ref.triangulate(P1, P2, x1, x2)
-    want /= want[:, 3:]
+    want = want / want[:, 3:]
     assert np.allclose(pts, want, rtol=1e-9, atol=1e-9)
-    # the fused call applies main.py's filter; scale the scene so that some depths fall inside (0, 1)
+    # the fused call applies main.py's filter; scale the scene so that some depths fall inside (0, 1).  (The scaled scene is not
+    # among the stored ones: its checker is oracle/np_reference.py, itself held to the stored outputs by test_ref_fixtures.py.)
     s = 0.2
     p1s, p2s = p1.copy(), p2.copy()
     p1s[:3, 3] *= s

@@ -124,6 +124,7 @@ HOOKS = {
     "vs_mo_profile": (C.c_int, [c_ctxp, C.c_int]),
     "vs_mo_profile_read": (C.c_int, [c_ctxp, c_f64p, C.c_int]),
     "vs_track_debug": (C.c_int, [c_ctxp, C.c_int, c_intp]),
+    "vs_debug_poison_alloc": (C.c_int, [c_ctxp, C.c_int]),
     "vs_pnp_profile": (C.c_int, [c_ctxp, C.c_int]),
     "vs_pnp_profile_read": (C.c_int, [c_ctxp, c_f64p, C.c_int]),
 }

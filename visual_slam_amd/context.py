@@ -96,6 +96,10 @@ class Context:
         """Where a large problem's sparsity structure is built: on the device (default) or by the host passes."""
         self._chk(self._lib.vs_tune_ba_structure(self._h, int(bool(on_host))))
 
+    def debug_poison_alloc(self, byte):
+        """Developer aid: fill every device buffer this context allocates from now on with `byte` (-1: off)."""
+        self._chk(self._lib.vs_debug_poison_alloc(self._h, int(byte)))
+
     def ba_structure_on_device(self):
         """True when the newest ba_solve of this context built its structure on the device."""
         return bool(self._lib.vs_ba_structure_on_device(self._h))

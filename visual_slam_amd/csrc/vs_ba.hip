@@ -3325,6 +3325,13 @@ VS_API int vs_tune_ba_structure(vs_ctx* ctx, int on_host) {
 
 VS_API int vs_ba_structure_on_device(vs_ctx* ctx) { return ctx ? ctx->ba_structure_dev : 0; }
 
+// developer hook (include/vslam_hip_dev.h): fill every device buffer allocated from now on with `byte` (-1: off)
+VS_API int vs_debug_poison_alloc(vs_ctx* ctx, int byte) {
+  if (!ctx || byte < -1 || byte > 255) return VS_EINVAL;
+  ctx->tune.poison_alloc = byte;
+  return VS_OK;
+}
+
 namespace vsba {
 // The one-launch motion-only solve needs all its camera workgroups resident at the same time (they rendezvous through
 // mailboxes).  The bound is what THIS device can hold -- compute units x workgroups of this kernel per unit, as the runtime

@@ -118,7 +118,7 @@ VS_API int vs_destroy(vs_ctx* ctx) {
   vs_buf* dev[] = {&ctx->d_q,   &ctx->d_t,    &ctx->d_mq,
                    &ctx->d_mt,  &ctx->d_md,   &ctx->d_cnt,     &ctx->d_bgr,  &ctx->d_gray,    &ctx->d_box,
                    &ctx->d_raw, &ctx->d_bandcnt, &ctx->d_hist, &ctx->d_xy,   &ctx->d_score,   &ctx->d_desc,
-                   &ctx->d_n,   &ctx->d_xy_in, &ctx->d_keep,   &ctx->d_ba,  &ctx->d_track, &ctx->d_bgr2, &ctx->d_pnp_tag, &ctx->d_pnp_stamps, &ctx->d_framehist, &ctx->d_match_stamps, &ctx->d_mo_stamps};
+                   &ctx->d_n,   &ctx->d_xy_in, &ctx->d_keep,   &ctx->d_ba,  &ctx->d_track, &ctx->d_bgr2, &ctx->d_pnp_tag, &ctx->d_pnp_stamps, &ctx->d_framehist, &ctx->d_match_stamps, &ctx->d_mo_stamps, &ctx->d_bandflag};
   for (vs_buf* b : dev) free_dev(b);
   for (vs_match_scratch& m : ctx->match_scratch) {
     free_dev(&m.partial);

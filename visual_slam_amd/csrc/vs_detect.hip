@@ -706,7 +706,9 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
       VS_TRY(vs_reserve(ctx, &ctx->d_gray, (size_t)w * h + 16));
       if (ctx->d_bandflag.cap < sizeof(unsigned) * (size_t)nbands) {
         VS_TRY(vs_reserve(ctx, &ctx->d_bandflag, sizeof(unsigned) * (size_t)nbands));
-        VS_HIP(ctx, hipMemsetAsync(ctx->d_bandflag.p, 0, sizeof(unsigned) * (size_t)nbands, ctx->stream));
+        // the whole capacity, not this frame's bands: vs_reserve over-allocates, and a later frame with more bands that still
+        // fits must not meet whatever hipMalloc returned (a word that compares >= seq lets a neighbour skip its wait)
+        VS_HIP(ctx, hipMemsetAsync(ctx->d_bandflag.p, 0, ctx->d_bandflag.cap, ctx->stream));
         ctx->det_seq = 0;
       }
       zero_copy = true;
@@ -736,7 +738,7 @@ int detect_common(vs_ctx* ctx, bool from_bgr, const uint8_t* host_img, int w, in
   }
   if (zero_copy) {
     if (++ctx->det_seq == 0x7FFFFFFFu) {  // the flags only ever grow: start over long before the comparison could wrap
-      VS_HIP(ctx, hipMemsetAsync(ctx->d_bandflag.p, 0, sizeof(unsigned) * (size_t)nbands, s));
+      VS_HIP(ctx, hipMemsetAsync(ctx->d_bandflag.p, 0, ctx->d_bandflag.cap, s));  // every flag the buffer holds (see above)
       ctx->det_seq = 1;
     }
     int* host_err = reinterpret_cast<int*>(ctx->h_pin.p) + 1;  // second word of the pinned result block's header

@@ -60,6 +60,7 @@ struct vs_tuning {
   int small_ns_cap = 512;       // cap on its slab count
   int win_per = 0;              // banded large windows: points per ba_schur_window workgroup (0: automatic)
   int motion_variant = 0;       // 0: one-launch motion-only solve where it applies, 1: one launch per LM step
+  int poison_alloc = -1;        // >= 0: every NEW device buffer of vs_reserve is filled with this byte (vs_debug_poison_alloc; tests: nothing may rely on what hipMalloc returns)
 };
 struct vs_prof_rec {
   hipEvent_t e0, e1;
@@ -227,6 +228,7 @@ static inline int vs_reserve(vs_ctx* ctx, vs_buf* b, size_t bytes) {
   hipError_t e = hipMalloc(&b->p, want);
   if (e != hipSuccess) return vs_fail(ctx, VS_ENOMEM, "hipMalloc(%s) failed: %s", "scratch", hipGetErrorString(e));
   b->cap = want;
+  if (ctx->tune.poison_alloc >= 0) VS_HIP(ctx, hipMemset(b->p, ctx->tune.poison_alloc & 255, want));  // developer aid
   return VS_OK;
 }
 

@@ -666,6 +666,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   VS_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   auto& T = ctx->track;
+  T.inject = 0;  // vs_track_debug arms a fault for the period it is called in
   // the one synchronisation of this call: the staging is free to be rewritten (or reallocated), the buffers are idle
   // (skipped when the previous period ended with all its results handed out: only tracking kernels touch these buffers, and
   // a synchronisation costs ~14 us per stream even when the stream is idle)
@@ -750,6 +751,7 @@ VS_API int vs_track_end(vs_ctx* ctx) {
   ctx->track.quiet = 1;
   ctx->track.dirty = 0;
   ctx->track.active = 0;
+  ctx->track.inject = 0;  // a fault armed for a period that never chained must not fire in a later one
   ctx->track.pending = -1;
   ctx->track.pending_step = -1;
   ctx->track.api_stage = 0;
@@ -1068,7 +1070,7 @@ VS_API int vs_mo_profile_read(vs_ctx* ctx, double* out, int cap_rows) {
 // developer entry point (include/vslam_hip_dev.h): fault injection and the redo counter of the tracking period
 VS_API int vs_track_debug(vs_ctx* ctx, int inject_fault, int* recoveries_out) {
   if (!ctx) return VS_EINVAL;
-  if (inject_fault == 1) ctx->track.inject = 1;
+  if (inject_fault == 1) ctx->track.inject = 1;  // armed for this period only: vs_track_begin / vs_track_end disarm it
   if (recoveries_out) *recoveries_out = ctx->track.recoveries;
   return VS_OK;
 }
