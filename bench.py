@@ -6,7 +6,11 @@ batch of synthetic descriptors already resident in HBM:
   N = 1 : BASELINE.json configs[2] -- 10 000 x 10 000 x 256-bit, k = 2 (the configuration the metric is quoted on)
   N > 1 : weak scaling of the same -- every rank matches its own 10 000-query shard against the replicated 10 000-row
           train set, then one RCCL all-gather of the per-shard best matches (16 B per query) assembles N*10 000 results.
-value = distance evaluations (Q*T) of all ranks / wall time of the K timed steps, in Gmatches/s.
+value = distance evaluations (Q*T) of all ranks / wall time of the K timed steps, in Gmatches/s.  ONE mode for `value`,
+`ms_per_step` and `roofline.frac`: one match launch at a time on one stream (at N > 1 the all-gather of step k runs on a
+second stream beside the kernel of step k + 1), so kernel time <= ms_per_step holds on the line's face and the kernel's
+duration agrees with the rocprofv3 summaries under profiles/.  The throughput with two launches overlapped on two streams
+is carried under its own key (`two_in_flight`), never as `value`.
 
 Rank 0 prints ONE JSON line.  Extra objects on the line:
   roofline      dominant kernel (hamming_knn2_kernel), HIP-event timed in this run.  bound = "valu": the kernel is bound
@@ -42,6 +46,8 @@ OPS_PER_MATCH = (OPS_2CYCLE + OPS_4CYCLE) / 8.0
 CLOCK_HZ, N_SIMD = 2.4e9, 256 * 4
 # uniform 4-cycle model (round 2's yard-stick): 16 lanes/clk/SIMD
 VALU_PEAK_UNIFORM_4CYCLE = N_SIMD * 16 * CLOCK_HZ                                   # 3.93e13 lane-ops/s
+# the guide's nominal figure: every VALU instruction at one wave64 op per 2 cycles per SIMD-32
+VALU_PEAK_GUIDE_NOMINAL = N_SIMD * 32 * CLOCK_HZ                                    # 7.86e13 lane-ops/s
 # mix-specific ceiling (the roofline `peak`): the 148 instructions of 8 distances need 64*2 + 84*4 = 464 issue cycles
 VALU_PEAK_LANE_OPS = N_SIMD * 64 * (OPS_2CYCLE + OPS_4CYCLE) / (2 * OPS_2CYCLE + 4 * OPS_4CYCLE) * CLOCK_HZ   # 5.02e13
 # what a dependent xor -> bcnt stream was MEASURED to issue at with 5 waves per SIMD (chain_grp_vv: 1.597 ns per instruction)
@@ -60,11 +66,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frames", action="store_true", help="skip the cfg2 / local BA / frames legs")
     ap.add_argument("--no-cfg5", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight on as many streams (1..4)")
+    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight of the SECONDARY figure `two_in_flight` (2..4); "
+                    "`value` is always one launch at a time on one stream")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="launcher mode (--gpus N started by hand): seconds after which ranks that have not exited are stopped")
     ap.add_argument("--buffers", type=int, default=0, help="rotating result buffer sets of a step (0: 2, or 4 with a collective)")
     ap.add_argument("--single-stream", action="store_true",
-                    help="one step at a time on one stream (default: two steps in flight on two streams); the rocprofv3 "
-                         "kernel summaries under profiles/ are taken this way so that kernel durations do not overlap")
+                    help="skip the secondary two-in-flight figure: every launch of the run is then one at a time on one stream "
+                         "(the rocprofv3 kernel summaries under profiles/ are taken this way so that kernel durations do not overlap)")
     ap.add_argument("--target-blocks", type=int, default=0, help="tuning: workgroups per launch of the match kernel")
     ap.add_argument("--force-collective", action="store_true",
                     help="rehearsal: run the RCCL all-gather even at world size 1 (exercises the N>1 code path)")
@@ -89,12 +98,15 @@ def launch_ranks(n, argv, worker=None, timeout=None):
     cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
     port = os.environ.get("MASTER_PORT") or str(_free_port())
     import tempfile
-    out0 = tempfile.TemporaryFile(mode="w+")  # rank 0's standard output (a pipe nobody drains could fill up and block the rank)
+    # every rank's standard output goes to a file of its own (a pipe nobody drains could fill up and block the rank): rank 0's
+    # is relayed, the others' are shown when a rank fails or the run times out
+    outs = [tempfile.TemporaryFile(mode="w+") for _ in range(n)]
+    out0 = outs[0]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0", VS_BENCH_LAUNCHED="1")
-        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=out0 if r == 0 else subprocess.DEVNULL))
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=outs[r]))
     deadline = None if timeout is None else time.time() + timeout
     rcs = [None] * n
     failed = None
@@ -119,12 +131,19 @@ def launch_ranks(n, argv, worker=None, timeout=None):
                 failed = -1
             break
         time.sleep(0.05)
-    out0.seek(0)
-    out = out0.read()
-    out0.close()
+    texts = []
+    for f in outs:
+        f.seek(0)
+        texts.append(f.read())
+        f.close()
+    out = texts[0]
     if failed is not None:
         sys.stderr.write("bench.py launcher: %s; ranks' exit codes %s\n"
-                         % ("timed out" if failed < 0 else "rank %d failed" % failed, rcs))
+                         % ("timed out after %.0f s (ranks still running were stopped)" % timeout if failed < 0
+                            else "rank %d failed" % failed, rcs))
+        for r in range(1, n):
+            if texts[r].strip():
+                sys.stderr.write("---- rank %d standard output\n%s\n" % (r, texts[r][-4000:]))
         sys.stdout.write(out)   # whatever rank 0 managed to say (diagnostics), but the exit code says failure
         return 1
     sys.stdout.write(out)
@@ -482,28 +501,45 @@ def frames_leg(ctx, cpu=True):
     return out
 
 
-def frames_replicas(ctx, dist, world, dev):
+def frames_replicas(ctx, dist, world, dev, track=None, sequence=None, sync=None, reps=7):
     """frames/s with one independent replica of the tracker per GPU (north_star: detection and BA stay single-GPU, so
     N GPUs track N streams): every rank runs the device-resident tracking period on the 20 fixture frames between two
-    barriers; the aggregate is ranks x frames / slowest rank."""
+    barriers; the aggregate is ranks x frames / slowest rank (the MAX over ranks of every repetition, median over the
+    repetitions), identical on every rank.  No data-path collective: the only communication is the barrier and the
+    reduction of the timings.  track / sequence / sync: injected by tests/test_bench_launcher.py (a stub tracker on gloo)."""
     import torch
-    from visual_slam_amd.harness import load_sequence, track_sequence_resident
-    frames, depth0 = load_sequence(20)
-    frames = [ctx.pin(f) for f in frames]
-    track_sequence_resident(ctx, frames[:4], depth0, pipelined=True)
-    times = []
-    for _ in range(7):
-        torch.cuda.synchronize()
+    if track is None:
+        from visual_slam_amd.harness import load_sequence, track_sequence_resident
+        frames, depth0 = load_sequence(20)
+        frames = [ctx.pin(f) for f in frames]
+
+        def track(fr):
+            track_sequence_resident(ctx, fr, depth0, pipelined=True)
+        sync = torch.cuda.synchronize
+    else:
+        frames = sequence
+    track(frames[:4])
+    times, own = [], []
+    for _ in range(reps):
+        if sync:
+            sync()
         dist.barrier()
         t0 = time.perf_counter()
-        track_sequence_resident(ctx, frames, depth0, pipelined=True)
+        track(frames)
+        if sync:
+            sync()
         dt = time.perf_counter() - t0
+        own.append(dt)
         te = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         times.append(float(te.item()))
     med = statistics.median(times)
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, len(frames) / statistics.median(own))
     return {"replicas": world, "frames_per_s": world * len(frames) / med, "seconds_slowest_rank_median": med,
-            "note": "one tracker replica per GPU on the same 20 frames (device-resident tracking period, pipelined)"}
+            "frames_per_s_per_rank": per_rank, "repetitions": reps,
+            "note": "one tracker replica per GPU on the same 20 frames (device-resident tracking period, pipelined); "
+                    "replicas only -- no data-path collective"}
 
 
 def timed_steps(step, drain, fence, steps, warmup, torch, dist, use_dist, dev, collect=True):
@@ -542,7 +578,7 @@ def main():
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:   # started by hand: become the launcher (before any GPU call)
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], timeout=args.launch_timeout if args.launch_timeout > 0 else None))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:   # a curve recorded with another rank count than the command line names would be meaningless
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python -m torch.distributed.run --nproc-per-node "
@@ -561,10 +597,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_collective
+    init_pg_s = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
+        t_pg = time.perf_counter()
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        init_pg_s = time.perf_counter() - t_pg
 
     from visual_slam_amd import Context, _capi
     from visual_slam_amd.sharded import ShardedMatcher, shard_bounds
@@ -597,8 +636,11 @@ def main():
         # the bench's inputs are resident long before the first step and results are only read after collect(): the steps'
         # kernels need no ordering behind the library's stream (static_inputs); with a collective, four buffer sets on the two
         # compute streams keep the in-place all-gather of a set off the chain of launches (sharded.py, _Plan)
-        plan = matcher.plan(qq, tt, n_total, single_stream=args.single_stream or single, in_flight=args.in_flight,
-                            buffers=args.buffers or (4 if use_dist else None), static_inputs=True)
+        one = args.single_stream or single
+        # one launch at a time: with a collective the plan keeps ordinary ordering (static_inputs off), which puts the in-place
+        # all-gather on a stream of its own beside the library's (sharded.py, _Plan)
+        plan = matcher.plan(qq, tt, n_total, single_stream=one, in_flight=max(2, args.in_flight),
+                            buffers=args.buffers or (4 if use_dist else None), static_inputs=not (one and use_dist))
         plans.append(plan)
 
         def step():
@@ -625,8 +667,8 @@ def main():
     # Everything the headline needs is prepared before it (plan, buffers, one garbage collection), so that the W warm-up
     # steps of the headline follow the last cfg5 step without an idle gap.
     import gc
-    head_step = make_step(q, t, nq * world)
-    solo_step = make_step(q, t, nq * world, single=True)  # the same step, one launch at a time on the library's stream
+    duo_step = None if args.single_stream else make_step(q, t, nq * world)  # secondary figure: launches overlapped on two streams
+    head_step = make_step(q, t, nq * world, single=True)  # THE step of `value`: one launch at a time on the library's stream
     gc.collect()
     gc.disable()
     cfg5 = None
@@ -639,7 +681,7 @@ def main():
             t5 = torch.from_numpy(t5_np).to(dev)
             del q5_np, t5_np
             k5, w5 = max(3, min(args.steps, 20)), max(1, min(args.warmup, 3))
-            el5, _ = timed_steps(make_step(q5, t5, Q5), drain, fence, k5, w5, torch, dist, use_dist, dev, collect=False)
+            el5, _ = timed_steps(make_step(q5, t5, Q5, single=True), drain, fence, k5, w5, torch, dist, use_dist, dev, collect=False)
 
             def local_only():
                 return matcher.knn2_local_shard(q5, t5)
@@ -657,18 +699,22 @@ def main():
         except Exception as e:  # all ranks take the same path: the collectives inside stay matched
             cfg5 = {"error": repr(e)}
 
-    plans.append(head_step.plan)  # drain() collects from the newest plan
+    # secondary figure first (it also keeps the clocks up): the same K steps with two launches overlapped on two streams
+    elapsed2 = None
+    if duo_step is not None:
+        plans.append(duo_step.plan)  # drain() collects from the newest plan
+        elapsed2, _ = timed_steps(duo_step, drain, fence, args.steps, args.warmup, torch, dist, use_dist, dev, collect=False)
+    # THE timed region of the contract: W warm-up steps, then exactly K steps, one launch at a time -- the mode of `value`,
+    # `ms_per_step` and `roofline.frac` alike
+    plans.append(head_step.plan)
     elapsed, _ = timed_steps(head_step, drain, fence, args.steps, args.warmup, torch, dist, use_dist, dev, collect=False)
-    # the same K steps under the same contract with ONE step in flight (one stream): the mode roofline.frac is measured in
-    plans.append(solo_step.plan)
-    elapsed1, _ = timed_steps(solo_step, drain, fence, args.steps, args.warmup, torch, dist, use_dist, dev, collect=False)
     gc.enable()
     q5 = t5 = None
     ms_per_step = elapsed / args.steps * 1e3
-    ms_per_step_1 = elapsed1 / args.steps * 1e3
     total_matches = float(nq) * nt * world
     value = total_matches / (ms_per_step * 1e-3) / 1e9
-    value_1 = total_matches / (ms_per_step_1 * 1e-3) / 1e9
+    ms_per_step_2 = None if elapsed2 is None else elapsed2 / args.steps * 1e3
+    value_2 = None if elapsed2 is None else total_matches / (ms_per_step_2 * 1e-3) / 1e9
 
     # ---- dominant kernel (hamming_knn2_kernel): HIP events recorded by the library on the launch stream around each
     # launch of K more steps, in this process, right after the timed region
@@ -744,11 +790,11 @@ def main():
         roof = {"bound": "valu", "achieved": achieved / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "Tlane-op/s",
                 "frac": achieved / VALU_PEAK_LANE_OPS, "traffic": traffic,
                 "kernel": "hamming_knn2_kernel", "kernel_ms": kernel_ms, "profiled_calls": int(ncalls),
-                "measured_in": "single_stream: one launch at a time on one stream -- the mode of value_single_stream / "
-                               "ms_per_step_single_stream, NOT of the headline value (two steps in flight on two streams)",
+                "measured_in": "single_stream: one launch at a time on one stream -- the mode of `value` and `ms_per_step` "
+                               "(kernel_ms <= ms_per_step; the difference is the host's share of a step)",
                 "kernel_ms_source": "HIP events on the launch stream: one pair around K launches issued back to back on ONE "
                                     "stream (no overlap between launches), divided by K; includes the ~1.5 us kernel boundary",
-                "steps_in_flight_of_value": 1 if args.single_stream else args.in_flight,
+                "steps_in_flight_of_value": 1,
                 "kernel_ms_event_pair_per_launch": kernel_ms_isolated, "kernel_ms_busy_start": busy_ms,
                 "lane_ops_per_match": OPS_PER_MATCH,
                 "lane_ops_model": "ISA of the main loop: per 8 distances 64 v_xor_b32 + 64 v_bcnt_u32_b32 + 8 v_lshl_or_b32 + "
@@ -758,11 +804,15 @@ def main():
                               "per 4 cycles: 148 x 64 lanes / 464 cycles x 1024 SIMDs x 2.4 GHz (tools/valu_probe2/3.hip, "
                               "profiles/r02_valu_probe*.log)",
                 "valu_ceiling_gmatches": VALU_PEAK_LANE_OPS / OPS_PER_MATCH / 1e9,
-                "frac_two_in_flight": frac_of(ms_per_step, VALU_PEAK_LANE_OPS) if world == 1 else None,
-                "frac_whole_step_single_stream": frac_of(ms_per_step_1, VALU_PEAK_LANE_OPS) if world == 1 else None,
+                "frac_whole_step": frac_of(ms_per_step, VALU_PEAK_LANE_OPS) if world == 1 else None,
+                "frac_two_in_flight": frac_of(ms_per_step_2, VALU_PEAK_LANE_OPS) if world == 1 and ms_per_step_2 else None,
+                "against_guide_nominal": {
+                    "peak": VALU_PEAK_GUIDE_NOMINAL / 1e12, "frac": achieved / VALU_PEAK_GUIDE_NOMINAL,
+                    "note": "the guide's nominal VALU issue rate for every instruction alike: 256 CUs x 4 SIMD-32 x 32 lanes x "
+                            "2.4 GHz = one wave64 op per 2 cycles per SIMD (MI355X_MICROARCH.md); `frac` above prices v_bcnt / "
+                            "v_lshl_or / v_min3 / v_med3 at the one per 4 cycles they were measured to issue at"},
                 "against_uniform_4cycle_peak": {
                     "peak": VALU_PEAK_UNIFORM_4CYCLE / 1e12, "frac": achieved / VALU_PEAK_UNIFORM_4CYCLE,
-                    "frac_two_in_flight": frac_of(ms_per_step, VALU_PEAK_UNIFORM_4CYCLE) if world == 1 else None,
                     "note": "round 2's yard-stick: every op priced at one wave64 op per 4 cycles per SIMD (understates the "
                             "roof by 1.28x for this mix: the xor operands are staged into VGPRs precisely to issue faster)"},
                 "shader_clock_ghz_measured": clock_ghz,
@@ -806,6 +856,12 @@ def main():
                              % (rank, rccl_ranks, world, devices))
             sys.exit(3)
 
+    # per rank: which exchange it uses and why, seconds spent creating the direct communicator, seconds in init_process_group
+    rank_diag = [dict(matcher.diagnostics(), init_process_group_s=init_pg_s, device=torch.cuda.current_device())]
+    if use_dist and world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_diag[0])
+        rank_diag = gathered
     replicas = None
     if use_dist and not args.no_frames:
         try:
@@ -838,16 +894,20 @@ def main():
             "metric": "10k x 10k 256-bit Hamming 2-NN brute-force match throughput", "value": value,
             "unit": "Gmatches/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "value_mode": "%d steps in flight on as many streams (throughput, not the latency of one launch)"
-                          % (1 if args.single_stream else args.in_flight),
-            "value_single_stream": value_1, "ms_per_step_single_stream": ms_per_step_1,
+            "value_mode": "one launch at a time on one stream" + ("" if not use_dist else
+                          "; the all-gather of step k on a second stream beside the kernel of step k + 1"),
+            "two_in_flight": None if value_2 is None else {
+                "value": value_2, "ms_per_step": ms_per_step_2, "steps_in_flight": max(2, args.in_flight),
+                "note": "the same K steps under the same contract with launches overlapped on as many streams (the tail of one "
+                        "launch -- fold, kernel boundary -- runs beside the body of the next): throughput of a caller that keeps "
+                        "two matches in flight; secondary, not the mode of value / ms_per_step / roofline"},
             "dtype": "u32 (xor + popcount on 256-bit descriptors)", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[2]: %d x %d x 256-bit descriptors, k=2, per GPU%s"
                                    % (nq, nt, "" if world == 1 else "; %d query shards + RCCL all-gather (16 B/query, overlapped with the next step)" % world),
                        "queries_per_gpu": nq, "train": nt, "parallelism": "query-shard x%d" % world},
             "roofline": roof,
             "rccl_ranks": rccl_ranks, "rank_devices": devices, "rccl_device_rank0": rccl_device,
-            "collective_path": matcher.collective_path(), "launched_by": "bench.py launcher" if os.environ.get(
+            "collective_path": matcher.collective_path(), "collective_ranks": rank_diag, "launched_by": "bench.py launcher" if os.environ.get(
                 "VS_BENCH_LAUNCHED") else "external launcher" if "WORLD_SIZE" in os.environ else "single process",
         }
         if cfg5 is not None:

@@ -142,6 +142,13 @@ int vs_hamming_knn2_packed_dev(vs_ctx* ctx, const void* d_q, int nq, const void*
 int vs_hamming_knn2_sharded_dev(vs_ctx* ctx, const void* d_q_shard, int nq_shard, const void* d_t, int nt,
                                 void* d_gathered, int per, int rank, int world, void* nccl_comm, void* compute_stream,
                                 void* comm_stream, void* done_event, void* after_stream);
+/* The device entry points only enqueue, so they cannot report what a launch finds out while it runs: a folding workgroup of
+ * hamming_knn2_kernel that gave up its bounded wait for a train chunk (a workgroup that never ran; ~0.5 s) writes -1 rows
+ * and raises a pinned flag.  vs_match_status returns VS_EHIP (once, and clears the flags) when that happened to any match
+ * launch of the context on any stream since the last call.  Call it where results are consumed -- after the done event or
+ * the synchronisation the caller waits on (ShardedMatcher does, in collect / close; the tracking period checks by itself
+ * before it hands a frame out).  A stream's next launch still refuses to start on a raised flag, as before. */
+int vs_match_status(vs_ctx* ctx);
 /* d_n_out: one int32 in HBM receiving the match count */
 int vs_match_ratio_dev(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, double ratio, void* d_match_q,
                        void* d_match_t, void* d_match_d, void* d_n_out, void* stream);

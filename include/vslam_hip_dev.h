@@ -14,8 +14,10 @@ extern "C" {
 #endif
 
 /* Matcher (csrc/vs_match.hip).  target_blocks: workgroups per launch the chunk planner aims at (0 = automatic);
- * tstage: 1 = train rows staged through LDS (default), 0 = wave-uniform scalar loads (sweep only -- that instantiation
- * carries scratch memory and is refused on a device-chained tracking period).  A negative value leaves a knob as it is. */
+ * tstage: 1 = train rows staged through LDS (default), 0 = wave-uniform scalar loads (sweep only; neither instantiation has a
+ * private segment -- tests/test_kernel_resources.py holds both at scratch 0 -- so both may run inside a device-chained tracking
+ * period; the kernels that DO carry scratch on the tracking path are ba_motion_step and ba_motion_persistent<true>, see
+ * track_redo / track_ba_batch in csrc/vs_track.hip).  A negative value leaves a knob as it is. */
 int vs_tune_match(vs_ctx* ctx, int target_blocks, int tstage);
 /* HIP-event pair around every launch of hamming_knn2_kernel on its launch stream while enabled. */
 int vs_match_profile(vs_ctx* ctx, int enable);
@@ -58,6 +60,11 @@ int vs_mo_profile_read(vs_ctx* ctx, double* out, int cap_rows);
  * nobody publishes -- every workgroup's bounded wait runs out, the frame is then redone host-paced (track_redo); 0: nothing.
  * *recoveries_out (may be NULL) = back halves redone so far on this context. */
 int vs_track_debug(vs_ctx* ctx, int inject_fault, int* recoveries_out);
+
+/* Raises the pinned "a train chunk did not report" word of every match scratch set in use, as a folding workgroup of
+ * hamming_knn2_kernel that ran out of its bounded wait does; returns how many.  Tests of where that report surfaces
+ * (vs_match_status, the tracking period's hand-out, vs_track_end, a stream's next launch). */
+int vs_match_debug_raise(vs_ctx* ctx);
 
 /* Allocation poisoning (tests).  byte in 0..255: every device buffer the context allocates FROM NOW ON (vs_reserve) is filled
  * with that byte before first use; -1: off (default).  A kernel or protocol that relies on what hipMalloc happens to return --

@@ -99,3 +99,91 @@ def test_bench_gpus_n_by_hand_becomes_the_launcher(tmp_path):
     assert p.returncode != 0
     assert "bench.py launcher: rank" in p.stderr and "failed" in p.stderr
     assert p.stderr.count("needs an MI355X") >= 1
+
+
+HANG_STUB = textwrap.dedent("""
+    import os, sys, time
+    print("rank %s is here" % os.environ["RANK"], flush=True)
+    if os.environ["RANK"] == "1":
+        time.sleep(600)   # alive, never exits: a rank stuck inside communicator bootstrap or a collective
+    time.sleep(600)
+""")
+
+
+def test_launcher_times_out_on_ranks_that_hang_alive_and_shows_what_they_said(tmp_path):
+    """A rank that hangs WITHOUT exiting (communicator bootstrap, a collective nobody completes) must not block the launcher for
+    ever: after the time limit the ranks are stopped by handle, the exit code is non-zero, and what the other ranks printed is
+    shown (round-4 advisor: their output went to /dev/null)."""
+    import time
+    stub = tmp_path / "hang.py"
+    stub.write_text(HANG_STUB)
+    driver = DRIVER.replace("timeout=60", "timeout=3")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", driver, "2", str(stub)], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and time.time() - t0 < 40
+    assert "timed out after 3 s" in p.stderr
+    assert "rank 1 standard output" in p.stderr and "rank 1 is here" in p.stderr
+    assert "rank 0 is here" in p.stdout
+
+
+def test_bench_launcher_mode_has_a_finite_default_time_limit():
+    import bench
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--gpus", "8"]
+        a = bench.parse()
+    finally:
+        sys.argv = old
+    assert 0 < a.launch_timeout <= 3600
+
+
+REPLICA_WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    import torch
+    import torch.distributed as dist
+    import bench
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def track(frames):           # stub tracker: rank r needs (1 + r) ms per frame
+        calls.append(len(frames))
+        time.sleep(0.001 * (1 + rank) * len(frames))
+
+    out = bench.frames_replicas(None, dist, world, torch.device("cpu"), track=track, sequence=list(range(20)), sync=None, reps=5)
+    out["calls"] = calls
+    print("REPLICAS " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+""" % ROOT)
+
+
+def test_frames_replicas_aggregates_over_ranks_by_the_slowest(tmp_path):
+    """The `frames/s at 1/2/4/8 GPUs` half of the metric (north_star: detection and BA stay single-GPU -> N replicas): two
+    gloo ranks, a stub tracker that needs 1 ms per frame on rank 0 and 2 ms on rank 1.  The aggregate is ranks x frames / the
+    SLOWEST rank's time, the same figure on both ranks, and every rank tracked the whole sequence every repetition."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    w = tmp_path / "replica_worker.py"
+    w.write_text(REPLICA_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(w)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e
+        outs.append(json.loads([ln for ln in o.splitlines() if ln.startswith("REPLICAS ")][0][9:]))
+    a, b = outs
+    assert a["replicas"] == b["replicas"] == 2
+    assert a["frames_per_s"] == b["frames_per_s"] and a["seconds_slowest_rank_median"] == b["seconds_slowest_rank_median"]
+    assert 0.040 <= a["seconds_slowest_rank_median"] < 0.080          # rank 1: 20 frames x 2 ms
+    assert abs(a["frames_per_s"] - 2 * 20 / a["seconds_slowest_rank_median"]) < 1e-9
+    assert a["frames_per_s_per_rank"] == b["frames_per_s_per_rank"] and len(a["frames_per_s_per_rank"]) == 2
+    assert a["frames_per_s_per_rank"][0] > 1.5 * a["frames_per_s_per_rank"][1]
+    assert a["calls"] == [4] + [20] * 5 and b["calls"] == a["calls"]

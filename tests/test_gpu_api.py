@@ -886,3 +886,59 @@ def test_class_api_fast_path_engages_for_the_reference_call_as_written(vs):
     # and the verbatim call differs from the corrected one only as far as the other start point moves RANSAC + LM
     fixed, _ = harness.track_sequence_api(frames, depth0, context=vs)
     assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(poses, fixed)) < 1e-2
+
+
+def test_a_lost_match_chunk_is_reported_where_results_are_handed_out(vs, oracle):
+    """Device entry points only enqueue: a folding workgroup of hamming_knn2_kernel that runs out of its bounded wait writes -1
+    rows and raises a pinned word.  Round 4 looked at that word only at the stream's NEXT launch -- the error was blamed on
+    an innocent call, or never reported when no launch followed.  Now it surfaces where results are handed out:
+    vs_match_status (ShardedMatcher's collect / close, Context.synchronize), the tracking period's frame hand-out, vs_track_end.
+    The word is raised here by the developer hook vs_match_debug_raise, exactly as the kernel raises it."""
+    import torch
+    import visual_slam_amd.context as vctx
+    from visual_slam_amd import harness
+    from visual_slam_amd.context import VsError
+    from visual_slam_amd.sharded import ShardedMatcher
+    vctx._DEFAULT = vs
+    lib, h = vs._lib, vs.handle
+    q, t = match_workload(1500, 1200, seed=3)
+    oidx, odist = oracle.hamming_knn2(q, t)
+    m = ShardedMatcher()
+    with torch.cuda.stream(m.torch_stream()):
+        dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+        plan = m.plan(dq, dt, len(q), in_flight=2)
+        s0 = plan.submit()
+        torch.cuda.synchronize()
+        assert lib.vs_match_status(h) == 0                      # nothing happened: quiet
+        assert lib.vs_match_debug_raise(h) >= 1
+        with pytest.raises(VsError, match="did not report within the bounded wait"):
+            plan.collect(s0)                                       # reported at the hand-out of THIS step ...
+        assert lib.vs_match_status(h) == 0                      # ... once
+        s1 = plan.submit()                                         # and the stream's next launch starts clean
+        idx, dist = plan.collect(s1)
+        assert np.array_equal(idx.cpu().numpy(), oidx) and np.array_equal(dist.cpu().numpy(), odist)
+        assert lib.vs_match_debug_raise(h) >= 1
+        with pytest.raises(VsError, match="did not report"):
+            vs.synchronize()
+        assert lib.vs_match_debug_raise(h) >= 1
+        with pytest.raises(VsError, match="did not report"):
+            m.close()                                              # the last step of a run: nothing goes unreported
+    # the tracking period: the report names the frame whose front half it belongs to, and vs_track_end does not swallow it
+    frames, depth0 = harness.load_sequence(4)
+    xy0, _, d0 = vs.detect_describe_bgr(frames[0], 20, 3000)
+    X = harness.backproject(xy0, depth0)
+    vs.track_begin(X, d0, np.eye(4), ICL_NUIM_K, max_frames=4)
+    good = vs.track_frame(frames[1])
+    assert lib.vs_match_debug_raise(h) >= 1
+    with pytest.raises(VsError, match="train chunk"):            # (the frame's own front-half launch finds the word first)
+        vs.track_frame(frames[2])
+    vs.track_end()
+    vs.track_begin(X, d0, np.eye(4), ICL_NUIM_K, max_frames=4)
+    again = vs.track_frame(frames[1])
+    assert np.array_equal(again["poses"], good["poses"])
+    assert lib.vs_match_debug_raise(h) >= 1
+    with pytest.raises(VsError, match="vs_track_end: a train chunk"):
+        vs.track_end()
+    vs.track_begin(X, d0, np.eye(4), ICL_NUIM_K, max_frames=4)   # and the context is usable afterwards
+    assert np.array_equal(vs.track_frame(frames[1])["poses"], good["poses"])
+    vs.track_end()

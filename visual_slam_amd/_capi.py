@@ -107,6 +107,7 @@ SIGNATURES = {
     "vs_track_end": (C.c_int, [c_ctxp]),
     "vs_ba_solve": (C.c_int, [c_ctxp, C.POINTER(BAProblem), C.POINTER(BAResult)]),
     "vs_ba_debug_cholesky": (C.c_int, [c_ctxp, c_f64p, C.c_int, c_f64p, c_f64p, c_intp]),
+    "vs_match_status": (C.c_int, [c_ctxp]),
     "vs_hamming_knn2_sharded_dev": (C.c_int, [c_ctxp, c_voidp, C.c_int, c_voidp, C.c_int, c_voidp, C.c_int,
                                               C.c_int, C.c_int, c_voidp, c_voidp, c_voidp, c_voidp, c_voidp]),
 }
@@ -123,6 +124,7 @@ HOOKS = {
     "vs_match_stamps_read": (C.c_int, [c_ctxp, c_f64p, C.c_int]),
     "vs_mo_profile": (C.c_int, [c_ctxp, C.c_int]),
     "vs_mo_profile_read": (C.c_int, [c_ctxp, c_f64p, C.c_int]),
+    "vs_match_debug_raise": (C.c_int, [c_ctxp]),
     "vs_track_debug": (C.c_int, [c_ctxp, C.c_int, c_intp]),
     "vs_debug_poison_alloc": (C.c_int, [c_ctxp, C.c_int]),
     "vs_pnp_profile": (C.c_int, [c_ctxp, C.c_int]),

@@ -76,6 +76,12 @@ class Context:
 
     def synchronize(self):
         self._chk(self._lib.vs_synchronize(self._h))
+        self._chk(self._lib.vs_match_status(self._h))  # device-side match launches report a lost train chunk here
+
+    def match_status(self):
+        """Raises VsError when a device-side match launch of this context gave up its bounded wait since the last check
+        (vs_match_status).  Cheap: reads pinned words."""
+        self._chk(self._lib.vs_match_status(self._h))
 
     # ------------------------------------------------------------------ test / sweep hooks (state of THIS context)
     def tune_match(self, target_blocks=-1, tstage=-1):
@@ -394,9 +400,10 @@ class Context:
         return t["poses"][:npo.value].reshape(-1, 4, 4).copy()
 
     def track_end(self):
-        self._chk(self._lib.vs_track_end(self._h))
+        rc = self._lib.vs_track_end(self._h)   # the period is closed whatever it reports (a lost match chunk of its last frame)
         self._track = None
         self._track_owner = None
+        self._chk(rc)
 
     # ------------------------------------------------------------------ two-view initialisation
     def essential_ransac(self, x1, x2, threshold, prob=0.999, max_iters=1000, seed=0):

@@ -115,6 +115,8 @@ VS_API int vs_destroy(vs_ctx* ctx) {
     return VS_OK;
   }
   (void)hipDeviceSynchronize();  // every stream the context has launched on (front half, a plan's match streams)
+  const int lost_rc = vs_match_lost_check(ctx, "vs_destroy");  // a last launch nobody asked about: at least the return value says so
+  if (lost_rc != VS_OK) fprintf(stderr, "libvslam_hip: %s\n", ctx->err);
   vs_buf* dev[] = {&ctx->d_q,   &ctx->d_t,    &ctx->d_mq,
                    &ctx->d_mt,  &ctx->d_md,   &ctx->d_cnt,     &ctx->d_bgr,  &ctx->d_gray,    &ctx->d_box,
                    &ctx->d_raw, &ctx->d_bandcnt, &ctx->d_hist, &ctx->d_xy,   &ctx->d_score,   &ctx->d_desc,
@@ -150,7 +152,7 @@ VS_API int vs_destroy(vs_ctx* ctx) {
     if (a) (void)hipStreamDestroy(a);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
-  return VS_OK;
+  return lost_rc;
 }
 
 bool vs_is_pinned(const void* p) {

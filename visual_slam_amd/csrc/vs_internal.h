@@ -270,5 +270,7 @@ int vs_detect_describe_dev_mirror(vs_ctx* ctx, const void* d_bgr, int w, int h, 
 size_t vs_match_chain_scratch_bytes(vs_ctx* ctx);
 size_t vs_detect_chain_scratch_bytes();
 
+// VS_EHIP (and the flags cleared) when a match launch on ANY stream of the context gave up its bounded wait since the last check
+int vs_match_lost_check(vs_ctx* ctx, const char* who);
 // implemented in vs_match.hip / vs_detect.hip / vs_ba.hip
 void vs_ctx_free_buffers(vs_ctx* ctx);

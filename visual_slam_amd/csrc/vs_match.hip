@@ -120,7 +120,8 @@ __device__ __forceinline__ void fold64(unsigned long long& B1, unsigned long lon
 // when the geometry of a stream's launches changes, or after 63 launches... the host clears the slots (knn2_dev_impl).
 // PACKED: one 16-byte row (idx0, idx1, dist0, dist1) per query -- the layout the query-sharded matcher all-gathers.
 // TSTAGE (how the wave-uniform train rows reach the VALU):
-//   false: scalar loads (s_load_dwordx16), the row is the SGPR operand of v_xor_b32 (sweeps only; carries scratch memory);
+//   false: scalar loads (s_load_dwordx16), the row is the SGPR operand of v_xor_b32 (sweeps only; no private segment either:
+//          tests/test_kernel_resources.py holds both instantiations at scratch 0);
 //   true : every wave stages 64 rows at a time in its own LDS slice (one coalesced 32-B load per lane, prefetched one
 //          batch ahead) and reads each row back as two broadcast ds_read_b128 -- both v_xor_b32 operands are then VGPRs.
 //          tools/valu_probe2.hip: v_xor/v_and/v_or with VGPR sources issue at the 2-cycle wave64 rate on gfx950, with an
@@ -549,6 +550,37 @@ static int match_check_flag(vs_ctx* ctx, hipStream_t s, const char* who) {
       return vs_fail(ctx, VS_EHIP, "%s: a train chunk of the match launch did not report within the bounded wait", who);
     }
   return VS_OK;
+}
+
+// the same question over EVERY scratch set (any stream): asked where results of device-side launches are handed out -- the
+// tracking period's back half, vs_track_end, vs_match_status (the sharded matcher's collect), vs_destroy -- so that a launch
+// that lost a chunk is reported against itself, not against the next, innocent launch on its stream (or never)
+int vs_match_lost_check(vs_ctx* ctx, const char* who) {
+  bool lost = false;
+  for (vs_match_scratch& m : ctx->match_scratch)
+    if (m.used && m.flag.p && *(volatile unsigned*)m.flag.p != 0u) {
+      *(volatile unsigned*)m.flag.p = 0u;
+      m.qtiles = m.nchunks = 0;
+      lost = true;
+    }
+  if (lost)
+    return vs_fail(ctx, VS_EHIP, "%s: a train chunk of a match launch did not report within the bounded wait (its rows are -1)", who);
+  return VS_OK;
+}
+
+VS_API int vs_match_status(vs_ctx* ctx) { return ctx ? vs_match_lost_check(ctx, "vs_match_status") : VS_EINVAL; }
+
+// developer hook (include/vslam_hip_dev.h): raise the pinned "lost a chunk" word of every scratch set in use, exactly as a
+// folding workgroup that gave up would -- tests of where the report surfaces; returns the number of words raised
+VS_API int vs_match_debug_raise(vs_ctx* ctx) {
+  if (!ctx) return VS_EINVAL;
+  int n = 0;
+  for (vs_match_scratch& m : ctx->match_scratch)
+    if (m.used && m.flag.p) {
+      *(volatile unsigned*)m.flag.p = 1u;
+      ++n;
+    }
+  return n;
 }
 
 static int knn2_dev_impl(vs_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, void* d_idx, void* d_dist,

@@ -561,6 +561,10 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   if (pnp_ran && T.pnp_iters > 0 && rb_res[16] < 0.0)
     return vs_fail(ctx, VS_EHIP, "%s: the PnP hypothesis workgroups did not report", "vs_track_frame");
   T.recoverable = 0;
+  // the frame's front half has completed (its counts are in the block just read): did its match launch lose a train chunk?
+  // Its rows were appended as "no match" then -- not redone (the front half is not repeatable once appended), but reported
+  // HERE, against this frame, instead of on the stream's next launch or never.
+  VS_TRY(vs_match_lost_check(ctx, "vs_track_frame"));
   if (rb_flags[0]) return vs_fail(ctx, VS_ENOMEM, "%s: observation capacity of the period exceeded", "vs_track_frame");
   bool copies = false;
   if (xy_out && n_kp > 0) {
@@ -598,6 +602,10 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
 // frame's back half again in the form that needs no in-kernel wait: event-ordered behind the front half, the motion-only solve
 // one launch per LM step.  Same arithmetic: the poses equal the undisturbed run's bit for bit (tests).  The frame's front half
 // is not repeated -- its rows were appended by kernels that depend on no back half.
+// ba_motion_step (what runs here, and in every host-paced solve) HAS a private segment: a kernel that needs scratch may be unable
+// to start while another kernel waits for it in-kernel, so it may only be launched when no kernel of the period is waiting
+// on a device-side tag -- which holds here (every stream is drained first) and in track_ba_batch's non-chained use (the host
+// paces the launches; chained periods use ba_motion_persistent<false>, the register-resident instantiation, only).
 int track_redo(vs_ctx* ctx, int set, double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found, float* xy_out,
                uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t, bool pnp_ran) {
   auto& T = ctx->track;
@@ -760,7 +768,7 @@ VS_API int vs_track_end(vs_ctx* ctx) {
             g_tt.n, g_tt.sum[0] / g_tt.n, g_tt.sum[1] / g_tt.n, g_tt.sum[2] / g_tt.n, g_tt.sum[3] / g_tt.n);
     g_tt = track_timing();
   }
-  return VS_OK;
+  return vs_match_lost_check(ctx, "vs_track_end");  // everything of the period has been waited for: nothing may go unreported
 }
 
 VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int stride, int thr, double ratio,

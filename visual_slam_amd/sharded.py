@@ -150,6 +150,10 @@ class ShardedMatcher:
         self._rccl_failed = False
         self._events = {}
         self._force_collective = force_collective
+        # diagnostics for a scaling record (bench.py puts them on its JSON line, per rank): seconds spent creating the direct
+        # communicator (unique id + broadcast + ncclCommInitRank + the agreement), and why this rank uses the path it uses
+        self.bootstrap_s = None
+        self.path_reason = "not decided yet (no step submitted)"
 
     # ---- HIP path: torch device tensors in, torch device tensors out, no host copies, no synchronisation
     def torch_stream(self):
@@ -247,9 +251,14 @@ class ShardedMatcher:
     # ncclAllGather on RCCL's own stream, ordered by events inside the library (no host synchronisation)
     def _direct_ready(self, q):
         import os
-        if self._local is not None or not q.is_cuda or self._rccl_failed \
-                or os.environ.get("VS_SHARDED_TORCH_COLLECTIVE", "0") == "1":
+        if self._local is not None or not q.is_cuda:
+            self.path_reason = "torch.distributed collective: " + ("injected CPU kernel" if self._local is not None else "host tensors")
             return False
+        if os.environ.get("VS_SHARDED_TORCH_COLLECTIVE", "0") == "1":
+            self.path_reason = "torch.distributed collective: VS_SHARDED_TORCH_COLLECTIVE=1"
+            return False
+        if self._rccl_failed:
+            return False  # (path_reason says why, from _init_direct)
         if self._rccl is None:
             self._init_direct(q.device)
         return self._rccl is not None
@@ -281,20 +290,28 @@ class ShardedMatcher:
         """Create the direct communicator on every rank, then agree on the outcome: if any rank failed (or timed out
         inside ncclCommInitRank), all ranks use torch.distributed's collective -- a rank alone in ncclAllGather would
         wait for ever."""
+        import time
         import torch
-        ok = 1
+        ok, why = 1, None
+        t0 = time.perf_counter()
         try:
             self._rccl = RcclAllGather(self.group)
             self._events = {}
-        except (OSError, AttributeError, RuntimeError):
-            self._rccl, ok = None, 0
+        except (OSError, AttributeError, RuntimeError) as e:
+            self._rccl, ok, why = None, 0, "%s: %s" % (type(e).__name__, e)
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
         self._dist.all_reduce(flag, op=self._dist.ReduceOp.MIN, group=self.group)
+        self.bootstrap_s = time.perf_counter() - t0
         if int(flag.item()) == 0:
             self._rccl_failed = True
+            self.path_reason = "torch.distributed collective: " + (
+                "this rank could not create its own communicator (%s)" % why if why else
+                "another rank could not create its communicator (all ranks fall back together)")
             if self._rccl is not None:
                 self._rccl.close()
                 self._rccl = None
+        else:
+            self.path_reason = "rccl_direct: ncclCommInitRank of %d rank(s) succeeded on every rank in %.3f s" % (self.world, self.bootstrap_s)
 
     def collect(self, ticket):
         """Wait for a ticket's all-gather; returns (idx [Q,2], dist [Q,2]) ordered for use on torch's current stream.
@@ -310,6 +327,8 @@ class ShardedMatcher:
                 h.wait()
         elif self._local is None and out.is_cuda:
             self._order_caller_after()
+        if self._local is None and self._ctx is not None:
+            self._ctx.match_status()   # (see _Plan.collect)
         return out[:n_query, 0:2], out[:n_query, 2:4]
 
     def plan(self, q_shard, train, n_query, single_stream=False, in_flight=2, buffers=None, static_inputs=False):
@@ -340,17 +359,29 @@ class ShardedMatcher:
         if self._rccl is not None:
             return "rccl_direct"
         collective = self._dist.is_initialized() and (self.world > 1 or self._force_collective)
+        if not collective:
+            self.path_reason = "none: one rank, no collective asked for"
         return "torch_distributed" if collective else "none"
+
+    def diagnostics(self):
+        """{path, reason, bootstrap_s, rccl_ranks} of THIS rank (bench.py gathers them over the ranks)."""
+        path = self.collective_path()
+        return {"rank": self.rank, "path": path, "reason": self.path_reason, "bootstrap_s": self.bootstrap_s,
+                "rccl_ranks": self.rccl_ranks()}
 
     def close(self):
         """Destroy the direct RCCL communicator (if one was created)."""
-        if self._rccl is not None:
-            try:
+        try:
+            if self._ctx is not None and self._local is None:
                 import torch
                 torch.cuda.synchronize()
-                self._rccl.close()
-            finally:
-                self._rccl = None
+                self._ctx.match_status()   # every step has completed: a lost chunk cannot go unreported past this point
+        finally:
+            if self._rccl is not None:
+                try:
+                    self._rccl.close()
+                finally:
+                    self._rccl = None
 
     def knn2(self, query, train):
         """query: the FULL query set (replicated input, as the reference's caller holds it); returns full results."""
@@ -405,6 +436,13 @@ class _Plan:
         # inputs nothing else is enqueued on the library's stream between collect()s, and it owns a queue: 49 us / step.
         # With per-step inputs the library's stream carries their producers, which must not queue behind an all-gather.
         comm = main if static_inputs else (m._rccl.stream if self.direct else None)
+        if in_flight == 1 and self.direct:
+            # one launch at a time on the library's stream; the exchange on the context's first auxiliary stream (made with the
+            # context: a hardware queue of its own), so the all-gather of step k overlaps the kernel of step k + 1 and nothing
+            # else -- compute on one stream, the collective on another
+            aux = m._ctx.aux_stream(0)
+            comm = torch.cuda.ExternalStream(aux, device=q.device) if aux else m._rccl.stream
+            self.comm_stream = comm
         # compute streams of the slots: the context's own auxiliary streams first (created with the context, each on a
         # hardware queue of its own -- streams made later may share a queue with the library's and then never overlap it),
         # torch streams only beyond those
@@ -476,4 +514,10 @@ class _Plan:
                 self.work[slot] = None
         elif self.streams[slot] is not self.m._stream or self.direct:
             self.m._stream.wait_event(self.done[slot])
+        # a launch that lost a train chunk (bounded wait of the fold, ~0.5 s) raised a pinned flag: reported where results are
+        # handed out.  The wait above is stream-side, so a flag of THIS step may not be up yet -- then the next collect(), or
+        # close(), reports it; one read of a few pinned words per step
+        rc = self.lib.vs_match_status(self.h)
+        if rc != 0:
+            self.m._ctx._chk(rc)
         return self.outs[slot]
