@@ -42,6 +42,19 @@ int vs_tune_ba(vs_ctx* ctx, int schur_variant, int points_per_workgroup, int max
 int vs_tune_ba_structure(vs_ctx* ctx, int on_host);
 int vs_ba_structure_on_device(vs_ctx* ctx); /* 1: the newest vs_ba_solve of this context built its structure on the device */
 
+/* Experiment (profiles/tried_and_dropped.md): on = 1 replays every batch of LM slots of vs_ba_solve (<= 10 slots of four launches,
+ * the export kernel, the read-back) as ONE captured hipGraph; 0 = launch by launch (default); any other value leaves it.
+ * *last_batch_us (may be NULL) = wall microseconds of the newest batch, graph launch (or first enqueue) to results on the host. */
+int vs_tune_ba_graph(vs_ctx* ctx, int on, double* last_batch_us);
+
+/* Which kernels the newest vs_ba_solve of this context took.  out6[0] Schur complement: 0 ba_schur (general, one slab of points per
+ * workgroup), 1 ba_schur_tile (tiles of 10 x 10 camera blocks), 2 ba_schur_small (single tile), 3 ba_schur_window (banded, FP64
+ * matrix cores), 4 none (motion-only: block diagonal); out6[1] reduced system: 0 ba_solve_block (LDS, <= 21 free cameras),
+ * 1 ba_chol_band + ba_chol_finish, 2 ba_chol_panel / ba_chol_update per block column + ba_chol_finish, 3 element-wise last
+ * resort, 4 none (motion-only); out6[2] unknowns of the reduced system; out6[3] band width handed to the factorisation (0: dense);
+ * out6[4] camera tiles; out6[5] widest camera span of a banded window's slab (0: no window plan). */
+int vs_ba_last_path(vs_ctx* ctx, int* out6);
+
 /* Phase stamps of pnp_ransac_kernel (csrc/vs_pnp.hip).  vs_pnp_profile_read synchronises and returns the stamps of the
  * newest profiled launch as microseconds since the launch's first stamp: rows 0..H-1 = hypotheses, row H = the finishing
  * workgroup; 8 doubles per row, 0 = not reached.  Returns the number of rows (0 when nothing was profiled). */

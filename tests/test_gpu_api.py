@@ -932,6 +932,7 @@ def test_a_lost_match_chunk_is_reported_where_results_are_handed_out(vs, oracle)
     assert lib.vs_match_debug_raise(h) >= 1
     with pytest.raises(VsError, match="train chunk"):            # (the frame's own front-half launch finds the word first)
         vs.track_frame(frames[2])
+    lib.vs_match_status(h)                                        # (the hook raised the words of the other streams' sets as well)
     vs.track_end()
     vs.track_begin(X, d0, np.eye(4), ICL_NUIM_K, max_frames=4)
     again = vs.track_frame(frames[1])

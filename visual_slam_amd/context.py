@@ -102,6 +102,17 @@ class Context:
         """Where a large problem's sparsity structure is built: on the device (default) or by the host passes."""
         self._chk(self._lib.vs_tune_ba_structure(self._h, int(bool(on_host))))
 
+    _SCHUR_NAMES = ("ba_schur", "ba_schur_tile", "ba_schur_small", "ba_schur_window", "none (motion-only)")
+    _DENSE_NAMES = ("ba_solve_block", "ba_chol_band", "ba_chol_panel", "ba_solve (element-wise)", "none (motion-only)")
+
+    def ba_last_path(self):
+        """dict(schur, dense, unknowns, band, tiles, window_cams) of the newest ba_solve of this context (vs_ba_last_path)."""
+        out = np.zeros(6, np.intc)
+        self._chk(self._lib.vs_ba_last_path(self._h, out.ctypes.data))
+        return dict(schur=self._SCHUR_NAMES[out[0]] if 0 <= out[0] < 5 else None,
+                    dense=self._DENSE_NAMES[out[1]] if 0 <= out[1] < 5 else None,
+                    unknowns=int(out[2]), band=int(out[3]), tiles=int(out[4]), window_cams=int(out[5]))
+
     def debug_poison_alloc(self, byte):
         """Developer aid: fill every device buffer this context allocates from now on with `byte` (-1: off)."""
         self._chk(self._lib.vs_debug_poison_alloc(self._h, int(byte)))

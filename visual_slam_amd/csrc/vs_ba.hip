@@ -3325,6 +3325,21 @@ VS_API int vs_tune_ba_structure(vs_ctx* ctx, int on_host) {
 
 VS_API int vs_ba_structure_on_device(vs_ctx* ctx) { return ctx ? ctx->ba_structure_dev : 0; }
 
+// developer hook (include/vslam_hip_dev.h): experiment -- every batch of LM slots replayed as one captured hipGraph
+VS_API int vs_tune_ba_graph(vs_ctx* ctx, int on, double* last_batch_us) {
+  if (!ctx) return VS_EINVAL;
+  if (on == 0 || on == 1) ctx->tune.ba_graph = on;
+  if (last_batch_us) *last_batch_us = ctx->ba_batch_us;
+  return VS_OK;
+}
+
+// developer hook (include/vslam_hip_dev.h): the kernels the newest vs_ba_solve of this context took
+VS_API int vs_ba_last_path(vs_ctx* ctx, int* out6) {
+  if (!ctx || !out6) return VS_EINVAL;
+  for (int i = 0; i < 6; ++i) out6[i] = ctx->ba_path[i];
+  return VS_OK;
+}
+
 // developer hook (include/vslam_hip_dev.h): fill every device buffer allocated from now on with `byte` (-1: off)
 VS_API int vs_debug_poison_alloc(vs_ctx* ctx, int byte) {
   if (!ctx || byte < -1 || byte > 255) return VS_EINVAL;
@@ -4264,17 +4279,28 @@ host_passes:
   }
   solve_plan splan;
   VS_TRY(plan_solve(ctx, np, &splan));
+  // which kernels this solve takes (vs_ba_last_path: tests of real-data problems assert the path they exercise)
+  ctx->ba_path[0] = motion_only ? 4 : win ? 3 : small ? 2 : tiled ? 1 : 0;
+  ctx->ba_path[1] = motion_only ? 4 : splan.lds ? 0 : (splan.band_ok && D.band > 0 && D.band <= kBandMax) ? 1 : splan.nbw > 0 ? 2 : 3;
+  ctx->ba_path[2] = np;
+  ctx->ba_path[3] = D.band;
+  ctx->ba_path[4] = ntile;
+  ctx->ba_path[5] = win ? win_cams : 0;
   if (!tiled && schur_lds > 160 * 1024) return vs_fail(ctx, VS_EINVAL, "%s: a point is observed by too many free cameras for the LDS staging", "vs_ba_solve");
 
   VS_TRY(vs_reserve_pinned(ctx, &ctx->h_pin, sizeof(lm_state) + sizeof(mo_state) + 128));
   lm_state* hst = reinterpret_cast<lm_state*>((uint8_t*)ctx->h_pin.p + 128);
   // one copy + one synchronisation bring back the LM state and, if the solve is over, everything else the host wants
   bool exported = false;
-  auto export_and_fetch = [&]() -> int {
+  auto enqueue_export = [&]() -> int {
     const unsigned blocks = (unsigned)std::min<size_t>((out_elems + 255) / 256, 1024);
     hipLaunchKernelGGL(ba_export, dim3(blocks), dim3(256), 0, s, D, d_out);
     VS_LAUNCH_CHECK(ctx, "ba_export");
     VS_HIP(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * out_elems, hipMemcpyDeviceToHost, s));
+    return VS_OK;
+  };
+  auto export_and_fetch = [&]() -> int {
+    VS_TRY(enqueue_export());
     VS_HIP(ctx, hipStreamSynchronize(s));
     memcpy(hst, h_out, sizeof(lm_state));
     exported = true;
@@ -4385,12 +4411,46 @@ host_passes:
     bool first = true;
     while (launched < max_slots) {
       const int batch = std::min(max_slots - launched, std::max(1, q.max_iterations));
+      if (ctx->tune.ba_graph) {
+        // experiment (vs_tune_ba_graph, profiles/tried_and_dropped.md): the batch -- its slots, the export kernel and the
+        // read-back -- captured from the stream and replayed as ONE hipGraph launch.  Capture + instantiation are host time
+        // outside the measured interval; ba_batch_us = graph launch to completion, to be compared with the same interval of
+        // the launch-by-launch form below.
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        VS_HIP(ctx, hipStreamSynchronize(s));
+        VS_HIP(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        int crc = VS_OK;
+        for (int k = 0; k < batch && crc == VS_OK; ++k) {
+          crc = launch_slot(first);
+          first = false;
+        }
+        if (crc == VS_OK) crc = enqueue_export();
+        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (crc != VS_OK) return crc;
+        if (ce != hipSuccess || !graph) return vs_fail(ctx, VS_EHIP, "%s: stream capture of the trial batch failed: %s", "vs_ba_solve", hipGetErrorString(ce));
+        VS_HIP(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        const auto tg0 = now();
+        VS_HIP(ctx, hipGraphLaunch(exec, s));
+        VS_HIP(ctx, hipStreamSynchronize(s));
+        ctx->ba_batch_us = us(tg0, now());
+        (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        memcpy(hst, h_out, sizeof(lm_state));
+        exported = true;
+        launched += batch;
+        if (hst->done) break;
+        continue;
+      }
+      VS_HIP(ctx, hipStreamSynchronize(s));  // (uploads done: the interval below is the batch alone, as in the graph form)
+      const auto tb0 = now();
       for (int k = 0; k < batch; ++k) {
         VS_TRY(launch_slot(first));
         first = false;
       }
       launched += batch;
       VS_TRY(export_and_fetch());
+      ctx->ba_batch_us = us(tb0, now());
       if (hst->done) break;
     }
   } else {

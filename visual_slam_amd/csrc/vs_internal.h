@@ -60,6 +60,7 @@ struct vs_tuning {
   int small_ns_cap = 512;       // cap on its slab count
   int win_per = 0;              // banded large windows: points per ba_schur_window workgroup (0: automatic)
   int motion_variant = 0;       // 0: one-launch motion-only solve where it applies, 1: one launch per LM step
+  int ba_graph = 0;             // experiment: the LM slot batches of vs_ba_solve replayed as captured hipGraphs (vs_tune_ba_graph)
   int poison_alloc = -1;        // >= 0: every NEW device buffer of vs_reserve is filled with this byte (vs_debug_poison_alloc; tests: nothing may rely on what hipMalloc returns)
 };
 struct vs_prof_rec {
@@ -167,6 +168,8 @@ struct vs_ctx {
   vs_buf d_mo_stamps;       // diagnostic step stamps of the newest one-launch motion-only solve of a tracking period (vs_mo_profile)
   bool mo_profile = false;
   bool ba_aux_copy_pending = false;  // a copy into the BA arena is in flight on aux_stream[0] and the main stream has not been ordered behind it yet
+  double ba_batch_us = 0;    // wall time of the newest LM slot batch, first enqueue (or graph launch) to results on the host
+  int ba_path[6] = {-1, -1, 0, 0, 0, 0};  // kernels of the newest vs_ba_solve (vs_ba_last_path)
   int ba_structure_dev = 0;  // 1: the newest vs_ba_solve built its structure on the device (vs_ba_structure_on_device)
   vs_buf d_match_stamps;    // diagnostic phase stamps of the newest stamped match launch (vs_match_stamps)
   bool match_stamps_on = false;

@@ -106,12 +106,22 @@ def two_view_init(frames, K, camera, be, map, min_matches=100, min_valid=0.9, lo
     raise RuntimeError("two-view initialisation failed: no frame pair with enough parallax")
 
 
+class _NoLaps:
+    """Stands where tools/keyframe_stages.py puts its stage clock: lap(name) after a statement of the key-frame block."""
+
+    @staticmethod
+    def lap(name):
+        pass
+
+
 def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, max_depth=1.0, log=None,
-                 pnp_guess="w2c", init="depth", resident_ctx=None):
+                 pnp_guess="w2c", init="depth", resident_ctx=None, stages=None):
     """frames: list of BGR images; depth0: metric depth of frames[0]; K4 = (fx, fy, cx, cy).
     resident_ctx: a Context -> the frames between two key frames run on the device-resident tracking period
     (Context.track_begin / track_frame: main.py:181-214 as one call); key-frame insertion stays on the class API.
+    stages: an object with lap(name), called after every statement of the key-frame block (tools/keyframe_stages.py).
     Returns dict(poses [n,4,4] camera-to-world, keyframes [indices], n_points, map, tracked [per frame])."""
+    lap = (stages or _NoLaps).lap
     fx, fy, cx, cy = K4
     K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
     camera = Camera(fx, fy, cx, cy)
@@ -216,6 +226,7 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
         period_full = resident and period["used"] >= period["cap"] and i + 1 < len(frames)
         if period_full or ((i - loop_idx > keyframe_gap or len(curMatchedPoints) < min_tracked) and (
                 len(curMatchedPoints) < 0.9 * n_known)):
+            lap("(tracking since the last key frame)")
             loop_idx = i
             cur_frame.SetAsKeyFrame()
             W_T_prev_key = map.GetFrame(id_frame - 1).GetPose()
@@ -227,21 +238,28 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             cur_frame.ClearParent()
             map.AddParentAndPose(parent_id=id_frame - 1, frame_id=id_frame, frame_obj=cur_frame,
                                  rel_pose_trans=_inv(W_T_prev_key) @ W_T_cur_key, pose=W_T_cur_key)
+            lap("track_end + AddParentAndPose")
             map.AddPointToFrameCorrespondences(point_ids=known_3d_matched_ids, image_points=curMatchedPoints,
                                                descriptors=curMatchedFeatures, frame_obj=cur_frame)
+            lap("AddPointToFrameCorrespondences")
             if id_frame >= 6 and id_frame % 4 == 0:
                 map.DiscardOutlierMapPoints(n_visible_frames=3)
+            lap("DiscardOutlierMapPoints")
             # unmatched keypoints of the previous key frame against the new one (main.py:237-244)
             image_points_already_in_map = map.GetImagePointsWithFrameID(id_frame - 1)[0]
+            lap("GetImagePointsWithFrameID(previous key frame)")
             kp1 = map.GetFrame(id_frame - 1).GetKeyPoints()
             desc1 = map.GetFrame(id_frame - 1).GetFeatures()
             idx = hf.GetListDiff(kp1, image_points_already_in_map)
+            lap("GetListDiff")
             kp1, desc1 = kp1[idx], desc1[idx]
+            lap("kp1[idx], desc1[idx]")
             n_new = 0
             if len(kp1) >= 1 and len(map.GetFrame(id_frame).GetKeyPoints()) >= 2:
                 _, last_kf_pts, last_kf_fts, cur_kf_pts, cur_kf_fts = be.matcher.match_features(
                     kp1=kp1, desc1=desc1, kp2=map.GetFrame(id_frame).GetKeyPoints(),
                     desc2=map.GetFrame(id_frame).GetFeatures())
+                lap("match_features(previous key frame's unmatched, new key frame)")
                 if len(last_kf_pts):
                     p1 = _inv(map.GetFrame(id_frame - 1).GetPose())
                     p2 = _inv(map.GetFrame(id_frame).GetPose())
@@ -249,12 +267,15 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
                     Proj2 = hf.CameraProjectionMatrix2(Pose=p2, K=K)
                     x1 = hf.MakeHomogeneous(last_kf_pts)
                     x2 = hf.MakeHomogeneous(cur_kf_pts)
+                    lap("projection matrices, MakeHomogeneous")
                     new_pts = np.array(be.triangulate(Proj1, Proj2, x1, x2), dtype=np.float64)
+                    lap("triangulate")
                     new_pts /= new_pts[:, 3:]
                     proj1 = p1 @ new_pts.T
                     proj2 = p2 @ new_pts.T
                     new_pts = new_pts[:, :3]
                     good = np.where((proj1[2] > 0) & (proj2[2] > 0) & (proj2[2] < max_depth) & (proj1[2] < max_depth))[0]
+                    lap("cheirality filter")
                     for pt, uv1, uv2, ft1, ft2 in zip(new_pts[good], last_kf_pts[good], cur_kf_pts[good],
                                                       last_kf_fts[good], cur_kf_fts[good]):
                         pt_object = Point(location=pt, id=id_point)
@@ -263,7 +284,9 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
                         map.AddPoint3D(point_id=id_point, point_3d=pt_object)
                         id_point += 1
                         n_new += 1
+                    lap("Point / AddFrame x2 / AddPoint3D per new point")
             be.ba(camera).localBundleAdjustement(map)  # main.py:322-323
+            lap("localBundleAdjustement")
             all_poses[i] = np.array(map.GetFrame(id_frame).GetPose())
             keyframes.append(i)
             if log:
@@ -273,10 +296,13 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             local_map.AddFrame(last_keyframe.GetID(), last_keyframe)
             id_frame += 1
             id_frame_local = id_frame
+            lap("copy(key frame), new local Map")
             if resident:
                 point_IDs, n_known = open_period(i + 1)
+                lap("open_period (GetImagePointsWithFrameID + track_begin)")
             else:
                 local_map.Store3DPoints(map.GetCopyOfPointObjects(last_keyframe.GetID()))
+                lap("GetCopyOfPointObjects + Store3DPoints")
         else:
             id_frame_local += 1
     if resident:
