@@ -482,6 +482,7 @@ def frames_leg(ctx, cpu=True):
         from visual_slam_amd import dataset, slam
         from visual_slam_amd.workloads import ICL_NUIM_K
         frames, depth0 = load_sequence(20)
+        frames = [ctx.pin(f) for f in frames]  # decoded frames live in pinned memory, as in the tracking-only legs (bench_frames)
         be = slam.Backends(context=ctx)
         res = {}
         med, _ = median_time(lambda: res.__setitem__("r", slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=4)),

@@ -209,6 +209,12 @@ int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, in
                    double* poses_out, int* n_poses_out, int* n_matches, int* pnp_found, float* xy_out /*[max_kp][2]*/,
                    uint8_t* desc_out /*[max_kp][32]*/, int* n_kp_out, int32_t* match_q /*[n_points]*/,
                    int32_t* match_t /*[n_points]*/);
+/* The optional per-frame arrays of the newest frame handed out by vs_track_frame / vs_track_frame_pipelined, fetched afterwards:
+ * main.py needs a tracked frame's key points, descriptors and match lists only when the frame becomes a key frame (main.py:221-236,
+ * one frame in twenty), so a caller passes NULL for them per frame and asks here for the one frame that needs them.  Valid until
+ * the next frame is submitted (frame by frame) / the next but one (pipelined), or the period ends.  Any output may be NULL. */
+int vs_track_last_frame(vs_ctx* ctx, float* xy_out /*[max_kp][2]*/, uint8_t* desc_out /*[max_kp][32]*/, int* n_kp_out,
+                        int32_t* match_q /*[n_points]*/, int32_t* match_t /*[n_points]*/, int* n_matches_out);
 /* Pipelined variant for recorded streams: the call for frame k+1 first enqueues the back half (append, PnP, BA) of frame
  * k on the context's stream, then prepares frame k+1's front half (upload, detect, match) on a second stream while that
  * runs, and finally returns frame k's results (*has_result = 1; 0 on the first call).  bgr == NULL flushes the pending

@@ -314,3 +314,159 @@ def test_correspondences_from_a_generator_and_the_read_only_cached_answer():
             with pytest.raises(ValueError):
                 arr[...] = 0
     assert np.array_equal(b[0], uv1) and b[3].tolist() == [1, 2, 4, 6]
+
+
+def _small_map(n=40, seed=3):
+    rng = np.random.default_rng(seed)
+    m = Map()
+    f0, f1 = _frame(0, np.eye(4), key=True), _frame(1, np.eye(4), key=True)
+    m.AddFrame(0, f0)
+    m.AddFrame(1, f1)
+    for pid in range(1, n + 1):
+        p = Point(rng.normal(size=3), pid)
+        p.AddFrame(f0, rng.uniform(0, 600, 2).astype(np.float32), rng.integers(0, 256, 32).astype(np.uint8))
+        m.AddPoint3D(pid, p)
+    m.AddPointToFrameCorrespondences(list(range(1, n + 1, 2)), rng.uniform(0, 600, (n // 2, 2)).astype(np.float32),
+                                     rng.integers(0, 256, (n // 2, 32)).astype(np.uint8), f1)
+    return m, rng
+
+
+def test_bulk_point_write_back_equals_one_update_per_point():
+    """Map._update_points (the BA write-back of all points at once) leaves the map as P calls of UpdatePoint3D would
+    (LocalBA.py:189-190) -- every answer the map gives, the mirror, the rebinding of location_3d -- and a second map that holds
+    the same Point objects hears of the change."""
+    a, rng = _small_map()
+    b, _ = _small_map()
+    other = Map()                                    # shares a's Point objects (a local map made without copying)
+    other.AddFrame(0, a.GetFrame(0))
+    for pid, p in list(a.points_3d.items())[:10]:
+        other.AddPoint3D(pid, p)
+    assert np.array_equal(other.GetImagePointsWithFrameID(0)[2], a.GetImagePointsWithFrameID(0)[2][:10])
+    new = rng.normal(size=(40, 3))
+    a.GetImagePointsWithFrameID(0)                   # (answers cached before the write-back must not survive it)
+    a._update_points(new)
+    for i, pid in enumerate(b.points_3d):
+        b.UpdatePoint3D(new[i], pid)
+    for fid in (0, 1):
+        for x, y in zip(a.GetImagePointsWithFrameID(fid), b.GetImagePointsWithFrameID(fid)):
+            assert np.array_equal(x, y)
+    assert np.array_equal(a.GetAll3DPoints(), new) and np.array_equal(a.soa().xyz[:40], new)
+    assert all(p.location_3d is r for p, r in zip(a.points_3d.values(), a.soa().xyz_refs))
+    assert np.array_equal(other.GetImagePointsWithFrameID(0)[2], new[:10])       # the sharing map follows
+    # the mirror is in sync afterwards: soa() does not rebuild (same object, same generation) and later edits still register
+    s = a.soa()
+    a.points_3d[3].UpdatePoint(np.array([9.0, 9.0, 9.0]))
+    assert a.soa() is s and np.array_equal(a.GetImagePointsWithFrameID(0)[2][2], [9.0, 9.0, 9.0])
+    # a mask (LocalBA.py:147-151 branch) and a wrong shape
+    keep = np.zeros(40, bool)
+    keep[::4] = True
+    newer = rng.normal(size=(40, 3))
+    a._update_points(newer, keep)
+    got = a.GetAll3DPoints()
+    assert np.array_equal(got[::4], newer[::4]) and np.array_equal(got[1], new[1])
+    with pytest.raises(ValueError):
+        a._update_points(new[:5])
+
+
+def test_local_ba_write_back_goes_through_the_bulk_path(oracle):
+    w = ba_workload(n_cams=3, n_points=30, seed=11)
+    m = _scene_map(w)
+    gen = m.soa().gen
+    BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve).localBundleAdjustement(m)
+    assert m.soa().gen == gen                                   # the mirror was not rebuilt by the write-back ...
+    X = m.GetAll3DPoints()
+    assert np.array_equal(m.soa().xyz[:len(X)], X)             # ... and holds what the Point objects hold
+    assert not np.allclose(X, w["points"])                    # (the solve moved the points)
+
+
+def test_get_list_diff_on_float32_key_points_keeps_the_loop_semantics():
+    """helper_functions.GetListDiff (helper_functions.py:316-324's loop: both coordinates equal): the float32 fast path against
+    the loop itself, including a negative zero (equal to +0.0) and a NaN (equal to nothing)."""
+    from visual_slam_amd import helper_functions as hf
+    rng = np.random.default_rng(5)
+    kp1 = rng.integers(0, 40, (300, 2)).astype(np.float32)
+    kp2 = kp1[rng.permutation(300)[:120]].copy()
+    kp1[7] = [-0.0, 5.0]
+    kp2[0] = [0.0, 5.0]
+    kp1[9] = [np.nan, 1.0]
+    kp2[1] = [np.nan, 1.0]
+
+    def loop(a, b):
+        out = []
+        for i, x in enumerate(a):
+            if not any(x[0] == k[0] and x[1] == k[1] for k in b):
+                out.append(i)
+        return out
+    want = loop(kp1, kp2)
+    assert hf.GetListDiff(kp1, kp2) == want and 7 not in want and 9 in want
+    assert hf.GetListDiff(kp1.astype(np.float64), kp2) == want          # mixed / other dtypes: the general path
+    assert hf.GetListDiff(kp1, kp2[:0]) == list(range(300)) and hf.GetListDiff(kp1[:0], kp2) == []
+
+
+def test_lazy_local_map_copies_equal_the_eager_ones(oracle):
+    """Map.GetCopyOfPointObjects hands out a dict whose Point copies are made when somebody looks at them, and Map.Store3DPoints
+    seeds the local map's mirror from the same arrays (main.py:345).  Every observable must equal the object-walk version's:
+    keys and their order, ids, positions (own copies), the one observation each, and everything a local map does afterwards."""
+    def local_maps(lazy):
+        Map.use_lazy_copies = lazy
+        try:
+            g, rng = _small_map(60, seed=9)
+            copies = g.GetCopyOfPointObjects(1)
+            lm = Map()
+            key = g.GetFrame(1)
+            lm.AddFrame(1, key)
+            lm.Store3DPoints(copies)
+            return g, lm, copies, rng
+        finally:
+            Map.use_lazy_copies = True
+    g0, a, ca, rng = local_maps(False)
+    g1, b, cb, _ = local_maps(True)
+    assert type(ca) is dict and type(cb).__name__ == "_LazyPoints" and len(ca) == len(cb) == 30
+    # the tracking loop's view of the local map, before any Point of the lazy one exists
+    for x, y in zip(a.GetImagePointsWithFrameID(1), b.GetImagePointsWithFrameID(1)):
+        assert np.array_equal(x, y)
+    f2a, f2b = _frame(2, np.eye(4)), _frame(2, np.eye(4))
+    ids = list(range(1, 61, 2))[::3]
+    uv2 = rng.uniform(0, 600, (len(ids), 2)).astype(np.float32)
+    d2 = rng.integers(0, 256, (len(ids), 32)).astype(np.uint8)
+    for m, f in ((a, f2a), (b, f2b)):
+        m.AddParentAndPose(parent_id=1, frame_id=2, frame_obj=f, rel_pose_trans=np.eye(4), pose=np.eye(4))
+        m.AddPointToFrameCorrespondences(ids, uv2, d2, f)
+    assert cb._seed is not None                                   # still nothing materialised
+    for fid in (1, 2):
+        for x, y in zip(a.GetImagePointsWithFrameID(fid), b.GetImagePointsWithFrameID(fid)):
+            assert np.array_equal(x, y)
+    # the motion-only problem built from either local map is the same
+    pa, pb = BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve), BundleAdjustment(Camera(*ICL_NUIM_K), solver=oracle.ba_solve)
+    pa._graph_from_soa(a, lambda i, f: f.IsKeyFrame(), True, False)
+    pb._graph_from_soa(b, lambda i, f: f.IsKeyFrame(), True, False)
+    for k in ("_obs_pose", "_obs_point", "_obs_uv", "_points", "_point_fixed"):
+        assert np.array_equal(getattr(pa, k), getattr(pb, k)), k
+    assert pa._point_ids == pb._point_ids and list(pa._point_ids) == list(pb._point_ids)
+    # now look at the objects
+    assert list(a.points_3d.keys()) == list(b.points_3d.keys()) and cb._seed is None
+    for (ka, p), (kb, q) in zip(a.points_3d.items(), b.points_3d.items()):
+        orig = g1.points_3d[kb]
+        assert ka == kb == p.ID == q.ID and np.array_equal(p.location_3d, q.location_3d) and q.location_3d is not orig.location_3d
+        assert list(p.frames) == list(q.frames) and q._rev == p._rev
+        for fid in p.frames:
+            (fa, ua, da), (fb, ub, db) = p.frames[fid], q.frames[fid]
+            assert np.array_equal(ua, ub) and np.array_equal(da, db) and fa.ID == fb.ID
+        assert q.frames[1][0] is g1.GetFrame(1) and q.IsVisibleTo(1) and q.IsVisibleTo(2) == p.IsVisibleTo(2)
+    # edits of a materialised copy are the local map's business only, and are noticed by its mirror
+    q = b.points_3d[ids[0]]
+    q.UpdatePoint(np.array([1.0, 2.0, 3.0]))
+    assert np.array_equal(b.GetImagePointsWithFrameID(1)[2][0], [1.0, 2.0, 3.0])
+    assert not np.array_equal(g1.points_3d[ids[0]].location_3d, [1.0, 2.0, 3.0])
+    # dict protocol of the lazy object
+    g2, _, _, _ = local_maps(True)
+    c = g2.GetCopyOfPointObjects(1)
+    assert len(c) == 30 and c._seed is not None and (3 in c) and c._seed is None and 2 not in c
+    assert {**g2.GetCopyOfPointObjects(1)}.keys() == ca.keys() and dict(g2.GetCopyOfPointObjects(1)).keys() == ca.keys()
+    assert [k for k in g2.GetCopyOfPointObjects(1)] == list(ca)
+    # the mirror cannot vouch for the answer -> the object walk: a frame re-numbered after its observations were recorded
+    g3, _ = _small_map(20, seed=2)
+    g3.GetFrame(1).AddID(7)
+    assert type(g3.GetCopyOfPointObjects(1)) is dict and len(g3.GetCopyOfPointObjects(1)) == 0
+    with pytest.raises(KeyError):
+        g3.GetCopyOfPointObjects(7)          # visible to "7" by the Frame's id, recorded under key 1 (map.py:67, as the reference)

@@ -86,6 +86,51 @@ def test_driver_with_the_resident_tracking_period_equals_the_class_api_driver(vs
     assert np.abs(pa - pb).max() < 1e-5    # low-parallax points amplify pose differences of ~1e-9 (see above)
 
 
+@pytest.mark.gpu
+def test_pipelined_resident_driver_equals_frame_by_frame(vs):
+    """run_sequence(resident_ctx=..., pipelined=True) submits frame i + 1 before it knows whether frame i becomes a key frame
+    (the submission is dropped and repeated when it does) and fetches a frame's key points and matches only for key frames:
+    bit for bit the trajectory, decisions and map of the frame-by-frame form."""
+    frames, depth0 = harness.load_sequence(20)
+    for gap in (4, 2, 20):
+        a = slam.run_sequence(frames, depth0, ICL_NUIM_K, slam.Backends(context=vs), keyframe_gap=gap, resident_ctx=vs, pipelined=False)
+        b = slam.run_sequence(frames, depth0, ICL_NUIM_K, slam.Backends(context=vs), keyframe_gap=gap, resident_ctx=vs, pipelined=True)
+        assert a["keyframes"] == b["keyframes"] and a["tracked"] == b["tracked"] and a["pnp_inliers"] == b["pnp_inliers"]
+        assert np.array_equal(a["poses"], b["poses"]) and a["n_points"] == b["n_points"]
+        pa = np.array([p.location_3d for p in a["map"].points_3d.values()])
+        pb = np.array([p.location_3d for p in b["map"].points_3d.values()])
+        assert np.array_equal(pa, pb)
+        for fa, fb in zip(a["map"].frames.values(), b["map"].frames.values()):
+            assert np.array_equal(fa.GetKeyPoints(), fb.GetKeyPoints()) and np.array_equal(fa.GetFeatures(), fb.GetFeatures())
+
+
+@pytest.mark.gpu
+def test_track_last_frame_hands_out_what_the_frame_call_would_have(vs):
+    frames, depth0 = harness.load_sequence(5)
+    xy0, _, d0 = vs.detect_describe_bgr(frames[0], 20, 3000)
+    X = harness.backproject(xy0, depth0)
+    from visual_slam_amd.context import VsError
+    vs.track_begin(X, d0, np.eye(4), ICL_NUIM_K, max_frames=8)
+    with pytest.raises(VsError):
+        vs.track_last_frame()                                      # nothing handed out yet
+    full = vs.track_frame(frames[1], seed=1, want_keypoints=True, want_matches=True)
+    late = vs.track_last_frame()
+    for k in ("xy", "desc", "match_q", "match_t"):
+        assert np.array_equal(full[k], late[k]), k
+    assert late["n_matches"] == full["n_matches"] == len(late["match_q"]) and late["n_keypoints"] == len(late["xy"])
+    # pipelined: frame 2's arrays while frame 3 is in flight
+    assert vs.track_frame_pipelined(frames[2], seed=2, want_matches=False) is None
+    r2 = vs.track_frame_pipelined(frames[3], seed=3, want_matches=False)
+    l2 = vs.track_last_frame()
+    xy2, _, desc2 = vs.detect_describe_bgr(frames[2], 20, 3000)
+    mq, mt, _ = vs.match_ratio(d0, desc2, 0.8)
+    assert np.array_equal(l2["xy"], xy2) and np.array_equal(l2["desc"], desc2) and r2["n_matches"] == len(mq)
+    assert np.array_equal(l2["match_q"], mq) and np.array_equal(l2["match_t"], mt)
+    vs.track_end()                                                 # (drops frame 3)
+    with pytest.raises(VsError):
+        vs.track_last_frame()
+
+
 def _two_view(be):
     """main.py:78-148 on the two committed frames with enough parallax (ICL-NUIM traj3 images 0 and 150, ~0.45 m and 33
     degrees apart; consecutive frames are millimetres apart and cannot initialise, as in the reference)."""

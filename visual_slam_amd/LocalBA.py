@@ -231,7 +231,7 @@ class BundleAdjustment:
                     self.AddScalingEdge(parent_id=parent_ID, child_id=frame_id,
                                         measurement=frame_obj.GetTransitionWithParentID(parent_ID))
         P = s.n_points
-        self._point_ids = dict(zip(map.points_3d.keys(), range(P)))
+        self._point_ids = dict(s.point_slot)  # point id -> row: the keys of map.points_3d in their order (the mirror's own index)
         self._points = np.array(s.xyz[:P], dtype=np.float64)
         self._point_fixed = np.full(P, 1 if points_fixed else 0, np.uint8)
         slot, fid, uv, _ = s.arrays()
@@ -275,9 +275,12 @@ class BundleAdjustment:
             new_pose[0:3, 3] /= median_depth
             map.UpdatePose(new_pose=new_pose, frame_id=frame_id)
         new_points = self.result["points"] / median_depth
-        for i, point_obj in enumerate(map.points_3d.values()):
-            if keep is None or keep[i]:
-                point_obj.UpdatePoint(new_points[i])  # what map.UpdatePoint3D does, without the per-point dict lookups
+        if hasattr(map, "_update_points"):
+            map._update_points(new_points, keep)  # all points at once; the map's mirror stays in sync (map.py)
+        else:
+            for i, point_obj in enumerate(map.points_3d.values()):
+                if keep is None or keep[i]:
+                    point_obj.UpdatePoint(new_points[i])  # what map.UpdatePoint3D does, without the per-point dict lookups
 
     def _drop_points(self, drop):
         """Removes the observations of the masked points from the problem and fixes those points (they then take no

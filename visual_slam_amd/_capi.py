@@ -95,6 +95,7 @@ SIGNATURES = {
     "vs_track_frame": (C.c_int, [c_ctxp, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                  C.c_uint64, C.c_int, C.c_double, c_f64p, c_intp, c_intp, c_intp, c_f32p, c_u8p, c_intp,
                                  c_i32p, c_i32p]),
+    "vs_track_last_frame": (C.c_int, [c_ctxp, c_f32p, c_u8p, c_intp, c_i32p, c_i32p, c_intp]),
     "vs_track_frame_pipelined": (C.c_int, [c_ctxp, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                            C.c_double, C.c_uint64, C.c_int, C.c_double, c_intp, c_f64p, c_intp, c_intp,
                                            c_intp, c_f32p, c_u8p, c_intp, c_i32p, c_i32p]),

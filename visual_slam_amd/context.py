@@ -291,10 +291,17 @@ class Context:
         self._chk(self._lib.vs_track_begin(self._h, ptr(xyz, c_f64p), ptr(desc, c_u8p), xyz.shape[0], ptr(key_pose, c_f64p),
                                            fx, fy, cx, cy, int(max_frames), int(max_kp), int(pnp_iterations)))
         self._track_owner = None
-        self._track = dict(P=xyz.shape[0], max_frames=int(max_frames), max_kp=int(max_kp),
-                           poses=np.zeros((int(max_frames) + 1, 16)), xy=np.zeros((int(max_kp), 2), np.float32),
-                           desc=np.zeros((int(max_kp), 32), np.uint8), mq=np.zeros(xyz.shape[0], np.int32),
-                           mt=np.zeros(xyz.shape[0], np.int32))
+        # per-frame result buffers in PINNED memory (the library DMAs into them; a pageable destination is staged), kept by the
+        # context across periods and grown when a period needs more
+        b = getattr(self, "_track_bufs", None)
+        P = xyz.shape[0]
+        if b is None or b["max_kp"] < int(max_kp) or b["P"] < P:
+            kp_cap, p_cap = max(int(max_kp), b["max_kp"] if b else 0), max(2 * P, b["P"] if b else 0, 1024)
+            b = self._track_bufs = dict(max_kp=kp_cap, P=p_cap, xy=self.pinned_empty((kp_cap, 2), np.float32),
+                                        desc=self.pinned_empty((kp_cap, 32), np.uint8), mq=self.pinned_empty((p_cap,), np.int32),
+                                        mt=self.pinned_empty((p_cap,), np.int32))
+        self._track = dict(P=P, max_frames=int(max_frames), max_kp=int(max_kp), poses=np.zeros((int(max_frames) + 1, 16)),
+                           xy=b["xy"], desc=b["desc"], mq=b["mq"], mt=b["mt"])
 
     def track_frame(self, bgr, thr=20, ratio=0.8, reproj_err=8.0, confidence=0.99, seed=0, lm_iterations=10,
                     huber_delta=float(np.sqrt(5.991)), want_keypoints=False, want_matches=True):
@@ -313,6 +320,24 @@ class Context:
             C.byref(nk), ptr(t["mq"], c_i32p) if want_matches else None, ptr(t["mt"], c_i32p) if want_matches else None))
         out = dict(poses=t["poses"][:npo.value].reshape(-1, 4, 4).copy(), n_matches=nm.value, pnp_found=bool(found.value),
                    pnp_inliers=found.value, n_keypoints=nk.value)
+        if want_matches:
+            out["match_q"], out["match_t"] = t["mq"][:nm.value].copy(), t["mt"][:nm.value].copy()
+        if want_keypoints:
+            out["xy"], out["desc"] = t["xy"][:nk.value].copy(), t["desc"][:nk.value].copy()
+        return out
+
+    def track_last_frame(self, want_keypoints=True, want_matches=True):
+        """The per-frame arrays of the newest frame handed out by track_frame / track_frame_pipelined, fetched afterwards
+        (vs_track_last_frame): dict(n_keypoints, n_matches [, xy, desc] [, match_q, match_t]).  For callers that need them only
+        for the rare frame that becomes a key frame and pass want_keypoints=False / want_matches=False per frame."""
+        t = self._track
+        if t is None:
+            raise VsError(-1, "track_last_frame: no tracking period (call track_begin)")
+        nk, nm = C.c_int(0), C.c_int(0)
+        self._chk(self._lib.vs_track_last_frame(
+            self._h, ptr(t["xy"], c_f32p) if want_keypoints else None, ptr(t["desc"], c_u8p) if want_keypoints else None,
+            C.byref(nk), ptr(t["mq"], c_i32p) if want_matches else None, ptr(t["mt"], c_i32p) if want_matches else None, C.byref(nm)))
+        out = dict(n_keypoints=nk.value, n_matches=nm.value)
         if want_matches:
             out["match_q"], out["match_t"] = t["mq"][:nm.value].copy(), t["mt"][:nm.value].copy()
         if want_keypoints:

@@ -4442,8 +4442,7 @@ host_passes:
         if (hst->done) break;
         continue;
       }
-      VS_HIP(ctx, hipStreamSynchronize(s));  // (uploads done: the interval below is the batch alone, as in the graph form)
-      const auto tb0 = now();
+      const auto tb0 = now();  // (the uploads may still be in flight: the product does not wait for them before it enqueues)
       for (int k = 0; k < batch; ++k) {
         VS_TRY(launch_slot(first));
         first = false;

@@ -157,6 +157,7 @@ struct vs_ctx {
     int recoveries = 0;         // back halves redone so far (vs_track_debug)
     int recoverable = 0;        // set by track_back_finish next to an error a redo can cure
     int in_redo = 0;            // a redo is running: the motion-only solve takes the launch-per-step form, nothing is chained
+    int last_set = -1, last_nkp = 0, last_M = 0;  // buffer set / counts of the newest frame handed out (vs_track_last_frame)
     int inject = 0;             // developer aid (vs_track_debug): the next chained PnP launch waits for a tag nobody publishes
     int dirty = 0;              // an entry point returned an error after enqueueing: vs_track_end / vs_track_begin synchronise fully
   } track;

@@ -588,6 +588,9 @@ int track_back_finish(vs_ctx* ctx, int set, int* step, double* poses_out, int* n
   memcpy(T.last_rec, h_cam + (size_t)k * kCamStride, sizeof T.last_rec);
   T.n_frames = k;
   T.obs_used += M;
+  T.last_set = set;  // where vs_track_last_frame finds this frame's key points and matches (until the set's next front half)
+  T.last_nkp = n_kp;
+  T.last_M = M;
   *n_poses_out = k + 1;
   *n_matches = M;
   if (n_kp_out) *n_kp_out = n_kp;
@@ -674,6 +677,7 @@ VS_API int vs_track_begin(vs_ctx* ctx, const double* xyz, const uint8_t* desc, i
   VS_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   auto& T = ctx->track;
+  T.last_set = -1;
   T.inject = 0;  // vs_track_debug arms a fault for the period it is called in
   // the one synchronisation of this call: the staging is free to be rewritten (or reallocated), the buffers are idle
   // (skipped when the previous period ended with all its results handed out: only tracking kernels touch these buffers, and
@@ -794,6 +798,43 @@ VS_API int vs_track_frame(vs_ctx* ctx, const uint8_t* bgr, int w, int h_img, int
     rc = track_redo(ctx, 0, poses_out, n_poses_out, n_matches, pnp_found, xy_out, desc_out, n_kp_out, match_q, match_t, true);
   if (rc == VS_OK) T.dirty = 0;
   return rc;
+}
+
+// The per-frame arrays of the newest frame handed out, fetched AFTERWARDS: a caller that needs a frame's key points, descriptors
+// and match lists only when the frame turns out to be a key frame (main.py:221-236 -- one frame in twenty) calls vs_track_frame
+// with those outputs NULL and comes here for the one frame that needs them.  The frame's buffer set is not written again before
+// the front half of the next frame but one (pipelined) / the next frame (frame by frame), so the rows are still there; the
+// copies run on an auxiliary stream that holds nothing of the period.  Destinations in pinned memory are DMA-ed directly.
+VS_API int vs_track_last_frame(vs_ctx* ctx, float* xy_out, uint8_t* desc_out, int* n_kp_out, int32_t* match_q, int32_t* match_t,
+                               int* n_matches_out) {
+  if (!ctx) return VS_EINVAL;
+  auto& T = ctx->track;
+  if (!T.active || T.last_set < 0)
+    return vs_fail(ctx, VS_EINVAL, "%s: no frame of an open tracking period has been handed out yet", "vs_track_last_frame");
+  VS_HIP(ctx, hipSetDevice(ctx->device));
+  const track_layout L = layout_of(ctx);
+  const track_front& F = L.f[T.last_set];
+  uint8_t* d = (uint8_t*)ctx->d_track.p;
+  hipStream_t s = ctx->aux_stream[0];
+  const int n_kp = T.last_nkp, M = T.last_M;
+  bool copies = false;
+  if (xy_out && n_kp > 0) {
+    VS_HIP(ctx, hipMemcpyAsync(xy_out, d + F.fxy, sizeof(float) * 2 * (size_t)n_kp, hipMemcpyDeviceToHost, s));
+    copies = true;
+  }
+  if (desc_out && n_kp > 0) {
+    VS_HIP(ctx, hipMemcpyAsync(desc_out, d + F.fdesc, 32 * (size_t)n_kp, hipMemcpyDeviceToHost, s));
+    copies = true;
+  }
+  if (match_q && match_t && M > 0) {
+    VS_HIP(ctx, hipMemcpyAsync(match_q, d + F.mq, sizeof(int) * (size_t)M, hipMemcpyDeviceToHost, s));
+    VS_HIP(ctx, hipMemcpyAsync(match_t, d + F.mt, sizeof(int) * (size_t)M, hipMemcpyDeviceToHost, s));
+    copies = true;
+  }
+  if (copies) VS_HIP(ctx, hipStreamSynchronize(s));
+  if (n_kp_out) *n_kp_out = n_kp;
+  if (n_matches_out) *n_matches_out = M;
+  return VS_OK;
 }
 
 // Host-fed back half: the caller (the class API: FeatureMatcher.match_features + solvePnPRansac, src/v2/main.py:185-204)

@@ -59,6 +59,18 @@ def GetListDiff(kp1, kp2):
         return []
     if kp2.size == 0:
         return list(range(len(kp1)))
+    if kp1.dtype == np.float32 and kp2.dtype == np.float32 and kp1.shape[1] >= 2 and kp2.shape[1] >= 2:
+        # key points as FeatureExtractor hands them out: a row is two float32 = ONE 64-bit word, and equal words are equal rows
+        # (+0.0 folds -0.0 onto +0.0; a NaN never equals anything in the reference's loop either: such rows stay "not found")
+        a = np.ascontiguousarray(kp1[:, :2] + np.float32(0.0)).view(np.uint64).ravel()
+        b = np.ascontiguousarray(kp2[:, :2] + np.float32(0.0)).view(np.uint64).ravel()
+        bs = np.sort(b)                                  # (np.isin costs three times this on a few hundred rows)
+        pos = np.searchsorted(bs, a)
+        pos[pos == bs.size] = bs.size - 1
+        found = bs[pos] == a
+        if np.isnan(kp1[:, :2]).any():
+            found &= ~np.isnan(kp1[:, :2]).any(axis=1)
+        return np.nonzero(~found)[0].tolist()
     a = kp1[:, :2].astype(np.float64).view(np.complex128).ravel()
     b = kp2[:, :2].astype(np.float64).view(np.complex128).ravel()
     return np.nonzero(~np.isin(a, b))[0].tolist()

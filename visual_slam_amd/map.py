@@ -15,12 +15,26 @@ per-frame `BundleAdjustment.motionOnlyBundleAdjustement(local_map)` calls: the c
 observations and start pose (vs_track_push_frame) instead of rebuilding and re-uploading the whole period.
 """
 import copy
+from collections import deque as _deque
+from functools import partial as _partial
 
 import numpy as np
 from operator import itemgetter as _itemgetter
 
+from .point import Point as _Point
+
+_SET_LOC = _Point._loc.__set__          # the slot descriptor: C-level `p._loc = r`
+_drain = _partial(_deque, maxlen=0)      # runs an iterator to its end without keeping anything
+
 
 _SOA_GENERATION = [0]  # every mirror ever built gets the next number: a cache key that, unlike id(), is never recycled
+
+
+class _UnknownFrames(dict):
+    """frame_objs of a mirror that took observations without being told their Frame objects: never consulted."""
+
+
+_UNKNOWN_FRAMES = _UnknownFrames()
 
 
 class _SoA:
@@ -40,6 +54,7 @@ class _SoA:
         self.batches = []         # chronological log of add_obs calls: (frame id or None for mixed ids, first row, rows)
         self.fid_rows = {}        # frame id -> number of observation rows carrying it
         self.batch_data = []      # per batch: (slot int32[k], uv [k,2]) as they arrived (no concatenation needed to read one)
+        self.frame_objs = {}      # frame id -> the Frame object recorded with its observations (None: several different ones)
 
     def add_point(self, point_id, location):
         slot = self.n_points
@@ -53,11 +68,31 @@ class _SoA:
         self.n_points += 1
         return slot
 
-    def add_obs(self, slots, frame_id, uvs, descs):
-        """frame_id: one id for the whole batch, or one per row."""
+    def note_frames(self, fids, objs):
+        """Remembers which Frame object the observations under a frame id were recorded with."""
+        fo = self.frame_objs
+        for f, o in zip(fids, objs):
+            have = fo.get(f, fo)
+            if have is fo:
+                fo[f] = o
+            elif have is not o:
+                fo[f] = None
+
+    def add_obs(self, slots, frame_id, uvs, descs, frame_obj=None):
+        """frame_id: one id for the whole batch, or one per row.  frame_obj: the Frame object(s) of the batch, likewise."""
         k = len(slots)
         if k == 0:
             return
+        if frame_obj is None:
+            self.frame_objs = _UNKNOWN_FRAMES  # observations without their Frame object: nothing may be inferred from ids
+        elif self.frame_objs is not _UNKNOWN_FRAMES:
+            try:
+                if isinstance(frame_obj, list):   # one Frame object per row
+                    self.note_frames(frame_id if isinstance(frame_id, (list, tuple, np.ndarray)) else [frame_id] * k, frame_obj)
+                else:                             # one Frame object for the whole batch (and one frame id)
+                    self.note_frames((frame_id,), (frame_obj,))
+            except TypeError:                     # unhashable frame ids
+                self.frame_objs = _UNKNOWN_FRAMES
         uv = np.asarray(uvs).reshape(k, 2)  # dtype as given (the reference hands float32 keypoints around)
         desc = None
         if descs is not None:
@@ -110,8 +145,57 @@ def mirror_of_points(points_3d, cell=None):
         s.rev += getattr(p, "_rev", 0)
         if p.frames:
             fids = list(p.frames.keys())
-            s.add_obs([slot] * len(fids), fids, [p.frames[f][1] for f in fids], [p.frames[f][2] for f in fids])
+            fr = p.frames
+            s.add_obs([slot] * len(fids), fids, [fr[f][1] for f in fids], [fr[f][2] for f in fids], [fr[f][0] for f in fids])
     return s
+
+
+class _LazyPoints(dict):
+    """`points_3d` of a local map as Map.GetCopyOfPointObjects hands it out (map.py:60-69: a copy of every point the key frame
+    sees, each keeping only that frame's observation) -- with the copies made when somebody LOOKS at them.  The reference's
+    tracking loop never does: between two key frames it reads the local map through GetImagePointsWithFrameID and adds to it
+    through AddPointToFrameCorrespondences (main.py:183-210), both served by the structure-of-arrays mirror, which is seeded
+    from the same arrays (Map.Store3DPoints).  Any dict access other than len() creates the Point objects -- ids, positions
+    (own copies), the one (Frame, uv, descriptor) triple each -- and from then on this is an ordinary dict."""
+    __slots__ = ("_seed", "_cell")
+
+    def __init__(self, seed):
+        dict.__init__(self)
+        self._seed = seed     # (ids, xyz [n,3] own copy, its rows as a list, uv [n,2], desc [n,D], frame id, Frame object, revs) or None
+        self._cell = None     # change counters of the Map that adopted this dict (Store3DPoints)
+
+    def _make(self):
+        seed, self._seed = self._seed, None
+        if seed is None:
+            return
+        from .point import Point
+        ids, _, rows, uv, desc, fid, frame_obj, revs = seed
+        cells = () if self._cell is None else (self._cell,)
+        new = Point.__new__
+        put = dict.__setitem__
+        for pid, X, u, d, rev in zip(ids, rows, list(uv), list(desc), revs):
+            q = new(Point)
+            q.ID, q._loc, q._frames, q._rev, q._cells = pid, X, {fid: (frame_obj, u, d)}, rev, cells
+            put(self, pid, q)
+
+    def __len__(self):
+        return len(self._seed[0]) if self._seed is not None else dict.__len__(self)
+
+
+def _lazy(name):
+    f = getattr(dict, name)
+
+    def method(self, *a, **k):
+        if self._seed is not None:
+            self._make()
+        return f(self, *a, **k)
+    method.__name__ = name
+    return method
+
+
+for _n in ("__getitem__", "__setitem__", "__delitem__", "__iter__", "__contains__", "__eq__", "__ne__", "__repr__", "__reversed__",
+           "__or__", "__ror__", "__ior__", "keys", "values", "items", "get", "pop", "popitem", "setdefault", "update", "copy", "clear"):
+    setattr(_LazyPoints, _n, _lazy(_n))
 
 
 class _PeriodMirror:
@@ -347,12 +431,14 @@ class _PeriodMirror:
 
 class Map:
     use_device_mirror = True  # False: motionOnlyBundleAdjustement always builds and uploads the whole problem
+    use_lazy_copies = True    # False: GetCopyOfPointObjects always walks the objects and copies them at once
 
     def __init__(self):
         self.frames = {}
         self.points_3d = {}
-        # shared with the points this map holds (point.py): [geometry edits, observation edits, flush callback or None]
-        self._cell = [0, 0, None]
+        # shared with the points this map holds (point.py): [geometry edits, observation edits, flush callback or None,
+        # True once any of this map's points is held by a second map as well (sticky)]
+        self._cell = [0, 0, None, False]
         self._pending = []        # observation batches not yet written into the Point objects (see _flush)
         self._added = []          # points added since the mirror was last used (see _absorb_added)
         self._soa = _SoA()
@@ -439,7 +525,7 @@ class Map:
                 sl = slot[sel]
                 if np.all(np.diff(sl) > 0):
                     try:
-                        ids = np.fromiter(self.points_3d.keys(), dtype=np.int64, count=s.n_points)
+                        ids = np.fromiter(s.point_slot.keys(), dtype=np.int64, count=s.n_points)  # (= points_3d's keys, in order)
                         out = (uv[sel], desc[sel], s.xyz[sl].copy(), ids[sl])
                         if key is not None:
                             # the cached answer is handed to every later caller as the same array objects (the descriptor
@@ -472,6 +558,9 @@ class Map:
         The reference deep-copies the whole Point first, which drags every observing Frame (images included) along;
         the copy here is of the Point only -- the (Frame, uv, descriptor) tuple of frame_id is shared, as after the
         reference's SubsetOfFrames the other frames are dropped anyway."""
+        lazy = self._lazy_copies(frame_id)
+        if lazy is not None:
+            return lazy
         points = {}
         for point_key, point_obj in self.points_3d.items():
             if point_obj.IsVisibleTo(frame_id):
@@ -480,6 +569,47 @@ class Map:
                 point_copy.frames = point_obj.SubsetOfFrames(frame_id)
                 points[point_key] = point_copy
         return points
+
+    def _lazy_copies(self, frame_id):
+        """GetCopyOfPointObjects from the mirror, as a _LazyPoints -- or None when the mirror cannot vouch for the answer: it must
+        hold the descriptors, one observation at most per (point, frame), and know the Frame object behind every frame id with
+        that object still carrying the id (IsVisibleTo, point.py:37-38, asks the Frame OBJECTS for their ids, not the keys)."""
+        if not self.use_lazy_copies:
+            return None
+        s = self.soa()
+        fo = s.frame_objs
+        if fo is _UNKNOWN_FRAMES or not s.n_obs:
+            return None
+        try:
+            frame_obj = fo.get(frame_id)
+            if frame_obj is None or any(o is None or o.ID != f for f, o in fo.items()):
+                return None
+        except (TypeError, AttributeError):
+            return None
+        slot, fid, uv, desc = s.arrays()
+        if desc is None:
+            return None
+        sel = np.nonzero(fid == frame_id)[0]
+        if sel.size == 0:
+            return None
+        sl = slot[sel]
+        if sl.size > 1 and not np.all(sl[1:] > sl[:-1]):
+            order = np.argsort(sl, kind="stable")
+            sel, sl = sel[order], sl[order]
+            if not np.all(sl[1:] > sl[:-1]):
+                return None  # a point observed twice from one frame: the object walk decides
+        pts = list(self.points_3d.values())
+        try:
+            picked = _itemgetter(*sl.tolist())(pts) if sl.size > 1 else (pts[int(sl[0])],)
+            ids = [p.ID for p in picked]
+            revs = [p._rev + 1 for p in picked]  # (a copy's `frames` is rebound to the one-entry dict: one more edit, point.py)
+            keys = _itemgetter(*sl.tolist())(list(self.points_3d.keys())) if sl.size > 1 else (next(iter(self.points_3d.keys())),)
+            if list(keys) != ids:
+                return None  # a point stored under another key than its own id: the copies' keys are the map's keys
+        except AttributeError:
+            return None
+        xyz = np.array(s.xyz[sl], np.float64)  # the copies' own positions (map.py:66 deep-copies location_3d)
+        return _LazyPoints((ids, xyz, list(xyz), uv[sel], desc[sel], frame_id, frame_obj, revs))
 
     def GetAllPoses(self):
         return [frame_obj.GetPose() for frame_obj in self.frames.values()]
@@ -502,8 +632,9 @@ class Map:
                 and self._soa_cell[0] + len(added) == c[0] and self._soa_cell[1] == c[1]
                 and all(hasattr(p, "_frames") for _, p in added)):
             return  # something else happened in between: soa() verifies and rebuilds
-        if c[2] is not None:
-            c[2]()  # observation batches not yet written into the Point objects: the dicts below must be complete
+        # (Pending observation batches -- AddPointToFrameCorrespondences rows not yet written into the Point objects -- never
+        # concern the points absorbed here: a batch only names points the mirror already held when it arrived, and every such
+        # call absorbs what was added before it.  The new points' own `_frames` dicts, read below, are complete.)
         n = len(added)
         pts = [p for _, p in added]
         locs = [p._loc for p in pts]
@@ -511,16 +642,18 @@ class Map:
             rows = np.array(locs, np.float64).reshape(n, 3)  # one conversion for the batch
         except (ValueError, TypeError):
             rows = None
+        fobjs = []
         if rows is None:  # ragged / exotic locations: one by one
             slots, fids, uvs, descs = [], [], [], []
             for pid, p in added:
                 slot = s.add_point(pid, p.location_3d)
                 s.rev += p._rev
-                for f, (_, uv, d) in p._frames.items():
+                for f, (fo_, uv, d) in p._frames.items():
                     slots.append(slot)
                     fids.append(f)
                     uvs.append(uv)
                     descs.append(d)
+                    fobjs.append(fo_)
         else:
             slot0 = s.n_points
             if slot0 + n > s.xyz.shape[0]:
@@ -539,16 +672,18 @@ class Map:
                 fids = [it[0] for it in items]
                 uvs = [it[1][1] for it in items]
                 descs = [it[1][2] for it in items]
+                fobjs = [it[1][0] for it in items]
             else:
                 slots, fids, uvs, descs = [], [], [], []
                 for k, fr in enumerate(frames):
-                    for f, (_, uv, d) in fr.items():
+                    for f, (fo_, uv, d) in fr.items():
                         slots.append(slot0 + k)
                         fids.append(f)
                         uvs.append(uv)
                         descs.append(d)
+                        fobjs.append(fo_)
         if len(slots):
-            s.add_obs(slots, fids, uvs, descs)
+            s.add_obs(slots, fids, uvs, descs, fobjs)
         self._soa_cell = (c[0], c[1])
 
     def UpdatePose(self, new_pose, frame_id):
@@ -562,6 +697,46 @@ class Map:
             self.points_3d[point_id].UpdatePoint(new_point)
         else:
             raise Exception("No point yet added")
+
+    def _update_points(self, new_points, keep=None):
+        """BA write-back for every point of the map at once (what LocalBA.py:189-190 does with one Map.UpdatePoint3D per point):
+        row i of new_points [P,3] becomes the position of the i-th point of points_3d (keep: optional boolean mask of the points
+        to touch).  Each Point's location_3d ends up rebound to its own row object, exactly as after P UpdatePoint calls -- but
+        the mirror takes the block as ONE array copy and STAYS IN SYNC: the next soa() / GetImagePointsWithFrameID does not walk
+        the points to find out what moved (that walk cost as much as the solve on the driver's key frames)."""
+        pts = self.points_3d
+        P = len(pts)
+        new_points = np.asarray(new_points)
+        if new_points.shape != (P, 3):
+            raise ValueError("_update_points: one row per point of the map")
+        s = self.soa()  # verified mirror (O(1) when nothing happened behind the map's back)
+        rows = list(new_points)  # P row views, one object per point (as `point_obj.UpdatePoint(new_points[i])` would bind)
+        cell = self._cell
+        fast = keep is None and s.n_points == P
+        if fast:
+            try:
+                if not cell[3]:
+                    # no point of this map is held by another map: rebinding `_loc` is all there is to do, and the slot's own
+                    # descriptor does it without a Python-level loop (Point.location_3d's setter minus the counter traffic)
+                    _drain(map(_SET_LOC, pts.values(), rows))
+                else:
+                    for p, r in zip(pts.values(), rows):
+                        p._loc = r
+                        if len(p._cells) != 1:      # held by another map as well: that map's mirror must hear of it
+                            for c in p._cells:
+                                if c is not cell:
+                                    c[0] += 1
+            except (AttributeError, TypeError):     # foreign point objects: the plain way
+                fast = False
+        if not fast:
+            for i, p in enumerate(pts.values()):
+                if keep is None or keep[i]:
+                    p.UpdatePoint(new_points[i])
+            return
+        s.xyz[:P] = new_points
+        s.xyz_refs[:] = rows
+        cell[0] += 1                                # geometry changed: cached answers (GetImagePointsWithFrameID) are stale ...
+        self._soa_cell = (cell[0], cell[1])         # ... but the mirror is not
 
     def GetFrame(self, frame_id):
         return self.frames[frame_id]
@@ -584,6 +759,26 @@ class Map:
     def Store3DPoints(self, points_dict):
         self._flush()
         self._added = []
+        if isinstance(points_dict, _LazyPoints) and points_dict._seed is not None and not self.points_3d and points_dict._cell is None:
+            # the copies GetCopyOfPointObjects described but has not made (main.py:345): this map adopts the description -- the
+            # mirror is filled from its arrays in one go, the Point objects appear if and when somebody looks at them
+            ids, xyz, rows, uv, desc, fid, frame_obj, revs = points_dict._seed
+            n = len(ids)
+            s = _SoA()
+            s.xyz = np.array(xyz, np.float64)
+            s.n_points = n
+            s.point_slot = dict(zip(ids, range(n)))
+            if len(s.point_slot) == n:
+                s.xyz_refs = list(rows)  # the very row objects the copies' location_3d will be bound to (_LazyPoints._make)
+                s.rev = sum(revs)
+                s.add_obs(np.arange(n, dtype=np.int32), fid, uv, desc, frame_obj)
+                points_dict._cell = self._cell
+                self.points_3d = points_dict
+                self._soa, self._soa_points_obj = s, points_dict
+                self._cell[0] += 1
+                self._soa_cell = (self._cell[0], self._cell[1])
+                self._img_cache = {}
+                return
         self.points_3d = {**self.points_3d, **points_dict}  # new dict object: the mirror is rebuilt on next use
 
     def AddParentAndPose(self, parent_id, frame_id, frame_obj, rel_pose_trans, pose):
@@ -631,7 +826,7 @@ class Map:
                 slots, n, new_frame = None, 0, False
             if slots is not None and new_frame and n and len(image_points) >= n and len(descriptors) >= n and (
                     n == 1 or bool(np.all(slots[1:] > slots[:-1])) or len(set(slots.tolist())) == n):
-                s.add_obs(slots, fid, image_points[:n], descriptors[:n])
+                s.add_obs(slots, fid, image_points[:n], descriptors[:n], frame_obj)
                 self._pending.append((list(point_ids), image_points, descriptors, frame_obj, fid))
                 c[2] = self._flush
                 return
@@ -649,7 +844,7 @@ class Map:
             try:
                 slots = [s.point_slot[pid] for pid in point_ids]
                 s.add_obs(slots, fid, image_points[:n] if hasattr(image_points, "__getitem__") else list(image_points),
-                          descriptors[:n] if hasattr(descriptors, "__getitem__") else None)
+                          descriptors[:n] if hasattr(descriptors, "__getitem__") else None, frame_obj)
             except KeyError:
                 s.n_obs = -1  # forces a rebuild
         elif not fresh:

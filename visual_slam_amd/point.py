@@ -53,6 +53,9 @@ class Point:
             self._cells = (cell,)
         elif all(c is not cell for c in cells):
             self._cells = cells + (cell,)
+            for c in self._cells:   # (sticky) these maps share a point: a bulk write-back in one must tell the other
+                if len(c) > 3:
+                    c[3] = True
 
     def __copy__(self):
         q = Point.__new__(Point)

@@ -115,10 +115,16 @@ class _NoLaps:
 
 
 def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, max_depth=1.0, log=None,
-                 pnp_guess="w2c", init="depth", resident_ctx=None, stages=None):
+                 pnp_guess="w2c", init="depth", resident_ctx=None, stages=None, pipelined=True):
     """frames: list of BGR images; depth0: metric depth of frames[0]; K4 = (fx, fy, cx, cy).
     resident_ctx: a Context -> the frames between two key frames run on the device-resident tracking period
     (Context.track_begin / track_frame: main.py:181-214 as one call); key-frame insertion stays on the class API.
+    pipelined (resident mode): frame i + 1 is submitted to the period BEFORE frame i's result is looked at
+    (Context.track_frame_pipelined: its upload, detection and match run beside frame i's PnP and motion-only BA).  Whether
+    frame i becomes a key frame is only known from that result, so the submission is a speculation: when frame i does become
+    one -- one frame in `keyframe_gap` -- the period ends, the frame in flight is dropped with it and goes to the new period
+    afresh.  A tracked frame's key points, descriptors and match lists are needed only if it becomes a key frame
+    (main.py:221-236) and are fetched then (Context.track_last_frame), not per frame.  Same results as frame by frame.
     stages: an object with lap(name), called after every statement of the key-frame block (tools/keyframe_stages.py).
     Returns dict(poses [n,4,4] camera-to-world, keyframes [indices], n_points, map, tracked [per frame])."""
     lap = (stages or _NoLaps).lap
@@ -179,17 +185,24 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
                                  pnp_iterations=100 if pnp_guess is not None else 0)
         return ids, len(xyz)
 
+    in_flight = -1  # resident + pipelined: index of the frame submitted to the period whose result has not been taken yet
     if resident:
         point_IDs, n_known = open_period(start)
     for i in range(start, len(frames)):
         cur_frame = Frame(frames[i], None, id_frame_local)
         if resident:
-            # main.py:181-214 as one call on the device-resident period (vs_track_frame)
-            r = resident_ctx.track_frame(frames[i], seed=i, want_keypoints=True, want_matches=True)
+            # main.py:181-214 as one call on the device-resident period (vs_track_frame / vs_track_frame_pipelined); the frame's
+            # key points and match lists stay on the device unless the frame becomes a key frame (below)
+            if pipelined:
+                if in_flight != i:  # first frame of a period
+                    resident_ctx.track_frame_pipelined(frames[i], seed=i, want_matches=False)
+                nxt = i + 1 if i + 1 < len(frames) and period["used"] + 2 <= period["cap"] else -1
+                r = resident_ctx.track_frame_pipelined(frames[nxt] if nxt >= 0 else None, seed=nxt, want_matches=False)
+                in_flight = nxt
+            else:
+                r = resident_ctx.track_frame(frames[i], seed=i, want_matches=False)
             period["used"] += 1
-            cur_frame.keypoints, cur_frame.features = r["xy"], r["desc"]
-            known_3d_matched_ids = [point_IDs[q] for q in r["match_q"]]
-            curMatchedPoints, curMatchedFeatures = r["xy"][r["match_t"]], r["desc"][r["match_t"]]
+            n_cur = r["n_matches"]
             W_T_cur = r["poses"][-1]
             pnp_inliers.append(r["pnp_inliers"])
         else:
@@ -198,8 +211,12 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             n_known = len(known_3d)
             matches, _, _, curMatchedPoints, curMatchedFeatures = be.matcher.match_features(kp_prev, features_prev, kp_cur,
                                                                                              features_cur)
-            known_3d_matched_ids = [point_IDs[m[0].queryIdx] for m in matches]
-            known_3d_matched = np.array([known_3d[m[0].queryIdx] for m in matches]).reshape(-1, 3)
+            if hasattr(matches, "query_idx"):  # MatchList: the same gathers as main.py:187-188's loops, as two fancy indexings
+                known_3d_matched_ids = np.asarray(point_IDs)[matches.query_idx]
+                known_3d_matched = np.asarray(known_3d).reshape(-1, 3)[matches.query_idx]
+            else:
+                known_3d_matched_ids = [point_IDs[m[0].queryIdx] for m in matches]
+                known_3d_matched = np.array([known_3d[m[0].queryIdx] for m in matches]).reshape(-1, 3)
             # pose from PnP-RANSAC with the previous frame as extrinsic guess (main.py:191-204)
             W_T_prev = np.array(local_map.GetFrame(id_frame_local - 1).GetPose(), dtype=np.float64)
             W_T_curr = W_T_prev.copy()
@@ -220,19 +237,24 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
                                                      descriptors=curMatchedFeatures, frame_obj=cur_frame)
             be.ba(camera).motionOnlyBundleAdjustement(local_map, scale=False, save=True)
             W_T_cur = np.array(local_map.GetFrame(id_frame_local).GetPose())
+            n_cur = len(curMatchedPoints)
         all_poses[i] = np.array(W_T_cur)
-        tracked.append(len(curMatchedPoints))
+        tracked.append(n_cur)
         # key-frame rule (main.py:221)
         period_full = resident and period["used"] >= period["cap"] and i + 1 < len(frames)
-        if period_full or ((i - loop_idx > keyframe_gap or len(curMatchedPoints) < min_tracked) and (
-                len(curMatchedPoints) < 0.9 * n_known)):
+        if period_full or ((i - loop_idx > keyframe_gap or n_cur < min_tracked) and (n_cur < 0.9 * n_known)):
             lap("(tracking since the last key frame)")
             loop_idx = i
             cur_frame.SetAsKeyFrame()
             W_T_prev_key = map.GetFrame(id_frame - 1).GetPose()
             W_T_cur_key = W_T_cur
             if resident:
-                resident_ctx.track_end()
+                lf = resident_ctx.track_last_frame()  # this frame's key points, descriptors and matches: needed now
+                resident_ctx.track_end()                # (a frame in flight is dropped with the period: it goes to the next one)
+                in_flight = -1
+                cur_frame.keypoints, cur_frame.features = lf["xy"], lf["desc"]
+                known_3d_matched_ids = np.asarray(point_IDs)[lf["match_q"]]
+                curMatchedPoints, curMatchedFeatures = lf["xy"][lf["match_t"]], lf["desc"][lf["match_t"]]
                 cur_frame.AddPose(W_T_cur_key)
                 cur_frame.AddID(id_frame)
             cur_frame.ClearParent()
