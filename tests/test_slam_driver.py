@@ -92,9 +92,14 @@ def test_pipelined_resident_driver_equals_frame_by_frame(vs):
     (the submission is dropped and repeated when it does) and fetches a frame's key points and matches only for key frames:
     bit for bit the trajectory, decisions and map of the frame-by-frame form."""
     frames, depth0 = harness.load_sequence(20)
-    for gap in (4, 2, 20):
-        a = slam.run_sequence(frames, depth0, ICL_NUIM_K, slam.Backends(context=vs), keyframe_gap=gap, resident_ctx=vs, pipelined=False)
-        b = slam.run_sequence(frames, depth0, ICL_NUIM_K, slam.Backends(context=vs), keyframe_gap=gap, resident_ctx=vs, pipelined=True)
+    # (gap, min_tracked): key frames that are due (no frame in flight when they come) and, with min_tracked out of reach, key
+    # frames decided by the tracked count alone -- every one of those drops the frame submitted ahead of it
+    for gap, min_tracked in ((4, 80), (2, 80), (20, 80), (100, 10 ** 6)):
+        kw = dict(keyframe_gap=gap, min_tracked=min_tracked, resident_ctx=vs)
+        a = slam.run_sequence(frames, depth0, ICL_NUIM_K, slam.Backends(context=vs), pipelined=False, **kw)
+        b = slam.run_sequence(frames, depth0, ICL_NUIM_K, slam.Backends(context=vs), pipelined=True, **kw)
+        if min_tracked > 1000:
+            assert len(a["keyframes"]) >= 3
         assert a["keyframes"] == b["keyframes"] and a["tracked"] == b["tracked"] and a["pnp_inliers"] == b["pnp_inliers"]
         assert np.array_equal(a["poses"], b["poses"]) and a["n_points"] == b["n_points"]
         pa = np.array([p.location_3d for p in a["map"].points_3d.values()])

@@ -196,7 +196,11 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             if pipelined:
                 if in_flight != i:  # first frame of a period
                     resident_ctx.track_frame_pipelined(frames[i], seed=i, want_matches=False)
-                nxt = i + 1 if i + 1 < len(frames) and period["used"] + 2 <= period["cap"] else -1
+                # ... unless this frame is due to become a key frame anyway (main.py:221's first condition holds before the frame is
+                # tracked): then the frame in flight would be dropped with the period, and the device would work on it while the
+                # key frame's bundle adjustment waits.  A guess that only decides whether work is wasted, never a result.
+                due = i - loop_idx > keyframe_gap
+                nxt = i + 1 if i + 1 < len(frames) and period["used"] + 2 <= period["cap"] and not due else -1
                 r = resident_ctx.track_frame_pipelined(frames[nxt] if nxt >= 0 else None, seed=nxt, want_matches=False)
                 in_flight = nxt
             else:
