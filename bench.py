@@ -586,6 +586,11 @@ def main():
                          "%d bench.py --gpus %d ...` (or by hand without WORLD_SIZE, and it launches its own ranks)\n"
                          % (args.gpus, world, args.gpus, args.gpus))
         sys.exit(2)
+    # ONE JSON line on standard output, nothing else: libraries that print there on their own (RCCL's version banner at
+    # communicator creation) are sent to standard error; the line itself goes through a private copy of the descriptor
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -638,10 +643,10 @@ def main():
         # kernels need no ordering behind the library's stream (static_inputs); with a collective, four buffer sets on the two
         # compute streams keep the in-place all-gather of a set off the chain of launches (sharded.py, _Plan)
         one = args.single_stream or single
-        # one launch at a time: with a collective the plan keeps ordinary ordering (static_inputs off), which puts the in-place
-        # all-gather on a stream of its own beside the library's (sharded.py, _Plan)
+        # one launch at a time: with a collective the kernels run back to back on one auxiliary stream of the context and the
+        # in-place all-gathers on another (sharded.py, _Plan)
         plan = matcher.plan(qq, tt, n_total, single_stream=one, in_flight=max(2, args.in_flight),
-                            buffers=args.buffers or (4 if use_dist else None), static_inputs=not (one and use_dist))
+                            buffers=args.buffers or (4 if use_dist else None), static_inputs=True)
         plans.append(plan)
 
         def step():
@@ -777,7 +782,7 @@ def main():
         alg_bytes = BYTES_PER_MATCH * pairs
         traffic = None
         pmc_src = None
-        for name in ("r04_pmc_match.json", "r03_pmc_match.json", "r02_pmc_match.json", "r01_pmc_match.json"):
+        for name in ("r05_pmc_match.json", "r04_pmc_match.json", "r03_pmc_match.json", "r02_pmc_match.json", "r01_pmc_match.json"):
             try:  # HBM bytes per launch from the committed PMC passes (profiles/), only for the workload they were taken on
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if (nq, nt) == (10000, 10000):
@@ -954,7 +959,8 @@ def main():
                                                      "rank 0's GPU only (north_star: detection and BA stay single-GPU)")
             except Exception as e:
                 line["frames"] = {"error": repr(e)}
-        print(json.dumps(line))
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     if use_dist:
         dist.barrier()  # the other ranks wait here while rank 0 runs the (replica) frames leg and prints
         matcher.close()

@@ -43,7 +43,8 @@ int vs_tune_ba_structure(vs_ctx* ctx, int on_host);
 int vs_ba_structure_on_device(vs_ctx* ctx); /* 1: the newest vs_ba_solve of this context built its structure on the device */
 
 /* Experiment (profiles/tried_and_dropped.md): on = 1 replays every batch of LM slots of vs_ba_solve (<= 10 slots of four launches,
- * the export kernel, the read-back) as ONE captured hipGraph; 0 = launch by launch (default); any other value leaves it.
+ * the export kernel, the read-back) as ONE captured hipGraph; 0 = launch by launch (default); 2 = launch by launch with the
+ * uploads waited for first, so that *last_batch_us covers the same interval as the graph form's; any other value leaves it.
  * *last_batch_us (may be NULL) = wall microseconds of the newest batch, graph launch (or first enqueue) to results on the host. */
 int vs_tune_ba_graph(vs_ctx* ctx, int on, double* last_batch_us);
 

@@ -244,11 +244,13 @@ def test_plan_keeps_steps_in_flight_without_racing_its_own_buffers(vs, oracle, i
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("collective", [True, False])
-def test_static_input_plan_runs_the_exchange_on_the_librarys_stream(vs, oracle, collective):
+@pytest.mark.parametrize("collective,in_flight", [(True, 2), (False, 2), (True, 1)])
+def test_static_input_plan_runs_the_exchange_on_the_librarys_stream(vs, oracle, collective, in_flight):
     """Round 4: plan(static_inputs=True, buffers=4) is what bench.py drives with a collective -- the step's kernel is not
     ordered behind the library's stream, more buffer sets rotate than streams run, and the in-place all-gather runs on the
-    library's own stream (a stream made later may share a hardware queue with a compute stream).  The inputs never change,
+    library's own stream (a stream made later may share a hardware queue with a compute stream).  in_flight = 1 with a collective
+    (round 5: the mode of bench.py's `value` at N > 1): the kernels one at a time on the context's first auxiliary stream, the
+    all-gathers on its second, the library's stream carrying only the consumers' waits.  The inputs never change,
     so every slot's buffer is poisoned after its results were read: a step that returned before its kernel and exchange had
     rewritten the slot would show the poison."""
     import torch
@@ -265,10 +267,13 @@ def test_static_input_plan_runs_the_exchange_on_the_librarys_stream(vs, oracle, 
         with torch.cuda.stream(stream):
             dq, dt = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
             stream.synchronize()
-            plan = m.plan(dq, dt, nq, in_flight=2, buffers=4, static_inputs=True)
-            assert plan.nslots == 4 and len({s.cuda_stream for s in plan.streams}) == 2
-            if collective:
+            plan = m.plan(dq, dt, nq, in_flight=in_flight, buffers=4, static_inputs=True)
+            assert plan.nslots == 4 and len({s.cuda_stream for s in plan.streams}) == in_flight
+            if collective and in_flight == 2:
                 assert plan.direct and plan.args[0][11] == stream.cuda_stream
+            elif collective:
+                comp, comm = plan.args[0][10], plan.args[0][11]
+                assert plan.direct and comp == vs.aux_stream(0) and comm == vs.aux_stream(1) and stream.cuda_stream not in (comp, comm)
             with pytest.raises(ValueError):
                 plan.submit(q=dq)
             pending, results = [], []

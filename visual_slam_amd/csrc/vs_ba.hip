@@ -3328,7 +3328,7 @@ VS_API int vs_ba_structure_on_device(vs_ctx* ctx) { return ctx ? ctx->ba_structu
 // developer hook (include/vslam_hip_dev.h): experiment -- every batch of LM slots replayed as one captured hipGraph
 VS_API int vs_tune_ba_graph(vs_ctx* ctx, int on, double* last_batch_us) {
   if (!ctx) return VS_EINVAL;
-  if (on == 0 || on == 1) ctx->tune.ba_graph = on;
+  if (on >= 0 && on <= 2) ctx->tune.ba_graph = on;
   if (last_batch_us) *last_batch_us = ctx->ba_batch_us;
   return VS_OK;
 }
@@ -4411,7 +4411,7 @@ host_passes:
     bool first = true;
     while (launched < max_slots) {
       const int batch = std::min(max_slots - launched, std::max(1, q.max_iterations));
-      if (ctx->tune.ba_graph) {
+      if (ctx->tune.ba_graph == 1) {
         // experiment (vs_tune_ba_graph, profiles/tried_and_dropped.md): the batch -- its slots, the export kernel and the
         // read-back -- captured from the stream and replayed as ONE hipGraph launch.  Capture + instantiation are host time
         // outside the measured interval; ba_batch_us = graph launch to completion, to be compared with the same interval of
@@ -4442,6 +4442,7 @@ host_passes:
         if (hst->done) break;
         continue;
       }
+      if (ctx->tune.ba_graph == 2) VS_HIP(ctx, hipStreamSynchronize(s));  // measurement only: the same interval as the graph form's
       const auto tb0 = now();  // (the uploads may still be in flight: the product does not wait for them before it enqueues)
       for (int k = 0; k < batch; ++k) {
         VS_TRY(launch_slot(first));

@@ -701,7 +701,17 @@ VS_API int vs_hamming_knn2_sharded_dev(vs_ctx* ctx, const void* d_q_shard, int n
   //  (1) done_event as recorded by the PREVIOUS step on this gather buffer -- its all-gather sends from, and receives into,
   //      the rows the kernel is about to overwrite (an event that was never recorded counts as complete);
   //  (2) the caller's stream up to now: the consumers of the previous results of d_gathered and the producers of q / t.
-  if (done_event) VS_HIP(ctx, hipStreamWaitEvent(cs, (hipEvent_t)done_event, 0));
+  if (done_event) {
+    // (a wait for an event that has already completed is still a barrier packet in front of the kernel -- with the record behind
+    // it, 17 us per step on a single compute stream; round 5, tools/shard_modes.py -- so it is only enqueued when it can matter)
+    const hipError_t qe = hipEventQuery((hipEvent_t)done_event);
+    if (qe == hipErrorNotReady) {
+      (void)hipGetLastError();
+      VS_HIP(ctx, hipStreamWaitEvent(cs, (hipEvent_t)done_event, 0));
+    } else if (qe != hipSuccess) {
+      return vs_fail(ctx, VS_EHIP, "%s: hipEventQuery(done_event) failed: %s", "vs_hamming_knn2_sharded_dev", hipGetErrorString(qe));
+    }
+  }
   if (after_stream && (hipStream_t)after_stream != cs) {
     if (!ctx->ev_after) VS_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_after, hipEventDisableTiming));
     VS_HIP(ctx, hipEventRecord(ctx->ev_after, (hipStream_t)after_stream));

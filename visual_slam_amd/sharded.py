@@ -436,12 +436,22 @@ class _Plan:
         # inputs nothing else is enqueued on the library's stream between collect()s, and it owns a queue: 49 us / step.
         # With per-step inputs the library's stream carries their producers, which must not queue behind an all-gather.
         comm = main if static_inputs else (m._rccl.stream if self.direct else None)
+        one_kernel_stream = None
         if in_flight == 1 and self.direct:
-            # one launch at a time on the library's stream; the exchange on the context's first auxiliary stream (made with the
-            # context: a hardware queue of its own), so the all-gather of step k overlaps the kernel of step k + 1 and nothing
-            # else -- compute on one stream, the collective on another
-            aux = m._ctx.aux_stream(0)
-            comm = torch.cuda.ExternalStream(aux, device=q.device) if aux else m._rccl.stream
+            # One launch at a time WITH a collective: compute on one stream, the exchange on another, and neither of them the
+            # library's.  collect() orders the library's stream (the caller's: the consumers) behind a step's all-gather; were
+            # the kernels launched on that stream too, kernel k + 2 would queue behind the all-gather of step k -- which a
+            # kernel that fills the device lets in only at its tail (measured at one rank, 10k x 10k: 81 us per step against 54
+            # without the collective).  So with static inputs the kernels run back to back on the context's first auxiliary
+            # stream and the all-gathers on its second (both made with the context: hardware queues of their own); a kernel
+            # waits only for the all-gather that last used ITS buffer set, `buffers` steps ago.  With per-step inputs the
+            # kernels must follow their producers on the library's stream: they stay there, the exchange on an auxiliary stream.
+            a0, a1 = m._ctx.aux_stream(0), m._ctx.aux_stream(1)
+            if static_inputs and a0 and a1:
+                one_kernel_stream = torch.cuda.ExternalStream(a0, device=q.device)
+                comm = torch.cuda.ExternalStream(a1, device=q.device)
+            else:
+                comm = torch.cuda.ExternalStream(a0, device=q.device) if a0 else m._rccl.stream
             self.comm_stream = comm
         # compute streams of the slots: the context's own auxiliary streams first (created with the context, each on a
         # hardware queue of its own -- streams made later may share a queue with the library's and then never overlap it),
@@ -449,7 +459,7 @@ class _Plan:
         pool = []
         for i in range(max(in_flight, 1)):
             aux = m._ctx.aux_stream(i) if in_flight > 1 else None
-            pool.append(main if in_flight == 1 else torch.cuda.ExternalStream(aux, device=q.device) if aux
+            pool.append((one_kernel_stream or main) if in_flight == 1 else torch.cuda.ExternalStream(aux, device=q.device) if aux
                         else torch.cuda.Stream(device=q.device))
         self.streams = [pool[slot % len(pool)] for slot in range(self.nslots)]
         self.args, self.outs, self.done, self.bufs, self.keep = [], [], [], [], []
@@ -476,6 +486,7 @@ class _Plan:
             self.keep.append((q, t))
             self.outs.append((out[:n_query, 0:2], out[:n_query, 2:4]))
         self.work = [None] * self.nslots
+        self.throttle = one_kernel_stream is not None
 
     def submit(self, q=None, t=None):
         """Enqueue one step; returns the slot to hand to collect().  q / t: this step's inputs (device tensors of the plan's
@@ -496,6 +507,11 @@ class _Plan:
         if self.work[slot] is not None:  # torch's collective of the slot's previous step was never collected
             self.work[slot].wait()
             self.work[slot] = None
+        if self.throttle:
+            # one kernel stream: the host stays at most `nslots` steps ahead of the device (it waits here for the step that last
+            # used this buffer set -- rarely for long), so that step's `done` event is complete and the library enqueues no wait
+            # for it in front of the kernel (a barrier packet there keeps back-to-back kernels apart)
+            self.done[slot].synchronize()
         rc = self.lib.vs_hamming_knn2_sharded_dev(*args)
         if rc != 0:
             self.m._ctx._chk(rc)
