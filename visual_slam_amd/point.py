@@ -91,10 +91,13 @@ class Point:
     # ---- observations --------------------------------------------------------------------------------- point.py:14-50
     def AddFrame(self, frame, uv, descriptor):
         """Records (or overwrites) the observation of this point in `frame`, keyed by the frame's current id."""
-        key = frame.GetID()
-        self.frames[key] = (frame, uv, descriptor)
+        cells = self._cells
+        for c in cells:   # (what the `frames` property does: a holding map first writes its pending observation batches)
+            if c[2] is not None:
+                c[2]()
+        self._frames[frame.GetID()] = (frame, uv, descriptor)
         self._rev += 1
-        for c in self._cells:
+        for c in cells:
             c[1] += 1
 
     def GetFrame(self, frame_id):
