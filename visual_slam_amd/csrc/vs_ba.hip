@@ -1537,8 +1537,16 @@ __global__ __launch_bounds__(kSolveThreads) void ba_solve(ba_dev D) {
 //   * row stride is odd so the 16 row-owners of a tile hit distinct banks
 //   * the backward substitution L^T x = y runs on wave 0 alone, wave-synchronously
 
-constexpr int kSolveBlock = 1024, kSolveTile = 32;  // threads as a kSolveTile x kSolveTile grid over matrix tiles
+constexpr int kSolveTile = 32;  // threads as rows of kSolveTile over matrix tiles
+#ifdef VS_SOLVE_STAMPS  // developer build: cycles of thread 0 per phase of a step, printed for the third trial of a solve
+#define VS_SOLVE_LAP(x) { const long long t_ = __builtin_readcyclecounter(); x += t_ - sts0; sts0 = t_; }
+#else
+#define VS_SOLVE_LAP(x)
+#endif
 
+// (256 / 512 threads for small systems were measured in round 5 and are no faster: a step is the chain on wave 0, not the barriers --
+// profiles/r05_solve_stamps.txt, profiles/tried_and_dropped.md)
+constexpr int kSolveBlock = 1024;
 __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   lm_state* st = D.st;
@@ -1605,8 +1613,13 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
     }
     if (!good) *s_flag = 1;
   };
+#ifdef VS_SOLVE_STAMPS
+  long long stsP = 0, stsB1 = 0, stsU = 0, stsF = 0, stsB2 = 0, sts0 = __builtin_readcyclecounter();
+  const long long stsBegin = sts0;
+#endif
   if (tid == 0 && nb > 0) factor_diag(0);
   __syncthreads();
+  VS_SOLVE_LAP(stsF)
   for (int J = 0; J < nb; ++J) {
     const int j0 = 6 * J;
     if (*s_flag) {  // uniform (written before the last barrier)
@@ -1628,7 +1641,9 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) A[r * ld + j0 + c] = a[c];
     }
+    VS_SOLVE_LAP(stsP)
     __syncthreads();
+    VS_SOLVE_LAP(stsB1)
     // (3) trailing update: A[r][c] -= sum_k A[r][j0+k] * A[c][j0+k]  for r > j0+5 (incl. rhs row), j0+5 < c <= min(r, n-1).
     // Wave 0 owns the next diagonal block (rows/columns j0+6 .. j0+11): 21 lanes update it, then lane 0 factorises it;
     // the other waves take the rest on a (kSolveTile - 2) x kSolveTile grid of their own.
@@ -1648,7 +1663,9 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
           A[rr * ld + cc] = acc;
         }
         wave_lds_sync();
+        VS_SOLVE_LAP(stsU)
         if (tid == 0) factor_diag(j0 + 6);
+        VS_SOLVE_LAP(stsF)
       }
     } else if ((tid >> 6) & 3) {
       // (waves 4, 8, 12 share wave 0's SIMD: they stay out of the update, the factorisation has the SIMD's issue slots to itself)
@@ -1668,7 +1685,15 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
       }
     }
     __syncthreads();
+    VS_SOLVE_LAP(stsB2)
   }
+#ifdef VS_SOLVE_STAMPS
+  if (tid == 0 && st->trials == 2)
+    printf("ba_solve_block<%d> n=%d: %d steps; cycles of thread 0: panel %lld, barrier after the panel %lld, next diagonal block updated %lld, "
+           "factorised %lld, barrier after the update %lld; factorisation loop %lld of which first block + load wait %lld (per step %lld)\n",
+           kSolveBlock, n, nb, stsP, stsB1, stsU, stsF, stsB2, (long long)__builtin_readcyclecounter() - stsBegin, 0LL,
+           nb ? ((long long)__builtin_readcyclecounter() - stsBegin) / nb : 0LL);
+#endif
   if (ok && *s_flag) ok = 0;  // the last look-ahead factorisation failed
   // backward substitution L^T x = y on wave 0, by 6x6 blocks from the bottom: lane 0 solves the block's triangular
   // system in registers (descending k, as the element-wise recurrence does), then the lanes subtract the block's
