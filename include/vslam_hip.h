@@ -38,7 +38,7 @@ typedef enum vs_status {
   VS_ENCCL = -6   /* RCCL is not loaded in the process, or the all-gather failed */
 } vs_status;
 
-#define VS_ABI_VERSION 4
+#define VS_ABI_VERSION 5
 #define VS_DESC_BYTES 32 /* BRIEF-256 */
 
 /* ---- context ---------------------------------------------------------------------------------------------- */

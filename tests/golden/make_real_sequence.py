@@ -98,6 +98,28 @@ def main():
                          for a, k, res in calls],
             "cpu_oracle_seconds": dt, "cpu_oracle_frames_per_s": N / dt}
         arrays["poses_" + init] = P
+        # how far the map is from the data set's own depth images at every key frame: for the points a key frame observes, depth in
+        # that camera (map units) / true depth at the observed pixel (metres) -- a constant ratio is a consistent scale; points first
+        # seen at this key frame or the one before (the newly triangulated ones) listed apart from the older ones
+        m = r["map"]
+        diag = []
+        for j, img in enumerate(kf):
+            f = m.GetFrame(j)
+            w2c = np.linalg.inv(np.asarray(f.GetPose(), np.float64))
+            D = seq.depth(img)
+            old, new = [], []
+            for p in m.points_3d.values():
+                o = p.frames.get(j)
+                if o is None:
+                    continue
+                zt = D[int(o[1][1]), int(o[1][0])]
+                if zt <= 0:
+                    continue
+                z = (w2c[:3, :3] @ np.asarray(p.location_3d, np.float64) + w2c[:3, 3])[2]
+                (new if j >= 2 and min(p.frames.keys()) >= j - 1 else old).append(z / zt)
+            q = lambda a: None if not a else [len(a), float(np.median(a)), float(np.percentile(a, 25)), float(np.percentile(a, 75))]  # noqa: E731
+            diag.append({"keyframe": j, "image": int(img), "older_points_n_median_q25_q75": q(old), "new_points_n_median_q25_q75": q(new)})
+        summary["runs"][init]["map_depth_over_true_depth_at_keyframes"] = diag
         if init == "depth":
             problems = calls
         print("%s: %.1f s, %d key frames, %d map points, ATE rmse %.3f m over %.2f m (first half: %.3f over %.2f)" % (

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (vs_\w+)", out))
     assert set(names) <= exported, sorted(set(names) - exported)
     assert set(names) == set(_capi.SIGNATURES), sorted(set(names) ^ set(_capi.SIGNATURES))
-    assert lib.vs_abi_version() == 4
+    assert lib.vs_abi_version() == 5
 
 
 def test_no_exported_symbol_is_undeclared():
