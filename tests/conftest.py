@@ -45,7 +45,11 @@ def vs():
     if _capi.device_count() == 0:
         pytest.skip("no GPU in this machine")
     from visual_slam_amd import Context
-    return Context(0)
+    ctx = Context(0)
+    poison = os.environ.get("VS_TEST_POISON")  # e.g. 127: the whole GPU suite on a context whose every device buffer starts out as 0x7F
+    if poison:
+        ctx.debug_poison_alloc(int(poison, 0))
+    return ctx
 
 
 def icl_frame(i):

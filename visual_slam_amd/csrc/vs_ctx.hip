@@ -147,6 +147,7 @@ VS_API int vs_destroy(vs_ctx* ctx) {
     if (e) (void)hipEventDestroy(e);
   if (ctx->ev_shard) (void)hipEventDestroy(ctx->ev_shard);
   if (ctx->ev_after) (void)hipEventDestroy(ctx->ev_after);
+  if (ctx->poison_stream) (void)hipStreamDestroy(ctx->poison_stream);
   if (ctx->track.front_stream) (void)hipStreamDestroy(ctx->track.front_stream);
   for (hipStream_t a : ctx->aux_stream)
     if (a) (void)hipStreamDestroy(a);

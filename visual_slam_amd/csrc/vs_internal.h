@@ -170,6 +170,8 @@ struct vs_ctx {
   bool mo_profile = false;
   bool ba_aux_copy_pending = false;  // a copy into the BA arena is in flight on aux_stream[0] and the main stream has not been ordered behind it yet
   double ba_batch_us = 0;    // wall time of the newest LM slot batch, first enqueue (or graph launch) to results on the host
+  int poison_count = 0;      // device allocations made while vs_debug_poison_alloc is on
+  hipStream_t poison_stream = nullptr;  // non-blocking stream of the poison fills (created on first use)
   int ba_path[6] = {-1, -1, 0, 0, 0, 0};  // kernels of the newest vs_ba_solve (vs_ba_last_path)
   int ba_structure_dev = 0;  // 1: the newest vs_ba_solve built its structure on the device (vs_ba_structure_on_device)
   vs_buf d_match_stamps;    // diagnostic phase stamps of the newest stamped match launch (vs_match_stamps)
@@ -232,7 +234,23 @@ static inline int vs_reserve(vs_ctx* ctx, vs_buf* b, size_t bytes) {
   hipError_t e = hipMalloc(&b->p, want);
   if (e != hipSuccess) return vs_fail(ctx, VS_ENOMEM, "hipMalloc(%s) failed: %s", "scratch", hipGetErrorString(e));
   b->cap = want;
-  if (ctx->tune.poison_alloc >= 0) VS_HIP(ctx, hipMemset(b->p, ctx->tune.poison_alloc & 255, want));  // developer aid
+  if (ctx->tune.poison_alloc >= 0) {  // developer aid (vs_debug_poison_alloc; VS_POISON_SKIP=n leaves the n-th allocation alone, VS_POISON_LOG=1 lists them)
+    static const int kSkip = getenv("VS_POISON_SKIP") ? atoi(getenv("VS_POISON_SKIP")) : -1;
+    static const int kUpto = getenv("VS_POISON_UPTO") ? atoi(getenv("VS_POISON_UPTO")) : 1 << 30;  // only the first n allocations
+    static const bool kLog = getenv("VS_POISON_LOG") != nullptr;
+    const int ordinal = ctx->poison_count++;
+    const bool skip = ordinal == kSkip || ordinal >= kUpto;
+    if (kLog) fprintf(stderr, "[poison] allocation %d: %zu bytes at %p (vs_buf at +%td)%s\n", ordinal, want, b->p, (char*)b - (char*)ctx, skip ? " SKIPPED" : "");
+    if (!skip) {
+      // on a non-blocking stream of its own: hipMemset runs on the legacy default stream, which waits for -- and holds back --
+      // every blocking stream of the process; with a chained tracking period in flight (kernels that wait in-kernel for work
+      // enqueued behind them) that is a deadlock until the bounded waits give up (seen in round 5 as "the device did not
+      // publish its results" under VS_TEST_POISON)
+      if (!ctx->poison_stream) VS_HIP(ctx, hipStreamCreateWithFlags(&ctx->poison_stream, hipStreamNonBlocking));
+      VS_HIP(ctx, hipMemsetAsync(b->p, ctx->tune.poison_alloc & 255, want, ctx->poison_stream));
+      VS_HIP(ctx, hipStreamSynchronize(ctx->poison_stream));
+    }
+  }
   return VS_OK;
 }
 
