@@ -470,3 +470,44 @@ def test_lazy_local_map_copies_equal_the_eager_ones(oracle):
     assert type(g3.GetCopyOfPointObjects(1)) is dict and len(g3.GetCopyOfPointObjects(1)) == 0
     with pytest.raises(KeyError):
         g3.GetCopyOfPointObjects(7)          # visible to "7" by the Frame's id, recorded under key 1 (map.py:67, as the reference)
+
+
+def test_rows_pack_helper():
+    """visual_slam_amd._rows.pack: a list of equally long contiguous rows -> the rows of one array; anything else is refused (the
+    caller then converts with numpy)."""
+    from visual_slam_amd import _rows
+    from visual_slam_amd.map import _rows_of
+    rng = np.random.default_rng(0)
+    base = rng.normal(size=(50, 3))
+    out = np.empty((50, 3))
+    assert _rows.pack(list(base), out) is True and np.array_equal(out, base)
+    assert _rows.pack(list(base[::-1]), out) is True and np.array_equal(out, base[::-1])            # any order, any owner
+    assert _rows.pack(list(base), np.empty((50, 3), np.float32)) is False                           # another element type
+    assert _rows.pack(list(base[:49]) + [base[0, :2]], out) is False                                # a ragged row
+    assert _rows.pack([base[:, 0]] * 3, np.empty((3, 50))) is False                                 # strided rows
+    assert _rows.pack([[1.0, 2.0, 3.0]] * 2, np.empty((2, 3))) is False                             # not buffers
+    with pytest.raises(TypeError):
+        _rows.pack(list(base), np.zeros((50, 3)).tobytes())                                        # read-only output
+    d = rng.integers(0, 256, (20, 32)).astype(np.uint8)
+    assert np.array_equal(_rows_of(list(d)), d) and _rows_of(list(d)).dtype == np.uint8
+    assert np.array_equal(_rows_of(list(base), np.float64), base)
+    assert np.array_equal(_rows_of([[1.0, 2.0], [3.0, 4.0]], np.float64), [[1.0, 2.0], [3.0, 4.0]])   # plain lists: numpy's way
+    assert _rows_of([np.zeros(3), np.zeros(2)]) is None
+    assert np.array_equal(_rows_of(list(base.astype(np.float32)), np.float64), base.astype(np.float32).astype(np.float64))
+
+
+def test_mirror_remembers_the_frame_objects_of_its_observations():
+    """GetCopyOfPointObjects answers from the mirror only when it knows the Frame object behind every frame id (IsVisibleTo asks
+    the objects): recorded by AddPointToFrameCorrespondences, by the absorption of added points and by a rebuild from the objects;
+    two different Frame objects under one id, or observations that arrived without their object, switch the fast path off."""
+    m, _ = _small_map(12, seed=4)
+    s = m.soa()
+    assert set(s.frame_objs) == {0, 1} and s.frame_objs[0] is m.GetFrame(0) and s.frame_objs[1] is m.GetFrame(1)
+    assert type(m.GetCopyOfPointObjects(1)).__name__ == "_LazyPoints"
+    m.points_3d[2].AddFrame(_frame(1, np.eye(4)), np.zeros(2, np.float32), np.zeros(32, np.uint8))   # ANOTHER object with id 1
+    s = m.soa()                                                                                       # (rebuilt from the objects)
+    assert s.frame_objs[1] is None and type(m.GetCopyOfPointObjects(1)) is dict
+    from visual_slam_amd.map import mirror_of_points, _UNKNOWN_FRAMES
+    s2 = mirror_of_points(m.points_3d)
+    s2.add_obs([0], 5, np.zeros((1, 2)), None)                                                       # no Frame object given
+    assert s2.frame_objs is _UNKNOWN_FRAMES
