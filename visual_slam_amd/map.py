@@ -24,6 +24,7 @@ from operator import itemgetter as _itemgetter
 from .point import Point as _Point
 
 _SET_LOC = _Point._loc.__set__          # the slot descriptor: C-level `p._loc = r`
+_LOC_REV_FRAMES = __import__("operator").attrgetter("_loc", "_rev", "_frames")
 _drain = _partial(_deque, maxlen=0)      # runs an iterator to its end without keeping anything
 
 try:  # rows handed over one by one (one small array per point) packed into one array in C: a third of np.array(list)'s time
@@ -108,8 +109,10 @@ class _SoA:
             self.frame_objs = _UNKNOWN_FRAMES  # observations without their Frame object: nothing may be inferred from ids
         elif self.frame_objs is not _UNKNOWN_FRAMES:
             try:
-                if isinstance(frame_obj, list):   # one Frame object per row
-                    self.note_frames(frame_id if isinstance(frame_id, (list, tuple, np.ndarray)) else [frame_id] * k, frame_obj)
+                if isinstance(frame_obj, list):   # one Frame object per row: the distinct (frame id, object) pairs, found in C
+                    ids = frame_id if isinstance(frame_id, (list, tuple, np.ndarray)) else [frame_id] * k
+                    uniq = dict(zip(zip(ids, map(id, frame_obj)), frame_obj))
+                    self.note_frames([f for f, _ in uniq], list(uniq.values()))
                 else:                             # one Frame object for the whole batch (and one frame id)
                     self.note_frames((frame_id,), (frame_obj,))
             except TypeError:                     # unhashable frame ids
@@ -640,12 +643,19 @@ class Map:
         return [frame_obj.GetPose() for frame_obj in self.frames.values()]
 
     def AddPoint3D(self, point_id, point_3d):
-        if point_id in self.points_3d.keys():
+        pts = self.points_3d
+        if point_id in pts:
             raise Exception("Duplicate point3d warning")
-        self.points_3d[point_id] = point_3d
-        if hasattr(point_3d, "_adopt"):
-            point_3d._adopt(self._cell)
-        self._cell[0] += 1  # the point set changed: cached answers and the device mirror are stale
+        pts[point_id] = point_3d
+        cell = self._cell
+        try:
+            if not point_3d._cells:          # the usual case: a new point, held by no map yet (Point._adopt, inlined)
+                point_3d._cells = (cell,)
+            else:
+                point_3d._adopt(cell)
+        except AttributeError:               # a foreign point object: the mirror is rebuilt from the objects when it is needed
+            pass
+        cell[0] += 1  # the point set changed: cached answers and the device mirror are stale
         self._added.append((point_id, point_3d))  # the mirror absorbs new points in bulk on its next use
 
     def _absorb_added(self):
@@ -661,8 +671,8 @@ class Map:
         # concern the points absorbed here: a batch only names points the mirror already held when it arrived, and every such
         # call absorbs what was added before it.  The new points' own `_frames` dicts, read below, are complete.)
         n = len(added)
-        pts = [p for _, p in added]
-        locs = [p._loc for p in pts]
+        pids, pts = zip(*added)
+        locs, revs, frames = map(list, zip(*map(_LOC_REV_FRAMES, pts)))  # three slots of every point in one C-level pass
         rows = _rows_of(locs, np.float64)  # one conversion for the batch
         if rows is not None and rows.shape != (n, 3):
             rows = None
@@ -685,18 +695,16 @@ class Map:
                 grown[:slot0] = s.xyz[:slot0]
                 s.xyz = grown
             s.xyz[slot0:slot0 + n] = rows
-            s.point_slot.update(zip([pid for pid, _ in added], range(slot0, slot0 + n)))
+            s.point_slot.update(zip(pids, range(slot0, slot0 + n)))
             s.xyz_refs.extend(locs)
             s.n_points += n
-            s.rev += sum([p._rev for p in pts])
-            frames = [p._frames for p in pts]  # observations attached before the points entered the map
-            if all([len(fr) == 1 for fr in frames]):  # the usual case: one observation each (main.py:130-135,312-318)
-                items = [next(iter(fr.items())) for fr in frames]
+            s.rev += sum(revs)
+            # `frames`: the observations attached before the points entered the map
+            if set(map(len, frames)) == {1}:  # the usual case: one observation each (main.py:130-135,312-318)
+                fids, triples = zip(*map(next, map(iter, map(dict.items, frames))))
+                fobjs, uvs, descs = map(list, zip(*triples))
+                fids = list(fids)
                 slots = range(slot0, slot0 + n)
-                fids = [it[0] for it in items]
-                uvs = [it[1][1] for it in items]
-                descs = [it[1][2] for it in items]
-                fobjs = [it[1][0] for it in items]
             else:
                 slots, fids, uvs, descs = [], [], [], []
                 for k, fr in enumerate(frames):
