@@ -67,25 +67,34 @@ def main():
                "runs": {}}
     arrays = {"gt": gt}
     problems = []
-    for init in ("depth", "two_view"):
+    guarded_problems = []
+    # two runs as main.py has it, and the same two with the driver's guards (NOT in the reference: parallax >= 1 degree and
+    # reprojection error <= 2 px for a new point, key-frame poses adjusted with the points held fixed; slam.run_sequence)
+    for init, guards in (("depth", False), ("two_view", False), ("depth", True), ("two_view", True)):
+        name = init + ("_guarded" if guards else "")
+        gkw = dict(new_point_min_parallax_deg=1.0, new_point_max_reproj_px=2.0, keyframe_ba="poses_only") if guards else {}
         be = oracle_backends(oracle)
         inner = be._solver
         calls = []
 
         def recording(*a, _inner=inner, _calls=calls, **k):
             r = _inner(*a, **k)
-            if not np.all(a[3]) and len(a[2]):  # a free point: a local bundle adjustment (motion-only solves fix every point)
+            # a local bundle adjustment: a free point, or (guarded runs) scale edges -- motion-only solves have neither
+            if len(a[2]) and (not np.all(a[3]) or k.get("scale_edges")):
                 _calls.append((a, k, r))
             return r
         be._solver = recording
         t0 = time.perf_counter()
-        r = slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=20, min_tracked=80, init=init)
+        r = slam.run_sequence(frames, depth0, ICL_NUIM_K, be, keyframe_gap=20, min_tracked=80, init=init, **gkw)
         dt = time.perf_counter() - t0
         P, kf = r["poses"], r["keyframes"]
         ate = dataset.ate_rmse(P, gt)
         half = dataset.ate_rmse(P[:N // 2], gt[:N // 2])
         G0 = np.array([np.linalg.inv(gt[0]) @ g for g in gt])
-        summary["runs"][init] = {
+        n350 = min(N, 350)
+        first350 = dataset.ate_rmse(P[:n350], gt[:n350])
+        summary["runs"][name] = {
+            "guards": gkw if guards else None, "ate_rmse_first_350_frames_m": first350["rmse"], "gt_path_length_first_350_frames_m": first350["path_length"],
             "ate_rmse_m": ate["rmse"], "ate_mean_m": ate["mean"], "ate_max_m": ate["max"], "sim3_scale": ate["scale"],
             "gt_path_length_m": ate["path_length"], "ate_rmse_first_half_m": half["rmse"], "gt_path_length_first_half_m": half["path_length"],
             "keyframes": [int(k) for k in kf], "map_points": int(r["n_points"]),
@@ -97,7 +106,7 @@ def main():
                           "chi2_initial": float(res["chi2_initial"]), "chi2_final": float(res["chi2_final"]), "trials": int(res["trials"])}
                          for a, k, res in calls],
             "cpu_oracle_seconds": dt, "cpu_oracle_frames_per_s": N / dt}
-        arrays["poses_" + init] = P
+        arrays["poses_" + name] = P
         # how far the map is from the data set's own depth images at every key frame: for the points a key frame observes, depth in
         # that camera (map units) / true depth at the observed pixel (metres) -- a constant ratio is a consistent scale; points first
         # seen at this key frame or the one before (the newly triangulated ones) listed apart from the older ones
@@ -119,16 +128,21 @@ def main():
                 (new if j >= 2 and min(p.frames.keys()) >= j - 1 else old).append(z / zt)
             q = lambda a: None if not a else [len(a), float(np.median(a)), float(np.percentile(a, 25)), float(np.percentile(a, 75))]  # noqa: E731
             diag.append({"keyframe": j, "image": int(img), "older_points_n_median_q25_q75": q(old), "new_points_n_median_q25_q75": q(new)})
-        summary["runs"][init]["map_depth_over_true_depth_at_keyframes"] = diag
-        if init == "depth":
+        summary["runs"][name]["map_depth_over_true_depth_at_keyframes"] = diag
+        if name == "depth":
             problems = calls
+        if name == "depth_guarded":
+            guarded_problems = calls
         print("%s: %.1f s, %d key frames, %d map points, ATE rmse %.3f m over %.2f m (first half: %.3f over %.2f)" % (
-            init, dt, len(kf), r["n_points"], ate["rmse"], ate["path_length"], half["rmse"], half["path_length"]))
+            name, dt, len(kf), r["n_points"], ate["rmse"], ate["path_length"], half["rmse"], half["path_length"]))
     # ---- three real problems: early (5 poses), middle, last
-    picks = {"early": next(i for i, c in enumerate(problems) if len(c[0][0]) >= 5), "middle": len(problems) // 2, "last": len(problems) - 1}
+    picks = {"early": (problems, next(i for i, c in enumerate(problems) if len(c[0][0]) >= 5)), "middle": (problems, len(problems) // 2),
+             "last": (problems, len(problems) - 1),
+             # the guarded run's key-frame adjustment at a key frame with 21 free cameras: every point fixed, a scale edge per key frame
+             "guarded": (guarded_problems, next(i for i, c in enumerate(guarded_problems) if len(c[0][0]) >= 22))}
     summary["ba_fixtures"] = {}
-    for name, i in picks.items():
-        a, k, res = problems[i]
+    for name, (plist, i) in picks.items():
+        a, k, res = plist[i]
         se = k.get("scale_edges")
         out = dict(poses=np.asarray(a[0], np.float64), pose_fixed=np.asarray(a[1], np.uint8), points=np.asarray(a[2], np.float64),
                    point_fixed=np.asarray(a[3], np.uint8), obs_pose=np.asarray(a[4], np.int32), obs_point=np.asarray(a[5], np.int32),

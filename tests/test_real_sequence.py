@@ -17,6 +17,7 @@ import pytest
 from conftest import GOLDEN
 
 NAMES = ("early", "middle", "last")
+GUARDED = "guarded"   # the key-frame pose adjustment of the guarded run: every point fixed, 21 free cameras, a scale edge each
 CONTRACT = 1e-4   # BASELINE.json: BA poses within 1e-4 relative Frobenius
 
 
@@ -53,28 +54,36 @@ def test_stored_record_is_consistent():
     z = np.load(os.path.join(GOLDEN, "real_sequence.npz"))
     from visual_slam_amd import dataset
     assert s["frames"] >= 400 and s["keyframe_gap"] == 20 and s["min_tracked"] == 80
-    for init in ("depth", "two_view"):
+    for init in ("depth", "two_view", "depth_guarded", "two_view_guarded"):
         r = s["runs"][init]
         P = z["poses_" + init]
         assert P.shape == (s["frames"], 4, 4) and z["gt"].shape == P.shape
         ate = dataset.ate_rmse(P, z["gt"])
         assert abs(ate["rmse"] - r["ate_rmse_m"]) < 1e-9 and r["gt_path_length_m"] > 2.0      # a path of metres
         assert len(r["keyframes"]) >= 15 and r["keyframes"][0] == 0
-        gaps = np.diff(r["keyframes"][1:] if init == "two_view" else r["keyframes"])
+        gaps = np.diff(r["keyframes"][1:] if init.startswith("two_view") else r["keyframes"])
         assert gaps.max() <= 21                                                             # main.py:221: i - loop_idx > 20
         assert len(r["local_ba"]) == len(r["keyframes"]) - 1 and r["local_ba"][-1]["poses"] == len(r["keyframes"])
         for P_ in P:
             assert np.allclose(P_[:3, :3] @ P_[:3, :3].T, np.eye(3), atol=1e-8)
-    for name in NAMES:
+    # what the record is there to say: main.py's control flow loses the scale (half a metre of error on 2.5 m), the same
+    # kernels behind two guards track the same 420 frames to centimetres
+    assert s["runs"]["depth"]["ate_rmse_m"] > 0.4 and s["runs"]["two_view"]["ate_rmse_m"] > 0.4
+    g = s["runs"]["depth_guarded"]
+    assert g["ate_rmse_m"] < 0.10 and g["ate_rmse_first_half_m"] < 0.03 and g["ate_rmse_first_350_frames_m"] < 0.04
+    assert 3.0 < g["sim3_scale"] < 4.0                     # the map's unit stays the initialisation's (median point norm 3.41 m)
+    assert s["runs"]["two_view_guarded"]["ate_rmse_m"] < 0.15
+    for name in NAMES + (GUARDED,):
         d, _, _ = _load(name)
         fx = s["ba_fixtures"][name]
         assert (len(d["poses"]), len(d["points"]), len(d["obs_pose"])) == (fx["poses"], fx["points"], fx["observations"])
         assert d["pose_fixed"].tolist() == [1] + [0] * (len(d["poses"]) - 1)                    # LocalBA.py:155-156
-        assert len(d["scale_parent"]) == len(d["poses"]) - 1 and not d["point_fixed"].any()    # LocalBA.py:159-162, 165
+        assert len(d["scale_parent"]) == len(d["poses"]) - 1                                    # LocalBA.py:159-162
+        assert bool(d["point_fixed"].all()) == (name == GUARDED) and (name == GUARDED or not d["point_fixed"].any())  # LocalBA.py:165 / the guard
         assert np.all(np.diff(d["obs_point"]) >= 0)                                            # point-major (LocalBA.py:164-172)
 
 
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", NAMES + (GUARDED,))
 def test_oracle_reproduces_its_stored_answers(oracle, name):
     d, args, kw = _load(name)
     o = oracle.ba_solve(*args, **kw)
@@ -116,6 +125,37 @@ def test_real_problems_on_the_hip_solver_equal_the_oracle(vs, oracle, name):
     # the first trial starts from identical states
     assert np.isclose(g["chi2_trace"][0], o["chi2_trace"][0], rtol=max(1e-9, 20.0 * sp_chi2))
     assert np.isclose(g["lambda_trace"][0], o["lambda_trace"][0], rtol=1e-9)
+
+
+@pytest.mark.gpu
+def test_guarded_keyframe_pose_adjustment_on_the_hip_solver(vs, oracle):
+    """The guarded driver's key-frame step (BundleAdjustment.keyframePoseAdjustement: every point FIXED, the key-frame poses free,
+    a scale edge per key frame) on a real problem: 21 free cameras, 4 715 observations.  No free point, so there is no Schur
+    complement -- but the scale edges couple the cameras, so it is NOT the block-diagonal motion-only problem either."""
+    d, args, kw = _load(GUARDED)
+    o = oracle.ba_solve(*args, **kw)
+    g = vs.ba_solve(*args, **kw)
+    path = vs.ba_last_path()
+    print("real_ba_guarded: %s" % path)
+    assert path["unknowns"] == 126 and path["schur"] != "none (motion-only)", path
+    sp_pose, sp_chi2 = _self_spread(oracle, d, kw, o)
+    rel = _rel(g["poses"], o["poses"])
+    print("real_ba_guarded: HIP vs oracle poses %.2e (oracle vs itself %.2e), chi2 %.6e vs %.6e, trials %d / %d" % (
+        rel, sp_pose, g["chi2_final"], o["chi2_final"], g["trials"], o["trials"]))
+    assert rel <= CONTRACT and rel <= max(1e-8, 20.0 * sp_pose)
+    assert np.array_equal(g["points"], d["points"])                       # fixed points come back untouched
+    assert np.isclose(g["chi2_initial"], o["chi2_initial"], rtol=1e-10)
+    assert np.isclose(g["chi2_final"], o["chi2_final"], rtol=max(1e-9, 20.0 * sp_chi2))
+    # With the points fixed this solve CONVERGES (chi2 stops moving in the ninth digit after a few iterations); from there on the
+    # gain ratio is rounding noise and accept / reject decisions -- hence trial and iteration counts -- may differ between two
+    # summation orders (tests/test_gpu_ba.py::_compare): lock step is asserted while the oracle's chi2 still moves
+    tr = np.concatenate([[o["chi2_initial"]], o["chi2_trace"]])
+    live = np.nonzero(np.abs(np.diff(tr)) > 1e-9 * tr[1:])[0]
+    n_live = int(live[-1]) + 1 if len(live) else 0
+    assert n_live >= 3 and np.allclose(g["chi2_trace"][:n_live], o["chi2_trace"][:n_live], rtol=max(1e-7, 20.0 * sp_chi2))
+    assert np.allclose(g["lambda_trace"][:max(n_live - 1, 0)], o["lambda_trace"][:max(n_live - 1, 0)], rtol=1e-6)
+    if n_live == len(o["chi2_trace"]):
+        assert g["iterations"] == o["iterations"] and g["trials"] == o["trials"]
 
 
 @pytest.mark.gpu

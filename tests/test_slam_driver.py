@@ -56,6 +56,53 @@ def test_driver_on_the_oracle_back_ends(oracle):
     assert all(p.GetNVisibleFrames() >= 1 for p in m.points_3d.values()) and list(m.frames)[0] == 0
 
 
+def test_new_point_guards():
+    """slam._new_point_guards (NOT in the reference): parallax between the two rays and reprojection error in both views."""
+    K = np.array([[ICL_NUIM_K[0], 0, ICL_NUIM_K[2]], [0, ICL_NUIM_K[1], ICL_NUIM_K[3]], [0, 0, 1.0]])
+    w2c1, w2c2 = np.eye(4), np.eye(4)
+    w2c2[0, 3] = -0.1                                   # second camera 10 cm to the right
+    P1, P2 = K @ w2c1[:3], K @ w2c2[:3]
+    X = np.array([[0.0, 0.0, 1.0], [0.2, -0.1, 4.0], [0.0, 0.0, 20.0]])   # parallax 5.7, 1.4 and 0.29 degrees
+    Xh = np.c_[X, np.ones(3)]
+    x1 = (P1 @ Xh.T).T
+    x2 = (P2 @ Xh.T).T
+    x1, x2 = x1 / x1[:, 2:], x2 / x2[:, 2:]
+    g = slam._new_point_guards
+    assert g(X, w2c1, w2c2, P1, P2, x1, x2, 1.0, None).tolist() == [True, True, False]
+    assert g(X, w2c1, w2c2, P1, P2, x1, x2, 2.0, None).tolist() == [True, False, False]
+    assert g(X, w2c1, w2c2, P1, P2, x1, x2, None, 2.0).tolist() == [True, True, True]
+    x2b = x2.copy()
+    x2b[1, 0] += 3.0                                    # three pixels off in the second view
+    assert g(X, w2c1, w2c2, P1, P2, x1, x2b, None, 2.0).tolist() == [True, False, True]
+    assert g(X, w2c1, w2c2, P1, P2, x1, x2b, 1.0, 2.0).tolist() == [True, False, False]
+
+
+def test_guarded_driver_on_the_oracle_back_ends(oracle):
+    """The driver's guards (new points need parallax and a small reprojection error; key-frame poses adjusted with the points held
+    fixed) on the 20 fixture frames: consecutive key frames are millimetres apart, so no new point passes the parallax guard --
+    the map keeps the initialisation's points, untouched by the key-frame adjustment, and the trajectory stays smooth."""
+    frames, depth0 = harness.load_sequence(20)
+    kw = dict(keyframe_gap=4, min_tracked=80, new_point_min_parallax_deg=1.0, new_point_max_reproj_px=2.0, keyframe_ba="poses_only")
+    r = slam.run_sequence(frames, depth0, ICL_NUIM_K, oracle_backends(oracle), **kw)
+    ref = slam.run_sequence(frames, depth0, ICL_NUIM_K, oracle_backends(oracle), keyframe_gap=4, min_tracked=80)
+    assert r["keyframes"] == ref["keyframes"] and r["n_points"] == 595 < ref["n_points"]
+    X = np.array([p.location_3d for p in r["map"].points_3d.values()])
+    X0 = np.array([p.location_3d for p in list(ref["map"].points_3d.values())[:595]])
+    assert not np.allclose(X, X0)                                           # (the reference's BA moved its points; this one did not)
+    step = np.linalg.norm(np.diff(r["poses"][:, :3, 3], axis=0), axis=1)
+    assert step.max() < 0.05
+
+
+@pytest.mark.gpu
+def test_guarded_driver_gpu_equals_oracle(vs, oracle):
+    frames, depth0 = harness.load_sequence(20)
+    kw = dict(keyframe_gap=4, min_tracked=80, new_point_min_parallax_deg=0.02, new_point_max_reproj_px=2.0, keyframe_ba="poses_only")
+    g = slam.run_sequence(frames, depth0, ICL_NUIM_K, slam.Backends(context=vs), resident_ctx=vs, **kw)
+    c = slam.run_sequence(frames, depth0, ICL_NUIM_K, oracle_backends(oracle), **kw)
+    assert g["keyframes"] == c["keyframes"] and g["tracked"] == c["tracked"] and g["n_points"] == c["n_points"] > 595
+    assert max(np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(g["poses"], c["poses"])) < 1e-4
+
+
 @pytest.mark.gpu
 def test_driver_gpu_equals_oracle(vs, oracle):
     g = _run(slam.Backends(context=vs))

@@ -282,6 +282,17 @@ class BundleAdjustment:
                 if keep is None or keep[i]:
                     point_obj.UpdatePoint(new_points[i])  # what map.UpdatePoint3D does, without the per-point dict lookups
 
+    def keyframePoseAdjustement(self, map):
+        """NOT IN THE REFERENCE (slam.run_sequence(keyframe_ba="poses_only")): localBundleAdjustement's graph -- all frames, frame 0
+        fixed, a scaling edge per parent, one edge per (point, observing frame) -- with every point held FIXED; the poses are written
+        back, the points are left alone.  The reference frees every point (LocalBA.py:165), which on real data with centimetre
+        baselines lets the map's scale drift and collapse."""
+        frame_ids = map.frames.keys()
+        self._graph_from_soa(map, lambda fid_, f_: fid_ == 0, points_fixed=True, with_scale_edges=True)
+        self.optimize()
+        for frame_id in frame_ids:
+            map.UpdatePose(new_pose=self.get_pose(frame_id).matrix(), frame_id=frame_id)
+
     def _drop_points(self, drop):
         """Removes the observations of the masked points from the problem and fixes those points (they then take no
         part in the solve, like vertices that were never added)."""

@@ -106,6 +106,26 @@ def two_view_init(frames, K, camera, be, map, min_matches=100, min_valid=0.9, lo
     raise RuntimeError("two-view initialisation failed: no frame pair with enough parallax")
 
 
+def _new_point_guards(X, w2c1, w2c2, Proj1, Proj2, x1, x2, min_parallax_deg, max_reproj_px):
+    """Boolean mask over triangulated points X [n,3]: parallax between the rays from the two camera centres, reprojection error
+    in both images.  Not in the reference (run_sequence's guards)."""
+    ok = np.ones(len(X), bool)
+    if min_parallax_deg is not None:
+        c1 = -w2c1[:3, :3].T @ w2c1[:3, 3]
+        c2 = -w2c2[:3, :3].T @ w2c2[:3, 3]
+        a, b = X - c1, X - c2
+        cos = np.sum(a * b, axis=1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+        ok &= np.degrees(np.arccos(np.clip(cos, -1.0, 1.0))) >= min_parallax_deg
+    if max_reproj_px is not None:
+        Xh = np.c_[X, np.ones(len(X))]
+        for P, x in ((Proj1, x1), (Proj2, x2)):
+            p = (P @ Xh.T).T
+            with np.errstate(divide="ignore", invalid="ignore"):
+                err = np.linalg.norm(p[:, :2] / p[:, 2:] - x[:, :2], axis=1)
+            ok &= err <= max_reproj_px
+    return ok
+
+
 class _NoLaps:
     """Stands where tools/keyframe_stages.py puts its stage clock: lap(name) after a statement of the key-frame block."""
 
@@ -115,7 +135,8 @@ class _NoLaps:
 
 
 def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, max_depth=1.0, log=None,
-                 pnp_guess="w2c", init="depth", resident_ctx=None, stages=None, pipelined=True):
+                 pnp_guess="w2c", init="depth", resident_ctx=None, stages=None, pipelined=True,
+                 new_point_min_parallax_deg=None, new_point_max_reproj_px=None, keyframe_ba="reference"):
     """frames: list of BGR images; depth0: metric depth of frames[0]; K4 = (fx, fy, cx, cy).
     resident_ctx: a Context -> the frames between two key frames run on the device-resident tracking period
     (Context.track_begin / track_frame: main.py:181-214 as one call); key-frame insertion stays on the class API.
@@ -125,6 +146,12 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
     one -- one frame in `keyframe_gap` -- the period ends, the frame in flight is dropped with it and goes to the new period
     afresh.  A tracked frame's key points, descriptors and match lists are needed only if it becomes a key frame
     (main.py:221-236) and are fetched then (Context.track_last_frame), not per frame.  Same results as frame by frame.
+    new_point_min_parallax_deg / new_point_max_reproj_px / keyframe_ba: GUARDS THAT THE REFERENCE DOES NOT HAVE (default: off =
+    main.py's behaviour).  main.py:291-309 accepts a triangulated point on positive depth (< 1) alone, and main.py:322 frees every
+    point in a bundle adjustment whose only gauge is the first pose; on real data either one collapses the map's
+    scale within a few key frames.  With the guards a new point also needs the given parallax between its two rays and the given
+    reprojection error in both views, and keyframe_ba="poses_only" adjusts the key-frame poses with the points held fixed
+    (BundleAdjustment.keyframePoseAdjustement).
     stages: an object with lap(name), called after every statement of the key-frame block (tools/keyframe_stages.py).
     Returns dict(poses [n,4,4] camera-to-world, keyframes [indices], n_points, map, tracked [per frame])."""
     lap = (stages or _NoLaps).lap
@@ -300,7 +327,10 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
                     proj1 = p1 @ new_pts.T
                     proj2 = p2 @ new_pts.T
                     new_pts = new_pts[:, :3]
-                    good = np.where((proj1[2] > 0) & (proj2[2] > 0) & (proj2[2] < max_depth) & (proj1[2] < max_depth))[0]
+                    ok = (proj1[2] > 0) & (proj2[2] > 0) & (proj2[2] < max_depth) & (proj1[2] < max_depth)
+                    if new_point_min_parallax_deg is not None or new_point_max_reproj_px is not None:
+                        ok &= _new_point_guards(new_pts, p1, p2, Proj1, Proj2, x1, x2, new_point_min_parallax_deg, new_point_max_reproj_px)
+                    good = np.where(ok)[0]
                     lap("cheirality filter")
                     for pt, uv1, uv2, ft1, ft2 in zip(new_pts[good], last_kf_pts[good], cur_kf_pts[good],
                                                       last_kf_fts[good], cur_kf_fts[good]):
@@ -311,7 +341,10 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
                         id_point += 1
                         n_new += 1
                     lap("Point / AddFrame x2 / AddPoint3D per new point")
-            be.ba(camera).localBundleAdjustement(map)  # main.py:322-323
+            if keyframe_ba == "poses_only":
+                be.ba(camera).keyframePoseAdjustement(map)
+            else:
+                be.ba(camera).localBundleAdjustement(map)  # main.py:322-323
             lap("localBundleAdjustement")
             all_poses[i] = np.array(map.GetFrame(id_frame).GetPose())
             keyframes.append(i)
