@@ -1800,42 +1800,50 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_panel(ba_dev D, int j0,
   }
   if (tid == 0) *s_flag = 0;
   __syncthreads();
-  for (int b0 = 0; b0 < nbw; b0 += 6) {
-    if (tid == 0) {
-      double L[6][6], ri[6];
-      int good = 1;
+  // Per 6-column step: (1) the diagonal block on one lane, (2) every row below solves its six entries against it, (3) the panel's
+  // remaining columns are updated.  (1) is a chain of ~160 instructions on ONE lane; since round 5 it is taken off the critical
+  // path as ba_solve_block does: in step b's update wave 0 first updates the NEXT diagonal block (21 lanes), then factorises it
+  // (lane 0), while the other waves update the rest -- two barriers per step instead of three, and the chain runs beside the
+  // update.  (A factorisation of 306 unknowns -- 52 key frames of a growing global bundle adjustment -- is 13 launches of this
+  // kernel per LM trial: tools/ba_growth.py.)  Every element receives the same subtractions in the same order as before.
+  auto factor_diag = [&](int b0) {  // thread 0: the 6 x 6 block at (b0, b0) in registers, reciprocal pivots to rinv
+    double L[6][6], ri[6];
+    int good = 1;
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+    for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 0; c <= r; ++c) L[r][c] = A[(b0 + r) * ld + b0 + c];
+      for (int c = 0; c <= r; ++c) L[r][c] = A[(b0 + r) * ld + b0 + c];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double d = L[c][c];
-        if (!(d > 0.0)) good = 0;
-        double r = __builtin_amdgcn_rsq(d);
-        r = r * (1.5 - 0.5 * d * r * r);
-        r = r * (1.5 - 0.5 * d * r * r);
-        double l = d * r;
-        l = l + 0.5 * r * (d - l * l);
-        L[c][c] = l;
-        ri[c] = r;
+    for (int c = 0; c < 6; ++c) {
+      const double d = L[c][c];
+      if (!(d > 0.0)) good = 0;
+      double r = __builtin_amdgcn_rsq(d);
+      r = r * (1.5 - 0.5 * d * r * r);
+      r = r * (1.5 - 0.5 * d * r * r);
+      double l = d * r;
+      l = l + 0.5 * r * (d - l * l);
+      L[c][c] = l;
+      ri[c] = r;
 #pragma unroll
-        for (int i = c + 1; i < 6; ++i) L[i][c] = L[i][c] * r;
+      for (int i = c + 1; i < 6; ++i) L[i][c] = L[i][c] * r;
 #pragma unroll
-        for (int i = c + 1; i < 6; ++i)
+      for (int i = c + 1; i < 6; ++i)
 #pragma unroll
-          for (int k = c + 1; k <= i; ++k) L[i][k] -= L[i][c] * L[k][c];
-      }
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-#pragma unroll
-        for (int c = 0; c <= r; ++c) A[(b0 + r) * ld + b0 + c] = L[r][c];
-        rinv[b0 + r] = ri[r];
-      }
-      if (!good) *s_flag = 1;
+        for (int k = c + 1; k <= i; ++k) L[i][k] -= L[i][c] * L[k][c];
     }
-    __syncthreads();
-    if (*s_flag) break;  // uniform
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll
+      for (int c = 0; c <= r; ++c) A[(b0 + r) * ld + b0 + c] = L[r][c];
+      rinv[b0 + r] = ri[r];
+    }
+    if (!good) *s_flag = 1;
+  };
+  if (tid == 0) factor_diag(0);
+  __syncthreads();
+  for (int b0 = 0; b0 < nbw; b0 += 6) {
+    if (*s_flag) break;  // uniform (written before the last barrier)
+    // (2) every row below the block (and the rhs row)
     for (int r = b0 + 6 + tid; r < rows; r += kPanelThreads) {
       double a[6];
 #pragma unroll
@@ -1851,16 +1859,37 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_panel(ba_dev D, int j0,
       for (int c = 0; c < 6; ++c) A[r * ld + b0 + c] = a[c];
     }
     __syncthreads();
-    // update of the panel's remaining columns: thread = (row, column), 6-term dot product
+    // (3) update of the panel's remaining columns b0+6 .. nbw-1.  Wave 0 owns the next diagonal block (rows and columns b0+6 ..
+    // b0+11): 21 lanes update its lower triangle, lane 0 factorises it; the other waves (not the one that shares wave 0's SIMD)
+    // take the rows from b0+12 on: thread = (row, column), 6-term dot product.
     const int wc = nbw - b0 - 6;
     if (wc > 0) {
-      for (int e = tid; e < (rows - b0 - 6) * wc; e += kPanelThreads) {
-        const int r = b0 + 6 + e / wc, c = b0 + 6 + e % wc;
-        if (c > r && r < rows - 1) continue;  // strictly upper part of the matrix rows (the rhs row keeps all columns)
-        double acc = A[r * ld + c];
+      if (tid < 64) {
+        if (tid < 21) {
+          int r = 0, c = tid;
+          while (c > r) {  // lane -> (r, c) of the lower triangle, row-major
+            c -= r + 1;
+            ++r;
+          }
+          const int rr = b0 + 6 + r, cc = b0 + 6 + c;
+          double acc = A[rr * ld + cc];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc -= A[r * ld + b0 + k] * A[c * ld + b0 + k];
-        A[r * ld + c] = acc;
+          for (int k = 0; k < 6; ++k) acc -= A[rr * ld + b0 + k] * A[cc * ld + b0 + k];
+          A[rr * ld + cc] = acc;
+        }
+        wave_lds_sync();
+        if (tid == 0) factor_diag(b0 + 6);
+      } else if ((tid >> 6) & 3) {
+        constexpr int kWorkers = (kPanelThreads / 64 - kPanelThreads / 256) * 64;  // the waves that share no SIMD with wave 0
+        const int wv_ = tid >> 6, t2 = (wv_ - 1 - (wv_ >> 2)) * 64 + (tid & 63);
+        for (int e = t2; e < (rows - b0 - 12) * wc; e += kWorkers) {
+          const int r = b0 + 12 + e / wc, c = b0 + 6 + e % wc;
+          if (c > r && r < rows - 1) continue;  // strictly upper part of the matrix rows (the rhs row keeps all columns)
+          double acc = A[r * ld + c];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc -= A[r * ld + b0 + k] * A[c * ld + b0 + k];
+          A[r * ld + c] = acc;
+        }
       }
       __syncthreads();
     }
@@ -1883,25 +1912,43 @@ __global__ __launch_bounds__(256) void ba_chol_update(ba_dev D, int j0, int nbw)
   if (blockIdx.x > blockIdx.y) return;
   const int n = D.np, c0 = j0 + nbw, tid = threadIdx.x;
   const int r_base = c0 + blockIdx.y * kUpdTile, c_base = c0 + blockIdx.x * kUpdTile;
-  for (int e = tid; e < kUpdTile * nbw; e += 256) {
-    const int r = e / nbw, k = e - r * nbw;
-    sR[r][k] = r_base + r <= n ? chol_row(D, r_base + r)[j0 + k] : 0.0;
-    sC[r][k] = c_base + r < n ? D.S[(size_t)(c_base + r) * n + j0 + k] : 0.0;
-  }
-  __syncthreads();
   const int tx = tid & 15, ty = tid >> 4;
+  // the thread's 2 x 2 elements stay in registers while the panel's columns pass through LDS 24 at a time (panels of 48 columns
+  // since round 5: half the launches of a factorisation; every element still receives its subtractions in ascending column order)
+  double acc[2][2];
+  bool live[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int lr = ty + 16 * a, lc = tx + 16 * b;
-      const int r = r_base + lr, c = c_base + lc;
-      if (r > n || c >= n || (c > r)) continue;
-      double* dst = chol_row(D, r) + c;
-      double acc = *dst;
-      for (int k = 0; k < nbw; ++k) acc -= sR[lr][k] * sC[lc][k];
-      *dst = acc;
+      const int r = r_base + ty + 16 * a, c = c_base + tx + 16 * b;
+      live[a][b] = !(r > n || c >= n || (c > r));
+      acc[a][b] = live[a][b] ? chol_row(D, r)[c] : 0.0;
     }
+  for (int kh = 0; kh < nbw; kh += 24) {
+    const int kw = min(24, nbw - kh);
+    if (kh) __syncthreads();  // the previous slice has been consumed
+    for (int e = tid; e < kUpdTile * kw; e += 256) {
+      const int r = e / kw, k = e - r * kw;
+      sR[r][k] = r_base + r <= n ? chol_row(D, r_base + r)[j0 + kh + k] : 0.0;
+      sC[r][k] = c_base + r < n ? D.S[(size_t)(c_base + r) * n + j0 + kh + k] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int lr = ty + 16 * a, lc = tx + 16 * b;
+        double v = acc[a][b];
+        for (int k = 0; k < kw; ++k) v -= sR[lr][k] * sC[lc][k];
+        acc[a][b] = v;
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      if (live[a][b]) chol_row(D, r_base + ty + 16 * a)[c_base + tx + 16 * b] = acc[a][b];
 }
 
 // Banded systems (ba_schur_window's windows: S[r][c] = 0 for r - c >= band): the whole factorisation in ONE launch, one
@@ -2221,37 +2268,91 @@ __global__ __launch_bounds__(kPanelThreads) void ba_chol_finish(ba_dev D, int nb
       }
       __syncthreads();
     } else {
-    // blocks of nbw rows from the bottom: triangular solve inside the block (wave 0), then one matvec for the rows above
-    // (the block's triangle and pivots are brought into LDS first: read from global memory inside the serial loop, every
-    // one of its steps waited for a round trip.  A banded system -- D.band -- has nothing but zeros above row k0 - band.)
-    double* T = x + n;  // [nbw][nbw + 1] rows k0 .. k1-1 of L, columns k0 .. k1-1; then the reciprocal pivots
-    double* ri = T + nbw * (nbw + 1);
-    for (int k1 = n; k1 > 0;) {
-      const int k0 = k1 - ((k1 % nbw) ? (k1 % nbw) : nbw), bw = k1 - k0;
-      for (int e = tid; e < bw * bw; e += kPanelThreads) {
-        const int k = e / bw, i = e - k * bw;
-        if (i < k) T[k * (nbw + 1) + i] = D.S[(size_t)(k0 + k) * n + k0 + i];
-      }
-      if (tid < bw) ri[tid] = D.rinv[k0 + tid];
-      __syncthreads();
+    // Dense L: blocks of kFinW rows from the bottom.  Per block (a) the triangular solve inside the block and (b) one matvec for
+    // the rows above.  Round 5 (the growing global bundle adjustment of real sequences: 52 key frames = 306 unknowns spent 89 us
+    // per LM trial here, tools/ba_growth.py): (a) used to run on wave 0 through LDS, two wave synchronisations per unknown; now the
+    // block's 24 x 24 triangle sits in wave 0's REGISTERS (lane = column, one register per row), x of the block in one register
+    // per lane, and step k is a cross-lane read of x_k and one predicated multiply-subtract -- the banded branch's scheme.  (b)'s
+    // operands S[k][i] do not depend on x: every thread requests them BEFORE the serial part and holds them in registers, so the
+    // global round trip runs beside (a).  Every x_i still receives its subtractions one product at a time in descending k -- the
+    // order of the form this replaces and of the banded branch: the same bits.
+    constexpr int kFinW = 24;  // block width; the first kPanelThreads rows above a block have their operands requested ahead
+    auto lane_read = [](double v, int l) {
+      const long long b = __double_as_longlong(v);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+      return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    // Software pipeline over the blocks: the operands of block J - 1 -- its triangle and pivots (wave 0) and the matvec rows
+    // S[k][i] (every thread) -- are requested while block J is solved; none of them depends on x.  The two barriers of a block
+    // order LDS traffic only (lds_barrier: __syncthreads would also wait for the loads just requested).
+    auto bounds = [&](int k1, int* k0, int* bw, int* i_lo) {
+      *k0 = k1 - ((k1 % kFinW) ? (k1 % kFinW) : kFinW);
+      *bw = k1 - *k0;
+      *i_lo = D.band > 0 ? max(*k0 - D.band, 0) : 0;
+    };
+    double tl[kFinW], mv[kFinW], ri = 0.0;
+    auto request = [&](int k0, int bw, int i_lo, double* tl_, double* mv_, double* ri_) {
+      const int i = min(i_lo + tid, n - 1), c = min(k0 + tid, n - 1);
+#pragma unroll
+      for (int k = 0; k < kFinW; ++k) mv_[k] = D.S[(size_t)min(k0 + k, n - 1) * n + i];
       if (tid < 64) {
-        for (int k = k1 - 1; k >= k0; --k) {
-          const double xk = x[k] * ri[k - k0];
-          wave_lds_sync();
-          if (tid == 0) x[k] = xk;
-          for (int i = k0 + tid; i < k; i += 64) x[i] -= T[(k - k0) * (nbw + 1) + i - k0] * xk;
-          wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < kFinW; ++k) tl_[k] = D.S[(size_t)min(k0 + k, n - 1) * n + c];
+        *ri_ = D.rinv[min(k0 + tid, n - 1)];
+      }
+    };
+    int k1 = n, k0, bw, i_lo;
+    bounds(k1, &k0, &bw, &i_lo);
+    request(k0, bw, i_lo, tl, mv, &ri);
+    while (k1 > 0) {
+      // (a) wave 0: the block's right-hand side into a register, then the serial steps
+      if (tid < 64) {
+        double xl = tid < bw ? x[k0 + tid] : 0.0;
+#pragma unroll
+        for (int k = kFinW - 1; k >= 0; --k) {
+          if (k >= bw) continue;  // uniform (the bottom block may be narrower)
+          const double xk = lane_read(xl * ri, k);  // lane k's value is final once the steps above it are through
+          if (tid < k) xl -= tl[k] * xk;
+        }
+        if (tid < bw) x[k0 + tid] = xl * ri;
+      }
+      // the next block's operands: requested now, used after the two barriers below
+      int k0n = 0, bwn = 0, i_lon = 0;
+      double tln[kFinW], mvn[kFinW], rin = 0.0;
+      if (k0 > 0) {  // uniform
+        bounds(k0, &k0n, &bwn, &i_lon);
+        request(k0n, bwn, i_lon, tln, mvn, &rin);
+      }
+      lds_barrier();
+      // (b) the rows above the block: the first kPanelThreads of them from the registers, the rest the plain way
+      {
+        const int i = i_lo + tid;
+        if (i < k0) {
+          double v = x[i];
+#pragma unroll
+          for (int k = kFinW - 1; k >= 0; --k)
+            if (k < bw) v -= mv[k] * x[k0 + k];
+          x[i] = v;
         }
       }
-      __syncthreads();
-      const int i_lo = D.band > 0 ? max(k0 - D.band, 0) : 0;
-      for (int i = i_lo + tid; i < k0; i += kPanelThreads) {
+      for (int i = i_lo + tid + kPanelThreads; i < k0; i += kPanelThreads) {
         double v = x[i];
         for (int k = k1 - 1; k >= k0; --k) v -= D.S[(size_t)k * n + i] * x[k];
         x[i] = v;
       }
-      __syncthreads();
+      lds_barrier();
       k1 = k0;
+      if (k1 > 0) {
+        k0 = k0n;
+        bw = bwn;
+        i_lo = i_lon;
+        ri = rin;
+#pragma unroll
+        for (int k = 0; k < kFinW; ++k) {
+          tl[k] = tln[k];
+          mv[k] = mvn[k];
+        }
+      }
     }
     }
     for (int i = tid; i < n; i += kPanelThreads) D.xp[i] = x[i];
@@ -3275,7 +3376,9 @@ int plan_solve(vs_ctx* ctx, int np, solve_plan* P) {
   P->panel_lds = 0;
   P->band_ok = false;
   if (!P->lds) {
-    // widest panel (24 / 12 / 6 columns) whose rows j0..n fit in LDS
+    // widest panel (24 / 12 / 6 columns) whose rows j0..n fit in LDS.  (48-column panels were measured in round 5 and are slower:
+    // the update of a panel's own remaining columns is one workgroup's work and grows with the square of the width -- 7 launches of
+    // 33 us against 13 of 14.5 at 306 unknowns; ba_chol_update takes any width in slices of 24 all the same.)
     for (int w : {24, 12, 6}) {
       const size_t b = sizeof(double) * ((size_t)(np + 1) * (w | 1) + w) + 64;
       if (b <= 150 * 1024 && sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64 <= 150 * 1024) {
