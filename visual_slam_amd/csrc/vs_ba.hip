@@ -3784,7 +3784,15 @@ host_passes:
   const int small_per = ctx->tune.small_per > 0 ? ctx->tune.small_per : kSmallPts;
   auto slabs_for = [&](bool tiled_, bool small_) {
     int n = nfl > 0 && nfp > 0 ? std::min(256, (nfl + 7) / 8) : 0;
-    if (tiled_) n = std::max(4, std::min(256, (16384 + ntile_pairs - 1) / ntile_pairs));  // >= 16k workgroups: most tiles are empty
+    if (tiled_) {
+      n = std::max(4, std::min(256, (16384 + ntile_pairs - 1) / ntile_pairs));  // >= 16k workgroups: most tiles are empty
+      // ... but not more slabs than the points can fill: at least 8 free points per slab (round 5: the real-sequence problems and
+      // the growing global BA have ~1 200 points -- 256 slabs of 5 points each made ba_schur_tile and ba_reduce 6 - 7 % of a
+      // trial slower than 150 slabs; 16 / 32 / 64 / 128 points per slab measured 424 / 428 / 438 / 487 us per trial at 52 key
+      // frames against 431 at 8 and 457 before; developer aid VS_BA_TILE_PER overrides)
+      static const int kTilePer = getenv("VS_BA_TILE_PER") ? atoi(getenv("VS_BA_TILE_PER")) : 8;
+      if (kTilePer > 0 && !small_ && ntile > 1) n = std::max(4, std::min(n, (nfl + kTilePer - 1) / kTilePer));  // (single tile: ba_schur_small's territory; the tile kernel only runs there when a test forces it)
+    }
     if (small_) n = std::max(1, std::min(ctx->tune.small_ns_cap, (nfl + small_per - 1) / small_per));
     if (!lds_slab && n > 0) n = std::min(n, std::max(1, (int)((512u << 20) / (sizeof(double) * slab_elems))));
     return n;
