@@ -433,6 +433,36 @@ def ba_scaled_leg(ctx):
                     "(profiles/r04_ba_scaled.log); counter traffic in profiles/r04_ba_scaled_pmc.txt"}
 
 
+def ba_growth_leg(ctx):
+    """The reference's key-frame bundle adjustment is GLOBAL (every key frame, every point: LocalBA.py:143-172), so its reduced camera
+    system grows with the sequence: scenes of 1 200 points seen from a random 30 % of N key frames (tools/ba_growth.py), and the three
+    problems a real 420-frame run handed to the solver (tests/golden/real_ba_*.npz)."""
+    from visual_slam_amd.workloads import ba_workload
+    out = {"synthetic_1200_points_30pct_visibility": [], "real_sequence_fixtures": []}
+    for n in (10, 22, 23, 52):
+        w = ba_workload(n_cams=n, n_points=1200, visibility=0.3, seed=n)
+        args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
+        g = ctx.ba_solve(*args)
+        med, _ = median_time(lambda: ctx.ba_solve(*args), 15, warm=3)
+        p = ctx.ba_last_path()
+        out["synthetic_1200_points_30pct_visibility"].append({
+            "key_frames": n, "unknowns": p["unknowns"], "observations": int(len(w["obs_pose"])), "ms_per_solve": med * 1e3,
+            "lm_trials": int(g["trials"]), "us_per_trial": med * 1e6 / max(int(g["trials"]), 1), "schur": p["schur"], "dense": p["dense"]})
+    golden = os.path.join(ROOT, "tests", "golden")
+    for name in ("early", "middle", "last", "guarded"):
+        f = np.load(os.path.join(golden, "real_ba_%s.npz" % name))
+        args = (f["poses"], f["pose_fixed"], f["points"], f["point_fixed"], f["obs_pose"], f["obs_point"], f["obs_uv"], tuple(f["K"]))
+        kw = dict(huber_delta=float(f["huber_delta"]), dcs_phi=float(f["dcs_phi"]),
+                  scale_edges=(f["scale_parent"].tolist(), f["scale_child"].tolist(), f["scale_meas"].tolist()))
+        g = ctx.ba_solve(*args, **kw)
+        med, _ = median_time(lambda: ctx.ba_solve(*args, **kw), 15, warm=3)
+        p = ctx.ba_last_path()
+        out["real_sequence_fixtures"].append({
+            "fixture": "real_ba_%s" % name, "poses": int(len(f["poses"])), "points": int(len(f["points"])), "observations": int(len(f["obs_pose"])),
+            "ms_per_solve": med * 1e3, "lm_trials": int(g["trials"]), "schur": p["schur"], "dense": p["dense"]})
+    return out
+
+
 def frames_leg(ctx, cpu=True):
     """frames/s of the 640x480 ICL-NUIM stream (detect+describe -> match -> PnP-RANSAC -> motion-only BA), GPU path and -- as the
     checker/baseline only -- the CPU oracle through the same harness.  GPU legs: medians of 20 repetitions (minima
@@ -949,6 +979,10 @@ def main():
                 line["local_ba_scaled"] = ba_scaled_leg(ctx)
             except Exception as e:
                 line["local_ba_scaled"] = {"error": repr(e)}
+            try:
+                line["local_ba_growth"] = ba_growth_leg(ctx)
+            except Exception as e:
+                line["local_ba_growth"] = {"error": repr(e)}
         if not args.no_frames:
             try:
                 line["frames"] = frames_leg(ctx, cpu=cpu)
