@@ -59,7 +59,15 @@ class Backends:
 
 
 def _inv(pose):
-    return Isometry3d(R=pose[0:3, 0:3], t=np.asarray(pose[:3, -1]).squeeze()).inverse().matrix()
+    """Inverse of a rigid 4x4: what main.py spells Isometry3d(R=..., t=...).inverse().matrix() (main.py:44-45: R.T, -R.T @ t) --
+    the same two products, without the three temporary objects (it runs three times per tracked frame)."""
+    pose = np.asarray(pose)
+    Rt = pose[0:3, 0:3].T
+    m = np.zeros((4, 4))
+    m[:3, :3] = Rt
+    m[:3, 3] = -Rt @ np.asarray(pose[:3, -1]).squeeze()
+    m[3, 3] = 1.0
+    return m
 
 
 def two_view_init(frames, K, camera, be, map, min_matches=100, min_valid=0.9, log=None):
@@ -251,8 +259,9 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
             # pose from PnP-RANSAC with the previous frame as extrinsic guess (main.py:191-204)
             W_T_prev = np.array(local_map.GetFrame(id_frame_local - 1).GetPose(), dtype=np.float64)
             W_T_curr = W_T_prev.copy()
+            prev_T_W = _inv(W_T_prev)
             if pnp_guess is not None and len(known_3d_matched) >= 5:
-                guess = W_T_prev if pnp_guess == "reference" else _inv(W_T_prev)
+                guess = W_T_prev if pnp_guess == "reference" else prev_T_W
                 retval, rvec, tvec, inl = be.pnp(known_3d_matched, curMatchedPoints, K, hf.Rtorvec(guess[:3, :3]),
                                                  np.array(guess[:3, 3]), seed=i)
                 if retval:
@@ -261,7 +270,7 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
                 pnp_inliers.append(len(inl))
             else:
                 pnp_inliers.append(0)
-            RelativePoseTransformation = _inv(W_T_prev) @ W_T_curr
+            RelativePoseTransformation = prev_T_W @ W_T_curr
             local_map.AddParentAndPose(parent_id=id_frame_local - 1, frame_id=id_frame_local, frame_obj=cur_frame,
                                        rel_pose_trans=RelativePoseTransformation, pose=W_T_curr)
             local_map.AddPointToFrameCorrespondences(point_ids=known_3d_matched_ids, image_points=curMatchedPoints,
