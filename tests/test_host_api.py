@@ -511,3 +511,81 @@ def test_mirror_remembers_the_frame_objects_of_its_observations():
     s2 = mirror_of_points(m.points_3d)
     s2.add_obs([0], 5, np.zeros((1, 2)), None)                                                       # no Frame object given
     assert s2.frame_objs is _UNKNOWN_FRAMES
+
+
+def _points_equal(a, b):
+    assert list(a.points_3d) == list(b.points_3d)
+    for pa, pb in zip(a.points_3d.values(), b.points_3d.values()):
+        assert pa.ID == pb.ID and pa._rev == pb._rev and np.array_equal(pa.location_3d, pb.location_3d)
+        assert len(pa._cells) == len(pb._cells) == 1
+        assert list(pa.frames) == list(pb.frames)
+        for k in pa.frames:
+            fa, fb = pa.frames[k], pb.frames[k]
+            assert fa[0].ID == fb[0].ID and np.array_equal(fa[1], fb[1]) and np.array_equal(fa[2], fb[2])
+            assert fa[1].dtype == fb[1].dtype and fa[2].dtype == fb[2].dtype
+
+
+@pytest.mark.parametrize("n_obs", [1, 2, 3])
+def test_points_added_as_one_batch_leave_the_map_as_the_loop_does(n_obs):
+    """Map.AddPoints3D (not in the reference; the resident driver's form of main.py:130-135 / 312-318) against the loop of
+    Point(...) / AddFrame / AddPoint3D it replaces: the same objects, dict order and change counters, the same rows in the same
+    order in the mirror, the same answers afterwards -- also when points and observations follow, and when the mirror was
+    out of sync at the time of the call."""
+    from visual_slam_amd.point import Point
+
+    def build(bulk, stale_mirror):
+        r = np.random.default_rng(5)
+        m = Map()
+        fr = [Frame(np.zeros((4, 4, 3), np.uint8), None, i) for i in range(3)]
+        for i, f in enumerate(fr):
+            m.AddFrame(i, f)
+        for rnd, n in enumerate((40, 25)):
+            X = r.normal(size=(n, 3))
+            obs = [(fr[j], r.normal(size=(n, 2)).astype(np.float32), r.integers(0, 255, (n, 32)).astype(np.uint8)) for j in range(n_obs)]
+            ids = range(1 + 100 * rnd, 1 + 100 * rnd + n)
+            if rnd == 1 and stale_mirror:
+                m.soa()
+                m.points_3d[3].AddFrame(frame=fr[2], uv=np.zeros(2, np.float32), descriptor=np.zeros(32, np.uint8))  # behind the map's back
+            if bulk:
+                m.AddPoints3D(ids, X, obs)
+            else:
+                for k, pid in enumerate(ids):
+                    p = Point(location=X[k], id=pid)
+                    for f, uv, d in obs:
+                        p.AddFrame(frame=f, uv=uv[k], descriptor=d[k])
+                    m.AddPoint3D(pid, p)
+            if rnd == 0:
+                m.GetImagePointsWithFrameID(0)   # the mirror is looked at between the two rounds
+        # observations of a later frame for some of the points, through the map
+        sel = list(m.points_3d)[::3]
+        m.AddPointToFrameCorrespondences(point_ids=sel, image_points=r.normal(size=(len(sel), 2)).astype(np.float32),
+                                         descriptors=r.integers(0, 255, (len(sel), 32)).astype(np.uint8), frame_obj=fr[2])
+        return m
+
+    for stale in (False, True):
+        a, b = build(False, stale), build(True, stale)
+        _points_equal(a, b)
+        assert a._cell[:2] == b._cell[:2]
+        sa, sb = a.soa(), b.soa()
+        for x, y in zip(sa.arrays(), sb.arrays()):
+            assert np.array_equal(x, y) and x.dtype == y.dtype
+        assert sa.n_points == sb.n_points and sa.rev == sb.rev and sa.fid_rows == sb.fid_rows and sa.point_slot == sb.point_slot
+        assert np.array_equal(sa.xyz[:sa.n_points], sb.xyz[:sb.n_points])
+        assert all(p.location_3d is r for p, r in zip(b.points_3d.values(), sb.xyz_refs))
+        for f in range(3):
+            for x, y in zip(a.GetImagePointsWithFrameID(f), b.GetImagePointsWithFrameID(f)):
+                assert np.array_equal(x, y)
+            la, lb = a.GetCopyOfPointObjects(f), b.GetCopyOfPointObjects(f)
+            assert list(la.keys()) == list(lb.keys())
+    # errors: a duplicate id raises with the reference's text and leaves the map untouched; ragged input
+    m = build(True, False)
+    n0 = len(m.points_3d)
+    with pytest.raises(Exception, match="Duplicate point3d warning"):
+        m.AddPoints3D([900, 1], np.zeros((2, 3)), [(m.GetFrame(0), np.zeros((2, 2)), np.zeros((2, 32), np.uint8))])
+    with pytest.raises(Exception, match="Duplicate point3d warning"):
+        m.AddPoints3D([900, 900], np.zeros((2, 3)), [(m.GetFrame(0), np.zeros((2, 2)), np.zeros((2, 32), np.uint8))])
+    with pytest.raises(ValueError):
+        m.AddPoints3D([900, 901], np.zeros((2, 3)), [(m.GetFrame(0), np.zeros((3, 2)), np.zeros((2, 32), np.uint8))])
+    assert len(m.points_3d) == n0
+    m.AddPoints3D([], np.zeros((0, 3)), [])
+    assert len(m.points_3d) == n0

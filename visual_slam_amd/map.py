@@ -658,6 +658,83 @@ class Map:
         cell[0] += 1  # the point set changed: cached answers and the device mirror are stale
         self._added.append((point_id, point_3d))  # the mirror absorbs new points in bulk on its next use
 
+    def AddPoints3D(self, point_ids, locations, observations):
+        """NOT in the reference (its callers add points one by one, main.py:130-135,312-318): n new points at once, each with one
+        observation per entry of `observations` = [(Frame object, uv [n,2], descriptors [n,D]), ...].  The map ends up exactly as after
+            for k in range(n):
+                p = Point(location=locations[k], id=point_ids[k])
+                for frame, uv, desc in observations: p.AddFrame(frame=frame, uv=uv[k], descriptor=desc[k])
+                self.AddPoint3D(point_ids[k], p)
+        -- the same Point objects (row k of each array as its position / image point / descriptor object), the same dict order, the
+        same change counters, the same rows in the same order in the structure-of-arrays mirror -- but the mirror takes the arrays as
+        they are instead of reading them back out of n objects, and the objects are filled slot by slot.  One difference: a duplicate
+        id raises before ANY point is added (the loop would have added the points in front of it)."""
+        pts = self.points_3d
+        ids = list(point_ids)
+        n = len(ids)
+        locations = np.asarray(locations)
+        obs = [(f, np.asarray(uv), np.asarray(d)) for f, uv, d in observations]
+        if locations.shape != (n, 3) or any(len(uv) != n or len(d) != n for _, uv, d in obs):
+            raise ValueError("AddPoints3D: one location and one observation per frame for every point id")
+        if n == 0:
+            return
+        if len(set(ids)) != n or any(i in pts for i in ids):
+            raise Exception("Duplicate point3d warning")
+        if self._added:
+            self._absorb_added()
+        s, cell = self._soa, self._cell
+        in_sync = (self._soa_points_obj is pts and s.n_obs >= 0 and s.n_points == len(pts)
+                   and self._soa_cell[0] == cell[0] and self._soa_cell[1] == cell[1])
+        rows = list(locations)                     # row k: the position object of point k (as `location=pts[k]` binds a row view)
+        fids = [f.GetID() for f, _, _ in obs]
+        m = len(obs)
+        per_frame = [(f, list(uv), list(d)) for f, uv, d in obs]
+        new, cells = _Point.__new__, (cell,)
+        if m == 1:
+            f, uvr, dr = per_frame[0]
+            fid = fids[0]
+            for pid, X, u, d in zip(ids, rows, uvr, dr):
+                q = new(_Point)
+                q.ID, q._loc, q._frames, q._rev, q._cells = pid, X, {fid: (f, u, d)}, 1, cells
+                pts[pid] = q
+        elif m == 2 and fids[0] != fids[1]:   # a new point of a key frame: seen from the previous key frame and from this one
+            (f0, uv0, de0), (f1, uv1, de1) = per_frame
+            i0, i1 = fids
+            for pid, X, u0, d0, u1, d1 in zip(ids, rows, uv0, de0, uv1, de1):
+                q = new(_Point)
+                q.ID, q._loc, q._frames, q._rev, q._cells = pid, X, {i0: (f0, u0, d0), i1: (f1, u1, d1)}, 2, cells
+                pts[pid] = q
+        else:
+            for k, (pid, X) in enumerate(zip(ids, rows)):
+                q = new(_Point)
+                fr = {}
+                for fid, (f, uvr, dr) in zip(fids, per_frame):   # (a frame id listed twice overwrites, as AddFrame would)
+                    fr[fid] = (f, uvr[k], dr[k])
+                q.ID, q._loc, q._frames, q._rev, q._cells = pid, X, fr, m, cells
+                pts[pid] = q
+        cell[0] += n  # (AddPoint3D: one per point)
+        if not in_sync or len(set(fids)) != m:
+            return    # the mirror is verified against the objects (and rebuilt) on its next use
+        slot0 = s.n_points
+        if slot0 + n > s.xyz.shape[0]:
+            grown = np.zeros((max(256, 2 * s.xyz.shape[0], slot0 + n), 3))
+            grown[:slot0] = s.xyz[:slot0]
+            s.xyz = grown
+        s.xyz[slot0:slot0 + n] = locations
+        s.point_slot.update(zip(ids, range(slot0, slot0 + n)))
+        s.xyz_refs.extend(rows)
+        s.n_points += n
+        s.rev += n * m
+        if m == 1:
+            s.add_obs(np.arange(slot0, slot0 + n, dtype=np.int32), fids[0], obs[0][1], obs[0][2], obs[0][0])
+        elif m > 1:   # point by point, frame by frame: the order in which the loop above records them
+            same_uv = len({(uv.dtype, uv.shape[1:]) for _, uv, _ in obs}) == 1
+            same_d = len({(d.dtype, d.shape[1:]) for _, _, d in obs}) == 1
+            uv_all = np.stack([uv for _, uv, _ in obs], 1).reshape(n * m, -1) if same_uv else [u for k in range(n) for _, uvr, _ in per_frame for u in (uvr[k],)]
+            d_all = np.stack([d for _, _, d in obs], 1).reshape((n * m,) + obs[0][2].shape[1:]) if same_d else [x for k in range(n) for _, _, dr in per_frame for x in (dr[k],)]
+            s.add_obs(np.repeat(np.arange(slot0, slot0 + n, dtype=np.int32), m), fids * n, uv_all, d_all, [f for f, _, _ in obs] * n)
+        self._soa_cell = (cell[0], cell[1])
+
     def _absorb_added(self):
         """Takes the points added since the last look into the mirror: one pass, one observation batch (the reference's
         callers add a few hundred points one by one, main.py:130-135,312-318)."""

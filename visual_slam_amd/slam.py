@@ -185,11 +185,15 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
         z = depth0[kp0[:, 1].astype(int), kp0[:, 0].astype(int)]
         pts = np.stack([(kp0[:, 0] - cx) * z / fx, (kp0[:, 1] - cy) * z / fy, z], 1)
         pts = pts / np.median(np.linalg.norm(pts, axis=1))  # LocalBA.py:178-190 (scale=True): median point norm = 1
-        for X, uv, ft in zip(pts, kp0, ft0):
-            pt_object = Point(location=X, id=id_point)
-            pt_object.AddFrame(frame=cur_frame, uv=uv, descriptor=ft)
-            map.AddPoint3D(point_id=id_point, point_3d=pt_object)
-            id_point += 1
+        if resident_ctx is not None:  # (the explicit resident period is this project's own driver: the points go in as one batch)
+            map.AddPoints3D(range(id_point, id_point + len(pts)), pts, [(cur_frame, kp0, ft0)])
+            id_point += len(pts)
+        else:                         # main.py's statements
+            for X, uv, ft in zip(pts, kp0, ft0):
+                pt_object = Point(location=X, id=id_point)
+                pt_object.AddFrame(frame=cur_frame, uv=uv, descriptor=ft)
+                map.AddPoint3D(point_id=id_point, point_3d=pt_object)
+                id_point += 1
         id_frame += 1
     resident = resident_ctx is not None
     last_keyframe = copy.copy(map.GetFrame(frame_id=id_frame - 1))  # main.py:153
@@ -341,14 +345,21 @@ def run_sequence(frames, depth0, K4, backends, keyframe_gap=20, min_tracked=80, 
                         ok &= _new_point_guards(new_pts, p1, p2, Proj1, Proj2, x1, x2, new_point_min_parallax_deg, new_point_max_reproj_px)
                     good = np.where(ok)[0]
                     lap("cheirality filter")
-                    for pt, uv1, uv2, ft1, ft2 in zip(new_pts[good], last_kf_pts[good], cur_kf_pts[good],
-                                                      last_kf_fts[good], cur_kf_fts[good]):
-                        pt_object = Point(location=pt, id=id_point)
-                        pt_object.AddFrame(frame=map.GetFrame(id_frame - 1), uv=uv1, descriptor=ft1)
-                        pt_object.AddFrame(frame=map.GetFrame(id_frame), uv=uv2, descriptor=ft2)
-                        map.AddPoint3D(point_id=id_point, point_3d=pt_object)
-                        id_point += 1
-                        n_new += 1
+                    if resident:  # main.py:312-318 as one batch (Map.AddPoints3D leaves the map as the loop below does)
+                        n_new = len(good)
+                        map.AddPoints3D(range(id_point, id_point + n_new), new_pts[good],
+                                        [(map.GetFrame(id_frame - 1), last_kf_pts[good], last_kf_fts[good]),
+                                         (map.GetFrame(id_frame), cur_kf_pts[good], cur_kf_fts[good])])
+                        id_point += n_new
+                    else:
+                        for pt, uv1, uv2, ft1, ft2 in zip(new_pts[good], last_kf_pts[good], cur_kf_pts[good],
+                                                          last_kf_fts[good], cur_kf_fts[good]):
+                            pt_object = Point(location=pt, id=id_point)
+                            pt_object.AddFrame(frame=map.GetFrame(id_frame - 1), uv=uv1, descriptor=ft1)
+                            pt_object.AddFrame(frame=map.GetFrame(id_frame), uv=uv2, descriptor=ft2)
+                            map.AddPoint3D(point_id=id_point, point_3d=pt_object)
+                            id_point += 1
+                            n_new += 1
                     lap("Point / AddFrame x2 / AddPoint3D per new point")
             if keyframe_ba == "poses_only":
                 be.ba(camera).keyframePoseAdjustement(map)
