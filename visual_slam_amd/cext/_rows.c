@@ -135,14 +135,97 @@ static PyObject* pack(PyObject* self, PyObject* args) {
   Py_RETURN_FALSE;
 }
 
+/* collect(points) -> (locs, rev_sum, counts, fids, frame_objs, uvs, descs) or None.  points: a sequence of Point objects (point.py:
+ * slots `_loc`, `_rev`, `_frames` = {frame id: (Frame, uv, descriptor)}).  One pass in C over what Map._absorb_added otherwise reads
+ * out of the objects with Python-level loops: locs[k] = the position object of point k, rev_sum = the sum of the `_rev` counters,
+ * counts[k] = its number of observations, and -- point by point, in dict order -- the frame id, Frame object, image point and
+ * descriptor of every observation.  None when an object does not look like a Point (the caller then walks the objects itself). */
+static PyObject *s_loc, *s_rev, *s_frames;
+static PyObject* collect(PyObject* self, PyObject* arg) {
+  PyObject* fast = PySequence_Fast(arg, "collect: a sequence of points");
+  if (!fast) return NULL;
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+  PyObject** items = PySequence_Fast_ITEMS(fast);
+  PyObject *locs = PyList_New(n), *counts = PyList_New(n), *fids = PyList_New(0), *fobjs = PyList_New(0), *uvs = PyList_New(0),
+           *descs = PyList_New(0), *out = NULL;
+  long long rev_sum = 0;
+  int ok = locs && counts && fids && fobjs && uvs && descs;
+  Py_ssize_t filled = 0;
+  for (Py_ssize_t k = 0; ok && k < n; ++k) {
+    PyObject* loc = PyObject_GetAttr(items[k], s_loc);
+    PyObject* rev = loc ? PyObject_GetAttr(items[k], s_rev) : NULL;
+    PyObject* fr = rev ? PyObject_GetAttr(items[k], s_frames) : NULL;
+    if (!fr || !PyDict_Check(fr) || !PyLong_Check(rev)) {
+      Py_XDECREF(loc);
+      Py_XDECREF(rev);
+      Py_XDECREF(fr);
+      ok = 0;
+      break;
+    }
+    rev_sum += PyLong_AsLongLong(rev);
+    Py_DECREF(rev);
+    PyList_SET_ITEM(locs, k, loc);  /* steals */
+    PyObject* cnt = PyLong_FromSsize_t(PyDict_GET_SIZE(fr));
+    if (!cnt) {
+      Py_DECREF(fr);
+      ok = 0;
+      break;
+    }
+    PyList_SET_ITEM(counts, k, cnt);
+    filled = k + 1;
+    Py_ssize_t pos = 0;
+    PyObject *key, *val;
+    while (ok && PyDict_Next(fr, &pos, &key, &val)) {
+      if (!PyTuple_Check(val) || PyTuple_GET_SIZE(val) != 3 || PyList_Append(fids, key) || PyList_Append(fobjs, PyTuple_GET_ITEM(val, 0)) ||
+          PyList_Append(uvs, PyTuple_GET_ITEM(val, 1)) || PyList_Append(descs, PyTuple_GET_ITEM(val, 2)))
+        ok = 0;
+    }
+    Py_DECREF(fr);
+  }
+  /* (PyList_New leaves NULL items: a list that was not filled to the end must not be handed out or traversed) */
+  if (locs && filled < n) {
+    for (Py_ssize_t k = filled; k < n; ++k) {
+      if (!PyList_GET_ITEM(locs, k)) {
+        Py_INCREF(Py_None);
+        PyList_SET_ITEM(locs, k, Py_None);
+      }
+      if (counts && !PyList_GET_ITEM(counts, k)) {
+        Py_INCREF(Py_None);
+        PyList_SET_ITEM(counts, k, Py_None);
+      }
+    }
+  }
+  if (ok) out = Py_BuildValue("(OLOOOOO)", locs, rev_sum, counts, fids, fobjs, uvs, descs);
+  Py_XDECREF(locs);
+  Py_XDECREF(counts);
+  Py_XDECREF(fids);
+  Py_XDECREF(fobjs);
+  Py_XDECREF(uvs);
+  Py_XDECREF(descs);
+  Py_DECREF(fast);
+  if (!ok) {
+    if (PyErr_Occurred()) {
+      if (PyErr_ExceptionMatches(PyExc_MemoryError)) return NULL;
+      PyErr_Clear();
+    }
+    Py_RETURN_NONE;
+  }
+  return out;
+}
+
 static PyMethodDef methods[] = {{"rows", rows, METH_VARARGS, "rows(query_idx, train_idx, distance: int32 buffers) -> [[DMatch], ...]"},
                                 {"pack", pack, METH_VARARGS, "pack(seq of equal buffers, out) -> bool: item i copied into row i of out"},
+                                {"collect", collect, METH_O, "collect(points) -> (locs, rev_sum, counts, fids, frame_objs, uvs, descs) or None"},
                                 {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_rows", "match rows of the class API, built in C (no GPU)", -1, methods};
 
 PyMODINIT_FUNC PyInit__rows(void) {
   if (PyType_Ready(&DMatchType) < 0) return NULL;
+  s_loc = PyUnicode_InternFromString("_loc");
+  s_rev = PyUnicode_InternFromString("_rev");
+  s_frames = PyUnicode_InternFromString("_frames");
+  if (!s_loc || !s_rev || !s_frames) return NULL;
   PyObject* m = PyModule_Create(&module);
   if (!m) return NULL;
   Py_INCREF(&DMatchType);

@@ -31,6 +31,10 @@ try:  # rows handed over one by one (one small array per point) packed into one 
     from ._rows import pack as _pack
 except ImportError:  # the C helper is not built: numpy's own conversion
     _pack = None
+try:  # what a batch of added points holds (positions, counters, observations), read out of the objects in one C pass
+    from ._rows import collect as _collect
+except ImportError:
+    _collect = None
 
 
 def _rows_of(seq, dtype=None):
@@ -741,14 +745,38 @@ class Map:
         added, self._added = self._added, []
         s, c = self._soa, self._cell
         if not (self._soa_points_obj is self.points_3d and s.n_obs >= 0 and s.n_points + len(added) == len(self.points_3d)
-                and self._soa_cell[0] + len(added) == c[0] and self._soa_cell[1] == c[1]
-                and all(hasattr(p, "_frames") for _, p in added)):
+                and self._soa_cell[0] + len(added) == c[0] and self._soa_cell[1] == c[1]):
             return  # something else happened in between: soa() verifies and rebuilds
         # (Pending observation batches -- AddPointToFrameCorrespondences rows not yet written into the Point objects -- never
         # concern the points absorbed here: a batch only names points the mirror already held when it arrived, and every such
         # call absorbs what was added before it.  The new points' own `_frames` dicts, read below, are complete.)
         n = len(added)
         pids, pts = zip(*added)
+        got = _collect(pts) if _collect is not None else None
+        if got is not None:
+            locs, rev_sum, counts, fids, fobjs, uvs, descs = got
+            rows = _rows_of(locs, np.float64)
+            if rows is not None and rows.shape == (n, 3):
+                slot0 = s.n_points
+                if slot0 + n > s.xyz.shape[0]:
+                    grown = np.zeros((max(256, 2 * s.xyz.shape[0], slot0 + n), 3))
+                    grown[:slot0] = s.xyz[:slot0]
+                    s.xyz = grown
+                s.xyz[slot0:slot0 + n] = rows
+                s.point_slot.update(zip(pids, range(slot0, slot0 + n)))
+                s.xyz_refs.extend(locs)
+                s.n_points += n
+                s.rev += rev_sum
+                if len(fids) == n and counts.count(1) == n:
+                    slots = range(slot0, slot0 + n)
+                else:
+                    slots = np.repeat(np.arange(slot0, slot0 + n, dtype=np.int32), counts)
+                if len(slots):
+                    s.add_obs(slots, fids, uvs, descs, fobjs)
+                self._soa_cell = (c[0], c[1])
+                return
+        if not all(hasattr(p, "_frames") for p in pts):
+            return  # foreign point objects: soa() rebuilds the mirror from the objects
         locs, revs, frames = map(list, zip(*map(_LOC_REV_FRAMES, pts)))  # three slots of every point in one C-level pass
         rows = _rows_of(locs, np.float64)  # one conversion for the batch
         if rows is not None and rows.shape != (n, 3):
