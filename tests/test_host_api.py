@@ -589,3 +589,43 @@ def test_points_added_as_one_batch_leave_the_map_as_the_loop_does(n_obs):
     assert len(m.points_3d) == n0
     m.AddPoints3D([], np.zeros((0, 3)), [])
     assert len(m.points_3d) == n0
+
+
+def test_collect_reads_added_points_in_one_pass_or_declines():
+    """_rows.collect (the C pass of Map._absorb_added): positions, counter sum, observation counts and the observations point by
+    point in dict order; None -- never an exception -- for objects that are not Points, wherever in the batch they stand."""
+    _rows = pytest.importorskip("visual_slam_amd._rows")
+    from visual_slam_amd.point import Point
+    fr = [Frame(np.zeros((4, 4, 3), np.uint8), None, i) for i in range(3)]
+    pts = []
+    for k in range(5):
+        p = Point(location=np.full(3, float(k)), id=k)
+        for j in range(k % 3 + 1):
+            p.AddFrame(frame=fr[j], uv=np.array([k, j], np.float32), descriptor=np.full(32, 10 * k + j, np.uint8))
+        pts.append(p)
+    locs, rev_sum, counts, fids, fobjs, uvs, descs = _rows.collect(pts)
+    assert all(a is p._loc for a, p in zip(locs, pts)) and rev_sum == sum(p._rev for p in pts)
+    assert counts == [len(p._frames) for p in pts]
+    flat = [(f, t) for p in pts for f, t in p._frames.items()]
+    assert fids == [f for f, _ in flat] and all(a is t[0] for a, (_, t) in zip(fobjs, flat))
+    assert all(a is t[1] for a, (_, t) in zip(uvs, flat)) and all(a is t[2] for a, (_, t) in zip(descs, flat))
+    assert _rows.collect([]) == ([], 0, [], [], [], [], [])
+    assert _rows.collect(tuple(pts))[2] == counts
+
+    class NotAPoint:
+        pass
+
+    class HalfAPoint:
+        _loc, _rev, _frames = np.zeros(3), 0, {0: "not a triple"}
+
+    for bad in (NotAPoint(), HalfAPoint(), 7):
+        for where in (0, 2, 5):
+            seq = list(pts)
+            seq.insert(where, bad)
+            assert _rows.collect(seq) is None
+    # ... and a map that meets such an object among its added points rebuilds its mirror from the objects instead
+    m = Map()
+    m.AddFrame(0, fr[0])
+    for k, p in enumerate(pts):
+        m.AddPoint3D(k, p)
+    assert m.soa().n_points == 5 and m.soa().n_obs == sum(counts)
