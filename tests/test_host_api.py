@@ -589,6 +589,15 @@ def test_points_added_as_one_batch_leave_the_map_as_the_loop_does(n_obs):
     assert len(m.points_3d) == n0
     m.AddPoints3D([], np.zeros((0, 3)), [])
     assert len(m.points_3d) == n0
+    # the mirror owns its rows: editing the arrays handed in afterwards does not reach it
+    f = Frame(np.zeros((4, 4, 3), np.uint8), None, 0)
+    m = Map()
+    m.AddFrame(0, f)
+    uv, d, X = np.ones((5, 2), np.float32), np.ones((5, 32), np.uint8), np.zeros((5, 3))
+    m.AddPoints3D(range(1, 6), X, [(f, uv, d)])
+    uv[:], d[:], X[:] = 7, 9, 3
+    arr = m.soa().arrays()
+    assert arr[2].max() == 1 and arr[3].max() == 1 and m.soa().xyz[:5].max() == 0
 
 
 def test_collect_reads_added_points_in_one_pass_or_declines():

@@ -730,7 +730,8 @@ class Map:
         s.n_points += n
         s.rev += n * m
         if m == 1:
-            s.add_obs(np.arange(slot0, slot0 + n, dtype=np.int32), fids[0], obs[0][1], obs[0][2], obs[0][0])
+            # (copies: the mirror's rows must not alias the caller's arrays -- the loop's rows are packed into fresh arrays, too)
+            s.add_obs(np.arange(slot0, slot0 + n, dtype=np.int32), fids[0], np.array(obs[0][1]), np.array(obs[0][2]), obs[0][0])
         elif m > 1:   # point by point, frame by frame: the order in which the loop above records them
             same_uv = len({(uv.dtype, uv.shape[1:]) for _, uv, _ in obs}) == 1
             same_d = len({(d.dtype, d.shape[1:]) for _, _, d in obs}) == 1
