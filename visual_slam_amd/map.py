@@ -104,12 +104,17 @@ class _SoA:
             elif have is not o:
                 fo[f] = None
 
-    def add_obs(self, slots, frame_id, uvs, descs, frame_obj=None):
-        """frame_id: one id for the whole batch, or one per row.  frame_obj: the Frame object(s) of the batch, likewise."""
+    def add_obs(self, slots, frame_id, uvs, descs, frame_obj=None, noted=None):
+        """frame_id: one id for the whole batch, or one per row.  frame_obj: the Frame object(s) of the batch, likewise.
+        noted: {frame id: (Frame object, rows)} when the caller knows the batch's frames and their row counts (Map.AddPoints3D):
+        the per-row bookkeeping of Frame objects and row counts is then two dict updates."""
         k = len(slots)
         if k == 0:
             return
-        if frame_obj is None:
+        if noted is not None:
+            if self.frame_objs is not _UNKNOWN_FRAMES:
+                self.note_frames(list(noted), [o for o, _ in noted.values()])
+        elif frame_obj is None:
             self.frame_objs = _UNKNOWN_FRAMES  # observations without their Frame object: nothing may be inferred from ids
         elif self.frame_objs is not _UNKNOWN_FRAMES:
             try:
@@ -144,8 +149,12 @@ class _SoA:
         else:
             fids = np.asarray(frame_id, np.int64)
             self.batches.append((None, self.n_obs, k))
-            for f in fids.tolist():
-                self.fid_rows[f] = self.fid_rows.get(f, 0) + 1
+            if noted is not None:
+                for f, (_, rows) in noted.items():
+                    self.fid_rows[f] = self.fid_rows.get(f, 0) + rows
+            else:
+                for f in fids.tolist():
+                    self.fid_rows[f] = self.fid_rows.get(f, 0) + 1
         slots = np.asarray(slots, np.int32)
         self._chunks.append((slots, fids, uv, desc))
         self.batch_data.append((slots, uv))
@@ -737,7 +746,12 @@ class Map:
             same_d = len({(d.dtype, d.shape[1:]) for _, _, d in obs}) == 1
             uv_all = np.stack([uv for _, uv, _ in obs], 1).reshape(n * m, -1) if same_uv else [u for k in range(n) for _, uvr, _ in per_frame for u in (uvr[k],)]
             d_all = np.stack([d for _, _, d in obs], 1).reshape((n * m,) + obs[0][2].shape[1:]) if same_d else [x for k in range(n) for _, _, dr in per_frame for x in (dr[k],)]
-            s.add_obs(np.repeat(np.arange(slot0, slot0 + n, dtype=np.int32), m), fids * n, uv_all, d_all, [f for f, _, _ in obs] * n)
+            try:
+                noted = {int(fid): (f, n) for fid, (f, _, _) in zip(fids, obs)} if all(np.ndim(fid) == 0 for fid in fids) else None
+            except (TypeError, ValueError):
+                noted = None
+            s.add_obs(np.repeat(np.arange(slot0, slot0 + n, dtype=np.int32), m), np.tile(np.asarray(fids, np.int64), n) if noted is not None else fids * n,
+                      uv_all, d_all, [f for f, _, _ in obs] * n if noted is None else None, noted=noted)
         self._soa_cell = (cell[0], cell[1])
 
     def _absorb_added(self):
