@@ -47,6 +47,10 @@ int vs_ba_structure_on_device(vs_ctx* ctx); /* 1: the newest vs_ba_solve of this
  * uploads waited for first, so that *last_batch_us covers the same interval as the graph form's; any other value leaves it.
  * *last_batch_us (may be NULL) = wall microseconds of the newest batch, graph launch (or first enqueue) to results on the host. */
 int vs_tune_ba_graph(vs_ctx* ctx, int on, double* last_batch_us);
+/* Dense solve of the reduced camera system in LDS (ba_solve_block): 0 automatic -- square storage up to 126 unknowns (21 free
+ * cameras), the lower triangle packed from 127 to 198 (33) --, 1 never packed (systems beyond 126 take the blocked factorisation in
+ * HBM), 2 packed at every size that fits.  Same operations in the same order either way; tests compare the bits. */
+int vs_tune_ba_solve(vs_ctx* ctx, int packed_mode);
 
 /* Which kernels the newest vs_ba_solve of this context took.  out6[0] Schur complement: 0 ba_schur (general, one slab of points per
  * workgroup), 1 ba_schur_tile (tiles of 10 x 10 camera blocks), 2 ba_schur_small (single tile), 3 ba_schur_window (banded, FP64

@@ -694,6 +694,48 @@ def test_banded_cholesky_is_bitwise_the_dense_factorisation(vs):
 
 
 @pytest.mark.gpu
+def test_packed_lds_solver_is_bitwise_the_other_dense_paths(vs, oracle):
+    """ba_solve_block with the lower triangle packed (127 .. 198 unknowns in 160 KB of LDS, vs_tune_ba_solve): the same subtractions
+    in the same order as the square layout (<= 126 unknowns) and as the blocked factorisation in HBM it replaces (ba_chol_panel /
+    ba_chol_update / ba_chol_finish) -- the same bits for the solution of the reduced system; an indefinite matrix is rejected; whole
+    solves agree with the oracle on either side of both size limits, and with each other to rounding."""
+    r = np.random.default_rng(3)
+    try:
+        for n in (6, 24, 54, 126, 132, 174, 198):
+            M = r.normal(size=(n, n))
+            S = M @ M.T + n * np.eye(n)
+            rhs = r.normal(size=n)
+            got = {}
+            for mode in (0, 1, 2):
+                vs.tune_ba_solve(mode)
+                ok, x = vs.debug_cholesky(S, rhs)
+                assert ok
+                got[mode] = x
+            assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2]), n
+            assert np.abs(got[0] - np.linalg.solve(S, rhs)).max() < 1e-10
+        vs.tune_ba_solve(0)
+        S[150, 150] = -1.0
+        assert not vs.debug_cholesky(S, rhs)[0]
+        # whole solves: 22 / 33 / 34 cameras (126 / 192 / 198 unknowns; 204 is past the packed limit)
+        for n_cams, want in ((22, "ba_solve_block"), (33, "ba_solve_block"), (34, "ba_solve_block"), (35, "ba_chol_panel")):
+            w = ba_workload(n_cams=n_cams, n_points=400, visibility=0.4, seed=n_cams)
+            a = vs.ba_solve(*_args(w), max_iterations=4)
+            path = vs.ba_last_path()
+            assert path["unknowns"] == 6 * (n_cams - 1) and path["dense"] == want, path
+            _compare(a, oracle.ba_solve(*_args(w), max_iterations=4))
+            vs.tune_ba_solve(1)
+            b = vs.ba_solve(*_args(w), max_iterations=4)
+            vs.tune_ba_solve(0)
+            # (the solutions of the reduced system are the same bits, above; the camera update behind them is not the same code in
+            # ba_solve_block and ba_chol_finish -- reciprocal square root + Newton steps against sqrt and a division for the unit
+            # quaternion -- so whole solves agree to rounding, with the same LM decisions)
+            assert np.abs(a["poses"] - b["poses"]).max() < 1e-11 and np.abs(a["points"] - b["points"]).max() < 1e-11
+            assert np.allclose(a["chi2_trace"], b["chi2_trace"], rtol=1e-12) and a["trials"] == b["trials"]
+    finally:
+        vs.tune_ba_solve(0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_cams,n_points", [(13, 20000), (16, 30000)])
 def test_window_plan_fits_the_arena_of_a_fresh_context(oracle, n_cams, n_points):
     """Round-3 advisor: the arena reservation covered the tile path's slabs (np * np + np doubles each) but not the banded-window

@@ -7,8 +7,11 @@ import time
 from visual_slam_amd import Context
 from visual_slam_amd.workloads import ba_workload
 
+import sys
 ctx = Context(0)
-for n in (10, 16, 21, 22, 23, 30, 40, 52, 60):
+if len(sys.argv) > 1:  # 1: systems beyond 126 unknowns through HBM (ba_chol_panel / ba_chol_update), as before the packed LDS solver
+    ctx.tune_ba_solve(int(sys.argv[1]))
+for n in (10, 16, 21, 22, 23, 27, 30, 34, 35, 40, 52, 60):
     w = ba_workload(n_cams=n, n_points=1200, visibility=0.3, seed=n)
     args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
     for _ in range(5):

@@ -120,6 +120,7 @@ HOOKS = {
     "vs_ba_structure_on_device": (C.c_int, [c_ctxp]),
     "vs_ba_last_path": (C.c_int, [c_ctxp, c_intp]),
     "vs_tune_ba_graph": (C.c_int, [c_ctxp, C.c_int, c_f64p]),
+    "vs_tune_ba_solve": (C.c_int, [c_ctxp, C.c_int]),
     "vs_tune_ba": (C.c_int, [c_ctxp, C.c_int, C.c_int, C.c_int, C.c_int]),  # schur variant, points / workgroup, slab cap, motion variant
     "vs_match_profile": (C.c_int, [c_ctxp, C.c_int]),
     "vs_match_profile_read": (C.c_int, [c_ctxp, C.POINTER(C.c_float)]),

@@ -98,6 +98,11 @@ class Context:
         self._chk(self._lib.vs_tune_ba(self._h, int(schur_variant), int(points_per_workgroup), int(max_slabs),
                                        int(motion_variant)))
 
+    def tune_ba_solve(self, packed_mode):
+        """Storage of the reduced system in ba_solve_block (vs_tune_ba_solve): 0 automatic (square up to 126 unknowns, packed lower
+        triangle from 127 to 198), 1 never packed (beyond 126: the blocked factorisation in HBM), 2 packed wherever it fits."""
+        self._chk(self._lib.vs_tune_ba_solve(self._h, int(packed_mode)))
+
     def tune_ba_structure(self, on_host):
         """Where a large problem's sparsity structure is built: on the device (default) or by the host passes."""
         self._chk(self._lib.vs_tune_ba_structure(self._h, int(bool(on_host))))

@@ -65,7 +65,8 @@ constexpr int kPtPerBlock = kPtThreads / kPtLanes;
 constexpr int kCamThreads = 512;  // ba_linearize: a camera's observations are spread over this many threads
 constexpr int kSchurThreads = 256;
 constexpr int kSolveThreads = 512;
-constexpr int kMaxLdsN = 126;   // reduced systems up to 126 x 126 (21 free cameras) are factorised in LDS by one wave
+constexpr int kMaxLdsN = 126;   // reduced systems up to 126 x 126 (21 free cameras) are factorised in LDS by one workgroup
+constexpr int kMaxLdsPacked = 198;  // ... up to 198 x 198 (33 free cameras) with the lower triangle packed (160 KB of LDS)
 constexpr int kMaxSlabN = 90;   // Schur slabs up to 90 x 90 (15 free cameras) live in LDS
 
 
@@ -1547,6 +1548,10 @@ constexpr int kSolveTile = 32;  // threads as rows of kSolveTile over matrix til
 // (256 / 512 threads for small systems were measured in round 5 and are no faster: a step is the chain on wave 0, not the barriers --
 // profiles/r05_solve_stamps.txt, profiles/tried_and_dropped.md)
 constexpr int kSolveBlock = 1024;
+// PACKED: the rows of the lower triangle one behind the other (row r at r (r + 1) / 2, the right-hand side as row n) instead of a
+// square: 160 KB of LDS then hold 198 unknowns (33 free cameras) instead of 126 (21) -- systems that otherwise take two launches
+// per 24 columns through HBM (ba_chol_panel / ba_chol_update).  Same operations in the same order: the same bits.
+template <bool PACKED>
 __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   extern __shared__ __attribute__((aligned(16))) double s_mem[];
   lm_state* st = D.st;
@@ -1559,15 +1564,16 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   if (tid < 64) __builtin_amdgcn_s_setprio(3);  // wave 0 factorises the diagonal blocks: the critical path of every step
 #endif
   const int ld = (n + 1) | 1;
-  double* A = s_mem;                        // (n + 1) rows of ld: rows 0..n-1 matrix, row n = rhs
-  double* rinv = s_mem + (size_t)(n + 1) * ld;  // [n]
+  auto IX = [ld](int r, int c) { return PACKED ? ((r * (r + 1)) >> 1) + c : r * ld + c; };
+  double* A = s_mem;                        // (n + 1) rows (of ld, or packed): rows 0..n-1 matrix, row n = rhs
+  double* rinv = s_mem + (PACKED ? (size_t)(n + 1) * (n + 2) / 2 : (size_t)(n + 1) * ld);  // [n]
   double* s_bp = rinv + n + 1;              // [n] right-hand side before the Schur complement (gain denominator)
   int* s_flag = reinterpret_cast<int*>(s_bp + n + 1);
   for (int r = ty; r < n; r += kSolveBlock / kSolveTile)  // the lower triangle: nothing else is read
-    for (int c = tx; c <= r; c += kSolveTile) A[r * ld + c] = D.S[(size_t)r * n + c];
+    for (int c = tx; c <= r; c += kSolveTile) A[IX(r, c)] = D.S[(size_t)r * n + c];
   const double* g_bp = lin_of(D, cur).bp;
   for (int c = tid; c < n; c += kSolveBlock) {
-    A[n * ld + c] = D.bs[c];
+    A[IX(n, c)] = D.bs[c];
     s_bp[c] = g_bp[c];
   }
   if (tid == 0) *s_flag = 0;
@@ -1586,7 +1592,7 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
 #pragma unroll
     for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int c = 0; c <= r; ++c) L[r][c] = A[(j0 + r) * ld + j0 + c];
+      for (int c = 0; c <= r; ++c) L[r][c] = A[IX(j0 + r, j0 + c)];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const double d = L[c][c];
@@ -1608,7 +1614,7 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
 #pragma unroll
-      for (int c = 0; c <= r; ++c) A[(j0 + r) * ld + j0 + c] = L[r][c];
+      for (int c = 0; c <= r; ++c) A[IX(j0 + r, j0 + c)] = L[r][c];
       rinv[j0 + r] = ri[r];
     }
     if (!good) *s_flag = 1;
@@ -1630,16 +1636,16 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
     for (int r = j0 + 6 + tid; r <= n; r += kSolveBlock) {
       double a[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) a[c] = A[r * ld + j0 + c];
+      for (int c = 0; c < 6; ++c) a[c] = A[IX(r, j0 + c)];
 #pragma unroll
       for (int c = 0; c < 6; ++c) {
         double v = a[c];
 #pragma unroll
-        for (int k = 0; k < c; ++k) v -= a[k] * A[(j0 + c) * ld + j0 + k];
+        for (int k = 0; k < c; ++k) v -= a[k] * A[IX(j0 + c, j0 + k)];
         a[c] = v * rinv[j0 + c];
       }
 #pragma unroll
-      for (int c = 0; c < 6; ++c) A[r * ld + j0 + c] = a[c];
+      for (int c = 0; c < 6; ++c) A[IX(r, j0 + c)] = a[c];
     }
     VS_SOLVE_LAP(stsP)
     __syncthreads();
@@ -1657,10 +1663,10 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
             ++r;
           }
           const int rr = j0 + 6 + r, cc = j0 + 6 + c;
-          double acc = A[rr * ld + cc];
+          double acc = A[IX(rr, cc)];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) acc -= A[rr * ld + j0 + k] * A[cc * ld + j0 + k];
-          A[rr * ld + cc] = acc;
+          for (int k = 0; k < 6; ++k) acc -= A[IX(rr, j0 + k)] * A[IX(cc, j0 + k)];
+          A[IX(rr, cc)] = acc;
         }
         wave_lds_sync();
         VS_SOLVE_LAP(stsU)
@@ -1674,13 +1680,13 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
       for (int r = j0 + (next_diag ? 12 : 6) + uy; r <= n; r += kRowsPer) {  // rows j0+6..j0+11 lie inside wave 0's block
         double ar[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) ar[k] = A[r * ld + j0 + k];
+        for (int k = 0; k < 6; ++k) ar[k] = A[IX(r, j0 + k)];
         const int cmax = r < n ? r : n - 1;
         for (int c = j0 + 6 + ux; c <= cmax; c += kSolveTile) {
-          double acc = A[r * ld + c];
+          double acc = A[IX(r, c)];
 #pragma unroll
-          for (int k = 0; k < 6; ++k) acc -= ar[k] * A[c * ld + j0 + k];
-          A[r * ld + c] = acc;
+          for (int k = 0; k < 6; ++k) acc -= ar[k] * A[IX(c, j0 + k)];
+          A[IX(r, c)] = acc;
         }
       }
     }
@@ -1698,7 +1704,7 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
   // backward substitution L^T x = y on wave 0, by 6x6 blocks from the bottom: lane 0 solves the block's triangular
   // system in registers (descending k, as the element-wise recurrence does), then the lanes subtract the block's
   // contribution from the rows above -- nb dependent steps instead of n.  x lives in row n.
-  double* x = A + n * ld;
+  double* x = A + IX(n, 0);
   if (ok && tid < 64) {
     for (int J = nb - 1; J >= 0; --J) {
       const int j0 = 6 * J;
@@ -1710,7 +1716,7 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
         for (int k = 5; k >= 0; --k) {
           xb[k] = xb[k] * rinv[j0 + k];
 #pragma unroll
-          for (int i = 0; i < k; ++i) xb[i] -= A[(j0 + k) * ld + j0 + i] * xb[k];
+          for (int i = 0; i < k; ++i) xb[i] -= A[IX(j0 + k, j0 + i)] * xb[k];
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) x[j0 + k] = xb[k];
@@ -1719,7 +1725,7 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
       for (int i = tid; i < j0; i += 64) {
         double v = x[i];
 #pragma unroll
-        for (int k = 5; k >= 0; --k) v -= A[(j0 + k) * ld + i] * x[j0 + k];
+        for (int k = 5; k >= 0; --k) v -= A[IX(j0 + k, i)] * x[j0 + k];
         x[i] = v;
       }
       wave_lds_sync();
@@ -1769,6 +1775,8 @@ __global__ __launch_bounds__(kSolveBlock) void ba_solve_block(ba_dev D) {
     }
   }
 }
+template __global__ void ba_solve_block<false>(ba_dev D);
+template __global__ void ba_solve_block<true>(ba_dev D);
 
 // Large systems (n > 126): blocked right-looking Cholesky in HBM, two launches per block column.
 //   ba_chol_panel(j0, nbw): one workgroup takes columns [j0, j0+nbw) of rows j0..n (row n = rhs, as above) into LDS,
@@ -3362,7 +3370,8 @@ struct arena {
 
 // dense solver of the reduced camera system: which kernels a system of np unknowns takes, and their launch
 struct solve_plan {
-  bool lds = false;        // np <= kMaxLdsN: ba_solve_block, one workgroup, [S | rhs] in LDS
+  bool lds = false;        // np <= kMaxLdsPacked: ba_solve_block, one workgroup, [S | rhs] in LDS
+  bool packed = false;     // ... as a packed lower triangle (np > kMaxLdsN)
   size_t lds_bytes = 0;
   int nbw = 0;             // otherwise: panel width of the blocked HBM factorisation (0: element-wise last resort)
   size_t panel_lds = 0;
@@ -3370,8 +3379,10 @@ struct solve_plan {
 };
 
 int plan_solve(vs_ctx* ctx, int np, solve_plan* P) {
-  P->lds = np <= kMaxLdsN;
-  P->lds_bytes = 32 + (P->lds ? sizeof(double) * ((size_t)(np + 1) * ((np + 1) | 1) + 2 * (size_t)np + 4) : 0);
+  const int mode = ctx->tune.ba_solve_packed;  // vs_tune_ba_solve: tests hold the three forms to the same bits
+  P->lds = np <= (mode == 1 ? kMaxLdsN : kMaxLdsPacked);
+  P->packed = P->lds && (np > kMaxLdsN || mode == 2);
+  P->lds_bytes = 32 + (!P->lds ? 0 : sizeof(double) * ((P->packed ? (size_t)(np + 1) * (np + 2) / 2 : (size_t)(np + 1) * ((np + 1) | 1)) + 2 * (size_t)np + 4));
   P->nbw = 0;
   P->panel_lds = 0;
   P->band_ok = false;
@@ -3395,15 +3406,19 @@ int plan_solve(vs_ctx* ctx, int np, solve_plan* P) {
       VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_chol_band, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBandLds));
     }
   }
-  if (P->lds_bytes > 64 * 1024)
-    VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_bytes));
+  if (P->lds_bytes > 64 * 1024) {
+    if (P->packed) VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve_block<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_bytes));
+    else VS_HIP(ctx, hipFuncSetAttribute((const void*)ba_solve_block<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P->lds_bytes));
+  }
   return VS_OK;
 }
 
 int launch_solve(vs_ctx* ctx, hipStream_t s, const ba_dev& D, const solve_plan& P) {
   const int np = D.np;
-  if (P.lds) {
-    hipLaunchKernelGGL(ba_solve_block, dim3(1), dim3(kSolveBlock), P.lds_bytes, s, D);
+  if (P.lds && P.packed) {
+    hipLaunchKernelGGL(ba_solve_block<true>, dim3(1), dim3(kSolveBlock), P.lds_bytes, s, D);
+  } else if (P.lds) {
+    hipLaunchKernelGGL(ba_solve_block<false>, dim3(1), dim3(kSolveBlock), P.lds_bytes, s, D);
   } else if (P.band_ok && D.band > 0 && D.band <= kBandMax) {
     hipLaunchKernelGGL(ba_chol_band, dim3(1), dim3(kBandThreads), kBandLds, s, D, std::max(D.band, 12));  // (the look-ahead wants the next diagonal block inside the window)
     hipLaunchKernelGGL(ba_chol_finish, dim3(1), dim3(kPanelThreads), sizeof(double) * ((size_t)np + 25 * 24 + 24) + 64, s, D, 24);
@@ -3458,6 +3473,13 @@ VS_API int vs_tune_ba_graph(vs_ctx* ctx, int on, double* last_batch_us) {
   if (!ctx) return VS_EINVAL;
   if (on >= 0 && on <= 2) ctx->tune.ba_graph = on;
   if (last_batch_us) *last_batch_us = ctx->ba_batch_us;
+  return VS_OK;
+}
+
+// developer hook (include/vslam_hip_dev.h): storage of the reduced system in ba_solve_block
+VS_API int vs_tune_ba_solve(vs_ctx* ctx, int packed_mode) {
+  if (!ctx) return VS_EINVAL;
+  if (packed_mode >= 0 && packed_mode <= 2) ctx->tune.ba_solve_packed = packed_mode;
   return VS_OK;
 }
 

@@ -61,6 +61,7 @@ struct vs_tuning {
   int win_per = 0;              // banded large windows: points per ba_schur_window workgroup (0: automatic)
   int motion_variant = 0;       // 0: one-launch motion-only solve where it applies, 1: one launch per LM step
   int ba_graph = 0;             // experiment: the LM slot batches of vs_ba_solve replayed as captured hipGraphs (vs_tune_ba_graph)
+  int ba_solve_packed = 0;      // dense solve in LDS (vs_tune_ba_solve): 0 automatic (packed triangle from 127 to 198 unknowns), 1 never packed, 2 packed at every size it fits
   int poison_alloc = -1;        // >= 0: every NEW device buffer of vs_reserve is filled with this byte (vs_debug_poison_alloc; tests: nothing may rely on what hipMalloc returns)
 };
 struct vs_prof_rec {
