@@ -314,7 +314,8 @@ def cpu_baseline(nq, nt):
 
 
 def detector_leg(ctx, torch, stream, cpu=True):
-    """BASELINE.json configs[1] / SURVEY 8d cfg2: one 640x480 frame, detect + describe.  Kernel-only time from HIP events
+    """(generator: yields its result dict after the GPU part and again after the CPU part, see `two_phase`)
+    BASELINE.json configs[1] / SURVEY 8d cfg2: one 640x480 frame, detect + describe.  Kernel-only time from HIP events
     on the launch stream around the two launches (frame resident in HBM), end-to-end through the host ABI (H2D + D2H
     included), on the synthetic frame SURVEY prescribes and on ICL-NUIM frame 0."""
     from visual_slam_amd.harness import load_sequence
@@ -359,19 +360,21 @@ def detector_leg(ctx, torch, stream, cpu=True):
                  "hbm_frac_of_8TBps": alg_bytes / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                  "launch_floor_us": 2 * LAUNCH_BOUNDARY_US,
                  "host_floor_us": 2 * LAUNCH_BOUNDARY_US + 3 * w * h / (PCIE_GBS * 1e3)}
-        if cpu:
-            from oracle import oracle
-            cm, _ = median_time(lambda: oracle.detect_describe_bgr(bgr, 20, max_kp), 20, warm=2)
-            entry["cpu_us_1_thread"] = cm * 1e6
         out[name] = entry
     out["note"] = ("kernels: detect_band_kernel + select_describe_kernel (two launches per frame); latency-bound as SURVEY 8d "
                    "predicts -- bytes / time is a tiny HBM fraction, the floor is two kernel boundaries (+ the 921 KB H2D "
                    "at PCIe rate on the host path); the per-kernel split is in profiles/ (rocprofv3 --kernel-trace --stats)")
-    return out
+    yield out  # ---- the GPU part is complete; resumed for the CPU baseline once every GPU leg has been measured (main)
+    if cpu:
+        from oracle import oracle
+        for name, bgr in cases.items():
+            cm, _ = median_time(lambda: oracle.detect_describe_bgr(bgr, 20, max_kp), 20, warm=2)
+            out[name]["cpu_us_1_thread"] = cm * 1e6
+    yield out
 
 
 def ba_leg(ctx, cpu=True):
-    """BASELINE.json configs[3]: local BA of 10 key frames x 2000 points (20 000 residuals), 10 LM iterations."""
+    """(generator, as detector_leg)  BASELINE.json configs[3]: local BA of 10 key frames x 2000 points (20 000 residuals), 10 LM iterations."""
     from visual_slam_amd.workloads import ba_workload
     w = ba_workload()
     args = (w["poses"], w["pose_fixed"], w["points"], w["point_fixed"], w["obs_pose"], w["obs_point"], w["obs_uv"], w["K"])
@@ -391,6 +394,7 @@ def ba_leg(ctx, cpu=True):
            "hbm_frac_of_8TBps": 178.0 * n_res * trials / med / 1e9 / HBM_PEAK_GBS,
            "note": "latency-bound (SURVEY 8d): 3.6 MB and 30 MFLOP per LM trial are ~1 us at either roof; the time is "
                    "dependent launches + one host structure pass + upload + read-back"}
+    yield out  # ---- GPU part complete (see detector_leg)
     if cpu:
         from oracle import oracle
         c = oracle.ba_solve(*args)
@@ -408,7 +412,7 @@ def ba_leg(ctx, cpu=True):
         out["gpu_solves_per_s"] = 1.0 / med
         out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
                                                          for a, b in zip(g["poses"], c["poses"])))
-    return out
+    yield out
 
 
 def ba_scaled_leg(ctx):
@@ -465,7 +469,7 @@ def ba_growth_leg(ctx):
 
 
 def frames_leg(ctx, cpu=True):
-    """frames/s of the 640x480 ICL-NUIM stream (detect+describe -> match -> PnP-RANSAC -> motion-only BA), GPU path and -- as the
+    """(generator, as detector_leg)  frames/s of the 640x480 ICL-NUIM stream (detect+describe -> match -> PnP-RANSAC -> motion-only BA), GPU path and -- as the
     checker/baseline only -- the CPU oracle through the same harness.  GPU legs: medians of 20 repetitions (minima
     beside them); CPU: median of 5 on one core, and one tracker per host core."""
     from visual_slam_amd.harness import HUBER, bench_frames, dataset_dir, load_sequence, track_sequence
@@ -507,6 +511,7 @@ def frames_leg(ctx, cpu=True):
         out["driver"] = {"error": repr(e)}
     finally:
         gc.unfreeze()
+    yield out  # ---- GPU part complete (see detector_leg)
     if cpu:
         from oracle import oracle
         oracle.load()
@@ -545,7 +550,21 @@ def frames_leg(ctx, cpu=True):
             out["cpu_all_threads"] = {"error": repr(e)}
         out["pose_rel_frobenius_vs_oracle"] = float(max(np.linalg.norm(a - b) / np.linalg.norm(b)
                                                          for a, b in zip(poses, cposes)))
-    return out
+    yield out
+
+
+def two_phase(gen):
+    """Runs a leg generator up to its first yield (the GPU part) and returns (result dict, finish), finish() running the rest
+    (the CPU baseline of the leg, which fills the same dict).  main() measures every GPU leg first and the CPU baselines after them:
+    the all-threads sweeps of the baselines leave the host in another state (the Python-heavy driver leg came out 5 - 8 % slower
+    behind them), and a GPU figure should not depend on which baseline happened to run in front of it."""
+    out = next(gen)
+
+    def finish():
+        for _ in gen:
+            pass
+        return out
+    return out, finish
 
 
 def frames_replicas(ctx, dist, world, dev, track=None, sequence=None, sync=None, reps=7):
@@ -966,15 +985,12 @@ def main():
             line["cfg5"] = cfg5
         if host_abi is not None:
             line["host_abi"] = host_abi
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(nq, nt)
-            except Exception as e:  # never lose the GPU numbers to a host-side problem
-                line["cpu_baseline"] = {"error": repr(e)}
         cpu = world == 1 and not args.no_cpu_baseline
+        finishers = []  # the CPU halves of the legs, run after every GPU leg (two_phase)
         if world == 1 and not args.no_frames:
             try:
-                line["cfg2"] = detector_leg(ctx, torch, stream, cpu=cpu)
+                line["cfg2"], fin = two_phase(detector_leg(ctx, torch, stream, cpu=cpu))
+                finishers.append(("cfg2", fin))
                 k2 = line["cfg2"]["synthetic_rng2_blur5"]
                 roof["kernels"]["detect_band_kernel+select_describe_kernel"] = {
                     "bound": "latency", "us_per_frame": k2["kernel_only_us"], "algorithmic_bytes": k2["algorithmic_bytes"],
@@ -982,7 +998,8 @@ def main():
             except Exception as e:
                 line["cfg2"] = {"error": repr(e)}
             try:
-                line["local_ba"] = ba_leg(ctx, cpu=cpu)
+                line["local_ba"], fin = two_phase(ba_leg(ctx, cpu=cpu))
+                finishers.append(("local_ba", fin))
                 lb = line["local_ba"]
                 roof["kernels"]["local_ba_cfg4 (ba_* kernels of one solve)"] = {
                     "bound": "latency", "us_per_lm_trial": lb["us_per_trial"],
@@ -1001,7 +1018,8 @@ def main():
                 line["local_ba_growth"] = {"error": repr(e)}
         if not args.no_frames:
             try:
-                line["frames"] = frames_leg(ctx, cpu=cpu)
+                line["frames"], fin = two_phase(frames_leg(ctx, cpu=cpu))
+                finishers.append(("frames", fin))
                 if replicas is not None:
                     line["frames"]["replicas"] = replicas
                 if world > 1:
@@ -1009,6 +1027,19 @@ def main():
                                                      "rank 0's GPU only (north_star: detection and BA stay single-GPU)")
             except Exception as e:
                 line["frames"] = {"error": repr(e)}
+        # ---- CPU baselines, after every GPU leg
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(nq, nt)
+            except Exception as e:  # never lose the GPU numbers to a host-side problem
+                line["cpu_baseline"] = {"error": repr(e)}
+        for key, fin in finishers:
+            try:
+                fin()
+            except Exception as e:
+                if isinstance(line.get(key), dict):
+                    line[key]["cpu_error"] = repr(e)
+        line["leg_order"] = "every GPU leg first, then the CPU baselines (cpu_baseline, cfg2 / local_ba / frames CPU halves)"
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
     if use_dist:
